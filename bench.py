@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py - images/sec of the HGR-Net zero-shot evaluation step on MI355X.
+
+Workload (BASELINE.json configs[1], metric "images/sec over 21K-class hierarchy, batch 512"):
+ViT-B/32 CLIP, N = 21 841 hierarchy nodes, batch 512 synthetic 224x224 images per GPU.  One step =
+the body of the reference's hot loop (main.py:131-191): ``logits = model(imgs)`` (image tower -> L2
+norm -> [512x512].[512x21841] logits GEMM, model/clip_tree.py:328-333) followed by the top-20 /
+top-1 / per-level arg-max metrics.  ``update_classifier`` (text tower over all prompts) is one-off per
+evaluation and runs before the timed region, sharded over ranks + RCCL all-gather when N > 1.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0) - see DESIGN.md "Measurement" for how each field is obtained.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+import types
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np
+import torch
+
+N_NODES, BATCH, ARCH = 21841, 512, "ViT-B/32"
+PEAK_TFLOPS_BF16 = 2500.0        # dense bf16 MFMA peak, MI355X_MICROARCH.md
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(sd, zsl_cpu, seconds_target=15.0):
+    """The oracle (CPU fp32 restatement of the reference path) timed on this box's host cores on a
+    bounded sample of the same workload: batches of 32 images through the same ViT-B/32 + N = 21 841
+    logits + top-20, repeated until ~seconds_target of CPU work."""
+    from hgr_net_amd import synth
+    from oracle import tree_ref
+    bs = 32
+    img = synth.images(bs, 224, 99)
+    t0 = time.time()
+    lg = tree_ref.forward(sd, img, zsl_cpu)
+    lg.topk(20, dim=1)
+    first = time.time() - t0
+    iters = max(1, min(20, int(seconds_target / max(first, 1e-3))))
+    t0 = time.time()
+    for _ in range(iters):
+        lg = tree_ref.forward(sd, img, zsl_cpu)
+        lg.topk(20, dim=1)
+    dt = time.time() - t0
+    return {"value": round(bs * iters / dt, 2), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{iters} x batch {bs} of the same ViT-B/32 N={zsl_cpu.shape[0]} forward+top20, oracle/ (torch fp32 CPU), "
+                      f"host cpu_count={os.cpu_count()}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--nodes", type=int, default=N_NODES)
+    ap.add_argument("--arch", default=ARCH)
+    ap.add_argument("--image-dtype", default="bf16")
+    ap.add_argument("--text-dtype", default="f16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
+    torch.cuda.set_device(local)
+    dev = f"cuda:{local}"
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(dev))     # "nccl" is RCCL on ROCm
+        group = dist.group.WORLD
+
+    from hgr_net_amd import evaluate, ops, synth
+    from hgr_net_amd.clip.model import build_model
+    from hgr_net_amd.hierarchy import build_hierarchy
+    from hgr_net_amd.model import tree_model
+
+    t0 = time.time()
+    cfg = synth.CLIP_CONFIGS[a.arch]
+    sd = synth.clip_state_dict(cfg, 0)
+    edges = synth.make_dag(a.nodes, depth=12, seed=7, multi_parent=0.03)
+    h = build_hierarchy(edges)
+    n_test = int(round(a.nodes * 13442 / 20842))                 # seen/unseen proportion of BASELINE configs[2]
+    splits = synth.make_splits(h.nodes, [len(c) == 0 for c in h.p2c], a.nodes - n_test, n_test, 13)
+    tokens = synth.make_tokens(a.nodes, 11, cfg["vocab_size"])
+    tmp = tempfile.mkdtemp(prefix="hgr_bench_")
+    gp = os.path.join(tmp, "graph.json")
+    json.dump(edges, open(gp, "w"))
+    opts = types.SimpleNamespace(device=dev, folder=tmp, exp_name="HGR", weights="equal", out_ratio=0.25, in_ratio=0.5,
+                                 from_epoch=-1, graph_path=gp, arch=a.arch, fetch=False, load=False, load_path="none", scale=1.0)
+    clip_model = build_model(sd, image_dtype=a.image_dtype, text_dtype=a.text_dtype).to(dev)
+    model = tree_model(opts, splits["all"], splits["rest"], node_tokens=tokens, clip_model=clip_model)
+    # synthetic single-class batches (every batch is one group), resident in HBM
+    base = synth.images(a.batch, cfg["image_resolution"], 1234 + rank).to(dev)
+    batches = [base, base.flip(0).contiguous()]
+    te = model.test_index.cpu().tolist()
+    targets = [te[(7 * i + rank) % len(te)] for i in range(a.steps + a.warmup)]
+    log(f"[bench] setup {time.time() - t0:.1f}s: {a.arch}, N={a.nodes} nodes (depth {h.max_depth}), batch {a.batch}/GPU, world {world}")
+
+    t0 = time.time()
+    model.update_classifier(group=group)
+    torch.cuda.synchronize()
+    log(f"[bench] update_classifier (text tower, {a.nodes} prompts, one-off, untimed): {time.time() - t0:.2f}s")
+
+    ev = evaluate.Evaluator(model)
+
+    def step(i):
+        logits = model(batches[i & 1], None)
+        ev.add_batch(logits, targets[i])
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(a.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms = elapsed / a.steps * 1e3
+    value = a.batch * world * a.steps / elapsed
+    summary = ev.summary(group)
+
+    # roofline of the dominant kernel (gemm_nt_128, the tower GEMMs): algorithmic FLOPs of every launch
+    # (2*M*N*K) / that launch's duration, from HIP events recorded on the launch stream around each call
+    # in a second, instrumented pass over the same steps (events perturb the timed pass, so it is separate).
+    roof = None
+    if rank == 0:
+        ops.PROFILE = []
+        for i in range(min(a.steps, 5)):
+            step(a.warmup + i)
+        torch.cuda.synchronize()
+        recs, ops.PROFILE = ops.PROFILE, None
+        tower = [(s.elapsed_time(e) * 1e-3, fl, by) for (name, s, e, fl, by) in recs if name == "gemm_nt" and fl > 2e10]
+        if tower:
+            tsum = sum(t for t, _, _ in tower)
+            fsum = sum(f for _, f, _ in tower)
+            ach = fsum / tsum / 1e12
+            roof = {"kernel": "gemm_nt_128 (image-tower GEMMs)", "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_TFLOPS_BF16,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS_BF16, 4), "traffic": None,
+                    "launches": len(tower), "avg_launch_us": round(tsum / len(tower) * 1e6, 1)}
+        lg = [(s.elapsed_time(e) * 1e-3, fl, by) for (name, s, e, fl, by) in recs if name == "gemm_nt" and by > 4e7 and fl < 2e10]
+        if lg and roof:
+            tl = sum(t for t, _, _ in lg) / len(lg)
+            roof["logits_gemm"] = {"us": round(tl * 1e6, 1), "tflops": round(lg[0][1] / tl / 1e12, 1),
+                                   "frac_mfma": round(lg[0][1] / tl / 1e12 / PEAK_TFLOPS_BF16, 4),
+                                   "gbps": round(lg[0][2] / tl / 1e9, 1), "frac_hbm": round(lg[0][2] / tl / 8e12, 4)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(sd, model.zsl_weights.float().cpu())
+
+    if rank == 0:
+        line = {"metric": "images/sec over 21K-class hierarchy, batch 512; hit@1 parity vs reference",
+                "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": a.image_dtype, "data": "synthetic",
+                "config": {"workload": f"{a.arch} zero-shot eval step: encode_image + L2 + [{a.batch}x512]x[512x{a.nodes}] logits "
+                                       f"+ top-20/top-1/level-argmax metrics (main.py:131-191), N={a.nodes} nodes, batch {a.batch}/GPU",
+                           "global_batch": a.batch * world, "parallelism": f"dp{world}", "text_dtype": a.text_dtype,
+                           "weights": "random-init (hash-seeded), no checkpoint offline"},
+                "roofline": roof, "cpu_baseline": cpu, "metrics_string": summary.strip()}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,64 @@
+"""ctypes binding of libhgr.so (include/hgr.h).  There is no fallback: if the library is missing or
+an entry point fails, the caller gets an exception - the product path never runs on the CPU."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("HGR_LIB", _HERE / "lib" / "libhgr.so"))
+
+HGR_BF16, HGR_F16 = 0, 1
+EPI_NONE, EPI_BIAS, EPI_BIAS_QUICKGELU, EPI_BIAS_RESIDUAL = 0, 1, 2, 3
+
+_p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+# name -> argtypes, exactly the prototypes of include/hgr.h
+SIGNATURES = {
+    "hgr_gemm_nt": [_p, _l, _p, _l, _p, _l, _p, _p, _l, _i, _i, _i, _i, _i, _i, _p],
+    "hgr_im2col_patches": [_p, _p, _i, _i, _i, _i, _i, _p],
+    "hgr_vit_embed_ln": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p],
+    "hgr_layernorm": [_p, _p, _p, _p, _i, _i, _l, _p, _f, _i, _i, _p],
+    "hgr_mha": [_p, _p, _i, _i, _i, _i, _i, _p],
+    "hgr_text_embed": [_p, _l, _p, _p, _p, _i, _i, _i, _i, _p],
+    "hgr_eot_index": [_p, _l, _p, _i, _i, _p],
+    "hgr_l2norm_rows": [_p, _p, _p, _i, _i, _i, _p],
+    "hgr_topk_rows": [_p, _l, _p, _i, _i, _p, _p, _i, _p],
+    "hgr_level_argmax": [_p, _l, _p, _i, _p, _i, _p, _i, _p],
+}
+
+
+class HgrError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libhgr.so once; raise (never fall back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.is_file():
+        raise HgrError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       f"or `make -C {_HERE / 'csrc'}`; there is no CPU fallback")
+    lib = C.CDLL(str(LIB_PATH))
+    lib.hgr_abi_version.restype = _i
+    lib.hgr_last_error.restype = C.c_char_p
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)            # AttributeError if the .so does not export a declared symbol
+        fn.argtypes = argtypes
+        fn.restype = _i
+    if lib.hgr_abi_version() != 1:
+        raise HgrError(f"libhgr.so ABI {lib.hgr_abi_version()} != 1")
+    _lib = lib
+    return lib
+
+
+def call(name: str, *args) -> None:
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise HgrError(f"{name} failed ({rc}): {lib.hgr_last_error().decode()}")

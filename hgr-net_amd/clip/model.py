@@ -1,0 +1,348 @@
+"""CLIP with the reference's module tree / ``state_dict`` schema and a libhgr.so forward.
+
+The module tree below exists to keep checkpoints interchangeable with the reference
+(clip/model.py:239-368; key dump in SURVEY.md section 8b): stock ``nn.LayerNorm`` / ``nn.Linear`` /
+``nn.MultiheadAttention`` / ``nn.Conv2d`` objects are used purely as *parameter containers*, so that
+``load_state_dict`` of a reference checkpoint, ``named_parameters()`` and helper functions that walk
+the tree with ``isinstance`` checks (utils.py:98-123) behave the same.  None of their ``forward``
+methods is ever called: ``encode_image`` / ``encode_text`` run the hand-written gfx950 kernels through
+the C ABI (``hgr_net_amd.ops``) on 16-bit copies of the weights, with an fp32 residual stream.
+
+Token layout is batch-major ([B*L, W] rows = b*L + t) instead of the reference's sequence-first
+[L, B, W]; it is the same arithmetic and keeps every per-token row contiguous.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Dict, Optional, Tuple, Union
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import ops
+from .._lib import EPI_BIAS, EPI_BIAS_QUICKGELU, EPI_BIAS_RESIDUAL, EPI_NONE, HgrError
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter containers (schema only)
+# ------------------------------------------------------------------------------------------------
+class QuickGELU(nn.Module):
+    """Placeholder so ``mlp`` keeps the reference's child names (c_fc, gelu, c_proj); the activation
+    itself is fused into the c_fc GEMM epilogue (HGR_EPI_BIAS_QUICKGELU)."""
+
+
+class ResidualAttentionBlock(nn.Module):
+    def __init__(self, d_model: int, n_head: int):
+        super().__init__()
+        self.attn = nn.MultiheadAttention(d_model, n_head)
+        self.ln_1 = nn.LayerNorm(d_model)
+        self.mlp = nn.Sequential(OrderedDict([("c_fc", nn.Linear(d_model, d_model * 4)), ("gelu", QuickGELU()),
+                                              ("c_proj", nn.Linear(d_model * 4, d_model))]))
+        self.ln_2 = nn.LayerNorm(d_model)
+
+
+class Transformer(nn.Module):
+    def __init__(self, width: int, layers: int, heads: int):
+        super().__init__()
+        self.width, self.layers, self.heads = width, layers, heads
+        self.resblocks = nn.Sequential(*[ResidualAttentionBlock(width, heads) for _ in range(layers)])
+
+
+class VisionTransformer(nn.Module):
+    def __init__(self, input_resolution: int, patch_size: int, width: int, layers: int, heads: int, output_dim: int):
+        super().__init__()
+        self.input_resolution, self.output_dim, self.patch_size = input_resolution, output_dim, patch_size
+        self.conv1 = nn.Conv2d(3, width, kernel_size=patch_size, stride=patch_size, bias=False)
+        scale = width ** -0.5
+        grid = input_resolution // patch_size
+        self.class_embedding = nn.Parameter(scale * torch.randn(width))
+        self.positional_embedding = nn.Parameter(scale * torch.randn(grid * grid + 1, width))
+        self.ln_pre = nn.LayerNorm(width)
+        self.transformer = Transformer(width, layers, heads)
+        self.ln_post = nn.LayerNorm(width)
+        self.proj = nn.Parameter(scale * torch.randn(width, output_dim))
+
+
+class _Bottleneck(nn.Module):
+    def __init__(self, inplanes, planes, stride=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.stride = stride
+        self.downsample = None
+        if stride > 1 or inplanes != planes * 4:
+            self.downsample = nn.Sequential(OrderedDict([("-1", nn.AvgPool2d(stride)),
+                                                         ("0", nn.Conv2d(inplanes, planes * 4, 1, bias=False)),
+                                                         ("1", nn.BatchNorm2d(planes * 4))]))
+
+
+class _AttentionPool2d(nn.Module):
+    def __init__(self, spacial_dim, embed_dim, num_heads, output_dim):
+        super().__init__()
+        self.positional_embedding = nn.Parameter(torch.randn(spacial_dim ** 2 + 1, embed_dim) / embed_dim ** 0.5)
+        self.k_proj = nn.Linear(embed_dim, embed_dim)
+        self.q_proj = nn.Linear(embed_dim, embed_dim)
+        self.v_proj = nn.Linear(embed_dim, embed_dim)
+        self.c_proj = nn.Linear(embed_dim, output_dim)
+        self.num_heads = num_heads
+
+
+class ModifiedResNet(nn.Module):
+    """Schema container for the RN towers (clip/model.py:93-150).  The HIP conv path is the next
+    row of the scope table; until then ``encode_image`` on an RN checkpoint raises."""
+
+    def __init__(self, layers, output_dim, heads, input_resolution=224, width=64):
+        super().__init__()
+        self.output_dim, self.input_resolution = output_dim, input_resolution
+        self.conv1 = nn.Conv2d(3, width // 2, 3, stride=2, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(width // 2)
+        self.conv2 = nn.Conv2d(width // 2, width // 2, 3, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(width // 2)
+        self.conv3 = nn.Conv2d(width // 2, width, 3, padding=1, bias=False)
+        self.bn3 = nn.BatchNorm2d(width)
+        inplanes = width
+        for li, nb in enumerate(layers):
+            planes = width * 2 ** li
+            blocks = [_Bottleneck(inplanes, planes, 1 if li == 0 else 2)]
+            inplanes = planes * 4
+            blocks += [_Bottleneck(inplanes, planes) for _ in range(1, nb)]
+            setattr(self, f"layer{li + 1}", nn.Sequential(*blocks))
+        self.attnpool = _AttentionPool2d(input_resolution // 32, width * 32, heads, output_dim)
+
+
+# ------------------------------------------------------------------------------------------------
+# weight preparation and the transformer engine
+# ------------------------------------------------------------------------------------------------
+def _w16(t: torch.Tensor, dt: torch.dtype) -> torch.Tensor:
+    return t.detach().to(dt).contiguous()
+
+
+def _f32(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().float().contiguous()
+
+
+class _Block16:
+    """16-bit GEMM weights + fp32 vectors of one residual block."""
+
+    def __init__(self, blk: ResidualAttentionBlock, dt: torch.dtype):
+        self.ln1 = (_f32(blk.ln_1.weight), _f32(blk.ln_1.bias))
+        self.ln2 = (_f32(blk.ln_2.weight), _f32(blk.ln_2.bias))
+        self.w_in, self.b_in = _w16(blk.attn.in_proj_weight, dt), _f32(blk.attn.in_proj_bias)
+        self.w_out, self.b_out = _w16(blk.attn.out_proj.weight, dt), _f32(blk.attn.out_proj.bias)
+        self.w_fc, self.b_fc = _w16(blk.mlp.c_fc.weight, dt), _f32(blk.mlp.c_fc.bias)
+        self.w_proj, self.b_proj = _w16(blk.mlp.c_proj.weight, dt), _f32(blk.mlp.c_proj.bias)
+
+
+class _Workspace:
+    """Named device buffers reused across calls (keeps the hot loop free of allocator traffic)."""
+
+    def __init__(self):
+        self._b: Dict[str, torch.Tensor] = {}
+
+    def get(self, name: str, shape, dtype, device) -> torch.Tensor:
+        n = int(np.prod(shape))
+        t = self._b.get(name)
+        if t is None or t.numel() < n or t.dtype != dtype or t.device != device:
+            t = torch.empty(n, dtype=dtype, device=device)
+            self._b[name] = t
+        return t[:n].view(*shape)
+
+
+def _run_blocks(x: torch.Tensor, blocks, heads: int, b: int, l: int, causal: bool, dt: torch.dtype, ws: _Workspace, tag: str,
+                taps: Optional[dict] = None, tap_prefix: str = ""):
+    """The residual stack (clip/model.py:185-188 per block) on the fp32 residual stream x [b*l, w]:
+    LN -> QKV GEMM(+bias) -> attention -> out GEMM(+bias, +residual) -> LN -> fc GEMM(+bias, QuickGELU)
+    -> proj GEMM(+bias, +residual).  7 kernel launches per block."""
+    m, w = x.shape
+    dev = x.device
+    h16 = ws.get(tag + ".h16", (m, w), dt, dev)
+    qkv = ws.get(tag + ".qkv", (m, 3 * w), dt, dev)
+    att = ws.get(tag + ".att", (m, w), dt, dev)
+    u16 = ws.get(tag + ".u16", (m, 4 * w), dt, dev)
+    for i, k in enumerate(blocks):
+        ops.layernorm(x, k.ln1[0], k.ln1[1], h16)
+        ops.gemm_nt(h16, k.w_in, qkv, bias=k.b_in, epilogue=EPI_BIAS)
+        ops.mha(qkv, att, b, l, heads, causal)
+        ops.gemm_nt(att, k.w_out, x, bias=k.b_out, residual=x, epilogue=EPI_BIAS_RESIDUAL)
+        ops.layernorm(x, k.ln2[0], k.ln2[1], h16)
+        ops.gemm_nt(h16, k.w_fc, u16, bias=k.b_fc, epilogue=EPI_BIAS_QUICKGELU)
+        ops.gemm_nt(u16, k.w_proj, x, bias=k.b_proj, residual=x, epilogue=EPI_BIAS_RESIDUAL)
+        if taps is not None:
+            taps[f"{tap_prefix}.resblocks.{i}"] = x.view(b, l, w).clone()
+    return x
+
+
+# ------------------------------------------------------------------------------------------------
+# CLIP
+# ------------------------------------------------------------------------------------------------
+class CLIP(nn.Module):
+    """Same constructor signature as the reference CLIP (clip/model.py:240-254) plus the two compute
+    dtypes.  ``image_dtype`` / ``text_dtype``: 16-bit MFMA input type of each tower ("bf16" | "f16");
+    accumulation, LayerNorm, softmax and the residual stream are fp32 in both."""
+
+    def __init__(self, embed_dim: int, image_resolution: int, vision_layers: Union[Tuple[int, int, int, int], int],
+                 vision_width: int, vision_patch_size: int, context_length: int, vocab_size: int,
+                 transformer_width: int, transformer_heads: int, transformer_layers: int,
+                 image_dtype: str = "bf16", text_dtype: str = "f16"):
+        super().__init__()
+        self.context_length = context_length
+        if isinstance(vision_layers, (tuple, list)):
+            self.visual = ModifiedResNet(vision_layers, embed_dim, vision_width * 32 // 64, image_resolution, vision_width)
+        else:
+            self.visual = VisionTransformer(image_resolution, vision_patch_size, vision_width, vision_layers,
+                                            vision_width // 64, embed_dim)
+        self.transformer = Transformer(transformer_width, transformer_layers, transformer_heads)
+        self.vocab_size = vocab_size
+        self.token_embedding = nn.Embedding(vocab_size, transformer_width)
+        self.positional_embedding = nn.Parameter(torch.empty(context_length, transformer_width).normal_(std=0.01))
+        self.ln_final = nn.LayerNorm(transformer_width)
+        self.text_projection = nn.Parameter(torch.empty(transformer_width, embed_dim).normal_(std=transformer_width ** -0.5))
+        self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / 0.07))
+        self.image_dtype = ops.TORCH16[ops.dtype_code(image_dtype)]
+        self.text_dtype = ops.TORCH16[ops.dtype_code(text_dtype)]
+        self.text_chunk = 8192          # prompts per text-tower pass (bounds the workspace; result is chunk-invariant)
+        self._prep: dict = {}
+        self._ws = _Workspace()
+
+    # -- reference surface ---------------------------------------------------------------------
+    @property
+    def dtype(self):
+        return self.visual.conv1.weight.dtype
+
+    def _fingerprint(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def _prepared(self) -> dict:
+        """16-bit weight copies, rebuilt whenever a parameter was replaced or written in place
+        (optimizer step, load_state_dict, .to())."""
+        fp = self._fingerprint()
+        if self._prep.get("fp") != fp:
+            p: dict = {"fp": fp}
+            v = self.visual
+            if isinstance(v, VisionTransformer):
+                dt = self.image_dtype
+                k = 3 * v.patch_size * v.patch_size
+                kp = (k + 63) // 64 * 64
+                wc = torch.zeros(v.conv1.weight.shape[0], kp, dtype=dt, device=v.conv1.weight.device)
+                wc[:, :k] = v.conv1.weight.detach().reshape(v.conv1.weight.shape[0], -1).to(dt)
+                p["conv_w"], p["kp"] = wc, kp
+                p["cls"], p["pos"] = _f32(v.class_embedding), _f32(v.positional_embedding)
+                p["ln_pre"] = (_f32(v.ln_pre.weight), _f32(v.ln_pre.bias))
+                p["ln_post"] = (_f32(v.ln_post.weight), _f32(v.ln_post.bias))
+                p["proj_t"] = _w16(v.proj.detach().t(), dt)                     # [D, W] for the NT GEMM
+                p["vblocks"] = [_Block16(b, dt) for b in v.transformer.resblocks]
+            dt = self.text_dtype
+            p["tok"], p["tpos"] = _f32(self.token_embedding.weight), _f32(self.positional_embedding)
+            p["ln_final"] = (_f32(self.ln_final.weight), _f32(self.ln_final.bias))
+            p["tproj_t"] = _w16(self.text_projection.detach().t(), dt)
+            p["tblocks"] = [_Block16(b, dt) for b in self.transformer.resblocks]
+            self._prep = p
+        return self._prep
+
+    @torch.no_grad()
+    def encode_image(self, image: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
+        """fp32 [B, embed_dim] image features (clip/model.py:336 -> VisionTransformer.forward :219-236)."""
+        v = self.visual
+        if not isinstance(v, VisionTransformer):
+            raise NotImplementedError("ModifiedResNet (RN50) tower: HIP conv kernels are the next scope-table row; "
+                                      "there is no CPU fallback (see DESIGN.md)")
+        if not image.is_cuda:
+            raise HgrError("encode_image needs a device tensor: the product path has no CPU fallback")
+        p = self._prepared()
+        dt, ws, dev = self.image_dtype, self._ws, image.device
+        image = image.float().contiguous()
+        b, _, r, _ = image.shape
+        if r != v.input_resolution:
+            raise ValueError(f"expected {v.input_resolution}x{v.input_resolution} input, got {r}")
+        ps = v.patch_size
+        g = r // ps
+        gg, l, w = g * g, g * g + 1, v.conv1.weight.shape[0]
+        patches = ws.get("v.patches", (b * gg, p["kp"]), dt, dev)
+        ops.im2col_patches(image, patches, ps)
+        pe = ws.get("v.pe", (b * gg, w), torch.float32, dev)
+        ops.gemm_nt(patches, p["conv_w"], pe)
+        x = ws.get("v.x", (b * l, w), torch.float32, dev)
+        ops.vit_embed_ln(pe, p["cls"], p["pos"], p["ln_pre"][0], p["ln_pre"][1], x, b, gg)
+        if taps is not None:
+            taps["visual.ln_pre"] = x.view(b, l, w).clone()
+        _run_blocks(x, p["vblocks"], w // 64, b, l, False, dt, ws, "v", taps, "visual.transformer")
+        cls16 = ws.get("v.cls16", (b, w), dt, dev)
+        ops.layernorm(x, p["ln_post"][0], p["ln_post"][1], cls16, rows=b, row_mul=l)
+        out = torch.empty((b, v.output_dim), dtype=torch.float32, device=dev)
+        ops.gemm_nt(cls16, p["proj_t"], out)
+        return out
+
+    @torch.no_grad()
+    def encode_text(self, text: torch.Tensor, trim: bool = True) -> torch.Tensor:
+        """fp32 [n, embed_dim] text features (clip/model.py:339-352).  With ``trim`` the blocks run on
+        positions <= max(EOT) only: exact, because the mask is causal and only the EOT row is read."""
+        if not text.is_cuda:
+            raise HgrError("encode_text needs a device tensor: the product path has no CPU fallback")
+        p = self._prepared()
+        dt, ws, dev = self.text_dtype, self._ws, text.device
+        text = text.long()
+        n, ctx = text.shape
+        w = self.transformer.width
+        d = self.text_projection.shape[1]
+        out = torch.empty((n, d), dtype=torch.float32, device=dev)
+        eot = torch.empty(n, dtype=torch.int32, device=dev)
+        ops.eot_index(text, eot)
+        l = int(eot.max().item()) + 1 if trim else ctx
+        for s in range(0, n, self.text_chunk):
+            e = min(n, s + self.text_chunk)
+            c = e - s
+            x = ws.get("t.x", (c * l, w), torch.float32, dev)
+            ops.text_embed(text[s:e], p["tok"], p["tpos"], x, l)
+            _run_blocks(x, p["tblocks"], w // 64, c, l, True, dt, ws, "t")
+            f16 = ws.get("t.f16", (c, w), dt, dev)
+            ops.layernorm(x, p["ln_final"][0], p["ln_final"][1], f16, rows=c, row_mul=l, row_idx=eot[s:e])
+            ops.gemm_nt(f16, p["tproj_t"], out[s:e])
+        return out
+
+    def forward(self, image, text):
+        """Scaled cosine logits (clip/model.py:354-368); L2 norm and the product run in libhgr."""
+        fi, ft = self.encode_image(image), self.encode_text(text)
+        dt = self.image_dtype
+        fi16 = torch.empty(fi.shape, dtype=dt, device=fi.device)
+        ft16 = torch.empty(ft.shape, dtype=dt, device=ft.device)
+        ops.l2norm_rows(fi, y16=fi16)
+        ops.l2norm_rows(ft, y16=ft16)
+        lg = torch.empty((fi.shape[0], (ft.shape[0] + 3) // 4 * 4), dtype=torch.float32, device=fi.device)
+        ops.gemm_nt(fi16, ft16, lg, n=ft.shape[0])
+        lg = lg[:, : ft.shape[0]] * self.logit_scale.exp()
+        return lg, lg.t()
+
+
+def infer_config(state_dict: dict) -> dict:
+    """Architecture from tensor shapes, the rule of the reference's ``build_model`` (clip/model.py:395-418)."""
+    vit = "visual.proj" in state_dict
+    if vit:
+        vw = state_dict["visual.conv1.weight"].shape[0]
+        vl = len([k for k in state_dict if k.startswith("visual.") and k.endswith(".attn.in_proj_weight")])
+        ps = state_dict["visual.conv1.weight"].shape[-1]
+        res = ps * round((state_dict["visual.positional_embedding"].shape[0] - 1) ** 0.5)
+    else:
+        vl = tuple(len({k.split(".")[2] for k in state_dict if k.startswith(f"visual.layer{b}")}) for b in (1, 2, 3, 4))
+        vw = state_dict["visual.layer1.0.conv1.weight"].shape[0]
+        ow = round((state_dict["visual.attnpool.positional_embedding"].shape[0] - 1) ** 0.5)
+        assert ow ** 2 + 1 == state_dict["visual.attnpool.positional_embedding"].shape[0]
+        ps, res = None, ow * 32
+    wt = state_dict["ln_final.weight"].shape[0]
+    return dict(embed_dim=state_dict["text_projection"].shape[1], image_resolution=res, vision_layers=vl,
+                vision_width=vw, vision_patch_size=ps, context_length=state_dict["positional_embedding"].shape[0],
+                vocab_size=state_dict["token_embedding.weight"].shape[0], transformer_width=wt, transformer_heads=wt // 64,
+                transformer_layers=len({k.split(".")[2] for k in state_dict if k.startswith("transformer.resblocks")}))
+
+
+def build_model(state_dict: dict, image_dtype: str = "bf16", text_dtype: str = "f16") -> CLIP:
+    """Construct from a reference-format state_dict (clip/model.py:395-432).  Master parameters stay
+    fp32 (the reference casts them to fp16 here; the 16-bit copies the kernels read are made lazily)."""
+    sd = {k: v for k, v in state_dict.items() if k not in ("input_resolution", "context_length", "vocab_size")}
+    model = CLIP(**infer_config(sd), image_dtype=image_dtype, text_dtype=text_dtype)
+    model.load_state_dict({k: (v.float() if v.is_floating_point() else v) for k, v in sd.items()})
+    return model.eval()

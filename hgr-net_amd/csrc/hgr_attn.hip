@@ -1,0 +1,156 @@
+// hgr_mha: softmax(q k^T / sqrt(d) [+ causal mask]) v for short sequences, d_head = 64.
+//
+// Sequences on this path are 50 (ViT-B/32, RN50 attnpool), <= 77 (text, usually trimmed to <= 16)
+// or 257 (ViT-L/14) tokens, so one workgroup holds all keys/values of one (batch, head) in LDS and
+// the whole score row of a query lives in registers: no online softmax, no rescaling.
+//
+// One 256-thread workgroup per (batch, head); wave w takes query tiles w, w+4, ... of 16 queries.
+//   S^T = K . Q^T   (v_mfma 16x16x32, K rows as the A operand from LDS, Q rows as the B operand
+//                    straight from global memory): lane (q = lane&15, g = lane>>4) then holds
+//                    S[q][key = 16t + 4g + e] in acc[t][e] - the query is on the lane, so the
+//                    softmax reduction is in-register plus two shuffles (xor 16, 32);
+//   O^T = V^T . P^T : the exponentiated accumulators ARE the B operand of the second product after
+//                    a 16-bit convert (accumulator-as-operand, cdna_hip_programming.md section 3):
+//                    k-slot j of lane-group g in 32-key step s is key 32s + 16(j>>2) + 4g + (j&3),
+//                    so the A operand reads V^T with the same key permutation (two 8-byte LDS reads
+//                    of a transposed V image).  No LDS round trip for P.
+// Output lane layout: 4 consecutive head dims of one query -> 8-byte stores.
+// HBM-bound in practice (reads 3W, writes W 16-bit values per token), the MFMA work is ~1 % of a layer.
+#include "hgr_common.h"
+
+namespace {
+
+template <int DT, int KT, bool CAUSAL>
+__global__ __launch_bounds__(256) void mha_fwd(const typename T16<DT>::elem *__restrict__ qkv,
+                                               typename T16<DT>::elem *__restrict__ out, int L, int H) {
+    typedef typename T16<DT>::elem E;
+    typedef typename T16<DT>::vec8 vec8;
+    typedef typename T16<DT>::vec4 vec4;
+    constexpr int LP = KT * 32;        // keys padded to the MFMA k-step
+    constexpr int VS = LP + 4;         // V^T row stride in elements (8-byte aligned rows, spreads banks)
+    __shared__ __attribute__((aligned(16))) char sK[LP * 128];
+    __shared__ __attribute__((aligned(16))) E sVt[64 * VS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    const int W = H * 64;
+    const int64_t ld = 3 * (int64_t)W;
+    const E *base = qkv + (int64_t)b * L * ld + h * 64;
+
+    // stage K (swizzled rows) and V^T (zero-filled past L: 0 * garbage must stay 0)
+    for (int idx = tid; idx < LP * 8; idx += 256) {
+        const int row = idx >> 3, c = idx & 7;
+        vec8 kv, vv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { kv[e] = (E)0.f; vv[e] = (E)0.f; }
+        if (row < L) {
+            kv = *(const vec8 *)(base + row * ld + W + c * 8);
+            vv = *(const vec8 *)(base + row * ld + 2 * W + c * 8);
+        }
+        *(vec8 *)(sK + row * 128 + ((c ^ (row & 7)) * 16)) = kv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sVt[(c * 8 + e) * VS + row] = vv[e];
+    }
+    __syncthreads();
+
+    const int sw0 = ((0 + g) ^ (r & 7)) * 16, sw1 = ((4 + g) ^ (r & 7)) * 16;
+    for (int qt = wave; qt * 16 < L; qt += 4) {
+        const int q = qt * 16 + r;
+        const int qrow = min(q, L - 1);
+        const vec8 q0 = *(const vec8 *)(base + qrow * ld + g * 8);
+        const vec8 q1 = *(const vec8 *)(base + qrow * ld + 32 + g * 8);
+
+        f32x4 acc[2 * KT];
+#pragma unroll
+        for (int t = 0; t < 2 * KT; ++t) {
+            acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const char *kr = sK + (t * 16 + r) * 128;
+            acc[t] = T16<DT>::mfma16(*(const vec8 *)(kr + sw0), q0, acc[t]);
+            acc[t] = T16<DT>::mfma16(*(const vec8 *)(kr + sw1), q1, acc[t]);
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2 * KT; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int key = t * 16 + g * 4 + e;
+                float s = acc[t][e] * 0.125f;     // 64^-0.5, exact
+                if (key >= L || (CAUSAL && key > q)) s = -INFINITY;
+                acc[t][e] = s;
+                mx = fmaxf(mx, s);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2 * KT; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float pexp = __expf(acc[t][e] - mx);
+                acc[t][e] = pexp;
+                sum += pexp;
+            }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+
+        f32x4 o[4];
+#pragma unroll
+        for (int td = 0; td < 4; ++td) o[td] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KT; ++s) {
+            vec8 pf;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { pf[e] = (E)acc[2 * s][e]; pf[4 + e] = (E)acc[2 * s + 1][e]; }
+#pragma unroll
+            for (int td = 0; td < 4; ++td) {
+                const E *vr = sVt + (td * 16 + r) * VS + s * 32 + g * 4;
+                const vec4 lo = *(const vec4 *)vr;
+                const vec4 hi = *(const vec4 *)(vr + 16);
+                vec8 vf;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = hi[e]; }
+                o[td] = T16<DT>::mfma16(vf, pf, o[td]);
+            }
+        }
+        if (q < L) {
+            E *orow = out + ((int64_t)b * L + q) * W + h * 64 + g * 4;
+#pragma unroll
+            for (int td = 0; td < 4; ++td)
+                *(vec4 *)(orow + td * 16) = cvt4<DT>(o[td][0] * inv, o[td][1] * inv, o[td][2] * inv, o[td][3] * inv);
+        }
+    }
+}
+
+template <int DT, int KT>
+void launch_kt(const void *qkv, void *out, int B, int L, int H, bool causal, hipStream_t s) {
+    typedef typename T16<DT>::elem E;
+    dim3 grid(B * H), block(256);
+    if (causal) hipLaunchKernelGGL((mha_fwd<DT, KT, true>), grid, block, 0, s, (const E *)qkv, (E *)out, L, H);
+    else hipLaunchKernelGGL((mha_fwd<DT, KT, false>), grid, block, 0, s, (const E *)qkv, (E *)out, L, H);
+}
+
+template <int DT>
+void launch_dt(const void *qkv, void *out, int B, int L, int H, bool causal, hipStream_t s) {
+    const int kt = (L + 31) / 32;
+    if (kt <= 1) launch_kt<DT, 1>(qkv, out, B, L, H, causal, s);
+    else if (kt <= 2) launch_kt<DT, 2>(qkv, out, B, L, H, causal, s);
+    else if (kt <= 3) launch_kt<DT, 3>(qkv, out, B, L, H, causal, s);
+    else if (kt <= 5) launch_kt<DT, 5>(qkv, out, B, L, H, causal, s);
+    else launch_kt<DT, 9>(qkv, out, B, L, H, causal, s);
+}
+
+}  // namespace
+
+extern "C" int hgr_mha(const void *qkv, void *out, int B, int L, int heads, int causal, int dtype, void *stream) {
+    HGR_REQUIRE(qkv && out, "hgr_mha: null operand");
+    HGR_REQUIRE(B >= 1 && heads >= 1 && L >= 1 && L <= 288, "hgr_mha: B=%d heads=%d L=%d unsupported (1 <= L <= 288)", B, heads, L);
+    HGR_REQUIRE((int64_t)B * heads < (1ll << 31), "hgr_mha: grid too large");
+    HGR_REQUIRE(hgr_aligned(qkv, 16) && hgr_aligned(out, 16), "hgr_mha: operands must be 16-byte aligned");
+    HGR_REQUIRE(dtype == HGR_BF16 || dtype == HGR_F16, "hgr_mha: bad dtype %d", dtype);
+    if (dtype == HGR_BF16) launch_dt<HGR_BF16>(qkv, out, B, L, heads, causal != 0, (hipStream_t)stream);
+    else launch_dt<HGR_F16>(qkv, out, B, L, heads, causal != 0, (hipStream_t)stream);
+    HGR_CHECK_LAUNCH("hgr_mha");
+    return HGR_OK;
+}

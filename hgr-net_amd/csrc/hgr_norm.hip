@@ -1,0 +1,179 @@
+// Row-wise fp32 normalisation kernels: LayerNorm (clip/model.py:153-159), ViT token assembly +
+// ln_pre (clip/model.py:223-225), row L2 normalisation (model/clip_tree.py:323,330).
+//
+// All three are HBM-bound streaming ops: one wave owns one row, the row lives in registers
+// (float4 per lane, up to 16 per lane = 4096 columns), loads and stores are 16-byte (8-byte for the
+// 16-bit outputs) and coalesced, statistics are two-pass (mean, then centred second moment) like
+// torch's LayerNorm, reduced with wave shuffles.  4 rows per 256-thread block.
+#include "hgr_common.h"
+
+namespace {
+
+constexpr int MAXV = 16;   // float4 per lane -> W <= 4096
+
+template <int DT, bool OUT32>
+__global__ __launch_bounds__(256) void layernorm_rows(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                      const float *__restrict__ beta, void *__restrict__ y,
+                                                      int rows, int W, int64_t row_mul, const int32_t *__restrict__ row_idx, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int64_t src = (int64_t)row * row_mul + (row_idx ? row_idx[row] : 0);
+    const f32x4 *xr = (const f32x4 *)(x + src * W);
+    const int nv = W >> 2;
+    f32x4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = i * 64 + lane;
+        if (i * 64 < nv) {
+            v[i] = (c < nv) ? xr[c] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        }
+    }
+    const float mean = wave_sum(s) / (float)W;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = i * 64 + lane;
+        if (i * 64 < nv && c < nv) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)W + eps);
+    const f32x4 *gv = (const f32x4 *)gamma, *bv = (const f32x4 *)beta;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = i * 64 + lane;
+        if (i * 64 < nv && c < nv) {
+            const f32x4 ga = gv[c], be = bv[c];
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * ga[e] + be[e];
+            if (OUT32) ((f32x4 *)((float *)y + (int64_t)row * W))[c] = o;
+            else ((typename T16<DT>::vec4 *)((typename T16<DT>::elem *)y + (int64_t)row * W))[c] = cvt4<DT>(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
+// x[b*L + t] = LN((t == 0 ? cls : patches[b*G + t-1]) + pos[t])
+__global__ __launch_bounds__(256) void vit_embed_ln(const float *__restrict__ patches, const float *__restrict__ cls,
+                                                    const float *__restrict__ pos, const float *__restrict__ gamma,
+                                                    const float *__restrict__ beta, float *__restrict__ x,
+                                                    int B, int G, int W, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int L = G + 1;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B * L) return;
+    const int b = row / L, t = row - b * L;
+    const f32x4 *src = (const f32x4 *)(t == 0 ? cls : patches + ((int64_t)b * G + (t - 1)) * W);
+    const f32x4 *pr = (const f32x4 *)(pos + (int64_t)t * W);
+    const int nv = W >> 2;
+    f32x4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = i * 64 + lane;
+        if (i * 64 < nv) {
+            v[i] = (c < nv) ? (src[c] + pr[c]) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        }
+    }
+    const float mean = wave_sum(s) / (float)W;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = i * 64 + lane;
+        if (i * 64 < nv && c < nv) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)W + eps);
+    const f32x4 *gv = (const f32x4 *)gamma, *bv = (const f32x4 *)beta;
+    f32x4 *out = (f32x4 *)(x + (int64_t)row * W);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = i * 64 + lane;
+        if (i * 64 < nv && c < nv) {
+            const f32x4 ga = gv[c], be = bv[c];
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * ga[e] + be[e];
+            out[c] = o;
+        }
+    }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void l2norm_rows(const float *__restrict__ x, void *__restrict__ y16, float *__restrict__ y32, int rows, int D) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const f32x4 *xr = (const f32x4 *)(x + (int64_t)row * D);
+    const int nv = D >> 2;
+    f32x4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = i * 64 + lane;
+        if (i * 64 < nv) {
+            v[i] = (c < nv) ? xr[c] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            s += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+        }
+    }
+    const float inv = 1.0f / sqrtf(wave_sum(s));
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = i * 64 + lane;
+        if (i * 64 < nv && c < nv) {
+            const f32x4 o = v[i] * inv;
+            if (y32) ((f32x4 *)(y32 + (int64_t)row * D))[c] = o;
+            if (y16) ((typename T16<DT>::vec4 *)((typename T16<DT>::elem *)y16 + (int64_t)row * D))[c] = cvt4<DT>(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int hgr_layernorm(const float *x, const float *gamma, const float *beta, void *y, int rows, int W,
+                             int64_t row_mul, const int32_t *row_idx, float eps, int dtype, int out_f32, void *stream) {
+    HGR_REQUIRE(x && gamma && beta && y, "hgr_layernorm: null operand");
+    HGR_REQUIRE(rows >= 1 && W >= 4 && W % 4 == 0 && W <= 4 * 64 * MAXV, "hgr_layernorm: rows=%d W=%d unsupported (W %% 4 == 0, W <= %d)", rows, W, 4 * 64 * MAXV);
+    HGR_REQUIRE(hgr_aligned(x, 16) && hgr_aligned(gamma, 16) && hgr_aligned(beta, 16) && hgr_aligned(y, 16), "hgr_layernorm: operands must be 16-byte aligned");
+    HGR_REQUIRE(dtype == HGR_BF16 || dtype == HGR_F16, "hgr_layernorm: bad dtype %d", dtype);
+    HGR_REQUIRE(row_mul >= 1, "hgr_layernorm: row_mul must be >= 1");
+    dim3 grid((rows + 3) / 4), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (out_f32) hipLaunchKernelGGL((layernorm_rows<HGR_BF16, true>), grid, block, 0, s, x, gamma, beta, y, rows, W, row_mul, row_idx, eps);
+    else if (dtype == HGR_BF16) hipLaunchKernelGGL((layernorm_rows<HGR_BF16, false>), grid, block, 0, s, x, gamma, beta, y, rows, W, row_mul, row_idx, eps);
+    else hipLaunchKernelGGL((layernorm_rows<HGR_F16, false>), grid, block, 0, s, x, gamma, beta, y, rows, W, row_mul, row_idx, eps);
+    HGR_CHECK_LAUNCH("hgr_layernorm");
+    return HGR_OK;
+}
+
+extern "C" int hgr_vit_embed_ln(const float *patches, const float *class_embedding, const float *positional_embedding,
+                                const float *gamma, const float *beta, float *x, int B, int G, int W, float eps, void *stream) {
+    HGR_REQUIRE(patches && class_embedding && positional_embedding && gamma && beta && x, "hgr_vit_embed_ln: null operand");
+    HGR_REQUIRE(B >= 1 && G >= 1 && W >= 4 && W % 4 == 0 && W <= 4 * 64 * MAXV, "hgr_vit_embed_ln: B=%d G=%d W=%d unsupported", B, G, W);
+    HGR_REQUIRE(hgr_aligned(patches, 16) && hgr_aligned(class_embedding, 16) && hgr_aligned(positional_embedding, 16) &&
+                hgr_aligned(gamma, 16) && hgr_aligned(beta, 16) && hgr_aligned(x, 16), "hgr_vit_embed_ln: operands must be 16-byte aligned");
+    const int rows = B * (G + 1);
+    hipLaunchKernelGGL(vit_embed_ln, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, patches, class_embedding,
+                       positional_embedding, gamma, beta, x, B, G, W, eps);
+    HGR_CHECK_LAUNCH("hgr_vit_embed_ln");
+    return HGR_OK;
+}
+
+extern "C" int hgr_l2norm_rows(const float *x, void *y16, float *y32, int rows, int D, int dtype, void *stream) {
+    HGR_REQUIRE(x && (y16 || y32), "hgr_l2norm_rows: null operand");
+    HGR_REQUIRE(rows >= 1 && D >= 4 && D % 4 == 0 && D <= 4 * 64 * MAXV, "hgr_l2norm_rows: rows=%d D=%d unsupported", rows, D);
+    HGR_REQUIRE(hgr_aligned(x, 16) && hgr_aligned(y16, 8) && hgr_aligned(y32, 16), "hgr_l2norm_rows: misaligned operand");
+    HGR_REQUIRE(dtype == HGR_BF16 || dtype == HGR_F16, "hgr_l2norm_rows: bad dtype %d", dtype);
+    dim3 grid((rows + 3) / 4), block(256);
+    if (dtype == HGR_BF16) hipLaunchKernelGGL((l2norm_rows<HGR_BF16>), grid, block, 0, (hipStream_t)stream, x, y16, y32, rows, D);
+    else hipLaunchKernelGGL((l2norm_rows<HGR_F16>), grid, block, 0, (hipStream_t)stream, x, y16, y32, rows, D);
+    HGR_CHECK_LAUNCH("hgr_l2norm_rows");
+    return HGR_OK;
+}

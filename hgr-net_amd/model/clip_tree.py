@@ -1,0 +1,211 @@
+"""``tree_model`` - the object main.py drives (reference model/clip_tree.py:19-333), on libhgr.so.
+
+Same constructor, attributes and methods as the reference class, so the
+reference's train/eval scripts can construct and call it unchanged:
+
+    tree_model(opts, candidates_train, candidates_test)
+    .update_classifier()  .__call__(imgs, targets) -> logits [B, N]  .save(opts, epoch)
+    .nodes .c2p .p2c .d2n .start_up .train_index .test_index .resolution .save_path .layer_weight
+
+Differences, all on purpose:
+  * logits are fp32 (the reference returns fp16 on GPU), computed by the MFMA GEMM of hgr_gemm_nt;
+  * prompts: if ``nltk``'s WordNet is importable the names come from it exactly like the reference
+    (clip_tree.py:52-60); otherwise pass ``node_tokens`` (int64 [N, 77]) - there is no WordNet offline;
+  * extra device arrays for the fused evaluation (depth per node, int32 index copies).
+"""
+from __future__ import annotations
+
+import copy
+import math
+import os
+import random
+from typing import Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from .. import clip, ops
+from ..hierarchy import build_hierarchy
+from .._lib import HgrError
+
+TEMPLATE = "a photo of a {}."     # data/templates.py TEMPLATES_SIMPLE[0], the only one used (clip_tree.py:52)
+
+
+class tree_model(nn.Module):
+    def __init__(self, opts, candidates_train: Sequence[str], candidates_test: Sequence[str],
+                 node_tokens: Optional[torch.Tensor] = None, clip_model: Optional[nn.Module] = None):
+        super().__init__()
+        self.opts = opts
+        self.device = f"cuda:{opts.device}" if isinstance(opts.device, int) else opts.device
+        self.save_path = "{}/{}/{}_{}_{}/".format(opts.folder, opts.exp_name, opts.weights, opts.out_ratio, opts.in_ratio)
+        self.file_path = self.save_path + "clip_{}".format(opts.from_epoch)
+        os.makedirs(self.save_path, exist_ok=True)
+
+        # semantic structure (utils.py:39-72)
+        import json
+        with open(opts.graph_path, "r") as f:
+            self.hierarchy = build_hierarchy(json.load(f))
+        self.p2c, self.c2p, self.d2n, self.nodes, self.start_up = self.hierarchy.as_tuple()
+        self.nodes_id = list(range(len(self.nodes)))
+
+        # CLIP (clip_tree.py:34-48)
+        if clip_model is None:
+            clip_model, _ = clip.load(name=opts.arch, device=self.device, download_root="pretrained",
+                                      image_dtype=getattr(opts, "image_dtype", "bf16"),
+                                      text_dtype=getattr(opts, "text_dtype", "f16"))
+        self.clip_model = clip_model
+        if getattr(opts, "fetch", False):
+            self.clip_model.load_state_dict(torch.load(opts.fetch_path, map_location=self.device))
+        if getattr(opts, "load", False):
+            path = self.file_path if opts.load_path == "none" else opts.load_path
+            self.clip_model.load_state_dict(torch.load(path, map_location=self.device))
+            print("successfully loaded")
+        self.clip_model.eval()
+        for p in self.clip_model.parameters():
+            p.requires_grad_(True)
+        self.loss = nn.CrossEntropyLoss()
+
+        # prompts -> token ids (clip_tree.py:52-60)
+        if node_tokens is None:
+            node_tokens = clip.tokenize([TEMPLATE.format(self._wordnet_name(n)) for n in self.nodes])
+        if node_tokens.shape[0] != len(self.nodes):
+            raise ValueError(f"node_tokens has {node_tokens.shape[0]} rows for {len(self.nodes)} nodes")
+        self.node_tokens = node_tokens.long().to(self.device)
+
+        # misc (clip_tree.py:63-74)
+        self.resolution = self.clip_model.visual.input_resolution
+        self.candidates_train, self.candidates_test = candidates_train, candidates_test
+        index = {n: i for i, n in enumerate(self.nodes)}
+        self.train_index = torch.tensor([index[c] for c in candidates_train]).to(self.device)
+        self.test_index = torch.tensor([index[c] for c in candidates_test]).to(self.device)
+        self.max_depth = max(self.d2n.keys())
+        if opts.weights == "adaptive":
+            num_layer = [len(self.d2n[layer]) for layer in self.d2n.keys()]
+            # a real leaf parameter (the reference multiplies after wrapping, which makes it a
+            # non-parameter and breaks SGD([layer_weight]): SURVEY.md F11-ii)
+            self.layer_weight = nn.Parameter((1.0 / torch.tensor(num_layer, dtype=torch.float32)) * opts.scale)
+
+        # device arrays for the evaluation kernels
+        self.train_index32 = self.train_index.to(torch.int32)
+        self.test_index32 = self.test_index.to(torch.int32)
+        self.depth32 = torch.from_numpy(self.hierarchy.depth).to(self.device)
+        self.zsl_weights = None
+        self._zsl16 = None
+
+    @staticmethod
+    def _wordnet_name(wnid: str) -> str:
+        try:
+            from nltk.corpus import wordnet as wn
+        except Exception as e:  # noqa: BLE001
+            raise RuntimeError("WordNet (nltk) is not available: pass node_tokens= to tree_model") from e
+        return wn.synset_from_pos_and_offset("n", int(wnid[1:])).name().split(".")[0].replace("_", " ")
+
+    def save(self, opts, epoch):
+        torch.save(self.clip_model.state_dict(), self.save_path + "clip_{}".format(epoch))
+
+    # ---------------------------------------------------------------------------------------------
+    # zero-shot forward path
+    # ---------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def update_classifier(self, group=None):
+        """Text-encode every node prompt, L2-normalise rows -> ``zsl_weights`` [N, D] fp32
+        (clip_tree.py:318-325).  With a process ``group`` each rank encodes N/world rows and the rows
+        are all-gathered over RCCL (hgr_net_amd.parallel)."""
+        n = len(self.nodes)
+        if group is not None:
+            from ..parallel import sharded_text_features
+            feats = sharded_text_features(self.clip_model, self.node_tokens, group)
+        else:
+            feats = self.clip_model.encode_text(self.node_tokens)
+        z32 = torch.empty_like(feats)
+        z16 = torch.empty(feats.shape, dtype=self.clip_model.image_dtype, device=feats.device)
+        ops.l2norm_rows(feats, y16=z16, y32=z32)
+        self.zsl_weights, self._zsl16 = z32, z16
+        assert z32.shape[0] == n
+
+    @torch.no_grad()
+    def forward(self, inputs, targets=None):
+        """logits[B, N] = normalise(encode_image(x)) @ zsl_weights.T, no temperature; ``targets`` is
+        ignored as in the reference (clip_tree.py:328-333)."""
+        if self._zsl16 is None:
+            raise HgrError("call update_classifier() before forward()")
+        feats = self.clip_model.encode_image(inputs)
+        b, n = feats.shape[0], self._zsl16.shape[0]
+        f16 = torch.empty(feats.shape, dtype=self._zsl16.dtype, device=feats.device)
+        ops.l2norm_rows(feats, y16=f16)
+        ld = (n + 63) // 64 * 64                   # 16-byte aligned rows for the vector stores
+        logits = torch.empty((b, ld), dtype=torch.float32, device=feats.device)
+        ops.gemm_nt(f16, self._zsl16, logits, n=n)
+        return logits[:, :n]
+
+    # ---------------------------------------------------------------------------------------------
+    # host-side sampling / weighting logic of the training step (no tensors involved)
+    # ---------------------------------------------------------------------------------------------
+    def get_contra_ids(self, method, target, depth=None, parents=None):
+        """Negative-class candidates + position of the target (clip_tree.py:80-196: 'random', 'topk',
+        'brothers').  Returns (list of node ids with the target inside, index of the target)."""
+        nc = self.opts.num_compare
+        if method == "random":
+            ids = random.sample(self.train_index.tolist(), nc)
+        elif method == "topk":
+            low, high = min(self.d2n.keys()), max(self.d2n.keys())
+            if depth - self.opts.k > low:
+                low = depth - self.opts.k
+            cand = []
+            for d in range(low, depth):
+                cand.extend(self.d2n[d])
+            if depth == 0:
+                cand.extend(self.d2n[depth])
+            ids = list(set(cand) - set(parents))
+            if len(ids) > nc:
+                ids = random.sample(ids, nc)
+        elif method == "brothers":
+            if len(parents) > 1 and depth > 0:
+                ids = copy.copy(self.p2c[parents[depth - 1]])
+            else:
+                ids = copy.copy(self.start_up)
+            if len(ids) > nc:
+                ids = random.sample(ids, nc)
+        else:
+            raise NotImplementedError(f"sample_strategy {method!r}")
+        if target not in ids:
+            ids.append(target)
+        return ids, ids.index(target)
+
+    def get_weights(self, method, max_depth=None):
+        """Layer weights (clip_tree.py:198-219)."""
+        dev = self.device
+        if method == "equal":
+            return (torch.ones(max_depth) / max_depth).to(dev)
+        if method == "decreasing":
+            w = torch.arange(start=max_depth, end=0, step=-1).to(dev)
+        elif method == "increasing":
+            w = torch.arange(start=1, end=max_depth + 1).to(dev)
+        elif method == "nl_increasing":
+            w = (torch.arange(start=1, end=max_depth + 1) ** 3).to(dev)
+        elif method == "nl_decreasing":
+            w = (torch.arange(start=max_depth, end=0, step=-1) ** 3).to(dev)
+        elif method == "adaptive":
+            return torch.softmax(100 ** self.layer_weight[:max_depth], dim=0)
+        else:
+            raise ValueError(method)
+        return w / w.sum()
+
+    def outer_inner_plan(self, target: int):
+        """The (p_out, p_in, depth, parents_in, k_loop, m_loop, K, M) schedule of one OM step
+        (clip_tree.py:228-251)."""
+        parents = copy.copy(self.c2p[target]) + [target]
+        k = max(1, math.ceil(self.opts.out_ratio * len(parents)))
+        outer = parents[::-1][:k]
+        plan = []
+        for k_loop, p_out in enumerate(outer):
+            parents_in = copy.copy(self.c2p[p_out]) + [p_out]
+            m = max(1, math.ceil(self.opts.in_ratio * len(parents_in)))
+            inner = parents_in[::-1][:m]
+            for m_loop, p_in in enumerate(inner):
+                plan.append(dict(p_out=p_out, p_in=p_in, depth=parents_in.index(p_in), parents_in=parents_in,
+                                 k_loop=k_loop, m_loop=m_loop, K=len(outer), M=len(inner)))
+        return plan
+
+    def train_batch(self, inputs, targets, training_method, sample_strategy):
+        raise NotImplementedError("OM training step (backward kernels) is a later scope-table row; see DESIGN.md")

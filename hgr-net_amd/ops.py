@@ -1,0 +1,132 @@
+"""Tensor-level wrappers over the C ABI: take torch CUDA(HIP) tensors, pass raw device pointers,
+sizes and the current HIP stream to libhgr.so.  torch is plumbing here (device memory, streams);
+all arithmetic happens in the hand-written kernels."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import EPI_BIAS, EPI_BIAS_QUICKGELU, EPI_BIAS_RESIDUAL, EPI_NONE, HGR_BF16, HGR_F16
+
+# when a list, every gemm_nt call appends (name, start_event, end_event, algorithmic flops, algorithmic bytes);
+# events are recorded on the launch stream (torch's current stream).  Used by bench.py's roofline pass only.
+PROFILE = None
+
+TORCH16 = {HGR_BF16: torch.bfloat16, HGR_F16: torch.float16}
+DT_OF = {torch.bfloat16: HGR_BF16, torch.float16: HGR_F16}
+
+
+def dtype_code(name) -> int:
+    if name in (HGR_BF16, HGR_F16):
+        return name
+    return {"bf16": HGR_BF16, "bfloat16": HGR_BF16, "f16": HGR_F16, "fp16": HGR_F16, "float16": HGR_F16,
+            torch.bfloat16: HGR_BF16, torch.float16: HGR_F16}[name]
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: Optional[torch.Tensor]) -> int:
+    if t is None:
+        return 0
+    if not t.is_cuda:
+        raise _lib.HgrError("libhgr ops need device tensors (no CPU path)")
+    return t.data_ptr()
+
+
+def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias: Optional[torch.Tensor] = None,
+            residual: Optional[torch.Tensor] = None, epilogue: int = EPI_NONE, n: Optional[int] = None) -> torch.Tensor:
+    """out[M, :N] = epilogue(a[M,K] @ w[N,K]^T); `out` fp32 or the operands' 16-bit type (may be wider than N)."""
+    assert a.dim() == 2 and w.dim() == 2 and out.dim() == 2 and a.dtype == w.dtype and a.stride(1) == 1 and w.stride(1) == 1
+    m, k = a.shape
+    nn = w.shape[0] if n is None else n
+    assert w.shape[1] == k and out.shape[0] == m and out.shape[1] >= nn and out.stride(1) == 1
+    out32 = out.dtype == torch.float32
+    assert out32 or out.dtype == a.dtype
+    if residual is not None:
+        assert residual.dtype == torch.float32 and residual.stride(1) == 1
+    prof = PROFILE
+    if prof is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    _lib.call("hgr_gemm_nt", _dev(a), a.stride(0), _dev(w), w.stride(0), _dev(out), out.stride(0),
+              _dev(bias), _dev(residual), residual.stride(0) if residual is not None else 0,
+              m, nn, k, DT_OF[a.dtype], epilogue, 1 if out32 else 0, _stream())
+    if prof is not None:
+        ev1.record()
+        byts = 2 * m * k + 2 * nn * k + (4 if out32 else 2) * m * nn + (4 * m * nn if residual is not None else 0)
+        prof.append(("gemm_nt", ev0, ev1, 2.0 * m * nn * k, float(byts)))
+    return out
+
+
+def im2col_patches(image: torch.Tensor, out: torch.Tensor, patch: int) -> torch.Tensor:
+    b, c, r, r2 = image.shape
+    assert c == 3 and r == r2 and image.dtype == torch.float32 and image.is_contiguous() and out.is_contiguous()
+    _lib.call("hgr_im2col_patches", _dev(image), _dev(out), b, r, patch, out.shape[1], DT_OF[out.dtype], _stream())
+    return out
+
+
+def vit_embed_ln(patches, cls, pos, gamma, beta, x, b, g, eps=1e-5):
+    _lib.call("hgr_vit_embed_ln", _dev(patches), _dev(cls), _dev(pos), _dev(gamma), _dev(beta), _dev(x), b, g, x.shape[1], eps, _stream())
+    return x
+
+
+def layernorm(x: torch.Tensor, gamma, beta, out: torch.Tensor, rows: Optional[int] = None, row_mul: int = 1,
+              row_idx: Optional[torch.Tensor] = None, eps: float = 1e-5) -> torch.Tensor:
+    w = x.shape[-1]
+    rows = out.shape[0] if rows is None else rows
+    out32 = out.dtype == torch.float32
+    _lib.call("hgr_layernorm", _dev(x), _dev(gamma), _dev(beta), _dev(out), rows, w, row_mul, _dev(row_idx), eps,
+              HGR_BF16 if out32 else DT_OF[out.dtype], 1 if out32 else 0, _stream())
+    return out
+
+
+def mha(qkv: torch.Tensor, out: torch.Tensor, b: int, l: int, heads: int, causal: bool) -> torch.Tensor:
+    assert qkv.is_contiguous() and out.is_contiguous() and qkv.shape[1] == 3 * heads * 64 and out.shape[1] == heads * 64
+    _lib.call("hgr_mha", _dev(qkv), _dev(out), b, l, heads, 1 if causal else 0, DT_OF[qkv.dtype], _stream())
+    return out
+
+
+def text_embed(tokens: torch.Tensor, emb: torch.Tensor, pos: torch.Tensor, x: torch.Tensor, l: int) -> torch.Tensor:
+    assert tokens.dtype == torch.int64 and tokens.stride(1) == 1
+    n = tokens.shape[0]
+    _lib.call("hgr_text_embed", _dev(tokens), tokens.stride(0), _dev(emb), _dev(pos), _dev(x), n, l, emb.shape[1], emb.shape[0], _stream())
+    return x
+
+
+def eot_index(tokens: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    assert tokens.dtype == torch.int64 and out.dtype == torch.int32
+    _lib.call("hgr_eot_index", _dev(tokens), tokens.stride(0), _dev(out), tokens.shape[0], tokens.shape[1], _stream())
+    return out
+
+
+def l2norm_rows(x: torch.Tensor, y16: Optional[torch.Tensor] = None, y32: Optional[torch.Tensor] = None) -> None:
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    dt = DT_OF[y16.dtype] if y16 is not None else HGR_BF16
+    _lib.call("hgr_l2norm_rows", _dev(x), _dev(y16), _dev(y32), x.shape[0], x.shape[1], dt, _stream())
+
+
+def topk_rows(logits: torch.Tensor, k: int, cols: Optional[torch.Tensor] = None, n_cols: Optional[int] = None,
+              want_values: bool = False):
+    """int32 [rows, k] node ids of the k largest logits over `cols` (int32) or the first n_cols columns."""
+    assert logits.dtype == torch.float32 and logits.stride(1) == 1
+    rows = logits.shape[0]
+    nc = cols.numel() if cols is not None else (logits.shape[1] if n_cols is None else n_cols)
+    idx = torch.empty((rows, k), dtype=torch.int32, device=logits.device)
+    val = torch.empty((rows, k), dtype=torch.float32, device=logits.device) if want_values else None
+    _lib.call("hgr_topk_rows", _dev(logits), logits.stride(0), _dev(cols), nc, k, _dev(idx), _dev(val), rows, _stream())
+    return (idx, val) if want_values else idx
+
+
+def level_argmax(logits: torch.Tensor, depth: torch.Tensor, n_levels: int, cols: Optional[torch.Tensor] = None,
+                 n_cols: Optional[int] = None) -> torch.Tensor:
+    """int32 [rows, n_levels]: per depth level the arg-max node id over `cols` (main.py:162-176)."""
+    assert logits.dtype == torch.float32 and logits.stride(1) == 1 and depth.dtype == torch.int32
+    rows = logits.shape[0]
+    nc = cols.numel() if cols is not None else (logits.shape[1] if n_cols is None else n_cols)
+    out = torch.empty((rows, n_levels), dtype=torch.int32, device=logits.device)
+    _lib.call("hgr_level_argmax", _dev(logits), logits.stride(0), _dev(cols), nc, _dev(depth), n_levels, _dev(out), rows, _stream())
+    return out

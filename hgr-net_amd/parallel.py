@@ -1,0 +1,70 @@
+"""Data parallelism for the zero-shot path: one process per GPU, torch.distributed backend "nccl"
+(= RCCL over xGMI on ROCm).  The reference has no multi-GPU code at all; the path
+shards naturally because evaluation batches are independent single-class units (F6):
+
+* hot loop: rank r evaluates batches r, r + world, ...  - NO collective inside the loop;
+* one exchange step before it: the class-embedding matrix zsl_weights [N, D].  Each rank text-encodes
+  a contiguous N/world slice of the prompts and the slices are all-gathered (each rank contributes
+  N/world x D fp32 = 5.6 MB at N = 21 841, D = 512, world 8), which also divides the text-tower work
+  by `world`; a broadcast from rank 0 (what the north-star wording suggests) would move 8x the bytes
+  and leave 7 GPUs idle during the text pass;
+* one all-reduce(sum) of the 9 metric counters at the end (evaluate.Evaluator.counters).
+
+The same functions run on CPU tensors over the "gloo" backend, which is how the sharding logic is
+tested without GPUs (tests/test_parallel.py).
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous [lo, hi) of rank's rows; the first n % world ranks get one extra row."""
+    q, r = divmod(n, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def all_gather_rows(local: torch.Tensor, n: int, group=None) -> torch.Tensor:
+    """Concatenate per-rank row slices (sizes from shard_bounds) into the full [n, D] matrix on every rank."""
+    world = dist.get_world_size(group)
+    sizes = [shard_bounds(n, world, r)[1] - shard_bounds(n, world, r)[0] for r in range(world)]
+    tail = tuple(local.shape[1:])
+    full = torch.empty((n,) + tail, dtype=local.dtype, device=local.device)
+    if len(set(sizes)) == 1:
+        if local.is_cuda:
+            dist.all_gather_into_tensor(full, local.contiguous(), group=group)   # one in-place RCCL all-gather
+        else:
+            dist.all_gather(list(full.chunk(world)), local.contiguous(), group=group)
+        return full
+    # all_gather needs equal sizes: pad every slice to the largest, gather, trim
+    mx = max(sizes)
+    pad = torch.zeros((mx,) + tail, dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    buf = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(buf, pad, group=group)
+    lo = 0
+    for r in range(world):
+        full[lo: lo + sizes[r]] = buf[r][: sizes[r]]
+        lo += sizes[r]
+    return full
+
+
+def sharded_rows(encode: Callable[[torch.Tensor], torch.Tensor], rows: torch.Tensor, group=None) -> torch.Tensor:
+    """encode(rows[lo:hi]) on every rank, all-gathered to the full result."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    lo, hi = shard_bounds(rows.shape[0], world, rank)
+    return all_gather_rows(encode(rows[lo:hi]), rows.shape[0], group)
+
+
+def sharded_text_features(clip_model, node_tokens: torch.Tensor, group=None) -> torch.Tensor:
+    """Text features [N, D] with the prompt rows sharded over the ranks of `group`."""
+    return sharded_rows(clip_model.encode_text, node_tokens, group)
+
+
+def batches_of_rank(num_batches: int, world: int, rank: int) -> range:
+    """Indices of the evaluation batches rank `rank` owns (round-robin keeps class sizes balanced)."""
+    return range(rank, num_batches, world)

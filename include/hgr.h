@@ -1,0 +1,137 @@
+/*
+ * libhgr.so - C ABI of the MI355X (gfx950) kernels under the HGR-Net zero-shot forward path.
+ *
+ * The reference (WilliamYi96/HGR-Net) is 100 % Python on stock PyTorch and has no FFI of its own;
+ * its de-facto boundary is the Python call surface between main.py and the model object
+ * (SURVEY.md section 8b).  This header is the boundary *underneath* that surface: every entry point
+ * replaces one stock-PyTorch call site of the reference, cited per function as file:line relative to
+ * the reference checkout.  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every tensor argument is a raw DEVICE pointer, row-major;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); every call is asynchronous
+ *     and stream-ordered, never synchronises, allocates no device memory and keeps no global state;
+ *   - returns 0 on success, a negative HGR_E* code otherwise; hgr_last_error() returns the message of
+ *     the last failure on the calling thread.  Arguments are validated on the host before any launch
+ *     (shape / alignment assumptions of the kernel), so a bad call fails loudly instead of faulting;
+ *   - `dtype` selects the 16-bit MFMA input type of an op: HGR_BF16 or HGR_F16 (same MFMA rate on
+ *     gfx950).  Accumulation, LayerNorm, softmax and the residual stream are always fp32.
+ */
+#ifndef HGR_H
+#define HGR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HGR_ABI_VERSION 1
+
+enum { HGR_OK = 0, HGR_EINVAL = -1, HGR_EUNSUPPORTED = -2, HGR_ELAUNCH = -3 };
+
+typedef enum { HGR_BF16 = 0, HGR_F16 = 1 } hgr_dtype_t;
+
+/* epilogues of hgr_gemm_nt */
+typedef enum {
+    HGR_EPI_NONE = 0,           /* C = A W^T                                                            */
+    HGR_EPI_BIAS = 1,           /* C = A W^T + bias                  (nn.Linear; in_proj of MHA)        */
+    HGR_EPI_BIAS_QUICKGELU = 2, /* C = g(A W^T + bias), g(x) = x*sigmoid(1.702x)  (clip/model.py:162-164,177-180) */
+    HGR_EPI_BIAS_RESIDUAL = 3   /* C = residual + A W^T + bias       (x + attn(..), x + mlp(..): clip/model.py:186-187) */
+} hgr_epilogue_t;
+
+int hgr_abi_version(void);
+const char *hgr_last_error(void);
+
+/*
+ * C[M,N] = epilogue(A[M,K] . W[N,K]^T), fp32 accumulate on MFMA.
+ * Replaces F.linear / nn.Linear / `@` at clip/model.py:171,183 (in/out projection inside
+ * nn.MultiheadAttention), :177-180 (mlp.c_fc, mlp.c_proj), :207,220-222 (patch conv as GEMM over
+ * disjoint patches), :234 (x @ proj), :350 (@ text_projection) and the logits product
+ * `feats @ zsl_weights.T` at model/clip_tree.py:331.
+ *   A, W      16-bit (`dtype`), leading dimensions lda/ldw in elements, both K-contiguous ("NT")
+ *   C         fp32 if out_f32 else 16-bit (`dtype`), leading dimension ldc
+ *   bias      fp32 [N] or NULL;  residual fp32 [M, ldr] or NULL (may alias C when out_f32)
+ * Requirements: K % 64 == 0; lda, ldw % 8 == 0; A, W 16-byte aligned; M, N >= 1.
+ */
+int hgr_gemm_nt(const void *A, int64_t lda, const void *W, int64_t ldw, void *C, int64_t ldc,
+                const float *bias, const float *residual, int64_t ldr,
+                int M, int N, int K, int dtype, int epilogue, int out_f32, void *stream);
+
+/*
+ * Patch extraction for the ViT stem: image fp32 NCHW [B,3,R,R] -> rows [B*g*g, Kp] of 16-bit
+ * values, g = R/P, row (b, gy, gx) holds the patch in (c, py, px) order = conv1.weight.reshape(W,-1)
+ * order, zero-padded from 3*P*P to Kp (Kp % 64 == 0).  With hgr_gemm_nt this replaces
+ * `self.conv1(x)` + reshape + permute at clip/model.py:220-222 (kernel = stride = P, no bias).
+ */
+int hgr_im2col_patches(const float *image, void *out, int B, int R, int P, int Kp, int dtype, void *stream);
+
+/*
+ * ViT token assembly + ln_pre (clip/model.py:223-225): x[b,0] = class_embedding, x[b,1+i] = patch
+ * row i; + positional_embedding; LayerNorm(eps) -> fp32 residual stream x [B*L, W], L = G + 1.
+ *   patches fp32 [B*G, W] (output of the patch GEMM)
+ */
+int hgr_vit_embed_ln(const float *patches, const float *class_embedding, const float *positional_embedding,
+                     const float *gamma, const float *beta, float *x,
+                     int B, int G, int W, float eps, void *stream);
+
+/*
+ * Row LayerNorm in fp32 (clip/model.py:153-159), fp32 in, 16-bit (`dtype`) or fp32 out.
+ * Source row of output row r is  x + (r*row_mul + (row_idx ? row_idx[r] : 0)) * W  so the same call
+ * serves ln_1/ln_2 (row_mul 1), ln_post on token 0 (row_mul L; clip/model.py:231) and ln_final on the
+ * EOT rows (row_mul L, row_idx = EOT position; clip/model.py:346-350).  W % 4 == 0, W <= 4096.
+ */
+int hgr_layernorm(const float *x, const float *gamma, const float *beta, void *y,
+                  int rows, int W, int64_t row_mul, const int32_t *row_idx,
+                  float eps, int dtype, int out_f32, void *stream);
+
+/*
+ * Multi-head self-attention core, d_head = 64 (clip/model.py:259,268,417), replacing the
+ * softmax(q k^T / sqrt(d) + mask) v part of nn.MultiheadAttention (clip/model.py:171,183 and
+ * :324-330 for the causal mask).  qkv 16-bit [B*L, 3W] packed (q | k | v), token rows batch-major
+ * (row = b*L + t); out 16-bit [B*L, W].  causal != 0 masks key > query.  1 <= L <= 288.
+ */
+int hgr_mha(const void *qkv, void *out, int B, int L, int heads, int causal, int dtype, void *stream);
+
+/*
+ * Text embedding (clip/model.py:340-342): x[i*L + t] = token_embedding[tokens[i, t]] + positional[t],
+ * t < L <= ctx (L < ctx = EOT trimming, exact under the causal mask), fp32 out [n*L, W].
+ * tokens int64 [n, ld_tokens].  Token ids are range-checked on device (clamped, error flag not raised).
+ */
+int hgr_text_embed(const int64_t *tokens, int64_t ld_tokens, const float *token_embedding,
+                   const float *positional_embedding, float *x, int n, int L, int W, int vocab, void *stream);
+
+/* eot[i] = argmax_t tokens[i, t] (first maximum), the row picked at clip/model.py:350. int32 out. */
+int hgr_eot_index(const int64_t *tokens, int64_t ld_tokens, int32_t *eot, int n, int ctx, void *stream);
+
+/*
+ * Row L2 normalisation (model/clip_tree.py:323,330): y = x / ||x||_2 per row, x fp32 [rows, D].
+ * Writes y16 (16-bit `dtype`, may be NULL) and/or y32 (fp32, may be NULL, may alias x).
+ */
+int hgr_l2norm_rows(const float *x, void *y16, float *y32, int rows, int D, int dtype, void *stream);
+
+/*
+ * Top-k per row over a column subset, largest first, ties to the lowest subset position
+ * (`logits[:, index].topk(k)`: main.py:136-139 with k = 20, :157 with k = 1).
+ *   logits fp32 [rows, ld]; cols int32 [n_cols] or NULL (= columns 0..n_cols-1)
+ *   out_idx int32 [rows, k] = node ids (cols[pos]), out_val fp32 [rows, k] or NULL
+ * 1 <= k <= 32, n_cols <= 40000 (one row is staged in the 160 KB LDS).
+ */
+int hgr_topk_rows(const float *logits, int64_t ld, const int32_t *cols, int n_cols, int k,
+                  int32_t *out_idx, float *out_val, int rows, void *stream);
+
+/*
+ * Level-segmented arg-max (the hierarchy "segmented reduce", main.py:162-176): for every row and
+ * every depth level l < n_levels, the node id  cols[p*]  where p* is the first position maximising
+ * v_p = (depth[cols[p]] == l ? logits[row, cols[p]] : -1)  over the subset positions p, which is what
+ * `logits.index_fill(1, rest, -1)[:, train_index].topk(1)` computes.  One coalesced pass over the row.
+ *   depth int32 [n_nodes] (shortest-path depth, utils.py:55,66-70); out int32 [rows, n_levels]
+ * n_levels <= 32.
+ */
+int hgr_level_argmax(const float *logits, int64_t ld, const int32_t *cols, int n_cols,
+                     const int32_t *depth, int n_levels, int32_t *out, int rows, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HGR_H */

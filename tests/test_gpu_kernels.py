@@ -1,0 +1,192 @@
+"""GPU: every libhgr kernel, called through the C ABI, against the CPU oracle / exact references."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from hgr_net_amd import ops, synth
+from hgr_net_amd._lib import EPI_BIAS, EPI_BIAS_QUICKGELU, EPI_BIAS_RESIDUAL, EPI_NONE
+from oracle import clip_ref, tree_ref
+
+DEV = "cuda"
+DTS = [torch.bfloat16, torch.float16]
+
+
+def _rand(shape, seed, scale=1.0):
+    return torch.from_numpy((scale * synth.normal(seed, "t", int(np.prod(shape)))).astype(np.float32).reshape(shape))
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_gemm_identity_asymmetric_exact(dt):
+    """A = I against an asymmetric integer B: catches a transposed or permuted C write exactly."""
+    m = n = 256
+    k = 256
+    a = torch.eye(m, k, dtype=torch.float32)
+    w = (torch.arange(n).view(-1, 1) * 3 + torch.arange(k).view(1, -1) * 7) % 61 - 30.0   # w[n][k], asymmetric
+    out = torch.empty(m, n, dtype=torch.float32, device=DEV)
+    ops.gemm_nt(a.to(dt).to(DEV), w.to(dt).to(DEV), out)
+    assert torch.equal(out.cpu(), a @ w.t())
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("m,n,k", [(128, 128, 64), (1, 1, 64), (200, 300, 128), (130, 129, 192), (64, 2053, 512), (1000, 768, 3072)])
+def test_gemm_shapes_edges(dt, m, n, k):
+    a = _rand((m, k), 1).to(dt)
+    w = _rand((n, k), 2).to(dt)
+    ref = a.float() @ w.float().t()
+    ld = (n + 3) // 4 * 4
+    for ldc in sorted({n, ld, ld + 4}):                     # odd ldc exercises the scalar store path
+        out = torch.full((m, ldc), 7.0, dtype=torch.float32, device=DEV)
+        ops.gemm_nt(a.to(DEV), w.to(DEV), out, n=n)
+        got = out.cpu()
+        assert torch.allclose(got[:, :n], ref, rtol=1e-4, atol=2e-4 * k ** 0.5)
+        assert (got[:, n:] == 7.0).all()                    # never writes past N
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_gemm_epilogues(dt):
+    m, n, k = 300, 384, 256
+    a, w = _rand((m, k), 3).to(dt), _rand((n, k), 4, 0.1).to(dt)
+    bias, res = _rand((n,), 5), _rand((m, n), 6)
+    base = a.float() @ w.float().t() + bias
+    tol = dict(rtol=1e-2, atol=1e-2) if dt == torch.bfloat16 else dict(rtol=2e-3, atol=2e-3)
+    out16 = torch.empty(m, n, dtype=dt, device=DEV)
+    ops.gemm_nt(a.to(DEV), w.to(DEV), out16, bias=bias.to(DEV), epilogue=EPI_BIAS)
+    assert torch.allclose(out16.float().cpu(), base, **tol)
+    ops.gemm_nt(a.to(DEV), w.to(DEV), out16, bias=bias.to(DEV), epilogue=EPI_BIAS_QUICKGELU)
+    assert torch.allclose(out16.float().cpu(), clip_ref.quick_gelu(base), **tol)
+    x = res.clone().to(DEV)                                  # in-place residual accumulate (fp32 stream)
+    ops.gemm_nt(a.to(DEV), w.to(DEV), x, bias=bias.to(DEV), residual=x, epilogue=EPI_BIAS_RESIDUAL)
+    assert torch.allclose(x.cpu(), base + res, rtol=1e-4, atol=1e-3)
+
+
+def test_gemm_rejects_bad_shapes():
+    from hgr_net_amd._lib import HgrError
+    a = torch.zeros(8, 96, dtype=torch.bfloat16, device=DEV)
+    out = torch.zeros(8, 8, dtype=torch.float32, device=DEV)
+    with pytest.raises(HgrError):
+        ops.gemm_nt(a, a, out)                               # K % 64 != 0 fails loudly, no launch
+
+
+@pytest.mark.parametrize("w", [64, 512, 768, 1024])
+def test_layernorm_and_l2norm(w):
+    rows = 37
+    x = _rand((rows, w), 7, 3.0) + 0.5
+    g, b = 1 + 0.1 * _rand((w,), 8), 0.1 * _rand((w,), 9)
+    ref = torch.nn.functional.layer_norm(x, (w,), g, b, 1e-5)
+    y32 = torch.empty(rows, w, dtype=torch.float32, device=DEV)
+    ops.layernorm(x.to(DEV), g.to(DEV), b.to(DEV), y32)
+    assert torch.allclose(y32.cpu(), ref, rtol=1e-5, atol=1e-5)
+    for dt in DTS:
+        y = torch.empty(rows, w, dtype=dt, device=DEV)
+        ops.layernorm(x.to(DEV), g.to(DEV), b.to(DEV), y)
+        assert torch.equal(y.cpu(), y32.cpu().to(dt)) or torch.allclose(y.float().cpu(), ref, rtol=1e-2, atol=1e-2)
+    # strided / indexed rows (ln_post on token 0, ln_final on the EOT row)
+    L = 5
+    xs = _rand((rows * L, w), 10)
+    idx = torch.from_numpy(synth.randint(3, "idx", rows, 0, L).astype(np.int32))
+    y = torch.empty(rows, w, dtype=torch.float32, device=DEV)
+    ops.layernorm(xs.to(DEV), g.to(DEV), b.to(DEV), y, rows=rows, row_mul=L, row_idx=idx.to(DEV))
+    pick = xs.view(rows, L, w)[torch.arange(rows), idx.long()]
+    assert torch.allclose(y.cpu(), torch.nn.functional.layer_norm(pick, (w,), g, b, 1e-5), rtol=1e-5, atol=1e-5)
+    z32 = torch.empty(rows, w, dtype=torch.float32, device=DEV)
+    z16 = torch.empty(rows, w, dtype=torch.bfloat16, device=DEV)
+    ops.l2norm_rows(x.to(DEV), y16=z16, y32=z32)
+    assert torch.allclose(z32.cpu(), x / x.norm(dim=-1, keepdim=True), rtol=1e-6, atol=1e-7)
+    assert torch.equal(z16.cpu(), z32.cpu().to(torch.bfloat16))
+
+
+def test_vit_embed_ln():
+    b, g, w = 3, 49, 768
+    pe, cls, pos = _rand((b * g, w), 11), _rand((w,), 12), _rand((g + 1, w), 13)
+    ga, be = 1 + 0.1 * _rand((w,), 14), 0.1 * _rand((w,), 15)
+    x = torch.empty(b * (g + 1), w, dtype=torch.float32, device=DEV)
+    ops.vit_embed_ln(pe.to(DEV), cls.to(DEV), pos.to(DEV), ga.to(DEV), be.to(DEV), x, b, g)
+    t = torch.cat([cls.expand(b, 1, w), pe.view(b, g, w)], 1) + pos
+    ref = torch.nn.functional.layer_norm(t, (w,), ga, be, 1e-5).view(-1, w)
+    assert torch.allclose(x.cpu(), ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("L,causal", [(1, False), (7, True), (16, True), (33, True), (50, False), (77, True), (130, False), (257, False)])
+def test_mha_vs_oracle(dt, L, causal):
+    b, heads = 3, 2
+    w = heads * 64
+    qkv = _rand((b * L, 3 * w), 20 + L, 1.0).to(dt)
+    out = torch.empty(b * L, w, dtype=dt, device=DEV)
+    ops.mha(qkv.to(DEV), out, b, L, heads, causal)
+    q, k, v = qkv.float().view(b, L, 3 * w).split(w, dim=-1)
+    sh = lambda t: t.reshape(b, L, heads, 64).transpose(1, 2)
+    s = (sh(q) @ sh(k).transpose(-1, -2)) * 0.125
+    if causal:
+        s = s + torch.full((L, L), float("-inf")).triu_(1)
+    ref = (torch.softmax(s, -1) @ sh(v)).transpose(1, 2).reshape(b * L, w)
+    tol = 2e-2 if dt == torch.bfloat16 else 3e-3
+    assert (out.float().cpu() - ref).abs().max() < tol
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("r,p", [(64, 32), (224, 32), (224, 16), (28, 14)])
+def test_im2col_exact(dt, r, p):
+    b = 2
+    img = _rand((b, 3, r, r), 30)
+    k = 3 * p * p
+    kp = (k + 63) // 64 * 64
+    out = torch.full((b * (r // p) ** 2, kp), 9.0, dtype=dt, device=DEV)
+    ops.im2col_patches(img.to(DEV), out, p)
+    g = r // p
+    ref = img.reshape(b, 3, g, p, g, p).permute(0, 2, 4, 1, 3, 5).reshape(b * g * g, k).to(dt)
+    assert torch.equal(out[:, :k].cpu(), ref)
+    assert (out[:, k:] == 0).all()
+
+
+def test_text_embed_and_eot_exact():
+    n, ctx, w, vocab = 9, 77, 64, 512
+    tok = synth.make_tokens(n, 11, vocab)
+    emb, pos = _rand((vocab, w), 31), _rand((ctx, w), 32)
+    eot = torch.empty(n, dtype=torch.int32, device=DEV)
+    ops.eot_index(tok.to(DEV), eot)
+    assert torch.equal(eot.cpu().long(), tok.argmax(-1))
+    L = int(eot.max()) + 1
+    x = torch.empty(n * L, w, dtype=torch.float32, device=DEV)
+    ops.text_embed(tok.to(DEV), emb.to(DEV), pos.to(DEV), x, L)
+    assert torch.equal(x.cpu(), (emb[tok[:, :L]] + pos[:L]).view(-1, w))
+
+
+@pytest.mark.parametrize("n,k", [(40, 20), (999, 20), (21841, 20), (21841, 1)])
+def test_topk_rows_exact(n, k):
+    rows = 5
+    lg = _rand((rows, n), 40 + n, 0.05)
+    lg[0, 3] = lg[0, 17]                                     # an exact tie: lowest position first
+    ld = (n + 63) // 64 * 64
+    buf = torch.zeros(rows, ld, dtype=torch.float32, device=DEV)
+    buf[:, :n] = lg.to(DEV)
+    cols = torch.from_numpy(np.argsort(synth.uniform(1, "perm", n), kind="stable")[: max(k, n // 2)].astype(np.int32))
+    idx, val = ops.topk_rows(buf[:, :n], k, cols=cols.to(DEV), want_values=True)
+    for r in range(rows):
+        sub = lg[r, cols.long()].numpy()
+        want = cols.numpy()[tree_ref.topk_desc(sub, k)]
+        assert np.array_equal(idx[r].cpu().numpy(), want)
+        assert np.array_equal(val[r].cpu().numpy(), lg[r, torch.from_numpy(want).long()].numpy())
+    idx2 = ops.topk_rows(buf[:, :n], k, n_cols=n)            # no subset: all columns
+    for r in range(rows):
+        assert np.array_equal(idx2[r].cpu().numpy(), tree_ref.topk_desc(lg[r].numpy(), k))
+
+
+@pytest.mark.parametrize("n,levels", [(90, 8), (3000, 12), (21841, 12), (500, 20)])
+def test_level_argmax_exact(n, levels):
+    rows = 4
+    lg = _rand((rows, n), 50 + n, 0.05)
+    depth = synth.randint(2, "depth", n, 0, levels).astype(np.int32)
+    if levels >= 12:
+        depth[depth == 5] = 4                                # an empty level: every column carries the -1 filler
+    perm = np.argsort(synth.uniform(2, "perm", n), kind="stable").astype(np.int32)
+    for cols in (None, perm[: n - n // 3]):
+        tr = np.arange(n, dtype=np.int64) if cols is None else cols.astype(np.int64)
+        got = ops.level_argmax(lg.to(DEV), torch.from_numpy(depth).to(DEV), levels,
+                               cols=None if cols is None else torch.from_numpy(cols).to(DEV), n_cols=n).cpu().numpy()
+        for l in range(levels):
+            same = [int(i) for i in np.nonzero(depth == l)[0]]
+            want = tree_ref.level_argmax(lg.numpy(), tr, same, n)
+            assert np.array_equal(got[:, l], want), (l, cols is None)
