@@ -71,7 +71,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--nodes", type=int, default=N_NODES)
     ap.add_argument("--arch", default=ARCH)
-    ap.add_argument("--image-dtype", default="bf16")
+    ap.add_argument("--image-dtype", default="f16")
     ap.add_argument("--text-dtype", default="f16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()

@@ -45,7 +45,7 @@ def _transform(n_px: int):
 
 
 def load(name: str, device: Union[str, torch.device, int] = "cuda", jit: bool = False, download_root: str = None,
-         image_dtype: str = "bf16", text_dtype: str = "f16"):
+         image_dtype: str = "f16", text_dtype: str = "f16"):
     """Returns ``(model, preprocess)`` like the reference.  ``device`` may be an int CUDA ordinal
     (the reference passes ``opts.device`` raw, model/clip_tree.py:23,34)."""
     if os.path.isfile(name):

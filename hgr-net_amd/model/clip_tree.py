@@ -51,7 +51,7 @@ class tree_model(nn.Module):
         # CLIP (clip_tree.py:34-48)
         if clip_model is None:
             clip_model, _ = clip.load(name=opts.arch, device=self.device, download_root="pretrained",
-                                      image_dtype=getattr(opts, "image_dtype", "bf16"),
+                                      image_dtype=getattr(opts, "image_dtype", "f16"),
                                       text_dtype=getattr(opts, "text_dtype", "f16"))
         self.clip_model = clip_model
         if getattr(opts, "fetch", False):

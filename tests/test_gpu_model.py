@@ -77,14 +77,21 @@ def _opts(tmp_path, edges, **kw):
     return o
 
 
+# north_star tolerance: fp32 logits within 1e-3 of the reference PyTorch path.  The default f16 towers meet
+# it with margin; bf16 MFMA inputs (8 mantissa bits) land at ~1e-3 on these small, large-logit models and
+# are held to their own measured bound - which is why bf16 is not the default (DESIGN.md "Precision").
+LOGIT_TOL = {"f16": 1e-3, "bf16": 2.5e-3}
+
+
+@pytest.mark.parametrize("idt", ["f16", "bf16"])
 @pytest.mark.parametrize("case", ["tinyvit_n90", "smallvit_n300"])
-def test_tree_model_forward_and_metrics_vs_reference(case, golden_dir, tmp_path):
+def test_tree_model_forward_and_metrics_vs_reference(case, idt, golden_dir, tmp_path):
     meta, z, cfg, edges = _tree_case(case, golden_dir)
     sd = synth.clip_state_dict(cfg, 0)
     from hgr_net_amd.hierarchy import build_hierarchy
     h = build_hierarchy(edges)
     splits = synth.make_splits(h.nodes, [len(c) == 0 for c in h.p2c], meta["n_train"], meta["n_test"], meta["split_seed"])
-    clip_model = build_model(sd, image_dtype="bf16", text_dtype="f16").to(DEV)
+    clip_model = build_model(sd, image_dtype=idt, text_dtype="f16").to(DEV)
     model = tree_model(_opts(tmp_path, edges), splits["all"], splits["rest"],
                        node_tokens=torch.from_numpy(z["node_tokens"].astype(np.int64)), clip_model=clip_model)
     assert model.nodes == meta["nodes"] and model.c2p == meta["c2p"]
