@@ -6,6 +6,12 @@ import ctypes as C
 import os
 from pathlib import Path
 
+# torch must be imported BEFORE libhgr.so is dlopen'ed: the wheel bundles its own libamdhip64.so.7, and a
+# process that ends up with two HIP runtimes (torch's and /opt/rocm's, pulled in by libhgr's NEEDED entry)
+# loses the device in whichever initialises second ("no ROCm-capable device is detected").  With torch's copy
+# already loaded, libhgr's NEEDED libamdhip64.so.7 resolves to it by soname and both share one runtime.
+import torch  # noqa: F401
+
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("HGR_LIB", _HERE / "lib" / "libhgr.so"))
 

@@ -19,8 +19,12 @@
 // ONE XCD (blocks b and b+8 share an XCD's L2), and the fastest-varying tile index is chosen on the
 // host so that the larger operand is read from HBM once (see hgr_gemm_nt below).
 #include "hgr_common.h"
+#include <stdlib.h>
+#include <type_traits>
 
 namespace {
+
+int hgr_gemm_force_tile();
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;       // one operand, one stage: 16 KB
@@ -41,6 +45,33 @@ struct GemmArgs {
 
 __device__ __forceinline__ float quick_gelu(float v) { return v / (1.0f + __expf(-1.702f * v)); }
 
+
+// One lane's 4 consecutive outputs C[m][n .. n+3] of an accumulator tile: bias / QuickGELU / residual,
+// then a 16-byte (fp32) or 8-byte (16-bit) store; scalar tail only at the N edge or for odd strides.
+template <int DT, int EPI, bool OUT32>
+__device__ __forceinline__ void store_quad(const GemmArgs &p, f32x4 v, int m, int n) {
+    typedef typename T16<DT>::elem E;
+    if (n + 3 < p.N && p.vec_ok) {
+        if (EPI != HGR_EPI_NONE) v += *(const f32x4 *)(p.bias + n);
+        if (EPI == HGR_EPI_BIAS_QUICKGELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
+        }
+        if (EPI == HGR_EPI_BIAS_RESIDUAL) v += *(const f32x4 *)(p.res + (int64_t)m * p.ldr + n);
+        if (OUT32) *(f32x4 *)((float *)p.C + (int64_t)m * p.ldc + n) = v;
+        else *(typename T16<DT>::vec4 *)((E *)p.C + (int64_t)m * p.ldc + n) = cvt4<DT>(v[0], v[1], v[2], v[3]);
+        return;
+    }
+    for (int e = 0; e < 4 && n + e < p.N; ++e) {
+        float x = v[e];
+        if (EPI != HGR_EPI_NONE) x += p.bias[n + e];
+        if (EPI == HGR_EPI_BIAS_QUICKGELU) x = quick_gelu(x);
+        if (EPI == HGR_EPI_BIAS_RESIDUAL) x += p.res[(int64_t)m * p.ldr + n + e];
+        if (OUT32) ((float *)p.C)[(int64_t)m * p.ldc + n + e] = x;
+        else ((E *)p.C)[(int64_t)m * p.ldc + n + e] = (E)x;
+    }
+}
+
 template <int DT, int EPI, bool OUT32>
 __global__ __launch_bounds__(NT) void gemm_nt_128(GemmArgs p) {
     typedef typename T16<DT>::vec8 vec8;
@@ -57,9 +88,20 @@ __global__ __launch_bounds__(NT) void gemm_nt_128(GemmArgs p) {
     const int orig = blockIdx.x;
     const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
     const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    // Grouped raster inside the XCD's range: GROUP panels of the big operand stay L2-resident while
+    // the walk slides over the other operand's panels, so ~GROUP concurrently running tiles share every
+    // panel either way (64 tiles in flight per XCD = 8 x 8 panels of 128 x K: ~3 MB at K = 768 < 4 MB L2).
+    constexpr int GROUP = 8;
     int tm, tn;
-    if (p.m_fastest) { tn = wg / p.tiles_m; tm = wg - tn * p.tiles_m; }
-    else             { tm = wg / p.tiles_n; tn = wg - tm * p.tiles_n; }
+    if (p.m_fastest) {
+        const int per = GROUP * p.tiles_m, grp = wg / per, first = grp * GROUP;
+        const int gs = min(GROUP, p.tiles_n - first), loc = wg - grp * per;
+        tn = first + loc % gs; tm = loc / gs;
+    } else {
+        const int per = GROUP * p.tiles_n, grp = wg / per, first = grp * GROUP;
+        const int gs = min(GROUP, p.tiles_m - first), loc = wg - grp * per;
+        tm = first + loc % gs; tn = loc / gs;
+    }
     const int m0 = tm * BM, n0 = tn * BN;
 
     // per-lane source rows of the 4 + 4 LDS-DMA pieces this thread issues per stage
@@ -131,7 +173,6 @@ __global__ __launch_bounds__(NT) void gemm_nt_128(GemmArgs p) {
 
     // epilogue: lane holds, for tile (i, j), C[m][n .. n+3] with
     //   m = m0 + wm*64 + j*16 + r,   n = n0 + wn*64 + i*16 + g*4
-    typedef typename T16<DT>::elem E;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int m = m0 + wm * 64 + j * 16 + r;
@@ -139,56 +180,231 @@ __global__ __launch_bounds__(NT) void gemm_nt_128(GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int n = n0 + wn * 64 + i * 16 + g * 4;
-            if (n >= p.N) continue;
-            f32x4 v = acc[i][j];
-            const bool full = (n + 3 < p.N);
-            if (EPI != HGR_EPI_NONE) {
+            if (n < p.N) store_quad<DT, EPI, OUT32>(p, acc[i][j], m, n);
+        }
+    }
+}
+
+
+// =================================================================================================
+// 256 x 256 x 64 tile, 512 threads = 8 waves as 2 (M) x 4 (N); each wave owns 128 (M) x 64 (N) =
+// 8 x 4 MFMA tiles = 128 accumulator registers.  128 flop per staged byte (2x the 128^2 kernel), which
+// is what the short-K tower GEMMs (K = 768: only 12 K-tiles) need: they are bound by bytes in flight.
+//
+// A K-tile is computed in 4 phases of 16 MFMAs per wave (one quadrant of the wave's output each):
+//     ph1: Q(m-half 0, n-half 0)   reads W n-half 0 (4 x ds_read_b128) and A m-half 0 (8 x)
+//     ph2: Q(0, 1)                 reads W n-half 1 (4 x)
+//     ph3: Q(1, 1)                 reads A m-half 1 (8 x, same registers as m-half 0)
+//     ph4: Q(1, 0)                 reads nothing (W n-half 0 is still in registers)
+// The K-tile is staged as 4 LDS-DMA "pieces" of 16 KB cut BY PHASE, not by row range:
+//     A0 = the m-half-0 rows of both wave rows (A rows 0-63,128-191)   first read in ph1
+//     W0 = the n-half-0 rows of all four wave columns                  first read in ph1
+//     W1 = the n-half-1 rows                                           first read in ph2
+//     A1 = the m-half-1 rows (A rows 64-127,192-255)                   first read in ph3
+// so a piece's LDS slot is free one phase after its first read and can be refilled for K-tile t+2
+// immediately: every phase issues exactly one piece (2 x global_load_lds_dwordx4 per thread) about
+// 6 phases before it is read, and 5 pieces (80 KB per CU) stay in flight across every wait:
+//     (t,1) issues A1(t+1)   (t,2) A0(t+2)   (t,3) W0(t+2)   (t,4) W1(t+2)
+// Waits are counted: vmcnt(10) = "all but my 10 youngest DMA instructions landed" = the piece the
+// NEXT phase reads has landed; then one raw s_barrier (every wave's share landed / every wave's reads
+// of the slot about to be refilled are done).  The last two K-tiles use the exact smaller counts.
+// Two LDS buffers x 4 pieces = 128 KB, one workgroup per CU.  (cdna_hip_programming.md section 5:
+// "Pipelining across barriers", counted vmcnt + raw s_barrier, all LDS in one array.)
+// =================================================================================================
+constexpr int NT256 = 512;
+constexpr int PIECE = 16384;
+
+#define HGR_WAIT_BARRIER(N) asm volatile("s_waitcnt vmcnt(" #N ")\n\ts_barrier" ::: "memory")
+#define HGR_BARRIER() asm volatile("s_barrier" ::: "memory")
+
+template <int DT, int EPI, bool OUT32>
+__global__ __launch_bounds__(NT256) void gemm_nt_256(GemmArgs p) {
+    typedef typename T16<DT>::vec8 vec8;
+    __shared__ __attribute__((aligned(1024))) char smem[2 * 4 * PIECE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int r = lane & 15, g = lane >> 4;
+
+    const int nwg = gridDim.x;
+    const int orig = blockIdx.x;
+    const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    constexpr int GROUP = 4;      // 32 tiles in flight per XCD = 4 x 8 panels of 256 x K
+    int tm, tn;
+    if (p.m_fastest) {
+        const int per = GROUP * p.tiles_m, grp = wg / per, first = grp * GROUP;
+        const int gs = min(GROUP, p.tiles_n - first), loc = wg - grp * per;
+        tn = first + loc % gs; tm = loc / gs;
+    } else {
+        const int per = GROUP * p.tiles_n, grp = wg / per, first = grp * GROUP;
+        const int gs = min(GROUP, p.tiles_m - first), loc = wg - grp * per;
+        tm = first + loc % gs; tn = loc / gs;
+    }
+    const int m0 = tm * 256, n0 = tn * 256;
+
+    // piece kinds in issue order: 0 = A0, 1 = W0, 2 = W1, 3 = A1.  Each thread moves 2 x 16 B per piece.
+    const char *src[4][2];
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (full || n + e < p.N) v[e] += p.bias[n + e];
-            }
-            if (EPI == HGR_EPI_BIAS_QUICKGELU) {
+    for (int j = 0; j < 2; ++j) {
+        const int id = (j * 8 + wave) * 64 + lane;       // 16-B chunk id inside the 128-row piece
+        const int pr = id >> 3, c = (id & 7) ^ (pr & 7); // piece row, swizzled source chunk
+        const int ra0 = pr + (pr >= 64 ? 64 : 0);        // A row of piece row (m-half 0 of wave row pr/64)
+        const int rw0 = (pr >> 5) * 64 + (pr & 31);      // W row of piece row (n-half 0 of wave col pr/32)
+        src[0][j] = p.A + ((int64_t)min(m0 + ra0, p.M - 1) * p.lda + c * 8) * 2;
+        src[3][j] = p.A + ((int64_t)min(m0 + ra0 + 64, p.M - 1) * p.lda + c * 8) * 2;
+        src[1][j] = p.W + ((int64_t)min(n0 + rw0, p.N - 1) * p.ldw + c * 8) * 2;
+        src[2][j] = p.W + ((int64_t)min(n0 + rw0 + 32, p.N - 1) * p.ldw + c * 8) * 2;
+    }
+    auto issue = [&](int kind, int t) {
+        char *dst = smem + (t & 1) * (4 * PIECE) + kind * PIECE + wave * 1024;
+        const int64_t koff = (int64_t)t * 128;
+        __builtin_amdgcn_global_load_lds((const AS1 void *)(src[kind][0] + koff), (AS3 void *)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const AS1 void *)(src[kind][1] + koff), (AS3 void *)(dst + 8192), 16, 0, 0);
+    };
+
+    f32x4 acc[2][2][4][2];      // [m-half][n-half][m tile][n tile]
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
-            }
-            if (full && p.vec_ok) {
-                if (EPI == HGR_EPI_BIAS_RESIDUAL) {
-                    const f32x4 rr = *(const f32x4 *)(p.res + (int64_t)m * p.ldr + n);
-                    v += rr;
-                }
-                if (OUT32) {
-                    *(f32x4 *)((float *)p.C + (int64_t)m * p.ldc + n) = v;
-                } else {
-                    *(typename T16<DT>::vec4 *)((E *)p.C + (int64_t)m * p.ldc + n) = cvt4<DT>(v[0], v[1], v[2], v[3]);
-                }
-            } else {
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (n + e >= p.N) break;
-                    float x = v[e];
-                    if (EPI == HGR_EPI_BIAS_RESIDUAL) x += p.res[(int64_t)m * p.ldr + n + e];
-                    if (OUT32) ((float *)p.C)[(int64_t)m * p.ldc + n + e] = x;
-                    else ((E *)p.C)[(int64_t)m * p.ldc + n + e] = (E)x;
-                }
-            }
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[a][b][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / 64;    // >= 2 (host guarantees)
+    // prologue: K-tile 0 complete, K-tile 1 without A1 (sequence numbers 0..6)
+    issue(0, 0); issue(1, 0); issue(2, 0); issue(3, 0);
+    issue(0, 1); issue(1, 1); issue(2, 1);
+    HGR_WAIT_BARRIER(10);       // A0(0), W0(0) landed
+
+    const int offA = (wm * 64 + r) * 128;      // + m tile * 2048, within pieces A0 / A1
+    const int offW = (wn * 32 + r) * 128;      // + n tile * 2048, within pieces W0 / W1
+    const int sw0 = ((0 + g) ^ (r & 7)) * 16, sw1 = ((4 + g) ^ (r & 7)) * 16;
+
+    vec8 af[4][2], wf0[2][2], wf1[2][2];
+
+    // MODE 0: steady state, 1: second-last K-tile (nothing left to issue after ph1), 2: last K-tile
+    auto ktile = [&](int t, auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        const char *buf = smem + (t & 1) * (4 * PIECE);
+        // ---- ph1 ------------------------------------------------------------------------------
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            wf0[j][0] = *(const vec8 *)(buf + 1 * PIECE + offW + j * 2048 + sw0);
+            wf0[j][1] = *(const vec8 *)(buf + 1 * PIECE + offW + j * 2048 + sw1);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            af[i][0] = *(const vec8 *)(buf + 0 * PIECE + offA + i * 2048 + sw0);
+            af[i][1] = *(const vec8 *)(buf + 0 * PIECE + offA + i * 2048 + sw1);
+        }
+        if (MODE <= 1) issue(3, t + 1);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[0][0][i][j] = T16<DT>::mfma16(wf0[j][kk], af[i][kk], acc[0][0][i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        if (MODE <= 1) HGR_WAIT_BARRIER(10); else HGR_WAIT_BARRIER(2);     // W1(t) landed
+        // ---- ph2 ------------------------------------------------------------------------------
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            wf1[j][0] = *(const vec8 *)(buf + 2 * PIECE + offW + j * 2048 + sw0);
+            wf1[j][1] = *(const vec8 *)(buf + 2 * PIECE + offW + j * 2048 + sw1);
+        }
+        if (MODE == 0) issue(0, t + 2);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[0][1][i][j] = T16<DT>::mfma16(wf1[j][kk], af[i][kk], acc[0][1][i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        if (MODE == 0) HGR_WAIT_BARRIER(10); else if (MODE == 1) HGR_WAIT_BARRIER(8); else HGR_WAIT_BARRIER(0);   // A1(t) landed
+        // ---- ph3 ------------------------------------------------------------------------------
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            af[i][0] = *(const vec8 *)(buf + 3 * PIECE + offA + i * 2048 + sw0);
+            af[i][1] = *(const vec8 *)(buf + 3 * PIECE + offA + i * 2048 + sw1);
+        }
+        if (MODE == 0) issue(1, t + 2);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[1][1][i][j] = T16<DT>::mfma16(wf1[j][kk], af[i][kk], acc[1][1][i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        // no barrier: ph4 reads nothing, and the slot ph4 refills (W1) was last read in ph2
+        // ---- ph4 ------------------------------------------------------------------------------
+        if (MODE == 0) issue(2, t + 2);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[1][0][i][j] = T16<DT>::mfma16(wf0[j][kk], af[i][kk], acc[1][0][i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        if (MODE == 0) HGR_WAIT_BARRIER(10); else if (MODE == 1) HGR_WAIT_BARRIER(4);   // A0(t+1), W0(t+1) landed
+    };
+
+    for (int t = 0; t < nk - 2; ++t) ktile(t, std::integral_constant<int, 0>());
+    ktile(nk - 2, std::integral_constant<int, 1>());
+    ktile(nk - 1, std::integral_constant<int, 2>());
+
+    // epilogue: tile (a, b, i, j) of this lane holds C[m][n .. n+3],
+    //   m = m0 + wm*128 + a*64 + i*16 + r,   n = n0 + wn*64 + b*32 + j*16 + g*4
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 128 + a * 64 + i * 16 + r;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + b * 32 + j * 16 + g * 4;
+            if (n < p.N) store_quad<DT, EPI, OUT32>(p, acc[a][b][i][j], m, n);
         }
     }
 }
 
 template <int DT, int EPI>
-void launch_epi(const GemmArgs &a, bool out32, dim3 grid, hipStream_t s) {
-    if (out32) hipLaunchKernelGGL((gemm_nt_128<DT, EPI, true>), grid, dim3(NT), 0, s, a);
-    else hipLaunchKernelGGL((gemm_nt_128<DT, EPI, false>), grid, dim3(NT), 0, s, a);
+void launch_epi(const GemmArgs &a, bool out32, dim3 grid, hipStream_t s, bool big) {
+    if (big) {
+        if (out32) hipLaunchKernelGGL((gemm_nt_256<DT, EPI, true>), grid, dim3(NT256), 0, s, a);
+        else hipLaunchKernelGGL((gemm_nt_256<DT, EPI, false>), grid, dim3(NT256), 0, s, a);
+    } else {
+        if (out32) hipLaunchKernelGGL((gemm_nt_128<DT, EPI, true>), grid, dim3(NT), 0, s, a);
+        else hipLaunchKernelGGL((gemm_nt_128<DT, EPI, false>), grid, dim3(NT), 0, s, a);
+    }
 }
 
 template <int DT>
-void launch_dt(const GemmArgs &a, int epi, bool out32, dim3 grid, hipStream_t s) {
+void launch_dt(const GemmArgs &a, int epi, bool out32, dim3 grid, hipStream_t s, bool big) {
     switch (epi) {
-        case HGR_EPI_NONE: launch_epi<DT, HGR_EPI_NONE>(a, out32, grid, s); break;
-        case HGR_EPI_BIAS: launch_epi<DT, HGR_EPI_BIAS>(a, out32, grid, s); break;
-        case HGR_EPI_BIAS_QUICKGELU: launch_epi<DT, HGR_EPI_BIAS_QUICKGELU>(a, out32, grid, s); break;
-        default: launch_epi<DT, HGR_EPI_BIAS_RESIDUAL>(a, out32, grid, s); break;
+        case HGR_EPI_NONE: launch_epi<DT, HGR_EPI_NONE>(a, out32, grid, s, big); break;
+        case HGR_EPI_BIAS: launch_epi<DT, HGR_EPI_BIAS>(a, out32, grid, s, big); break;
+        case HGR_EPI_BIAS_QUICKGELU: launch_epi<DT, HGR_EPI_BIAS_QUICKGELU>(a, out32, grid, s, big); break;
+        default: launch_epi<DT, HGR_EPI_BIAS_RESIDUAL>(a, out32, grid, s, big); break;
     }
+}
+
+// HGR_GEMM_TILE=128|256 pins the tile (tests exercise both kernels on every shape); unset = heuristic
+int hgr_gemm_force_tile() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("HGR_GEMM_TILE"); v = e ? atoi(e) : 0; }
+    return v;
 }
 
 }  // namespace
@@ -212,18 +428,30 @@ extern "C" int hgr_gemm_nt(const void *A, int64_t lda, const void *W, int64_t ld
     a.A = (const char *)A; a.lda = lda; a.W = (const char *)W; a.ldw = ldw;
     a.C = C; a.ldc = ldc; a.bias = bias; a.res = residual; a.ldr = ldr;
     a.M = M; a.N = N; a.K = K;
-    a.tiles_m = (M + BM - 1) / BM;
-    a.tiles_n = (N + BN - 1) / BN;
+    // tile choice: the 256^2 deep-pipelined kernel when its workgroups fill the 256 CUs evenly, otherwise
+    // 128^2 tiles at 2 workgroups per CU (N = 768 outputs: 300 big tiles would run at 59 %; the logits GEMM
+    // with M = 512; small shapes)
+    const int force = hgr_gemm_force_tile();
+    const int64_t t256 = (int64_t)((M + 255) / 256) * ((N + 255) / 256);
+    // one 512-thread workgroup per CU: the launch runs in ceil(t256 / 256) rounds, the last one partly empty
+    const double eff256 = (double)t256 / (double)(((t256 + 255) / 256) * 256);
+    bool big = (K >= 128) && (eff256 >= 0.85);
+    if (force == 128) big = false;
+    if (force == 256 && K >= 128) big = true;
+    const int T = big ? 256 : 128;
+    a.tiles_m = (M + T - 1) / T;
+    a.tiles_n = (N + T - 1) / T;
     // each XCD owns a contiguous range of tile ids; the operand indexed by the slow tile index is
     // fetched ~once, the other one once per XCD.  Make the bigger operand the once-fetched one.
     a.m_fastest = ((int64_t)N * K > (int64_t)M * K) ? 1 : 0;
     bool vec = (ldc % 4 == 0) && hgr_aligned(C, out_f32 ? 16 : 8);
+    if (epilogue != HGR_EPI_NONE) vec = vec && hgr_aligned(bias, 16);
     if (epilogue == HGR_EPI_BIAS_RESIDUAL) vec = vec && (ldr % 4 == 0) && hgr_aligned(residual, 16);
     a.vec_ok = vec ? 1 : 0;
     dim3 grid((unsigned)(a.tiles_m * a.tiles_n));
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == HGR_BF16) launch_dt<HGR_BF16>(a, epilogue, out_f32 != 0, grid, s);
-    else launch_dt<HGR_F16>(a, epilogue, out_f32 != 0, grid, s);
+    if (dtype == HGR_BF16) launch_dt<HGR_BF16>(a, epilogue, out_f32 != 0, grid, s, big);
+    else launch_dt<HGR_F16>(a, epilogue, out_f32 != 0, grid, s, big);
     HGR_CHECK_LAUNCH("hgr_gemm_nt");
     return HGR_OK;
 }
