@@ -1,0 +1,162 @@
+"""CPU: the C-ABI library loads and exports every symbol include/hgr.h declares (no compute calls
+without a GPU), host logic of tree_model / parallel sharding, and a world-size-2 gloo run."""
+import json
+import os
+import re
+import subprocess
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_library_exports_every_declared_symbol():
+    from hgr_net_amd import _lib
+    lib = _lib.load()
+    header = (ROOT / "include" / "hgr.h").read_text()
+    declared = set(re.findall(r"\b(hgr_[a-z0-9_]+)\s*\(", header))
+    assert {"hgr_gemm_nt", "hgr_mha", "hgr_layernorm", "hgr_level_argmax", "hgr_topk_rows"} <= declared
+    for name in declared:
+        assert hasattr(lib, name), f"libhgr.so does not export {name}"
+    assert declared - {"hgr_abi_version", "hgr_last_error"} == set(_lib.SIGNATURES), "ctypes table out of sync with hgr.h"
+    assert lib.hgr_abi_version() == 1
+
+
+def test_product_path_has_no_cpu_fallback():
+    """CPU tensors must be refused loudly: the product never computes on the host."""
+    from hgr_net_amd import synth
+    from hgr_net_amd._lib import HgrError
+    from hgr_net_amd.clip.model import build_model
+    model = build_model(synth.clip_state_dict("tiny-vit", 0))
+    with pytest.raises(HgrError):
+        model.encode_image(synth.images(1, 64, 0))
+    with pytest.raises(HgrError):
+        model.encode_text(synth.make_tokens(2, 11, 512))
+    rn = build_model(synth.clip_state_dict("tiny-rn", 0))
+    with pytest.raises(NotImplementedError):
+        rn.encode_image(synth.images(1, 64, 0))
+
+
+def test_state_dict_schema_roundtrip():
+    from hgr_net_amd import synth
+    from hgr_net_amd.clip.model import build_model, infer_config
+    for name in ("tiny-vit", "tiny-rn", "small-vit"):
+        sd = synth.clip_state_dict(name, 0)
+        m = build_model(sd)
+        out = m.state_dict()
+        assert set(out) == set(sd)
+        assert all(torch.equal(out[k].float(), sd[k].float()) for k in sd)
+        assert infer_config(out) == {**synth.CLIP_CONFIGS[name]}
+
+
+def test_tree_model_host_logic(tmp_path):
+    """ctor attributes, OM schedule and negative sampling follow the reference's rules (clip_tree.py:116-141,228-251)."""
+    import random
+    from hgr_net_amd import synth
+    from hgr_net_amd.clip.model import build_model
+    from hgr_net_amd.hierarchy import build_hierarchy
+    from hgr_net_amd.model import tree_model
+    edges = synth.make_dag(120, depth=8, seed=3, multi_parent=0.05)
+    g = tmp_path / "g.json"
+    g.write_text(json.dumps(edges))
+    h = build_hierarchy(edges)
+    splits = synth.make_splits(h.nodes, [len(c) == 0 for c in h.p2c], 40, 50, 13)
+    o = types.SimpleNamespace(device="cpu", folder=str(tmp_path), exp_name="HGR", weights="adaptive", out_ratio=0.25, in_ratio=0.5,
+                              from_epoch=-1, graph_path=str(g), arch="x", fetch=False, load=False, load_path="none", scale=1.0,
+                              num_compare=16, k=1, sample_strategy="topk", weighting="both")
+    m = tree_model(o, splits["all"], splits["rest"], node_tokens=synth.make_tokens(120, 11, 512),
+                   clip_model=build_model(synth.clip_state_dict("tiny-vit", 0)))
+    assert m.train_index.dtype == torch.int64 and len(m.train_index) == 120 and len(m.test_index) == 50
+    assert m.max_depth == max(m.d2n) and m.resolution == 64
+    assert isinstance(m.layer_weight, torch.nn.Parameter) and m.layer_weight.is_leaf      # F11-ii fixed on purpose
+    assert os.path.isdir(m.save_path)
+    deep = max(range(120), key=lambda i: len(m.c2p[i]))
+    plan = m.outer_inner_plan(deep)
+    L = len(m.c2p[deep]) + 1
+    import math
+    assert plan[0]["K"] == max(1, math.ceil(0.25 * L)) and plan[0]["p_out"] == deep
+    for st in plan:
+        random.seed(0)
+        ids, pos = m.get_contra_ids("topk", st["p_out"], st["depth"], st["parents_in"])
+        assert ids[pos] == st["p_out"] and len(ids) <= 17 and len(set(ids)) == len(ids)
+        assert not (set(ids) - {st["p_out"]}) & set(st["parents_in"])
+        lo = max(min(m.d2n), st["depth"] - 1)
+        allowed = set(sum([m.d2n[d] for d in range(lo, st["depth"])], [])) | (set(m.d2n[0]) if st["depth"] == 0 else set())
+        assert set(ids) - {st["p_out"]} <= allowed
+    w = m.get_weights("increasing", 4)
+    assert torch.allclose(w, torch.tensor([0.1, 0.2, 0.3, 0.4]))
+    assert abs(float(m.get_weights("adaptive", 3).sum()) - 1) < 1e-6
+
+
+def test_shard_bounds_cover_everything():
+    from hgr_net_amd.parallel import batches_of_rank, shard_bounds
+    for n in (1, 7, 8, 21841):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+    assert sorted(sum([list(batches_of_rank(10, 4, r)) for r in range(4)], [])) == list(range(10))
+
+
+_WORKER = r'''
+import os, sys, json
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from hgr_net_amd import parallel
+from hgr_net_amd.evaluate import COUNTERS
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+torch.manual_seed(0)
+table = torch.randn(50, 6)                    # "encode" = a deterministic row-wise function
+enc = lambda rows: table[rows] * 2.0 + 1.0
+for n in (10, 11, 37):                         # even and uneven shards
+    rows = torch.arange(n) % 50
+    full = parallel.sharded_rows(enc, rows)
+    assert torch.equal(full, enc(rows)), n
+# counters: every rank adds its own batches; the all-reduced sum equals the single-process sum
+acc = torch.zeros(len(COUNTERS), dtype=torch.float64)
+for b in parallel.batches_of_rank(9, world, rank):
+    acc += torch.arange(len(COUNTERS), dtype=torch.float64) * (b + 1)
+dist.all_reduce(acc)
+want = sum(torch.arange(len(COUNTERS), dtype=torch.float64) * (b + 1) for b in range(9))
+assert torch.equal(acc, want)
+dist.barrier()
+if rank == 0: print("OK")
+dist.destroy_process_group()
+'''
+
+
+def test_world_size_2_gloo_sharding(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), str(ROOT)], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "OK" in outs[0]
+
+
+def test_tokenizer_matches_reference_ids(golden_dir):
+    """BPE ids captured from the reference's tokenizer (tools: see tests/golden/tokenizer_ids.json).
+    Needs the user's merges file; skipped where it is absent (it is reference data, not shipped)."""
+    from hgr_net_amd.clip import simple_tokenizer as st
+    try:
+        path = st.default_bpe_path()
+    except FileNotFoundError:
+        pytest.skip("BPE merges file not available (set HGR_BPE_VOCAB)")
+    tok = st.SimpleTokenizer(path)
+    gold = json.load(open(golden_dir / "tokenizer_ids.json"))
+    for text, ids in zip(gold["texts"], gold["ids"]):
+        assert tok.encode(text) == ids
+    from hgr_net_amd import clip
+    t = clip.tokenize(["a photo of a cat.", "x"])
+    assert t.shape == (2, 77) and t[0, 0] == 49406 and t[0].max() == 49407 and t[1, 3:].sum() == 0
+    with pytest.raises(RuntimeError):
+        clip.tokenize(["word " * 200])

@@ -103,7 +103,8 @@ def test_tree_model_forward_and_metrics_vs_reference(case, idt, golden_dir, tmp_
         lg = model(img.to(DEV), None)
         assert lg.shape == (meta["bsz"], meta["n_nodes"])
         # north_star tolerance: fp32 logits within 1e-3 of the reference PyTorch path
-        assert np.abs(lg.cpu().numpy() - z["logits"][i]).max() < 1e-3
+        err = float(np.abs(lg.cpu().numpy() - z["logits"][i]).max())
+        assert err < LOGIT_TOL[idt], f"max |logit - reference| = {err:.3e} ({idt})"
         # index work is checked bit-exactly on the REFERENCE's logits (same inputs to the kernels)
         ref_lg = torch.from_numpy(z["logits"][i]).to(DEV)
         pred, path = ev.add_batch(ref_lg, meta["targets"][i])
