@@ -41,9 +41,14 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     int m_fastest;   // 1: consecutive tile ids walk M first (W panel shared), 0: walk N first
     int vec_ok;      // C / residual rows allow 4-element vector access
+    int dbg;         // diagnostics only (HGR_GEMM_DBG): 1 = skip MFMAs, 2 = skip LDS-DMA issue, 3 = skip epilogue
 };
 
-__device__ __forceinline__ float quick_gelu(float v) { return v / (1.0f + __expf(-1.702f * v)); }
+// x * sigmoid(1.702 x) with v_exp_f32 + v_rcp_f32 (1 ulp each): an IEEE fp32 divide costs ~10 VALU ops per
+// element and, at 128 elements per lane, dominated the c_fc epilogue (measured 88 us of a 206 us launch).
+__device__ __forceinline__ float quick_gelu(float v) {
+    return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * v));
+}
 
 
 // One lane's 4 consecutive outputs C[m][n .. n+3] of an accumulator tile: bias / QuickGELU / residual,
@@ -214,18 +219,25 @@ __global__ __launch_bounds__(NT) void gemm_nt_128(GemmArgs p) {
 constexpr int NT256 = 512;
 constexpr int PIECE = 16384;
 
-#define HGR_WAIT_BARRIER(N) asm volatile("s_waitcnt vmcnt(" #N ")\n\ts_barrier" ::: "memory")
-#define HGR_BARRIER() asm volatile("s_barrier" ::: "memory")
+// R interval end: my share of the piece the NEXT read interval needs has landed (counted vmcnt), my own
+// ds_reads are complete (so the slot they read may be refilled), then the barrier.  M interval end: barrier.
+#define HGR_RWAIT(N) do { __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define HGR_RBAR() do { __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define HGR_MBAR() do { __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
 template <int DT, int EPI, bool OUT32>
 __global__ __launch_bounds__(NT256) void gemm_nt_256(GemmArgs p) {
     typedef typename T16<DT>::vec8 vec8;
-    __shared__ __attribute__((aligned(1024))) char smem[2 * 4 * PIECE];
+    typedef typename T16<DT>::elem E;
+    __shared__ __attribute__((aligned(1024))) char smem[2 * 4 * PIECE + 8 * 2048];   // + epilogue row padding
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;      // waves w and w+4 share a SIMD: wm is also the ping-pong group
     const int r = lane & 15, g = lane >> 4;
 
     const int nwg = gridDim.x;
@@ -258,7 +270,9 @@ __global__ __launch_bounds__(NT256) void gemm_nt_256(GemmArgs p) {
         src[1][j] = p.W + ((int64_t)min(n0 + rw0, p.N - 1) * p.ldw + c * 8) * 2;
         src[2][j] = p.W + ((int64_t)min(n0 + rw0 + 32, p.N - 1) * p.ldw + c * 8) * 2;
     }
+    const bool do_mma = p.dbg != 1, do_ld = p.dbg != 2;
     auto issue = [&](int kind, int t) {
+        if (!do_ld) return;
         char *dst = smem + (t & 1) * (4 * PIECE) + kind * PIECE + wave * 1024;
         const int64_t koff = (int64_t)t * 128;
         __builtin_amdgcn_global_load_lds((const AS1 void *)(src[kind][0] + koff), (AS3 void *)dst, 16, 0, 0);
@@ -279,7 +293,8 @@ __global__ __launch_bounds__(NT256) void gemm_nt_256(GemmArgs p) {
     // prologue: K-tile 0 complete, K-tile 1 without A1 (sequence numbers 0..6)
     issue(0, 0); issue(1, 0); issue(2, 0); issue(3, 0);
     issue(0, 1); issue(1, 1); issue(2, 1);
-    HGR_WAIT_BARRIER(10);       // A0(0), W0(0) landed
+    HGR_RWAIT(10);              // A0(0), W0(0) landed
+    if (wm) HGR_MBAR();         // ping-pong: group 1 runs one barrier interval behind group 0
 
     const int offA = (wm * 64 + r) * 128;      // + m tile * 2048, within pieces A0 / A1
     const int offW = (wn * 32 + r) * 128;      // + n tile * 2048, within pieces W0 / W1
@@ -287,11 +302,12 @@ __global__ __launch_bounds__(NT256) void gemm_nt_256(GemmArgs p) {
 
     vec8 af[4][2], wf0[2][2], wf1[2][2];
 
-    // MODE 0: steady state, 1: second-last K-tile (nothing left to issue after ph1), 2: last K-tile
+    // MODE 0: steady state, 1: second-last K-tile (nothing left to issue after ph1), 2: last K-tile.
+    // Every phase = R interval (reads, 1 piece issued, wait) | barrier | M interval (16 MFMAs) | barrier.
     auto ktile = [&](int t, auto mode_tag) {
         constexpr int MODE = decltype(mode_tag)::value;
         const char *buf = smem + (t & 1) * (4 * PIECE);
-        // ---- ph1 ------------------------------------------------------------------------------
+        // ---- ph1: Q(0,0) ----------------------------------------------------------------------
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             wf0[j][0] = *(const vec8 *)(buf + 1 * PIECE + offW + j * 2048 + sw0);
@@ -303,7 +319,9 @@ __global__ __launch_bounds__(NT256) void gemm_nt_256(GemmArgs p) {
             af[i][1] = *(const vec8 *)(buf + 0 * PIECE + offA + i * 2048 + sw1);
         }
         if (MODE <= 1) issue(3, t + 1);
+        if (MODE <= 1) HGR_RWAIT(10); else HGR_RWAIT(2);          // W1(t) landed
         __builtin_amdgcn_s_setprio(1);
+        if (do_mma)
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -311,15 +329,17 @@ __global__ __launch_bounds__(NT256) void gemm_nt_256(GemmArgs p) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[0][0][i][j] = T16<DT>::mfma16(wf0[j][kk], af[i][kk], acc[0][0][i][j]);
         __builtin_amdgcn_s_setprio(0);
-        if (MODE <= 1) HGR_WAIT_BARRIER(10); else HGR_WAIT_BARRIER(2);     // W1(t) landed
-        // ---- ph2 ------------------------------------------------------------------------------
+        HGR_MBAR();
+        // ---- ph2: Q(0,1) ----------------------------------------------------------------------
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             wf1[j][0] = *(const vec8 *)(buf + 2 * PIECE + offW + j * 2048 + sw0);
             wf1[j][1] = *(const vec8 *)(buf + 2 * PIECE + offW + j * 2048 + sw1);
         }
         if (MODE == 0) issue(0, t + 2);
+        if (MODE == 0) HGR_RWAIT(10); else if (MODE == 1) HGR_RWAIT(8); else HGR_RWAIT(0);   // A1(t) landed
         __builtin_amdgcn_s_setprio(1);
+        if (do_mma)
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -327,15 +347,17 @@ __global__ __launch_bounds__(NT256) void gemm_nt_256(GemmArgs p) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[0][1][i][j] = T16<DT>::mfma16(wf1[j][kk], af[i][kk], acc[0][1][i][j]);
         __builtin_amdgcn_s_setprio(0);
-        if (MODE == 0) HGR_WAIT_BARRIER(10); else if (MODE == 1) HGR_WAIT_BARRIER(8); else HGR_WAIT_BARRIER(0);   // A1(t) landed
-        // ---- ph3 ------------------------------------------------------------------------------
+        HGR_MBAR();
+        // ---- ph3: Q(1,1) ----------------------------------------------------------------------
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             af[i][0] = *(const vec8 *)(buf + 3 * PIECE + offA + i * 2048 + sw0);
             af[i][1] = *(const vec8 *)(buf + 3 * PIECE + offA + i * 2048 + sw1);
         }
         if (MODE == 0) issue(1, t + 2);
+        HGR_RBAR();                                               // ph4 reads nothing new
         __builtin_amdgcn_s_setprio(1);
+        if (do_mma)
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -343,10 +365,12 @@ __global__ __launch_bounds__(NT256) void gemm_nt_256(GemmArgs p) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[1][1][i][j] = T16<DT>::mfma16(wf1[j][kk], af[i][kk], acc[1][1][i][j]);
         __builtin_amdgcn_s_setprio(0);
-        // no barrier: ph4 reads nothing, and the slot ph4 refills (W1) was last read in ph2
-        // ---- ph4 ------------------------------------------------------------------------------
+        HGR_MBAR();
+        // ---- ph4: Q(1,0) ----------------------------------------------------------------------
         if (MODE == 0) issue(2, t + 2);
+        if (MODE == 0) HGR_RWAIT(10); else if (MODE == 1) HGR_RWAIT(4); else HGR_RBAR();     // A0(t+1), W0(t+1) landed
         __builtin_amdgcn_s_setprio(1);
+        if (do_mma)
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -354,15 +378,73 @@ __global__ __launch_bounds__(NT256) void gemm_nt_256(GemmArgs p) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[1][0][i][j] = T16<DT>::mfma16(wf0[j][kk], af[i][kk], acc[1][0][i][j]);
         __builtin_amdgcn_s_setprio(0);
-        if (MODE == 0) HGR_WAIT_BARRIER(10); else if (MODE == 1) HGR_WAIT_BARRIER(4);   // A0(t+1), W0(t+1) landed
+        HGR_MBAR();
     };
 
     for (int t = 0; t < nk - 2; ++t) ktile(t, std::integral_constant<int, 0>());
     ktile(nk - 2, std::integral_constant<int, 1>());
     ktile(nk - 1, std::integral_constant<int, 2>());
+    if (!wm) HGR_MBAR();
+    if (p.dbg == 3) { if (acc[0][0][0][0][0] == 123.456f) ((float *)p.C)[0] = 1.f; return; }
+    // group 0 waits for group 1's last interval: every LDS read is done, no DMA in flight
 
-    // epilogue: tile (a, b, i, j) of this lane holds C[m][n .. n+3],
+    // tile (a, b, i, j) of this lane holds C[m][n .. n+3],
     //   m = m0 + wm*128 + a*64 + i*16 + r,   n = n0 + wn*64 + b*32 + j*16 + g*4
+    if (!OUT32 && p.vec_ok && (p.ldc & 7) == 0) {
+        // 16-bit output: transpose the wave's 128 x 64 tile through its private LDS slice (rows of 128 B
+        // + 16 B pad) and write full 128-byte lines with 16-byte stores (8 lanes per row, 8 rows per
+        // instruction) instead of 32-byte fragments of 16 different lines per instruction.
+        constexpr int RS = 144;
+        char *my = smem + wave * (128 * RS);
+        // the lane's 4 bias quads depend on (b, j) only: fetch them once (scalar-guarded at the N edge)
+        f32x4 bq[2][2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + b * 32 + j * 16 + g * 4;
+            bq[b][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (EPI != HGR_EPI_NONE) {
+                if (n + 3 < p.N) bq[b][j] = *(const f32x4 *)(p.bias + n);
+                else
+                    for (int e = 0; e < 4; ++e) if (n + e < p.N) bq[b][j][e] = p.bias[n + e];
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f32x4 v = acc[a][b][i][j] + bq[b][j];
+            if (EPI == HGR_EPI_BIAS_QUICKGELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
+            }
+            *(typename T16<DT>::vec4 *)(my + (a * 64 + i * 16 + r) * RS + (b * 32 + j * 16 + g * 4) * 2) = cvt4<DT>(v[0], v[1], v[2], v[3]);
+        }
+        // LDS ops of one wave complete in order, and the slice is private to the wave: no barrier needed
+        const int ch = lane & 7, rr = lane >> 3;
+        const int nb = n0 + wn * 64 + ch * 8;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int row = q * 8 + rr;
+            const int m = m0 + wm * 128 + row;
+            const u32x4 v = *(const u32x4 *)(my + row * RS + ch * 16);
+            if (p.dbg == 4) { if (v[0] == 0x12345678u) ((float *)p.C)[0] = 1.f; continue; }
+            if (m < p.M) {
+                E *dst = (E *)p.C + (int64_t)m * p.ldc + nb;
+                if (nb + 7 < p.N) *(u32x4 *)dst = v;
+                else {
+                    const E *ve = (const E *)&v;
+                    for (int e = 0; e < 8 && nb + e < p.N; ++e) dst[e] = ve[e];
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -448,6 +530,7 @@ extern "C" int hgr_gemm_nt(const void *A, int64_t lda, const void *W, int64_t ld
     if (epilogue != HGR_EPI_NONE) vec = vec && hgr_aligned(bias, 16);
     if (epilogue == HGR_EPI_BIAS_RESIDUAL) vec = vec && (ldr % 4 == 0) && hgr_aligned(residual, 16);
     a.vec_ok = vec ? 1 : 0;
+    { static int dbg = -1; if (dbg < 0) { const char *e = getenv("HGR_GEMM_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
     dim3 grid((unsigned)(a.tiles_m * a.tiles_n));
     hipStream_t s = (hipStream_t)stream;
     if (dtype == HGR_BF16) launch_dt<HGR_BF16>(a, epilogue, out_f32 != 0, grid, s, big);
