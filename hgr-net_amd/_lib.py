@@ -31,7 +31,7 @@ SIGNATURES = {
     "hgr_eot_index": [_p, _l, _p, _i, _i, _p],
     "hgr_l2norm_rows": [_p, _p, _p, _i, _i, _i, _p],
     "hgr_topk_rows": [_p, _l, _p, _i, _i, _p, _p, _i, _p],
-    "hgr_level_argmax": [_p, _l, _p, _i, _p, _i, _p, _i, _p],
+    "hgr_level_argmax": [_p, _l, _p, _i, _p, _i, _p, _p, _i, _p],
 }
 
 

@@ -20,40 +20,88 @@ __device__ __forceinline__ Best wave_best(Best b) {
     return b;
 }
 
-// One workgroup per row.  The row's subset is staged once in LDS (<= 40000 floats); every thread
-// keeps the best of its own strided slice; each of the k rounds is one block reduction, and only
-// the thread that owned the winner rescans its slice.
+// One workgroup per row; the row's subset is staged once in LDS (<= 40000 floats).
+//   1. every thread finds the best element of its strided slice;
+//   2. the k-th best of those 256 slice maxima is a lower bound t of the true k-th largest value
+//      (k distinct elements are >= t), found by rank counting (256 broadcast LDS reads per thread);
+//   3. only slices whose maximum reaches t can hold candidates: they append every element >= t
+//      (by (value, position) order) to a small LDS list - typically k .. 2k entries;
+//   4. candidates are ranked by brute-force comparison and ranks < k are written out.
+// Exact for any input (ties broken towards the lowest position); if the candidate list overflows
+// (adversarial, heavily duplicated data) the block falls back to k rounds of block-wide arg-max.
+constexpr int TOPK_CAND = 1024;
+
 __global__ __launch_bounds__(256) void topk_rows(const float *__restrict__ logits, int64_t ld, const int32_t *__restrict__ cols,
                                                  int n_cols, int k, int32_t *__restrict__ out_idx, float *__restrict__ out_val) {
     extern __shared__ __attribute__((aligned(16))) char dyn[];
     float *vals = (float *)dyn;
-    __shared__ float s_v[4];
-    __shared__ int s_p[4];
-    __shared__ int s_win;
+    __shared__ float s_mv[256];
+    __shared__ int s_mp[256];
+    __shared__ float s_cv[TOPK_CAND];
+    __shared__ int s_cp[TOPK_CAND];
+    __shared__ float s_t;
+    __shared__ int s_tp, s_cnt, s_win;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row = blockIdx.x;
     const float *lr = logits + (int64_t)row * ld;
-    for (int p = tid; p < n_cols; p += 256) vals[p] = lr[cols ? cols[p] : p];
+    Best mine = {-INFINITY, 0x7fffffff};
+    for (int p = tid; p < n_cols; p += 256) {
+        const float v = lr[cols ? cols[p] : p];
+        vals[p] = v;
+        if (v > mine.v) { mine.v = v; mine.p = p; }      // ascending p: strict '>' keeps the lowest position
+    }
+    s_mv[tid] = mine.v; s_mp[tid] = mine.p;
+    if (tid == 0) s_cnt = 0;
     __syncthreads();
-
+    // rank of my slice maximum among the 256 maxima (threads with an empty slice hold (-inf, INT_MAX))
+    int rank = 0;
+    for (int j = 0; j < 256; ++j) rank += better(s_mv[j], s_mp[j], mine.v, mine.p) ? 1 : 0;
+    const int kth = min(k, n_cols) - 1;                    // n_cols >= k is guaranteed by the host; < 256 slices may be empty
+    if (rank == min(kth, min(n_cols, 256) - 1)) { s_t = mine.v; s_tp = mine.p; }
+    __syncthreads();
+    const float t = s_t; const int tp = s_tp;
+    // candidates: everything not worse than (t, tp); only slices whose maximum qualifies can contain any
+    if (!better(t, tp, mine.v, mine.p)) {
+        for (int p = tid; p < n_cols; p += 256) {
+            const float v = vals[p];
+            if (!better(t, tp, v, p)) {
+                const int slot = atomicAdd(&s_cnt, 1);
+                if (slot < TOPK_CAND) { s_cv[slot] = v; s_cp[slot] = p; }
+            }
+        }
+    }
+    __syncthreads();
+    const int cnt = s_cnt;
+    if (cnt <= TOPK_CAND) {
+        for (int c = tid; c < cnt; c += 256) {
+            const float v = s_cv[c]; const int p = s_cp[c];
+            int rk = 0;
+            for (int j = 0; j < cnt; ++j) rk += better(s_cv[j], s_cp[j], v, p) ? 1 : 0;
+            if (rk < k) {
+                out_idx[(int64_t)row * k + rk] = cols ? cols[p] : p;
+                if (out_val) out_val[(int64_t)row * k + rk] = v;
+            }
+        }
+        return;
+    }
+    // fallback: k rounds of block arg-max with removal
     auto scan = [&]() {
         Best b = {-INFINITY, 0x7fffffff};
         for (int p = tid; p < n_cols; p += 256) {
             const float v = vals[p];
-            if (v > b.v) { b.v = v; b.p = p; }       // ascending p: strict '>' keeps the lowest position
+            if (v > b.v) { b.v = v; b.p = p; }
         }
         return b;
     };
-    Best mine = scan();
     for (int j = 0; j < k; ++j) {
         const Best w = wave_best(mine);
-        if (lane == 0) { s_v[wave] = w.v; s_p[wave] = w.p; }
+        if (lane == 0) { s_mv[wave] = w.v; s_mp[wave] = w.p; }
         __syncthreads();
         if (tid == 0) {
-            Best b = {s_v[0], s_p[0]};
+            Best b = {s_mv[0], s_mp[0]};
 #pragma unroll
             for (int i = 1; i < 4; ++i)
-                if (better(s_v[i], s_p[i], b.v, b.p)) { b.v = s_v[i]; b.p = s_p[i]; }
+                if (better(s_mv[i], s_mp[i], b.v, b.p)) { b.v = s_mv[i]; b.p = s_mp[i]; }
             s_win = b.p;
             const bool ok = b.p < n_cols;
             out_idx[(int64_t)row * k + j] = ok ? (cols ? cols[b.p] : b.p) : -1;
@@ -61,7 +109,7 @@ __global__ __launch_bounds__(256) void topk_rows(const float *__restrict__ logit
             if (ok) vals[b.p] = -INFINITY;
         }
         __syncthreads();
-        if (mine.p == s_win) mine = scan();           // exactly one thread owned it
+        if (mine.p == s_win) mine = scan();
         __syncthreads();
     }
 }
@@ -71,8 +119,10 @@ __global__ __launch_bounds__(256) void topk_rows(const float *__restrict__ logit
 // itself is in level l (then the first position of another level).
 template <int NLV>
 __global__ __launch_bounds__(256) void level_argmax(const float *__restrict__ logits, int64_t ld, const int32_t *__restrict__ cols,
-                                                    int n_cols, const int32_t *__restrict__ depth, int n_levels, int32_t *__restrict__ out) {
+                                                    int n_cols, const int32_t *__restrict__ depth, int n_levels, int32_t *__restrict__ out, int32_t *__restrict__ out_top1) {
     __shared__ float s_v[4][NLV];
+    __shared__ float s_bv[NLV];
+    __shared__ int s_bp[NLV];
     __shared__ int s_p[4][NLV];
     __shared__ int s_fd[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -116,6 +166,18 @@ __global__ __launch_bounds__(256) void level_argmax(const float *__restrict__ lo
         if (has_c && (!has_f || b.v > -1.0f || (b.v == -1.0f && b.p < fo))) win = b.p;
         else win = has_f ? fo : b.p;
         out[(int64_t)row * n_levels + l] = cols ? cols[win] : win;
+        s_bv[l] = b.v; s_bp[l] = b.p;
+    }
+    if (out_top1) {
+        // every subset column belongs to exactly one level, so the unmasked top-1 over the subset
+        // (main.py:157) is the best of the per-level bests
+        __syncthreads();
+        if (tid == 0) {
+            Best b = {-INFINITY, 0x7fffffff};
+            for (int l = 0; l < n_levels; ++l)
+                if (better(s_bv[l], s_bp[l], b.v, b.p)) { b.v = s_bv[l]; b.p = s_bp[l]; }
+            out_top1[row] = b.p < n_cols ? (cols ? cols[b.p] : b.p) : -1;
+        }
     }
 }
 
@@ -140,12 +202,12 @@ extern "C" int hgr_topk_rows(const float *logits, int64_t ld, const int32_t *col
 }
 
 extern "C" int hgr_level_argmax(const float *logits, int64_t ld, const int32_t *cols, int n_cols,
-                                const int32_t *depth, int n_levels, int32_t *out, int rows, void *stream) {
+                                const int32_t *depth, int n_levels, int32_t *out, int32_t *out_top1, int rows, void *stream) {
     HGR_REQUIRE(logits && depth && out, "hgr_level_argmax: null operand");
     HGR_REQUIRE(rows >= 1 && n_cols >= 1 && n_levels >= 1 && n_levels <= 32, "hgr_level_argmax: rows=%d n_cols=%d n_levels=%d unsupported (n_levels <= 32)", rows, n_cols, n_levels);
     hipStream_t s = (hipStream_t)stream;
-    if (n_levels <= 16) hipLaunchKernelGGL((level_argmax<16>), dim3(rows), dim3(256), 0, s, logits, ld, cols, n_cols, depth, n_levels, out);
-    else hipLaunchKernelGGL((level_argmax<32>), dim3(rows), dim3(256), 0, s, logits, ld, cols, n_cols, depth, n_levels, out);
+    if (n_levels <= 16) hipLaunchKernelGGL((level_argmax<16>), dim3(rows), dim3(256), 0, s, logits, ld, cols, n_cols, depth, n_levels, out, out_top1);
+    else hipLaunchKernelGGL((level_argmax<32>), dim3(rows), dim3(256), 0, s, logits, ld, cols, n_cols, depth, n_levels, out, out_top1);
     HGR_CHECK_LAUNCH("hgr_level_argmax");
     return HGR_OK;
 }

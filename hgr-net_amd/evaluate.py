@@ -51,9 +51,9 @@ class Evaluator:
         correct = pred == (targets.to(torch.int32).view(-1, 1) if targets is not None else target)
         csum = correct.cumsum(dim=1).sum(dim=0).to(torch.float64)                    # hits for every k at once
         parents, levels, L = self._parents(target)
-        p1 = ops.topk_rows(logits, 1, cols=m.train_index32)                          # T2 main.py:157
+        # T3 main.py:162-176 (every level in one pass) and T2 main.py:157 (top-1 = best of the level bests)
+        lv, p1 = ops.level_argmax(logits, m.depth32, self.n_levels, cols=m.train_index32, want_top1=True)
         hits_all = (p1 == parents.view(1, -1)).sum().to(torch.float64)
-        lv = ops.level_argmax(logits, m.depth32, self.n_levels, cols=m.train_index32)  # T3 main.py:162-176
         dict_path = lv[:, levels]                                                    # [B, L]
         match = dict_path == parents.view(1, -1)                                     # T4 main.py:177-191
         point = match.sum().to(torch.float64)

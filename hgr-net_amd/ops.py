@@ -122,11 +122,13 @@ def topk_rows(logits: torch.Tensor, k: int, cols: Optional[torch.Tensor] = None,
 
 
 def level_argmax(logits: torch.Tensor, depth: torch.Tensor, n_levels: int, cols: Optional[torch.Tensor] = None,
-                 n_cols: Optional[int] = None) -> torch.Tensor:
-    """int32 [rows, n_levels]: per depth level the arg-max node id over `cols` (main.py:162-176)."""
+                 n_cols: Optional[int] = None, want_top1: bool = False):
+    """int32 [rows, n_levels]: per depth level the arg-max node id over `cols` (main.py:162-176);
+    with want_top1 also int32 [rows, 1]: the unmasked top-1 over `cols` (main.py:157)."""
     assert logits.dtype == torch.float32 and logits.stride(1) == 1 and depth.dtype == torch.int32
     rows = logits.shape[0]
     nc = cols.numel() if cols is not None else (logits.shape[1] if n_cols is None else n_cols)
     out = torch.empty((rows, n_levels), dtype=torch.int32, device=logits.device)
-    _lib.call("hgr_level_argmax", _dev(logits), logits.stride(0), _dev(cols), nc, _dev(depth), n_levels, _dev(out), rows, _stream())
-    return out
+    top1 = torch.empty((rows, 1), dtype=torch.int32, device=logits.device) if want_top1 else None
+    _lib.call("hgr_level_argmax", _dev(logits), logits.stride(0), _dev(cols), nc, _dev(depth), n_levels, _dev(out), _dev(top1), rows, _stream())
+    return (out, top1) if want_top1 else out

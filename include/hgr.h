@@ -126,10 +126,12 @@ int hgr_topk_rows(const float *logits, int64_t ld, const int32_t *cols, int n_co
  * v_p = (depth[cols[p]] == l ? logits[row, cols[p]] : -1)  over the subset positions p, which is what
  * `logits.index_fill(1, rest, -1)[:, train_index].topk(1)` computes.  One coalesced pass over the row.
  *   depth int32 [n_nodes] (shortest-path depth, utils.py:55,66-70); out int32 [rows, n_levels]
- * n_levels <= 32.
+ *   out_top1 int32 [rows] or NULL: the unmasked top-1 node id over the same subset
+ *   (`logits[:, train_index].topk(1)`, main.py:157), which is the best of the per-level bests.
+ * n_levels <= 32; every depth[cols[p]] must be < n_levels.
  */
 int hgr_level_argmax(const float *logits, int64_t ld, const int32_t *cols, int n_cols,
-                     const int32_t *depth, int n_levels, int32_t *out, int rows, void *stream);
+                     const int32_t *depth, int n_levels, int32_t *out, int32_t *out_top1, int rows, void *stream);
 
 #ifdef __cplusplus
 }

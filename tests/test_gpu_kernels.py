@@ -174,6 +174,20 @@ def test_topk_rows_exact(n, k):
         assert np.array_equal(idx2[r].cpu().numpy(), tree_ref.topk_desc(lg[r].numpy(), k))
 
 
+def test_topk_rows_duplicates_and_fallback():
+    """heavily duplicated values: exact tie order, and the candidate-overflow fallback path"""
+    rows, n, k = 3, 5000, 20
+    lg = torch.zeros(rows, n)
+    lg[0] = 0.25                                             # all equal -> every element is a candidate (fallback)
+    lg[1] = torch.from_numpy((synth.randint(1, "dup", n, 0, 7)).astype(np.float32))   # 7 distinct values
+    lg[2, ::2] = 1.0                                         # 2500 ties for the maximum
+    idx, val = ops.topk_rows(lg.to(DEV), k, n_cols=n, want_values=True)
+    for r in range(rows):
+        want = tree_ref.topk_desc(lg[r].numpy(), k)
+        assert np.array_equal(idx[r].cpu().numpy(), want)
+        assert np.array_equal(val[r].cpu().numpy(), lg[r].numpy()[want])
+
+
 @pytest.mark.parametrize("n,levels", [(90, 8), (3000, 12), (21841, 12), (500, 20)])
 def test_level_argmax_exact(n, levels):
     rows = 4
@@ -184,8 +198,11 @@ def test_level_argmax_exact(n, levels):
     perm = np.argsort(synth.uniform(2, "perm", n), kind="stable").astype(np.int32)
     for cols in (None, perm[: n - n // 3]):
         tr = np.arange(n, dtype=np.int64) if cols is None else cols.astype(np.int64)
-        got = ops.level_argmax(lg.to(DEV), torch.from_numpy(depth).to(DEV), levels,
-                               cols=None if cols is None else torch.from_numpy(cols).to(DEV), n_cols=n).cpu().numpy()
+        got, top1 = ops.level_argmax(lg.to(DEV), torch.from_numpy(depth).to(DEV), levels,
+                                     cols=None if cols is None else torch.from_numpy(cols).to(DEV), n_cols=n, want_top1=True)
+        got = got.cpu().numpy()
+        for rr in range(rows):
+            assert int(top1[rr, 0]) == tr[tree_ref.topk_desc(lg[rr, torch.from_numpy(tr)].numpy(), 1)[0]]
         for l in range(levels):
             same = [int(i) for i in np.nonzero(depth == l)[0]]
             want = tree_ref.level_argmax(lg.numpy(), tr, same, n)
