@@ -185,7 +185,7 @@ def main():
                 "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                 "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": a.image_dtype, "data": "synthetic",
-                "config": {"workload": f"{a.arch} zero-shot eval step: encode_image + L2 + [{a.batch}x512]x[512x{a.nodes}] logits "
+                "config": {"workload": f"{a.arch} zero-shot eval step: encode_image + L2 + [{a.batch}x{cfg['embed_dim']}]x[{cfg['embed_dim']}x{a.nodes}] logits "
                                        f"+ top-20/top-1/level-argmax metrics (main.py:131-191), N={a.nodes} nodes, batch {a.batch}/GPU",
                            "global_batch": a.batch * world, "parallelism": f"dp{world}", "text_dtype": a.text_dtype,
                            "weights": "random-init (hash-seeded), no checkpoint offline"},

@@ -16,7 +16,7 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("HGR_LIB", _HERE / "lib" / "libhgr.so"))
 
 HGR_BF16, HGR_F16 = 0, 1
-EPI_NONE, EPI_BIAS, EPI_BIAS_QUICKGELU, EPI_BIAS_RESIDUAL = 0, 1, 2, 3
+EPI_NONE, EPI_BIAS, EPI_BIAS_QUICKGELU, EPI_BIAS_RESIDUAL, EPI_BIAS_RELU, EPI_BIAS_ADD16_RELU = 0, 1, 2, 3, 4, 5
 
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -32,6 +32,11 @@ SIGNATURES = {
     "hgr_l2norm_rows": [_p, _p, _p, _i, _i, _i, _p],
     "hgr_topk_rows": [_p, _l, _p, _i, _i, _p, _p, _i, _p],
     "hgr_level_argmax": [_p, _l, _p, _i, _p, _i, _p, _p, _i, _p],
+    "hgr_conv3x3_nhwc": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "hgr_stem_im2col": [_p, _p, _i, _i, _i, _p],
+    "hgr_avgpool2_nhwc": [_p, _p, _i, _i, _i, _i, _i, _p],
+    "hgr_attnpool_tokens": [_p, _p, _p, _i, _i, _i, _i, _p],
+    "hgr_attnpool_attend": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
 }
 
 

@@ -21,7 +21,8 @@ import torch
 from torch import nn
 
 from .. import ops
-from .._lib import EPI_BIAS, EPI_BIAS_QUICKGELU, EPI_BIAS_RESIDUAL, EPI_NONE, HgrError
+from .._lib import (EPI_BIAS, EPI_BIAS_ADD16_RELU, EPI_BIAS_QUICKGELU, EPI_BIAS_RELU, EPI_BIAS_RESIDUAL, EPI_NONE,
+                    HgrError)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -93,8 +94,7 @@ class _AttentionPool2d(nn.Module):
 
 
 class ModifiedResNet(nn.Module):
-    """Schema container for the RN towers (clip/model.py:93-150).  The HIP conv path is the next
-    row of the scope table; until then ``encode_image`` on an RN checkpoint raises."""
+    """Schema container for the RN towers (clip/model.py:93-150); the forward is `_rn_forward` below."""
 
     def __init__(self, layers, output_dim, heads, input_resolution=224, width=64):
         super().__init__()
@@ -177,6 +177,107 @@ def _run_blocks(x: torch.Tensor, blocks, heads: int, b: int, l: int, causal: boo
     return x
 
 
+
+# ------------------------------------------------------------------------------------------------
+# ModifiedResNet engine: NHWC 16-bit activations, BN folded, 1x1 convs = GEMMs, 3x3 = implicit GEMM
+# ------------------------------------------------------------------------------------------------
+def _fold(conv: nn.Conv2d, bn: nn.BatchNorm2d, dt: torch.dtype):
+    """Inference BatchNorm folded into the preceding conv (legal: the model is always in eval(),
+    model/clip_tree.py:46).  Returns (w16 [Cout, Kp] in (ky, kx, c) order, bias fp32 [Cout])."""
+    w = conv.weight.detach().float()
+    s = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+    b = bn.bias.detach().float() - bn.running_mean.detach().float() * s
+    w = (w * s.view(-1, 1, 1, 1)).permute(0, 2, 3, 1).reshape(w.shape[0], -1)          # [Cout, kh*kw*Cin]
+    k = w.shape[1]
+    kp = (k + 63) // 64 * 64
+    out = torch.zeros(w.shape[0], kp, dtype=dt, device=w.device)
+    out[:, :k] = w.to(dt)
+    return out.contiguous(), b.contiguous()
+
+
+class _RNBlock16:
+    def __init__(self, blk, dt):
+        self.c1, self.c2, self.c3 = _fold(blk.conv1, blk.bn1, dt), _fold(blk.conv2, blk.bn2, dt), _fold(blk.conv3, blk.bn3, dt)
+        self.down = _fold(blk.downsample[1], blk.downsample[2], dt) if blk.downsample is not None else None
+        self.stride = blk.stride
+        self.planes = blk.conv1.weight.shape[0]
+
+
+def _rn_prepare(v: "ModifiedResNet", dt: torch.dtype) -> dict:
+    p = {"stem": [_fold(v.conv1, v.bn1, dt), _fold(v.conv2, v.bn2, dt), _fold(v.conv3, v.bn3, dt)]}
+    p["blocks"] = [_RNBlock16(b, dt) for li in (1, 2, 3, 4) for b in getattr(v, f"layer{li}")]
+    a = v.attnpool
+    p["pos"] = _f32(a.positional_embedding)
+    for nm in ("q_proj", "k_proj", "v_proj", "c_proj"):
+        lin = getattr(a, nm)
+        p[nm] = (_w16(lin.weight, dt), _f32(lin.bias))
+    return p
+
+
+def _rn_forward(v: "ModifiedResNet", p: dict, image: torch.Tensor, dt: torch.dtype, ws: _Workspace) -> torch.Tensor:
+    """ModifiedResNet.forward (clip/model.py:135-150) on libhgr: stem (3 conv+BN+ReLU, avgpool) ->
+    4 stages of Bottlenecks (clip/model.py:40-53) -> AttentionPool2d (clip/model.py:66-90)."""
+    dev = image.device
+    b, _, r, _ = image.shape
+    width = v.conv3.weight.shape[0]
+    if width % 64 or (width & (width - 1)):
+        raise NotImplementedError(f"RN width {width}: the conv kernels need power-of-two channel counts >= 64 (RN50/RN101)")
+    h = (r - 1) // 2 + 1
+    m = b * h * h
+    (w1, b1), (w2, b2), (w3, b3) = p["stem"]
+    col = ws.get("r.col", (m, 64), dt, dev)
+    ops.stem_im2col(image, col)
+    a1 = ws.get("r.a", (m, w1.shape[0]), dt, dev)
+    ops.gemm_nt(col, w1, a1, bias=b1, epilogue=EPI_BIAS_RELU)
+    a2 = ws.get("r.b", (m, w2.shape[0]), dt, dev)
+    ops.conv3x3_nhwc(a1, w2, b2, a2, b, h, h, w1.shape[0])
+    a3 = ws.get("r.c", (m, w3.shape[0]), dt, dev)
+    ops.conv3x3_nhwc(a2, w3, b3, a3, b, h, h, w2.shape[0])
+    h //= 2
+    x = ws.get("r.x0", (b * h * h, width), dt, dev)
+    ops.avgpool2_nhwc(a3, x, b, 2 * h, 2 * h, width)
+    cin, flip = width, 0
+    for k in p["blocks"]:
+        m = b * h * h
+        pl = k.planes
+        t1 = ws.get("r.t1", (m, pl), dt, dev)
+        ops.gemm_nt(x, k.c1[0], t1, bias=k.c1[1], epilogue=EPI_BIAS_RELU)
+        t2 = ws.get("r.t2", (m, pl), dt, dev)
+        ops.conv3x3_nhwc(t1, k.c2[0], k.c2[1], t2, b, h, h, pl)
+        ho = h // k.stride
+        mo = b * ho * ho
+        xin = x
+        if k.stride > 1:                                   # anti-aliased stride: avgpool after conv2 and on the skip path
+            t2p = ws.get("r.t2p", (mo, pl), dt, dev)
+            ops.avgpool2_nhwc(t2, t2p, b, h, h, pl)
+            t2 = t2p
+            if k.down is not None:
+                xin = ws.get("r.xp", (mo, cin), dt, dev)
+                ops.avgpool2_nhwc(x, xin, b, h, h, cin)
+        idn = xin
+        if k.down is not None:
+            idn = ws.get("r.idn", (mo, 4 * pl), dt, dev)
+            ops.gemm_nt(xin, k.down[0], idn, bias=k.down[1], epilogue=EPI_BIAS)
+        out = ws.get(f"r.out{flip}", (mo, 4 * pl), dt, dev)
+        ops.gemm_nt(t2, k.c3[0], out, bias=k.c3[1], residual=idn, epilogue=EPI_BIAS_ADD16_RELU)
+        x, cin, h, flip = out, 4 * pl, ho, flip ^ 1
+    # attention pool: only token 0's query is ever used (the module returns x[0])
+    a = v.attnpool
+    e, l = cin, h * h + 1
+    tok = ws.get("r.tok", (b * l, e), dt, dev)
+    ops.attnpool_tokens(x, p["pos"], tok, b, h, e)
+    kk = ws.get("r.k", (b * l, e), dt, dev)
+    vv = ws.get("r.v", (b * l, e), dt, dev)
+    ops.gemm_nt(tok, p["k_proj"][0], kk, bias=p["k_proj"][1], epilogue=EPI_BIAS)
+    ops.gemm_nt(tok, p["v_proj"][0], vv, bias=p["v_proj"][1], epilogue=EPI_BIAS)
+    q = ws.get("r.q", (b, e), torch.float32, dev)
+    ops.gemm_nt(tok.view(b, l * e)[:, :e], p["q_proj"][0], q, bias=p["q_proj"][1], epilogue=EPI_BIAS)   # rows b*l (token 0)
+    o16 = ws.get("r.o", (b, e), dt, dev)
+    ops.attnpool_attend(q, kk, vv, o16, b, l, a.num_heads)
+    out = torch.empty((b, v.output_dim), dtype=torch.float32, device=dev)
+    ops.gemm_nt(o16, p["c_proj"][0], out, bias=p["c_proj"][1], epilogue=EPI_BIAS)
+    return out
+
 # ------------------------------------------------------------------------------------------------
 # CLIP
 # ------------------------------------------------------------------------------------------------
@@ -241,6 +342,8 @@ class CLIP(nn.Module):
                 p["ln_post"] = (_f32(v.ln_post.weight), _f32(v.ln_post.bias))
                 p["proj_t"] = _w16(v.proj.detach().t(), dt)                     # [D, W] for the NT GEMM
                 p["vblocks"] = [_Block16(b, dt) for b in v.transformer.resblocks]
+            else:
+                p["rn"] = _rn_prepare(v, self.image_dtype)
             dt = self.text_dtype
             p["tok"], p["tpos"] = _f32(self.token_embedding.weight), _f32(self.positional_embedding)
             p["ln_final"] = (_f32(self.ln_final.weight), _f32(self.ln_final.bias))
@@ -253,9 +356,6 @@ class CLIP(nn.Module):
     def encode_image(self, image: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
         """fp32 [B, embed_dim] image features (clip/model.py:336 -> VisionTransformer.forward :219-236)."""
         v = self.visual
-        if not isinstance(v, VisionTransformer):
-            raise NotImplementedError("ModifiedResNet (RN50) tower: HIP conv kernels are the next scope-table row; "
-                                      "there is no CPU fallback (see DESIGN.md)")
         if not image.is_cuda:
             raise HgrError("encode_image needs a device tensor: the product path has no CPU fallback")
         p = self._prepared()
@@ -264,6 +364,8 @@ class CLIP(nn.Module):
         b, _, r, _ = image.shape
         if r != v.input_resolution:
             raise ValueError(f"expected {v.input_resolution}x{v.input_resolution} input, got {r}")
+        if not isinstance(v, VisionTransformer):
+            return _rn_forward(v, p["rn"], image, dt, ws)
         ps = v.patch_size
         g = r // ps
         gg, l, w = g * g, g * g + 1, v.conv1.weight.shape[0]

@@ -42,7 +42,12 @@ struct GemmArgs {
     int m_fastest;   // 1: consecutive tile ids walk M first (W panel shared), 0: walk N first
     int vec_ok;      // C / residual rows allow 4-element vector access
     int dbg;         // diagnostics only (HGR_GEMM_DBG): 1 = skip MFMAs, 2 = skip LDS-DMA issue, 3 = skip epilogue
+    // implicit-GEMM 3x3 convolution (CONV kernels only): A is an NHWC image [B, H, W, C], pad 1
+    int cH, cW, cC, cLog2C, cStride, cHo, cWo;
 };
+
+// 16 zero bytes every out-of-bounds conv tap (and the K padding) is loaded from
+__device__ __attribute__((aligned(16))) unsigned int hgr_zero_page[4] = {0u, 0u, 0u, 0u};
 
 // x * sigmoid(1.702 x) with v_exp_f32 + v_rcp_f32 (1 ulp each): an IEEE fp32 divide costs ~10 VALU ops per
 // element and, at 128 elements per lane, dominated the c_fc epilogue (measured 88 us of a 206 us launch).
@@ -63,6 +68,15 @@ __device__ __forceinline__ void store_quad(const GemmArgs &p, f32x4 v, int m, in
             for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
         }
         if (EPI == HGR_EPI_BIAS_RESIDUAL) v += *(const f32x4 *)(p.res + (int64_t)m * p.ldr + n);
+        if (EPI == HGR_EPI_BIAS_ADD16_RELU) {
+            const typename T16<DT>::vec4 idn = *(const typename T16<DT>::vec4 *)((const E *)(const void *)p.res + (int64_t)m * p.ldr + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (float)idn[e];
+        }
+        if (EPI == HGR_EPI_BIAS_RELU || EPI == HGR_EPI_BIAS_ADD16_RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
         if (OUT32) *(f32x4 *)((float *)p.C + (int64_t)m * p.ldc + n) = v;
         else *(typename T16<DT>::vec4 *)((E *)p.C + (int64_t)m * p.ldc + n) = cvt4<DT>(v[0], v[1], v[2], v[3]);
         return;
@@ -72,12 +86,14 @@ __device__ __forceinline__ void store_quad(const GemmArgs &p, f32x4 v, int m, in
         if (EPI != HGR_EPI_NONE) x += p.bias[n + e];
         if (EPI == HGR_EPI_BIAS_QUICKGELU) x = quick_gelu(x);
         if (EPI == HGR_EPI_BIAS_RESIDUAL) x += p.res[(int64_t)m * p.ldr + n + e];
+        if (EPI == HGR_EPI_BIAS_ADD16_RELU) x += (float)((const E *)(const void *)p.res)[(int64_t)m * p.ldr + n + e];
+        if (EPI == HGR_EPI_BIAS_RELU || EPI == HGR_EPI_BIAS_ADD16_RELU) x = fmaxf(x, 0.f);
         if (OUT32) ((float *)p.C)[(int64_t)m * p.ldc + n + e] = x;
         else ((E *)p.C)[(int64_t)m * p.ldc + n + e] = (E)x;
     }
 }
 
-template <int DT, int EPI, bool OUT32>
+template <int DT, int EPI, bool OUT32, bool CONV = false>
 __global__ __launch_bounds__(NT) void gemm_nt_128(GemmArgs p) {
     typedef typename T16<DT>::vec8 vec8;
     __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE_BYTES];
@@ -111,14 +127,31 @@ __global__ __launch_bounds__(NT) void gemm_nt_128(GemmArgs p) {
 
     // per-lane source rows of the 4 + 4 LDS-DMA pieces this thread issues per stage
     const char *srcA[4], *srcW[4];
+    int cchunk[4];              // CONV: this lane's logical 16-B chunk (8 input channels) inside a K-tile
+    unsigned vmask[4];          // CONV: bit t set = tap t of this output pixel is inside the image
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int id = (i * 4 + wave) * 64 + lane;    // 16-B chunk id inside the 128 x 64 tile
         const int row = id >> 3, c = (id & 7) ^ (row & 7);
         const int gm = min(m0 + row, p.M - 1);        // edge rows: load a valid row, never store it
         const int gn = min(n0 + row, p.N - 1);
-        srcA[i] = p.A + ((int64_t)gm * p.lda + c * 8) * 2;
         srcW[i] = p.W + ((int64_t)gn * p.ldw + c * 8) * 2;
+        if (CONV) {
+            // output pixel (b, ho, wo) of row gm; tap (ky, kx) reads input pixel (ho*s - 1 + ky, wo*s - 1 + kx)
+            const int wo = gm % p.cWo, t1 = gm / p.cWo, ho = t1 % p.cHo, b = t1 / p.cHo;
+            const int hi0 = ho * p.cStride - 1, wi0 = wo * p.cStride - 1;
+            unsigned vm = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int hi = hi0 + t / 3, wi = wi0 + t % 3;
+                if (hi >= 0 && hi < p.cH && wi >= 0 && wi < p.cW) vm |= 1u << t;
+            }
+            vmask[i] = vm;
+            cchunk[i] = c;
+            srcA[i] = p.A + (((int64_t)b * p.cH + hi0) * p.cW + wi0) * p.cC * 2;     // tap (0,0), channel 0
+        } else {
+            srcA[i] = p.A + ((int64_t)gm * p.lda + c * 8) * 2;
+        }
     }
 
     auto stage = [&](int buf, int kt) {
@@ -126,9 +159,20 @@ __global__ __launch_bounds__(NT) void gemm_nt_128(GemmArgs p) {
         char *sW = sA + TILE_BYTES;
         const int64_t koff = (int64_t)kt * BK * 2;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((const AS1 void *)(srcA[i] + koff),
-                                             (AS3 void *)(sA + (i * 4 + wave) * 1024), 16, 0, 0);
+        for (int i = 0; i < 4; ++i) {
+            const char *src;
+            if (CONV) {
+                // implicit im2col: K index = tap * C + channel (C a power of two >= 8), 8 channels per chunk
+                const int kq = kt * BK + cchunk[i] * 8;
+                const int tap = kq >> p.cLog2C, cin = kq & (p.cC - 1);
+                const int ky = (tap * 11) >> 5, kx = tap - ky * 3;               // tap / 3, tap % 3 for tap < 9
+                const bool ok = tap < 9 && ((vmask[i] >> tap) & 1u);
+                src = ok ? srcA[i] + ((int64_t)(ky * p.cW + kx) * p.cC + cin) * 2 : (const char *)hgr_zero_page;
+            } else {
+                src = srcA[i] + koff;
+            }
+            __builtin_amdgcn_global_load_lds((const AS1 void *)src, (AS3 void *)(sA + (i * 4 + wave) * 1024), 16, 0, 0);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             __builtin_amdgcn_global_load_lds((const AS1 void *)(srcW[i] + koff),
@@ -390,7 +434,7 @@ __global__ __launch_bounds__(NT256) void gemm_nt_256(GemmArgs p) {
 
     // tile (a, b, i, j) of this lane holds C[m][n .. n+3],
     //   m = m0 + wm*128 + a*64 + i*16 + r,   n = n0 + wn*64 + b*32 + j*16 + g*4
-    if (!OUT32 && p.vec_ok && (p.ldc & 7) == 0) {
+    if (!OUT32 && p.vec_ok && (p.ldc & 7) == 0 && EPI <= HGR_EPI_BIAS_QUICKGELU) {
         // 16-bit output: transpose the wave's 128 x 64 tile through its private LDS slice (rows of 128 B
         // + 16 B pad) and write full 128-byte lines with 16-byte stores (8 lanes per row, 8 rows per
         // instruction) instead of 32-byte fragments of 16 different lines per instruction.
@@ -478,6 +522,8 @@ void launch_dt(const GemmArgs &a, int epi, bool out32, dim3 grid, hipStream_t s,
         case HGR_EPI_NONE: launch_epi<DT, HGR_EPI_NONE>(a, out32, grid, s, big); break;
         case HGR_EPI_BIAS: launch_epi<DT, HGR_EPI_BIAS>(a, out32, grid, s, big); break;
         case HGR_EPI_BIAS_QUICKGELU: launch_epi<DT, HGR_EPI_BIAS_QUICKGELU>(a, out32, grid, s, big); break;
+        case HGR_EPI_BIAS_RELU: launch_epi<DT, HGR_EPI_BIAS_RELU>(a, out32, grid, s, big); break;
+        case HGR_EPI_BIAS_ADD16_RELU: launch_epi<DT, HGR_EPI_BIAS_ADD16_RELU>(a, out32, grid, s, big); break;
         default: launch_epi<DT, HGR_EPI_BIAS_RESIDUAL>(a, out32, grid, s, big); break;
     }
 }
@@ -492,7 +538,7 @@ int hgr_gemm_force_tile() {
 }  // namespace
 
 extern "C" int hgr_gemm_nt(const void *A, int64_t lda, const void *W, int64_t ldw, void *C, int64_t ldc,
-                           const float *bias, const float *residual, int64_t ldr,
+                           const float *bias, const void *residual, int64_t ldr,
                            int M, int N, int K, int dtype, int epilogue, int out_f32, void *stream) {
     HGR_REQUIRE(A && W && C, "hgr_gemm_nt: null operand");
     HGR_REQUIRE(M >= 1 && N >= 1 && K >= BK, "hgr_gemm_nt: bad shape M=%d N=%d K=%d", M, N, K);
@@ -501,14 +547,15 @@ extern "C" int hgr_gemm_nt(const void *A, int64_t lda, const void *W, int64_t ld
     HGR_REQUIRE(hgr_aligned(A, 16) && hgr_aligned(W, 16), "hgr_gemm_nt: A and W must be 16-byte aligned");
     HGR_REQUIRE(ldc >= N, "hgr_gemm_nt: ldc=%lld < N=%d", (long long)ldc, N);
     HGR_REQUIRE(dtype == HGR_BF16 || dtype == HGR_F16, "hgr_gemm_nt: bad dtype %d", dtype);
-    HGR_REQUIRE(epilogue >= HGR_EPI_NONE && epilogue <= HGR_EPI_BIAS_RESIDUAL, "hgr_gemm_nt: bad epilogue %d", epilogue);
+    HGR_REQUIRE(epilogue >= HGR_EPI_NONE && epilogue <= HGR_EPI_BIAS_ADD16_RELU, "hgr_gemm_nt: bad epilogue %d", epilogue);
     HGR_REQUIRE(epilogue == HGR_EPI_NONE || bias, "hgr_gemm_nt: epilogue %d needs bias", epilogue);
-    HGR_REQUIRE(epilogue != HGR_EPI_BIAS_RESIDUAL || (residual && ldr >= N), "hgr_gemm_nt: residual epilogue needs residual with ldr >= N");
+    HGR_REQUIRE((epilogue != HGR_EPI_BIAS_RESIDUAL && epilogue != HGR_EPI_BIAS_ADD16_RELU) || (residual && ldr >= N), "hgr_gemm_nt: residual epilogue needs residual with ldr >= N");
+    HGR_REQUIRE(epilogue != HGR_EPI_BIAS_ADD16_RELU || !out_f32, "hgr_gemm_nt: ADD16_RELU writes 16-bit output");
     HGR_REQUIRE(hgr_aligned(C, out_f32 ? 4 : 2), "hgr_gemm_nt: C misaligned");
 
     GemmArgs a;
     a.A = (const char *)A; a.lda = lda; a.W = (const char *)W; a.ldw = ldw;
-    a.C = C; a.ldc = ldc; a.bias = bias; a.res = residual; a.ldr = ldr;
+    a.C = C; a.ldc = ldc; a.bias = bias; a.res = (const float *)residual; a.ldr = ldr;
     a.M = M; a.N = N; a.K = K;
     // tile choice: the 256^2 deep-pipelined kernel when its workgroups fill the 256 CUs evenly, otherwise
     // 128^2 tiles at 2 workgroups per CU (N = 768 outputs: 300 big tiles would run at 59 %; the logits GEMM
@@ -529,6 +576,7 @@ extern "C" int hgr_gemm_nt(const void *A, int64_t lda, const void *W, int64_t ld
     bool vec = (ldc % 4 == 0) && hgr_aligned(C, out_f32 ? 16 : 8);
     if (epilogue != HGR_EPI_NONE) vec = vec && hgr_aligned(bias, 16);
     if (epilogue == HGR_EPI_BIAS_RESIDUAL) vec = vec && (ldr % 4 == 0) && hgr_aligned(residual, 16);
+    if (epilogue == HGR_EPI_BIAS_ADD16_RELU) vec = vec && (ldr % 4 == 0) && hgr_aligned(residual, 8);
     a.vec_ok = vec ? 1 : 0;
     { static int dbg = -1; if (dbg < 0) { const char *e = getenv("HGR_GEMM_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
     dim3 grid((unsigned)(a.tiles_m * a.tiles_n));
@@ -536,5 +584,32 @@ extern "C" int hgr_gemm_nt(const void *A, int64_t lda, const void *W, int64_t ld
     if (dtype == HGR_BF16) launch_dt<HGR_BF16>(a, epilogue, out_f32 != 0, grid, s, big);
     else launch_dt<HGR_F16>(a, epilogue, out_f32 != 0, grid, s, big);
     HGR_CHECK_LAUNCH("hgr_gemm_nt");
+    return HGR_OK;
+}
+
+extern "C" int hgr_conv3x3_nhwc(const void *x, const void *w, const float *bias, void *out,
+                                int B, int H, int W, int C, int Cout, int stride, int Kp, int dtype, void *stream) {
+    HGR_REQUIRE(x && w && bias && out, "hgr_conv3x3_nhwc: null operand");
+    HGR_REQUIRE(B >= 1 && H >= 1 && W >= 1 && Cout >= 1 && (stride == 1 || stride == 2), "hgr_conv3x3_nhwc: bad geometry B=%d H=%d W=%d Cout=%d stride=%d", B, H, W, Cout, stride);
+    HGR_REQUIRE(C >= 8 && (C & (C - 1)) == 0, "hgr_conv3x3_nhwc: C=%d must be a power of two >= 8", C);
+    HGR_REQUIRE(Kp >= 9 * C && Kp % BK == 0, "hgr_conv3x3_nhwc: Kp=%d must be >= 9*C and a multiple of %d", Kp, BK);
+    HGR_REQUIRE(hgr_aligned(x, 16) && hgr_aligned(w, 16) && hgr_aligned(out, 8) && hgr_aligned(bias, 16) && Cout % 4 == 0, "hgr_conv3x3_nhwc: misaligned operand / Cout %% 4 != 0");
+    HGR_REQUIRE(dtype == HGR_BF16 || dtype == HGR_F16, "hgr_conv3x3_nhwc: bad dtype %d", dtype);
+    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    const int64_t M64 = (int64_t)B * Ho * Wo;
+    HGR_REQUIRE(M64 < (1ll << 31), "hgr_conv3x3_nhwc: too many output pixels");
+    GemmArgs a;
+    a.A = (const char *)x; a.lda = 0; a.W = (const char *)w; a.ldw = Kp;
+    a.C = out; a.ldc = Cout; a.bias = bias; a.res = nullptr; a.ldr = 0;
+    a.M = (int)M64; a.N = Cout; a.K = Kp;
+    a.tiles_m = (a.M + BM - 1) / BM; a.tiles_n = (Cout + BN - 1) / BN;
+    a.m_fastest = 0; a.vec_ok = 1; a.dbg = 0;
+    a.cH = H; a.cW = W; a.cC = C; a.cStride = stride; a.cHo = Ho; a.cWo = Wo;
+    int l2 = 0; while ((1 << l2) < C) ++l2;
+    a.cLog2C = l2;
+    dim3 grid((unsigned)(a.tiles_m * a.tiles_n));
+    if (dtype == HGR_BF16) hipLaunchKernelGGL((gemm_nt_128<HGR_BF16, HGR_EPI_BIAS_RELU, false, true>), grid, dim3(NT), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((gemm_nt_128<HGR_F16, HGR_EPI_BIAS_RELU, false, true>), grid, dim3(NT), 0, (hipStream_t)stream, a);
+    HGR_CHECK_LAUNCH("hgr_conv3x3_nhwc");
     return HGR_OK;
 }

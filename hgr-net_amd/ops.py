@@ -8,7 +8,8 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import EPI_BIAS, EPI_BIAS_QUICKGELU, EPI_BIAS_RESIDUAL, EPI_NONE, HGR_BF16, HGR_F16
+from ._lib import (EPI_BIAS, EPI_BIAS_ADD16_RELU, EPI_BIAS_QUICKGELU, EPI_BIAS_RELU, EPI_BIAS_RESIDUAL, EPI_NONE, HGR_BF16,
+                   HGR_F16)
 
 # when a list, every gemm_nt call appends (name, start_event, end_event, algorithmic flops, algorithmic bytes);
 # events are recorded on the launch stream (torch's current stream).  Used by bench.py's roofline pass only.
@@ -47,7 +48,7 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias: Optional[
     out32 = out.dtype == torch.float32
     assert out32 or out.dtype == a.dtype
     if residual is not None:
-        assert residual.dtype == torch.float32 and residual.stride(1) == 1
+        assert residual.stride(1) == 1 and residual.dtype == (a.dtype if epilogue == EPI_BIAS_ADD16_RELU else torch.float32)
     prof = PROFILE
     if prof is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -132,3 +133,35 @@ def level_argmax(logits: torch.Tensor, depth: torch.Tensor, n_levels: int, cols:
     top1 = torch.empty((rows, 1), dtype=torch.int32, device=logits.device) if want_top1 else None
     _lib.call("hgr_level_argmax", _dev(logits), logits.stride(0), _dev(cols), nc, _dev(depth), n_levels, _dev(out), _dev(top1), rows, _stream())
     return (out, top1) if want_top1 else out
+
+
+# ---- ModifiedResNet (RN) tower -------------------------------------------------------------------
+def conv3x3_nhwc(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out: torch.Tensor, b: int, h: int, wd: int, c: int,
+                 stride: int = 1) -> torch.Tensor:
+    """out NHWC = relu(conv3x3(x NHWC, pad 1) + bias); w [Cout, Kp] in (ky, kx, c) order (BN folded)."""
+    assert x.is_contiguous() and w.is_contiguous() and out.is_contiguous() and x.dtype == w.dtype == out.dtype
+    _lib.call("hgr_conv3x3_nhwc", _dev(x), _dev(w), _dev(bias), _dev(out), b, h, wd, c, w.shape[0], stride, w.shape[1],
+              DT_OF[x.dtype], _stream())
+    return out
+
+
+def stem_im2col(image: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    assert image.dtype == torch.float32 and image.is_contiguous() and out.is_contiguous() and out.shape[1] == 64
+    _lib.call("hgr_stem_im2col", _dev(image), _dev(out), image.shape[0], image.shape[2], DT_OF[out.dtype], _stream())
+    return out
+
+
+def avgpool2_nhwc(x: torch.Tensor, out: torch.Tensor, b: int, h: int, w: int, c: int) -> torch.Tensor:
+    _lib.call("hgr_avgpool2_nhwc", _dev(x), _dev(out), b, h, w, c, DT_OF[x.dtype], _stream())
+    return out
+
+
+def attnpool_tokens(x: torch.Tensor, pos: torch.Tensor, out: torch.Tensor, b: int, s: int, c: int) -> torch.Tensor:
+    _lib.call("hgr_attnpool_tokens", _dev(x), _dev(pos), _dev(out), b, s, c, DT_OF[x.dtype], _stream())
+    return out
+
+
+def attnpool_attend(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, b: int, l: int, heads: int) -> torch.Tensor:
+    assert q.dtype == torch.float32 and q.is_contiguous() and k.is_contiguous() and v.is_contiguous()
+    _lib.call("hgr_attnpool_attend", _dev(q), _dev(k), _dev(v), _dev(out), b, l, heads, DT_OF[k.dtype], _stream())
+    return out

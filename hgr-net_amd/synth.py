@@ -94,9 +94,13 @@ CLIP_CONFIGS: Dict[str, dict] = {
     "small-vit": dict(embed_dim=128, image_resolution=96, vision_layers=3, vision_width=256,
                       vision_patch_size=32, context_length=77, vocab_size=1024,
                       transformer_width=128, transformer_heads=2, transformer_layers=3),
-    "tiny-rn": dict(embed_dim=64, image_resolution=64, vision_layers=(1, 1, 1, 1), vision_width=16,
+    # RN widths must be real ones (64): the conv kernels need power-of-two channel counts >= 64 past the stem
+    "tiny-rn": dict(embed_dim=64, image_resolution=64, vision_layers=(1, 1, 1, 1), vision_width=64,
                     vision_patch_size=None, context_length=77, vocab_size=512,
                     transformer_width=64, transformer_heads=1, transformer_layers=2),
+    "small-rn": dict(embed_dim=128, image_resolution=96, vision_layers=(2, 1, 2, 1), vision_width=64,
+                     vision_patch_size=None, context_length=77, vocab_size=512,
+                     transformer_width=64, transformer_heads=1, transformer_layers=2),
 }
 
 

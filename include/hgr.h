@@ -37,7 +37,10 @@ typedef enum {
     HGR_EPI_NONE = 0,           /* C = A W^T                                                            */
     HGR_EPI_BIAS = 1,           /* C = A W^T + bias                  (nn.Linear; in_proj of MHA)        */
     HGR_EPI_BIAS_QUICKGELU = 2, /* C = g(A W^T + bias), g(x) = x*sigmoid(1.702x)  (clip/model.py:162-164,177-180) */
-    HGR_EPI_BIAS_RESIDUAL = 3   /* C = residual + A W^T + bias       (x + attn(..), x + mlp(..): clip/model.py:186-187) */
+    HGR_EPI_BIAS_RESIDUAL = 3,  /* C = residual + A W^T + bias       (x + attn(..), x + mlp(..): clip/model.py:186-187) */
+    HGR_EPI_BIAS_RELU = 4,      /* C = relu(A W^T + bias)            (conv + folded BN + ReLU: clip/model.py:43-44,137-138) */
+    HGR_EPI_BIAS_ADD16_RELU = 5 /* C = relu(A W^T + bias + identity) (bn3(conv3) ; out += identity ; relu: clip/model.py:46-52);
+                                   `residual` points at 16-bit values [M, ldr], 16-bit output only */
 } hgr_epilogue_t;
 
 int hgr_abi_version(void);
@@ -51,11 +54,12 @@ const char *hgr_last_error(void);
  * `feats @ zsl_weights.T` at model/clip_tree.py:331.
  *   A, W      16-bit (`dtype`), leading dimensions lda/ldw in elements, both K-contiguous ("NT")
  *   C         fp32 if out_f32 else 16-bit (`dtype`), leading dimension ldc
- *   bias      fp32 [N] or NULL;  residual fp32 [M, ldr] or NULL (may alias C when out_f32)
+ *   bias      fp32 [N] or NULL;  residual fp32 [M, ldr] (16-bit for HGR_EPI_BIAS_ADD16_RELU) or NULL;
+ *             may alias C when element sizes match
  * Requirements: K % 64 == 0; lda, ldw % 8 == 0; A, W 16-byte aligned; M, N >= 1.
  */
 int hgr_gemm_nt(const void *A, int64_t lda, const void *W, int64_t ldw, void *C, int64_t ldc,
-                const float *bias, const float *residual, int64_t ldr,
+                const float *bias, const void *residual, int64_t ldr,
                 int M, int N, int K, int dtype, int epilogue, int out_f32, void *stream);
 
 /*
@@ -132,6 +136,48 @@ int hgr_topk_rows(const float *logits, int64_t ld, const int32_t *cols, int n_co
  */
 int hgr_level_argmax(const float *logits, int64_t ld, const int32_t *cols, int n_cols,
                      const int32_t *depth, int n_levels, int32_t *out, int32_t *out_top1, int rows, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * ModifiedResNet (RN50) tower, clip/model.py:93-150.  Activations are NHWC 16-bit ([B, H, W, C] =
+ * a row-major [B*H*W, C] matrix), so every 1x1 convolution IS hgr_gemm_nt; inference BatchNorm
+ * (the model is always in eval(): model/clip_tree.py:46) is folded into the weights and a bias.
+ * ------------------------------------------------------------------------------------------------ */
+
+/*
+ * 3x3 convolution, padding 1, stride 1 or 2, + folded BN + ReLU as an IMPLICIT GEMM
+ * (conv2 of every Bottleneck and the stem's conv2/conv3: clip/model.py:20-21,43,106-109).
+ *   x   NHWC 16-bit [B, H, W, C], C a power of two >= 8
+ *   w   16-bit [Cout, Kp], K order (ky, kx, c) = weight.permute(0,2,3,1).reshape(Cout, 9C), zero
+ *       padded to Kp (multiple of 64);  bias fp32 [Cout];  out NHWC 16-bit [B, Ho, Wo, Cout]
+ * No im2col buffer: the LDS-DMA loader gathers the taps, out-of-bounds taps read a zero page.
+ */
+int hgr_conv3x3_nhwc(const void *x, const void *w, const float *bias, void *out,
+                     int B, int H, int W, int C, int Cout, int stride, int Kp, int dtype, void *stream);
+
+/*
+ * im2col of the stem's first convolution (3 -> width/2 channels, 3x3, stride 2, pad 1,
+ * clip/model.py:105) straight from the fp32 NCHW image: out 16-bit [B*Ho*Wo, 64], K order
+ * (ky, kx, c), 27 values + zero padding.  Followed by hgr_gemm_nt with HGR_EPI_BIAS_RELU.
+ */
+int hgr_stem_im2col(const float *image, void *out, int B, int R, int dtype, void *stream);
+
+/* 2x2 average pooling, stride 2 (nn.AvgPool2d(2): clip/model.py:22,34,111), NHWC 16-bit, C % 8 == 0. */
+int hgr_avgpool2_nhwc(const void *x, void *out, int B, int H, int W, int C, int dtype, void *stream);
+
+/*
+ * AttentionPool2d token assembly (clip/model.py:66-69): tokens[b, 0] = mean over the S*S cells,
+ * tokens[b, 1 + i] = cell i; + positional_embedding.  x NHWC 16-bit [B, S, S, C]; pos fp32
+ * [S*S + 1, C]; out 16-bit [B*(S*S+1), C].  C % 8 == 0.
+ */
+int hgr_attnpool_tokens(const void *x, const float *pos, void *out, int B, int S, int C, int dtype, void *stream);
+
+/*
+ * AttentionPool2d attention for the ONLY query that is used, token 0 (the module returns x[0],
+ * clip/model.py:90): out[b, h*64 + d] = sum_j softmax_j(q[b,h] . k[b,j,h] / 8) v[b,j,h,d].
+ *   q fp32 [B, E] (projected mean token), k, v 16-bit [B*L, E], out 16-bit [B, E]; E = heads*64, L <= 64.
+ */
+int hgr_attnpool_attend(const float *q, const void *k, const void *v, void *out, int B, int L, int heads,
+                        int dtype, void *stream);
 
 #ifdef __cplusplus
 }

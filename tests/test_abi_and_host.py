@@ -38,7 +38,7 @@ def test_product_path_has_no_cpu_fallback():
     with pytest.raises(HgrError):
         model.encode_text(synth.make_tokens(2, 11, 512))
     rn = build_model(synth.clip_state_dict("tiny-rn", 0))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(HgrError):
         rn.encode_image(synth.images(1, 64, 0))
 
 

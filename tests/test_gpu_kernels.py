@@ -207,3 +207,77 @@ def test_level_argmax_exact(n, levels):
             same = [int(i) for i in np.nonzero(depth == l)[0]]
             want = tree_ref.level_argmax(lg.numpy(), tr, same, n)
             assert np.array_equal(got[:, l], want), (l, cols is None)
+
+
+# ---- ModifiedResNet kernels ------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("b,h,w,c,cout,stride", [(2, 8, 8, 64, 64, 1), (1, 7, 9, 32, 32, 1), (3, 14, 14, 128, 128, 1),
+                                                  (2, 16, 16, 8, 16, 1), (2, 12, 12, 64, 128, 2), (1, 5, 5, 512, 512, 1)])
+def test_conv3x3_implicit_gemm_vs_conv2d(dt, b, h, w, c, cout, stride):
+    x = _rand((b, c, h, w), 60).to(dt)                       # NCHW reference layout
+    wt = _rand((cout, c, 3, 3), 61, (2.0 / (9 * c)) ** 0.5).to(dt)
+    bias = _rand((cout,), 62, 0.1)
+    ref = torch.relu(torch.nn.functional.conv2d(x.float(), wt.float(), bias, stride=stride, padding=1))
+    ho, wo = ref.shape[2], ref.shape[3]
+    k = 9 * c
+    kp = (k + 63) // 64 * 64
+    w2 = torch.zeros(cout, kp, dtype=dt)
+    w2[:, :k] = wt.permute(0, 2, 3, 1).reshape(cout, k)
+    xn = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    out = torch.empty(b * ho * wo, cout, dtype=dt, device=DEV)
+    ops.conv3x3_nhwc(xn, w2.to(DEV), bias.to(DEV), out, b, h, w, c, stride)
+    got = out.float().cpu().view(b, ho, wo, cout).permute(0, 3, 1, 2)
+    tol = 3e-2 if dt == torch.bfloat16 else 4e-3
+    assert (got - ref).abs().max() < tol * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_gemm_relu_epilogues(dt):
+    m, n, k = 260, 192, 128
+    a, w = _rand((m, k), 63).to(dt), _rand((n, k), 64, 0.1).to(dt)
+    bias, idn = _rand((n,), 65), _rand((m, n), 66).to(dt)
+    base = a.float() @ w.float().t() + bias
+    tol = dict(rtol=1e-2, atol=2e-2) if dt == torch.bfloat16 else dict(rtol=2e-3, atol=3e-3)
+    out = torch.empty(m, n, dtype=dt, device=DEV)
+    ops.gemm_nt(a.to(DEV), w.to(DEV), out, bias=bias.to(DEV), epilogue=4)
+    assert torch.allclose(out.float().cpu(), torch.relu(base), **tol)
+    ops.gemm_nt(a.to(DEV), w.to(DEV), out, bias=bias.to(DEV), residual=idn.to(DEV), epilogue=5)
+    assert torch.allclose(out.float().cpu(), torch.relu(base + idn.float()), **tol)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_stem_im2col_avgpool_attnpool(dt):
+    b, r = 2, 20
+    img = _rand((b, 3, r, r), 67)
+    ho = (r - 1) // 2 + 1
+    col = torch.full((b * ho * ho, 64), 5.0, dtype=dt, device=DEV)
+    ops.stem_im2col(img.to(DEV), col)
+    unf = torch.nn.functional.unfold(img, 3, padding=1, stride=2)          # [b, c*9, L] in (c, ky, kx) order
+    ref = unf.view(b, 3, 9, ho * ho).permute(0, 3, 2, 1).reshape(b * ho * ho, 27).to(dt)   # -> (ky, kx, c)
+    assert torch.equal(col[:, :27].cpu(), ref) and (col[:, 27:] == 0).all()
+    # 2x2 average pool, NHWC
+    h, w, c = 6, 10, 24
+    x = _rand((b, h, w, c), 68).to(dt)
+    out = torch.empty(b, h // 2, w // 2, c, dtype=dt, device=DEV)
+    ops.avgpool2_nhwc(x.to(DEV), out, b, h, w, c)
+    ref = torch.nn.functional.avg_pool2d(x.float().permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+    assert (out.float().cpu() - ref).abs().max() < (2e-2 if dt == torch.bfloat16 else 2e-3)
+    # attention pool: tokens and the single-query attention vs the oracle's arithmetic
+    s, e, heads = 3, 128, 2
+    l = s * s + 1
+    xx = _rand((b, s, s, e), 69).to(dt)
+    pos = _rand((l, e), 70, 0.1)
+    tok = torch.empty(b * l, e, dtype=dt, device=DEV)
+    ops.attnpool_tokens(xx.to(DEV), pos.to(DEV), tok, b, s, e)
+    cells = xx.float().view(b, s * s, e)
+    tref = torch.cat([cells.mean(1, keepdim=True), cells], 1) + pos
+    assert (tok.float().cpu().view(b, l, e) - tref).abs().max() < (3e-2 if dt == torch.bfloat16 else 3e-3)
+    q = _rand((b, e), 71)
+    k16, v16 = _rand((b * l, e), 72).to(dt), _rand((b * l, e), 73).to(dt)
+    o = torch.empty(b, e, dtype=dt, device=DEV)
+    ops.attnpool_attend(q.to(DEV), k16.to(DEV), v16.to(DEV), o, b, l, heads)
+    qh = q.view(b, 1, heads, 64).transpose(1, 2)
+    kh = k16.float().view(b, l, heads, 64).transpose(1, 2)
+    vh = v16.float().view(b, l, heads, 64).transpose(1, 2)
+    oref = (torch.softmax(qh @ kh.transpose(-1, -2) * 0.125, -1) @ vh).transpose(1, 2).reshape(b, e)
+    assert (o.float().cpu() - oref).abs().max() < (2e-2 if dt == torch.bfloat16 else 2e-3)

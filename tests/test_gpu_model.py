@@ -27,7 +27,7 @@ def _cfg(z):
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
-@pytest.mark.parametrize("case", ["tiny-vit", "small-vit", "ViT-B_32"])
+@pytest.mark.parametrize("case", ["tiny-vit", "small-vit", "ViT-B_32", "tiny-rn", "small-rn", "RN50"])
 def test_towers_vs_reference_fixture(case, dt, golden_dir):
     z = np.load(golden_dir / f"clip_{case}.npz")
     cfg = _cfg(z)
@@ -84,7 +84,7 @@ LOGIT_TOL = {"f16": 1e-3, "bf16": 2.5e-3}
 
 
 @pytest.mark.parametrize("idt", ["f16", "bf16"])
-@pytest.mark.parametrize("case", ["tinyvit_n90", "smallvit_n300"])
+@pytest.mark.parametrize("case", ["tinyvit_n90", "smallvit_n300", "tinyrn_n64"])
 def test_tree_model_forward_and_metrics_vs_reference(case, idt, golden_dir, tmp_path):
     meta, z, cfg, edges = _tree_case(case, golden_dir)
     sd = synth.clip_state_dict(cfg, 0)

@@ -223,6 +223,7 @@ def main():
         clip_fixture(ref_clip, "tiny-vit", C["tiny-vit"], 4, 6, tmp)
         clip_fixture(ref_clip, "small-vit", C["small-vit"], 3, 5, tmp)
         clip_fixture(ref_clip, "tiny-rn", C["tiny-rn"], 3, 4, tmp)
+        clip_fixture(ref_clip, "small-rn", C["small-rn"], 3, 4, tmp)
         if not a.skip_big:
             clip_fixture(ref_clip, "ViT-B/32", C["ViT-B/32"], 2, 8, tmp)
             clip_fixture(ref_clip, "RN50", C["RN50"], 2, 2, tmp)
