@@ -9,9 +9,9 @@
 
 namespace {
 
-constexpr int MAXV = 16;   // float4 per lane -> W <= 4096
+constexpr int MAXV = 16;   // float4 per lane -> W <= 4096 (kernels are instantiated for 1, 2, 4, 8, 16 so narrow rows keep full occupancy)
 
-template <int DT, bool OUT32>
+template <int DT, bool OUT32, int NV>
 __global__ __launch_bounds__(256) void layernorm_rows(const float *__restrict__ x, const float *__restrict__ gamma,
                                                       const float *__restrict__ beta, void *__restrict__ y,
                                                       int rows, int W, int64_t row_mul, const int32_t *__restrict__ row_idx, float eps) {
@@ -21,10 +21,10 @@ __global__ __launch_bounds__(256) void layernorm_rows(const float *__restrict__ 
     const int64_t src = (int64_t)row * row_mul + (row_idx ? row_idx[row] : 0);
     const f32x4 *xr = (const f32x4 *)(x + src * W);
     const int nv = W >> 2;
-    f32x4 v[MAXV];
+    f32x4 v[NV];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = i * 64 + lane;
         if (i * 64 < nv) {
             v[i] = (c < nv) ? xr[c] : (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void layernorm_rows(const float *__restrict__ 
     const float mean = wave_sum(s) / (float)W;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = i * 64 + lane;
         if (i * 64 < nv && c < nv) {
 #pragma unroll
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void layernorm_rows(const float *__restrict__ 
     const float rstd = rsqrtf(wave_sum(q) / (float)W + eps);
     const f32x4 *gv = (const f32x4 *)gamma, *bv = (const f32x4 *)beta;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = i * 64 + lane;
         if (i * 64 < nv && c < nv) {
             const f32x4 ga = gv[c], be = bv[c];
@@ -58,6 +58,7 @@ __global__ __launch_bounds__(256) void layernorm_rows(const float *__restrict__ 
 }
 
 // x[b*L + t] = LN((t == 0 ? cls : patches[b*G + t-1]) + pos[t])
+template <int NV>
 __global__ __launch_bounds__(256) void vit_embed_ln(const float *__restrict__ patches, const float *__restrict__ cls,
                                                     const float *__restrict__ pos, const float *__restrict__ gamma,
                                                     const float *__restrict__ beta, float *__restrict__ x,
@@ -70,10 +71,10 @@ __global__ __launch_bounds__(256) void vit_embed_ln(const float *__restrict__ pa
     const f32x4 *src = (const f32x4 *)(t == 0 ? cls : patches + ((int64_t)b * G + (t - 1)) * W);
     const f32x4 *pr = (const f32x4 *)(pos + (int64_t)t * W);
     const int nv = W >> 2;
-    f32x4 v[MAXV];
+    f32x4 v[NV];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = i * 64 + lane;
         if (i * 64 < nv) {
             v[i] = (c < nv) ? (src[c] + pr[c]) : (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(256) void vit_embed_ln(const float *__restrict__ pa
     const float mean = wave_sum(s) / (float)W;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = i * 64 + lane;
         if (i * 64 < nv && c < nv) {
 #pragma unroll
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(256) void vit_embed_ln(const float *__restrict__ pa
     const f32x4 *gv = (const f32x4 *)gamma, *bv = (const f32x4 *)beta;
     f32x4 *out = (f32x4 *)(x + (int64_t)row * W);
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = i * 64 + lane;
         if (i * 64 < nv && c < nv) {
             const f32x4 ga = gv[c], be = bv[c];
@@ -106,17 +107,17 @@ __global__ __launch_bounds__(256) void vit_embed_ln(const float *__restrict__ pa
     }
 }
 
-template <int DT>
+template <int DT, int NV>
 __global__ __launch_bounds__(256) void l2norm_rows(const float *__restrict__ x, void *__restrict__ y16, float *__restrict__ y32, int rows, int D) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const f32x4 *xr = (const f32x4 *)(x + (int64_t)row * D);
     const int nv = D >> 2;
-    f32x4 v[MAXV];
+    f32x4 v[NV];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = i * 64 + lane;
         if (i * 64 < nv) {
             v[i] = (c < nv) ? xr[c] : (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(256) void l2norm_rows(const float *__restrict__ x, 
     }
     const float inv = 1.0f / sqrtf(wave_sum(s));
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = i * 64 + lane;
         if (i * 64 < nv && c < nv) {
             const f32x4 o = v[i] * inv;
@@ -146,9 +147,15 @@ extern "C" int hgr_layernorm(const float *x, const float *gamma, const float *be
     HGR_REQUIRE(row_mul >= 1, "hgr_layernorm: row_mul must be >= 1");
     dim3 grid((rows + 3) / 4), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (out_f32) hipLaunchKernelGGL((layernorm_rows<HGR_BF16, true>), grid, block, 0, s, x, gamma, beta, y, rows, W, row_mul, row_idx, eps);
-    else if (dtype == HGR_BF16) hipLaunchKernelGGL((layernorm_rows<HGR_BF16, false>), grid, block, 0, s, x, gamma, beta, y, rows, W, row_mul, row_idx, eps);
-    else hipLaunchKernelGGL((layernorm_rows<HGR_F16, false>), grid, block, 0, s, x, gamma, beta, y, rows, W, row_mul, row_idx, eps);
+#define HGR_LN(NVV)                                                                                                          \
+    do {                                                                                                                     \
+        if (out_f32) hipLaunchKernelGGL((layernorm_rows<HGR_BF16, true, NVV>), grid, block, 0, s, x, gamma, beta, y, rows, W, row_mul, row_idx, eps); \
+        else if (dtype == HGR_BF16) hipLaunchKernelGGL((layernorm_rows<HGR_BF16, false, NVV>), grid, block, 0, s, x, gamma, beta, y, rows, W, row_mul, row_idx, eps); \
+        else hipLaunchKernelGGL((layernorm_rows<HGR_F16, false, NVV>), grid, block, 0, s, x, gamma, beta, y, rows, W, row_mul, row_idx, eps); \
+    } while (0)
+    const int nvl = (W / 4 + 63) / 64;
+    if (nvl <= 1) HGR_LN(1); else if (nvl <= 2) HGR_LN(2); else if (nvl <= 4) HGR_LN(4); else if (nvl <= 8) HGR_LN(8); else HGR_LN(16);
+#undef HGR_LN
     HGR_CHECK_LAUNCH("hgr_layernorm");
     return HGR_OK;
 }
@@ -160,8 +167,10 @@ extern "C" int hgr_vit_embed_ln(const float *patches, const float *class_embeddi
     HGR_REQUIRE(hgr_aligned(patches, 16) && hgr_aligned(class_embedding, 16) && hgr_aligned(positional_embedding, 16) &&
                 hgr_aligned(gamma, 16) && hgr_aligned(beta, 16) && hgr_aligned(x, 16), "hgr_vit_embed_ln: operands must be 16-byte aligned");
     const int rows = B * (G + 1);
-    hipLaunchKernelGGL(vit_embed_ln, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, patches, class_embedding,
-                       positional_embedding, gamma, beta, x, B, G, W, eps);
+#define HGR_VE(NVV) hipLaunchKernelGGL((vit_embed_ln<NVV>), dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, patches, class_embedding, positional_embedding, gamma, beta, x, B, G, W, eps)
+    const int nvl = (W / 4 + 63) / 64;
+    if (nvl <= 1) HGR_VE(1); else if (nvl <= 2) HGR_VE(2); else if (nvl <= 4) HGR_VE(4); else if (nvl <= 8) HGR_VE(8); else HGR_VE(16);
+#undef HGR_VE
     HGR_CHECK_LAUNCH("hgr_vit_embed_ln");
     return HGR_OK;
 }
@@ -172,8 +181,14 @@ extern "C" int hgr_l2norm_rows(const float *x, void *y16, float *y32, int rows, 
     HGR_REQUIRE(hgr_aligned(x, 16) && hgr_aligned(y16, 8) && hgr_aligned(y32, 16), "hgr_l2norm_rows: misaligned operand");
     HGR_REQUIRE(dtype == HGR_BF16 || dtype == HGR_F16, "hgr_l2norm_rows: bad dtype %d", dtype);
     dim3 grid((rows + 3) / 4), block(256);
-    if (dtype == HGR_BF16) hipLaunchKernelGGL((l2norm_rows<HGR_BF16>), grid, block, 0, (hipStream_t)stream, x, y16, y32, rows, D);
-    else hipLaunchKernelGGL((l2norm_rows<HGR_F16>), grid, block, 0, (hipStream_t)stream, x, y16, y32, rows, D);
+#define HGR_L2(NVV)                                                                                                    \
+    do {                                                                                                               \
+        if (dtype == HGR_BF16) hipLaunchKernelGGL((l2norm_rows<HGR_BF16, NVV>), grid, block, 0, (hipStream_t)stream, x, y16, y32, rows, D); \
+        else hipLaunchKernelGGL((l2norm_rows<HGR_F16, NVV>), grid, block, 0, (hipStream_t)stream, x, y16, y32, rows, D); \
+    } while (0)
+    const int nvl = (D / 4 + 63) / 64;
+    if (nvl <= 1) HGR_L2(1); else if (nvl <= 2) HGR_L2(2); else if (nvl <= 4) HGR_L2(4); else if (nvl <= 8) HGR_L2(8); else HGR_L2(16);
+#undef HGR_L2
     HGR_CHECK_LAUNCH("hgr_l2norm_rows");
     return HGR_OK;
 }
