@@ -16,7 +16,7 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("HGR_LIB", _HERE / "lib" / "libhgr.so"))
 
 HGR_BF16, HGR_F16 = 0, 1
-EPI_NONE, EPI_BIAS, EPI_BIAS_QUICKGELU, EPI_BIAS_RESIDUAL, EPI_BIAS_RELU, EPI_BIAS_ADD16_RELU = 0, 1, 2, 3, 4, 5
+EPI_NONE, EPI_BIAS, EPI_BIAS_QUICKGELU, EPI_BIAS_RESIDUAL, EPI_BIAS_RELU, EPI_BIAS_ADD16_RELU, EPI_ACCUM = 0, 1, 2, 3, 4, 5, 6
 
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -37,6 +37,20 @@ SIGNATURES = {
     "hgr_avgpool2_nhwc": [_p, _p, _i, _i, _i, _i, _i, _p],
     "hgr_attnpool_tokens": [_p, _p, _p, _i, _i, _i, _i, _p],
     "hgr_attnpool_attend": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "hgr_transpose16": [_p, _l, _p, _l, _i, _i, _p],
+    "hgr_colsum": [_p, _l, _i, _i, _i, _i, _p, _i, _f, _p, _p],
+    "hgr_cast16": [_p, _p, _l, _i, _p],
+    "hgr_quickgelu16": [_p, _p, _p, _l, _i, _i, _p],
+    "hgr_layernorm_bwd": [_p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _l, _p, _f, _i, _p],
+    "hgr_layernorm_bwd_scratch_floats": [_i, _i],
+    "hgr_mha_bwd": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "hgr_ce_rows": [_p, _l, _p, _i, _i, _f, _p, _p, _l, _p],
+    "hgr_l2norm_bwd": [_p, _p, _p, _i, _i, _i, _p],
+    "hgr_matmul_f32": [_p, _l, _l, _p, _l, _l, _p, _l, _i, _i, _i, _f, _i, _p],
+    "hgr_embed_scatter_add": [_p, _l, _p, _p, _i, _i, _i, _i, _p],
+    "hgr_rows_axpy": [_p, _l, _p, _p, _i, _i, _f, _p],
+    "hgr_sumsq": [_p, _l, _p, _p],
+    "hgr_adamw": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _p, _f, _p],
 }
 
 
@@ -61,7 +75,7 @@ def load() -> C.CDLL:
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)            # AttributeError if the .so does not export a declared symbol
         fn.argtypes = argtypes
-        fn.restype = _i
+        fn.restype = _l if name.endswith("_scratch_floats") else _i
     if lib.hgr_abi_version() != 1:
         raise HgrError(f"libhgr.so ABI {lib.hgr_abi_version()} != 1")
     _lib = lib

@@ -62,7 +62,8 @@ template <int DT, int EPI, bool OUT32>
 __device__ __forceinline__ void store_quad(const GemmArgs &p, f32x4 v, int m, int n) {
     typedef typename T16<DT>::elem E;
     if (n + 3 < p.N && p.vec_ok) {
-        if (EPI != HGR_EPI_NONE) v += *(const f32x4 *)(p.bias + n);
+        if (EPI != HGR_EPI_NONE && EPI != HGR_EPI_ACCUM) v += *(const f32x4 *)(p.bias + n);
+        if (EPI == HGR_EPI_ACCUM) v += *(const f32x4 *)((const float *)p.C + (int64_t)m * p.ldc + n);
         if (EPI == HGR_EPI_BIAS_QUICKGELU) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
@@ -83,7 +84,8 @@ __device__ __forceinline__ void store_quad(const GemmArgs &p, f32x4 v, int m, in
     }
     for (int e = 0; e < 4 && n + e < p.N; ++e) {
         float x = v[e];
-        if (EPI != HGR_EPI_NONE) x += p.bias[n + e];
+        if (EPI != HGR_EPI_NONE && EPI != HGR_EPI_ACCUM) x += p.bias[n + e];
+        if (EPI == HGR_EPI_ACCUM) x += ((const float *)p.C)[(int64_t)m * p.ldc + n + e];
         if (EPI == HGR_EPI_BIAS_QUICKGELU) x = quick_gelu(x);
         if (EPI == HGR_EPI_BIAS_RESIDUAL) x += p.res[(int64_t)m * p.ldr + n + e];
         if (EPI == HGR_EPI_BIAS_ADD16_RELU) x += (float)((const E *)(const void *)p.res)[(int64_t)m * p.ldr + n + e];
@@ -448,7 +450,7 @@ __global__ __launch_bounds__(NT256) void gemm_nt_256(GemmArgs p) {
         for (int j = 0; j < 2; ++j) {
             const int n = n0 + wn * 64 + b * 32 + j * 16 + g * 4;
             bq[b][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (EPI != HGR_EPI_NONE) {
+            if (EPI != HGR_EPI_NONE && EPI != HGR_EPI_ACCUM) {
                 if (n + 3 < p.N) bq[b][j] = *(const f32x4 *)(p.bias + n);
                 else
                     for (int e = 0; e < 4; ++e) if (n + e < p.N) bq[b][j][e] = p.bias[n + e];
@@ -524,6 +526,7 @@ void launch_dt(const GemmArgs &a, int epi, bool out32, dim3 grid, hipStream_t s,
         case HGR_EPI_BIAS_QUICKGELU: launch_epi<DT, HGR_EPI_BIAS_QUICKGELU>(a, out32, grid, s, big); break;
         case HGR_EPI_BIAS_RELU: launch_epi<DT, HGR_EPI_BIAS_RELU>(a, out32, grid, s, big); break;
         case HGR_EPI_BIAS_ADD16_RELU: launch_epi<DT, HGR_EPI_BIAS_ADD16_RELU>(a, out32, grid, s, big); break;
+        case HGR_EPI_ACCUM: launch_epi<DT, HGR_EPI_ACCUM>(a, out32, grid, s, big); break;
         default: launch_epi<DT, HGR_EPI_BIAS_RESIDUAL>(a, out32, grid, s, big); break;
     }
 }
@@ -547,8 +550,9 @@ extern "C" int hgr_gemm_nt(const void *A, int64_t lda, const void *W, int64_t ld
     HGR_REQUIRE(hgr_aligned(A, 16) && hgr_aligned(W, 16), "hgr_gemm_nt: A and W must be 16-byte aligned");
     HGR_REQUIRE(ldc >= N, "hgr_gemm_nt: ldc=%lld < N=%d", (long long)ldc, N);
     HGR_REQUIRE(dtype == HGR_BF16 || dtype == HGR_F16, "hgr_gemm_nt: bad dtype %d", dtype);
-    HGR_REQUIRE(epilogue >= HGR_EPI_NONE && epilogue <= HGR_EPI_BIAS_ADD16_RELU, "hgr_gemm_nt: bad epilogue %d", epilogue);
-    HGR_REQUIRE(epilogue == HGR_EPI_NONE || bias, "hgr_gemm_nt: epilogue %d needs bias", epilogue);
+    HGR_REQUIRE(epilogue >= HGR_EPI_NONE && epilogue <= HGR_EPI_ACCUM, "hgr_gemm_nt: bad epilogue %d", epilogue);
+    HGR_REQUIRE(epilogue != HGR_EPI_ACCUM || out_f32, "hgr_gemm_nt: ACCUM accumulates into an fp32 C");
+    HGR_REQUIRE(epilogue == HGR_EPI_NONE || epilogue == HGR_EPI_ACCUM || bias, "hgr_gemm_nt: epilogue %d needs bias", epilogue);
     HGR_REQUIRE((epilogue != HGR_EPI_BIAS_RESIDUAL && epilogue != HGR_EPI_BIAS_ADD16_RELU) || (residual && ldr >= N), "hgr_gemm_nt: residual epilogue needs residual with ldr >= N");
     HGR_REQUIRE(epilogue != HGR_EPI_BIAS_ADD16_RELU || !out_f32, "hgr_gemm_nt: ADD16_RELU writes 16-bit output");
     HGR_REQUIRE(hgr_aligned(C, out_f32 ? 4 : 2), "hgr_gemm_nt: C misaligned");
@@ -574,7 +578,7 @@ extern "C" int hgr_gemm_nt(const void *A, int64_t lda, const void *W, int64_t ld
     // fetched ~once, the other one once per XCD.  Make the bigger operand the once-fetched one.
     a.m_fastest = ((int64_t)N * K > (int64_t)M * K) ? 1 : 0;
     bool vec = (ldc % 4 == 0) && hgr_aligned(C, out_f32 ? 16 : 8);
-    if (epilogue != HGR_EPI_NONE) vec = vec && hgr_aligned(bias, 16);
+    if (epilogue != HGR_EPI_NONE && epilogue != HGR_EPI_ACCUM) vec = vec && hgr_aligned(bias, 16);
     if (epilogue == HGR_EPI_BIAS_RESIDUAL) vec = vec && (ldr % 4 == 0) && hgr_aligned(residual, 16);
     if (epilogue == HGR_EPI_BIAS_ADD16_RELU) vec = vec && (ldr % 4 == 0) && hgr_aligned(residual, 8);
     a.vec_ok = vec ? 1 : 0;

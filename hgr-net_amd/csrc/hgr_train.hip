@@ -1,0 +1,571 @@
+// Backward / optimizer kernels of the OM training step (reference: model/clip_tree.py:222-281 `train_batch`,
+// main.py:86-94 clip_grad_norm_ + AdamW).  The heavy products reuse hgr_gemm_nt (dX = dY . W with the weight
+// pre-transposed, dW = dY^T . X on transposed activations with the fp32 accumulate epilogue); everything here
+// is the glue around them: streaming element-wise / row-wise kernels (HBM-bound) and small fp32 products.
+#include "hgr_common.h"
+
+namespace {
+
+unsigned grid1(int64_t total, int per = 256, int cap = 16384) { int64_t g = (total + per - 1) / per; return (unsigned)(g < cap ? (g > 0 ? g : 1) : cap); }
+
+// ---- y[c][r] = x[r][c], 16-bit, 64 x 64 tiles through LDS ------------------------------------------------
+__global__ __launch_bounds__(256) void transpose16(const unsigned short *__restrict__ x, int64_t ldx, unsigned short *__restrict__ y, int64_t ldy, int rows, int cols) {
+    __shared__ unsigned short t[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        t[i][tx] = (r < rows && c < cols) ? x[(int64_t)r * ldx + c] : (unsigned short)0;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < cols && r < rows) y[(int64_t)c * ldy + r] = t[tx][i];
+    }
+}
+
+// ---- column sums: partial[rb][c] = sum over a 512-row band, then out[c] (+)= sum_rb partial ----------------
+template <int DT, bool F32>
+__global__ __launch_bounds__(256) void colsum_partial(const void *__restrict__ x, int64_t ldx, int rows, int cols, float *__restrict__ partial) {
+    typedef typename T16<DT>::elem E;
+    __shared__ float s[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * 512, r1 = min(rows, r0 + 512);
+    float acc = 0.f;
+    if (c < cols)
+        for (int r = r0 + q; r < r1; r += 4)
+            acc += F32 ? ((const float *)x)[(int64_t)r * ldx + c] : (float)((const E *)x)[(int64_t)r * ldx + c];
+    s[q][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (q == 0 && c < cols) partial[(int64_t)blockIdx.y * cols + c] = s[0][threadIdx.x] + s[1][threadIdx.x] + s[2][threadIdx.x] + s[3][threadIdx.x];
+}
+__global__ __launch_bounds__(256) void colsum_final(const float *__restrict__ partial, int nrb, int cols, float *__restrict__ out, int accumulate, float alpha) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float acc = 0.f;
+    for (int rb = 0; rb < nrb; ++rb) acc += partial[(int64_t)rb * cols + c];      // fixed order: bit-reproducible
+    out[c] = (accumulate ? out[c] : 0.f) + alpha * acc;
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void cast16(const float *__restrict__ x, typename T16<DT>::elem *__restrict__ y, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const f32x4 v = ((const f32x4 *)x)[i];
+        ((typename T16<DT>::vec4 *)y)[i] = cvt4<DT>(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// ---- QuickGELU forward / backward on 16-bit tensors (training keeps the pre-activation) ------------------
+__device__ __forceinline__ float sigm(float z) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z)); }
+template <int DT, bool BWD>
+__global__ __launch_bounds__(256) void gelu16(const typename T16<DT>::elem *__restrict__ a, const typename T16<DT>::elem *__restrict__ du,
+                                              typename T16<DT>::elem *__restrict__ out, int64_t n8) {
+    typedef typename T16<DT>::vec8 vec8;
+    typedef typename T16<DT>::elem E;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const vec8 av = ((const vec8 *)a)[i];
+        vec8 dv, o;
+        if (BWD) dv = ((const vec8 *)du)[i];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = (float)av[e], s = sigm(1.702f * x);
+            o[e] = BWD ? (E)((float)dv[e] * s * (1.0f + 1.702f * x * (1.0f - s))) : (E)(x * s);
+        }
+        ((vec8 *)out)[i] = o;
+    }
+}
+
+// ---- LayerNorm backward: dx[src] += dLN ; per-wave partial dgamma/dbeta rows (reduced by colsum) -----------
+template <int DT, bool DYF32, int NV>
+__global__ __launch_bounds__(256) void layernorm_bwd(const void *__restrict__ dy, const float *__restrict__ x, const float *__restrict__ gamma,
+                                                     float *__restrict__ dx, float *__restrict__ pg, float *__restrict__ pb,
+                                                     int rows, int W, int64_t row_mul, const int32_t *__restrict__ row_idx, float eps) {
+    typedef typename T16<DT>::elem E;
+    const int lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+    const int nv = W >> 2;
+    f32x4 ag[NV], ab[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { ag[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; ab[i] = ag[i]; }
+    for (int row = wid; row < rows; row += nw) {
+        const int64_t src = (int64_t)row * row_mul + (row_idx ? row_idx[row] : 0);
+        const f32x4 *xr = (const f32x4 *)(x + src * W);
+        f32x4 v[NV], g[NV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = i * 64 + lane;
+            v[i] = (c < nv) ? xr[c] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        }
+        const float mean = wave_sum(s) / (float)W;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = i * 64 + lane;
+            if (c < nv)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+        }
+        const float rstd = rsqrtf(wave_sum(q) / (float)W + eps);
+        // g = dy * gamma ; xhat = (x - mean) * rstd ; dx = rstd * (g - mean(g) - xhat * mean(g * xhat))
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = i * 64 + lane;
+            g[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (c < nv) {
+                f32x4 d;
+                if (DYF32) d = ((const f32x4 *)((const float *)dy + (int64_t)row * W))[c];
+                else {
+                    const typename T16<DT>::vec4 d16 = ((const typename T16<DT>::vec4 *)((const E *)dy + (int64_t)row * W))[c];
+                    d = (f32x4){(float)d16[0], (float)d16[1], (float)d16[2], (float)d16[3]};
+                }
+                const f32x4 ga = ((const f32x4 *)gamma)[c];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xh = (v[i][e] - mean) * rstd;
+                    ag[i][e] += d[e] * xh;
+                    ab[i][e] += d[e];
+                    g[i][e] = d[e] * ga[e];
+                    sg += g[i][e];
+                    sgx += g[i][e] * xh;
+                    v[i][e] = xh;
+                }
+            }
+        }
+        const float mg = wave_sum(sg) / (float)W, mgx = wave_sum(sgx) / (float)W;
+        f32x4 *dxr = (f32x4 *)(dx + src * W);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = i * 64 + lane;
+            if (c < nv) {
+                f32x4 o = dxr[c];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] += rstd * (g[i][e] - mg - v[i][e] * mgx);
+                dxr[c] = o;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = i * 64 + lane;
+        if (c < nv) {
+            ((f32x4 *)(pg + (int64_t)wid * W))[c] = ag[i];
+            ((f32x4 *)(pb + (int64_t)wid * W))[c] = ab[i];
+        }
+    }
+}
+
+// ---- attention backward, L <= 64, d_head 64: one workgroup per (batch, head), fp32 VALU on LDS tiles ---------
+// S = QK^T/8 (+mask), P = softmax(S); dV = P^T dO; dP = dO V^T; dS = P (dP - rowsum(P dP)) / 8; dQ = dS K; dK = dS^T Q
+template <int DT, bool CAUSAL>
+__global__ __launch_bounds__(256) void mha_bwd64(const typename T16<DT>::elem *__restrict__ qkv, const typename T16<DT>::elem *__restrict__ dout,
+                                                 typename T16<DT>::elem *__restrict__ dqkv, int L, int H) {
+    typedef typename T16<DT>::elem E;
+    __shared__ float sQ[64][65], sK[64][65], sV[64][65], sO[64][65], sP[64][65];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    const int W = H * 64;
+    const int64_t ld = 3 * (int64_t)W;
+    const E *base = qkv + (int64_t)b * L * ld + h * 64;
+    const E *dob = dout + (int64_t)b * L * W + h * 64;
+    for (int i = tid; i < 64 * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        const bool ok = r < L;
+        sQ[r][c] = ok ? (float)base[r * ld + c] : 0.f;
+        sK[r][c] = ok ? (float)base[r * ld + W + c] : 0.f;
+        sV[r][c] = ok ? (float)base[r * ld + 2 * W + c] : 0.f;
+        sO[r][c] = ok ? (float)dob[(int64_t)r * W + c] : 0.f;
+    }
+    __syncthreads();
+    const int ti = (tid >> 4) * 4, tj = (tid & 15) * 4;        // this thread's 4 x 4 output block
+    float acc[4][4];
+    auto zero = [&]() {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[a][c] = 0.f;
+    };
+    // S[i][j] = sum_d Q[i][d] K[j][d]
+    zero();
+    for (int d = 0; d < 64; ++d) {
+        float qa[4], kb[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) { qa[a] = sQ[ti + a][d]; kb[a] = sK[tj + a][d]; }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[a][c] += qa[a] * kb[c];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int i = ti + a, j = tj + c;
+            sP[i][j] = (j >= L || (CAUSAL && j > i)) ? -INFINITY : acc[a][c] * 0.125f;
+        }
+    __syncthreads();
+    // row softmax: 4 threads per row
+    {
+        const int row = tid >> 2, part = tid & 3;
+        float mx = -INFINITY;
+        for (int j = part; j < 64; j += 4) mx = fmaxf(mx, sP[row][j]);
+        mx = fmaxf(mx, __shfl_xor(mx, 1)); mx = fmaxf(mx, __shfl_xor(mx, 2));
+        float sum = 0.f;
+        for (int j = part; j < 64; j += 4) { const float e = __expf(sP[row][j] - mx); sP[row][j] = e; sum += e; }
+        sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2);
+        const float inv = (row < L) ? 1.0f / sum : 0.f;          // padded query rows contribute nothing
+        for (int j = part; j < 64; j += 4) sP[row][j] *= inv;
+    }
+    __syncthreads();
+    // dV[j][d] = sum_i P[i][j] dO[i][d]   (thread block: j = ti.., d = tj..)
+    zero();
+    for (int i = 0; i < 64; ++i) {
+        float pa[4], ob[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) { pa[a] = sP[i][ti + a]; ob[a] = sO[i][tj + a]; }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[a][c] += pa[a] * ob[c];
+    }
+    E *dqb = dqkv + (int64_t)b * L * ld + h * 64;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+        if (ti + a < L)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dqb[(int64_t)(ti + a) * ld + 2 * W + tj + c] = (E)acc[a][c];
+    // dP[i][j] = sum_d dO[i][d] V[j][d]
+    zero();
+    for (int d = 0; d < 64; ++d) {
+        float oa[4], vb[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) { oa[a] = sO[ti + a][d]; vb[a] = sV[tj + a][d]; }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[a][c] += oa[a] * vb[c];
+    }
+    __syncthreads();                                   // everyone is done reading sO / sV as operands of dV, dP
+    // dS = P * (dP - rowsum(P * dP)) / 8 : row sums need all 16 column-threads of the row -> stage P*dP partials in sO
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        float part = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) part += sP[ti + a][tj + c] * acc[a][c];
+        sO[ti + a][tid & 15] = part;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        float rs = 0.f;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) rs += sO[ti + a][t];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[a][c] = sP[ti + a][tj + c] * (acc[a][c] - rs) * 0.125f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) sV[ti + a][tj + c] = acc[a][c];          // sV now holds dS[i][j]
+    __syncthreads();
+    // dQ[i][d] = sum_j dS[i][j] K[j][d]
+    zero();
+    for (int j = 0; j < 64; ++j) {
+        float sa[4], kb[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) { sa[a] = sV[ti + a][j]; kb[a] = sK[j][tj + a]; }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[a][c] += sa[a] * kb[c];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+        if (ti + a < L)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dqb[(int64_t)(ti + a) * ld + tj + c] = (E)acc[a][c];
+    // dK[j][d] = sum_i dS[i][j] Q[i][d]
+    zero();
+    for (int i = 0; i < 64; ++i) {
+        float sa[4], qb[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) { sa[a] = sV[i][ti + a]; qb[a] = sQ[i][tj + a]; }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[a][c] += sa[a] * qb[c];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+        if (ti + a < L)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dqb[(int64_t)(ti + a) * ld + W + tj + c] = (E)acc[a][c];
+}
+
+// ---- softmax cross-entropy over rows of fp32 logits: loss_row, dlogits = (softmax - onehot) * gscale ----------
+__global__ __launch_bounds__(256) void ce_rows(const float *__restrict__ logits, int64_t ld, const int32_t *__restrict__ labels, int rows, int n,
+                                               float gscale, float *__restrict__ loss_rows, float *__restrict__ dlogits, int64_t ldd) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *lr = logits + (int64_t)row * ld;
+    float mx = -INFINITY;
+    for (int j = lane; j < n; j += 64) mx = fmaxf(mx, lr[j]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < n; j += 64) sum += __expf(lr[j] - mx);
+    sum = wave_sum(sum);
+    const int lab = labels[row];
+    const float lse = mx + __logf(sum);
+    if (lane == 0) loss_rows[row] = lse - lr[lab];
+    if (dlogits)
+        for (int j = lane; j < n; j += 64) dlogits[(int64_t)row * ldd + j] = (__expf(lr[j] - lse) - (j == lab ? 1.f : 0.f)) * gscale;
+}
+
+// ---- y = x/|x| backward: dx (+)= (dy - y (y . dy)) / |x| -------------------------------------------------------
+__global__ __launch_bounds__(256) void l2norm_bwd(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ dx, int rows, int D, int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *xr = x + (int64_t)row * D, *dr = dy + (int64_t)row * D;
+    float ss = 0.f, sd = 0.f;
+    for (int j = lane; j < D; j += 64) { ss += xr[j] * xr[j]; sd += xr[j] * dr[j]; }
+    ss = wave_sum(ss); sd = wave_sum(sd);
+    const float inv = 1.0f / sqrtf(ss);
+    const float k = sd * inv * inv * inv;                 // (y . dy) / |x| * (1/|x|) with y = x / |x|
+    float *o = dx + (int64_t)row * D;
+    for (int j = lane; j < D; j += 64) o[j] = (accumulate ? o[j] : 0.f) + dr[j] * inv - xr[j] * k;
+}
+
+// ---- small fp32 product C[M,N] = alpha * sum_k A(m,k) B(k,n) (+ C), generic strides (any transposition) ----------
+__global__ __launch_bounds__(256) void matmul_f32(const float *__restrict__ A, int64_t sam, int64_t sak, const float *__restrict__ B, int64_t sbk, int64_t sbn,
+                                                  float *__restrict__ C, int64_t ldc, int M, int N, int K, float alpha, int accumulate) {
+    __shared__ float sA[32][33], sB[32][33];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        for (int i = threadIdx.x; i < 1024; i += 256) {
+            const int r = i >> 5, c = i & 31;
+            sA[r][c] = (m0 + r < M && k0 + c < K) ? A[(int64_t)(m0 + r) * sam + (int64_t)(k0 + c) * sak] : 0.f;
+            sB[r][c] = (k0 + r < K && n0 + c < N) ? B[(int64_t)(k0 + r) * sbk + (int64_t)(n0 + c) * sbn] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) {
+            const float a0 = sA[ty * 2][k], a1 = sA[ty * 2 + 1][k], b0 = sB[k][tx * 2], b1 = sB[k][tx * 2 + 1];
+            acc[0][0] += a0 * b0; acc[0][1] += a0 * b1; acc[1][0] += a1 * b0; acc[1][1] += a1 * b1;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int m = m0 + ty * 2 + a, n = n0 + tx * 2 + c;
+            if (m < M && n < N) C[(int64_t)m * ldc + n] = (accumulate ? C[(int64_t)m * ldc + n] : 0.f) + alpha * acc[a][c];
+        }
+}
+
+// ---- token-embedding gradient: table[token[i,t]] += dx[i*L+t] (fp32 atomics; repeated tokens contend) -------------
+__global__ __launch_bounds__(256) void embed_scatter_add(const int64_t *__restrict__ tokens, int64_t ldt, const float *__restrict__ dx, float *__restrict__ dtable,
+                                                         int n, int L, int W, int vocab) {
+    const int64_t total = (int64_t)n * L * W;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % W);
+        const int64_t row = i / W;
+        const int t = (int)(row % L);
+        int64_t id = tokens[(row / L) * ldt + t];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        atomicAdd(dtable + id * W + c, dx[i]);
+    }
+}
+
+// ---- sum of squares (global grad norm) and fused AdamW with the clip factor read from device memory -----------------
+__global__ __launch_bounds__(256) void sumsq(const float *__restrict__ x, int64_t n, float *__restrict__ out) {
+    __shared__ float s[4];
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) acc += x[i] * x[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, s[0] + s[1] + s[2] + s[3]);
+}
+// torch.optim.AdamW semantics: p *= 1 - lr*wd ; m, v EMA ; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps).
+// `sumsq_total` (may be NULL) holds the squared global grad norm: grads are scaled by min(1, max_norm/(norm+1e-6))
+// like torch.nn.utils.clip_grad_norm_ (main.py:88).
+__global__ __launch_bounds__(256) void adamw(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v, int64_t n,
+                                             float lr, float b1, float b2, float eps, float wd, float bc1, float bc2, const float *__restrict__ sumsq_total, float max_norm) {
+    float clip = 1.f;
+    if (sumsq_total) { const float norm = sqrtf(*sumsq_total); clip = fminf(1.f, max_norm / (norm + 1e-6f)); }
+    const float rs2 = rsqrtf(bc2);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float gi = g[i] * clip;
+        const float mi = b1 * m[i] + (1.f - b1) * gi, vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        p[i] = p[i] * (1.f - lr * wd) - (lr / bc1) * mi / (sqrtf(vi) * rs2 + eps);
+    }
+}
+
+// gather / scatter-add of rows (EOT rows, class-token rows): out[r] = x[r*mul + idx[r]] ; x[...] += in[r]
+__global__ __launch_bounds__(256) void rows_axpy(float *__restrict__ dst, int64_t dst_mul, const int32_t *__restrict__ dst_idx, const float *__restrict__ src, int rows, int W, float alpha) {
+    const int64_t total = (int64_t)rows * W;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int r = (int)(i / W), c = (int)(i % W);
+        const int64_t d = (int64_t)r * dst_mul + (dst_idx ? dst_idx[r] : 0);
+        dst[d * W + c] += alpha * src[i];
+    }
+}
+
+}  // namespace
+
+#define DT_OK(name) HGR_REQUIRE(dtype == HGR_BF16 || dtype == HGR_F16, name ": bad dtype %d", dtype)
+
+extern "C" int hgr_transpose16(const void *x, int64_t ldx, void *y, int64_t ldy, int rows, int cols, void *stream) {
+    HGR_REQUIRE(x && y && rows >= 1 && cols >= 1 && ldx >= cols && ldy >= rows, "hgr_transpose16: bad arguments");
+    hipLaunchKernelGGL(transpose16, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const unsigned short *)x, ldx, (unsigned short *)y, ldy, rows, cols);
+    HGR_CHECK_LAUNCH("hgr_transpose16");
+    return HGR_OK;
+}
+
+extern "C" int hgr_colsum(const void *x, int64_t ldx, int rows, int cols, int x_f32, int dtype, float *out, int accumulate, float alpha, float *scratch, void *stream) {
+    HGR_REQUIRE(x && out && scratch && rows >= 1 && cols >= 1 && ldx >= cols, "hgr_colsum: bad arguments");
+    DT_OK("hgr_colsum");
+    const int nrb = (rows + 511) / 512;
+    dim3 g((cols + 63) / 64, nrb);
+    hipStream_t s = (hipStream_t)stream;
+    if (x_f32) hipLaunchKernelGGL((colsum_partial<HGR_BF16, true>), g, dim3(256), 0, s, x, ldx, rows, cols, scratch);
+    else if (dtype == HGR_BF16) hipLaunchKernelGGL((colsum_partial<HGR_BF16, false>), g, dim3(256), 0, s, x, ldx, rows, cols, scratch);
+    else hipLaunchKernelGGL((colsum_partial<HGR_F16, false>), g, dim3(256), 0, s, x, ldx, rows, cols, scratch);
+    hipLaunchKernelGGL(colsum_final, dim3((cols + 255) / 256), dim3(256), 0, s, scratch, nrb, cols, out, accumulate, alpha);
+    HGR_CHECK_LAUNCH("hgr_colsum");
+    return HGR_OK;
+}
+
+extern "C" int hgr_cast16(const float *x, void *y, int64_t n, int dtype, void *stream) {
+    HGR_REQUIRE(x && y && n >= 4 && n % 4 == 0 && hgr_aligned(x, 16) && hgr_aligned(y, 8), "hgr_cast16: n %% 4 == 0 and aligned operands required");
+    DT_OK("hgr_cast16");
+    if (dtype == HGR_BF16) hipLaunchKernelGGL((cast16<HGR_BF16>), dim3(grid1(n / 4)), dim3(256), 0, (hipStream_t)stream, x, (__bf16 *)y, n / 4);
+    else hipLaunchKernelGGL((cast16<HGR_F16>), dim3(grid1(n / 4)), dim3(256), 0, (hipStream_t)stream, x, (_Float16 *)y, n / 4);
+    HGR_CHECK_LAUNCH("hgr_cast16");
+    return HGR_OK;
+}
+
+extern "C" int hgr_quickgelu16(const void *a, const void *du, void *out, int64_t n, int backward, int dtype, void *stream) {
+    HGR_REQUIRE(a && out && (!backward || du) && n >= 8 && n % 8 == 0 && hgr_aligned(a, 16) && hgr_aligned(out, 16) && hgr_aligned(du, 16), "hgr_quickgelu16: bad arguments");
+    DT_OK("hgr_quickgelu16");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 g(grid1(n / 8));
+    if (dtype == HGR_BF16) {
+        if (backward) hipLaunchKernelGGL((gelu16<HGR_BF16, true>), g, dim3(256), 0, s, (const __bf16 *)a, (const __bf16 *)du, (__bf16 *)out, n / 8);
+        else hipLaunchKernelGGL((gelu16<HGR_BF16, false>), g, dim3(256), 0, s, (const __bf16 *)a, (const __bf16 *)du, (__bf16 *)out, n / 8);
+    } else {
+        if (backward) hipLaunchKernelGGL((gelu16<HGR_F16, true>), g, dim3(256), 0, s, (const _Float16 *)a, (const _Float16 *)du, (_Float16 *)out, n / 8);
+        else hipLaunchKernelGGL((gelu16<HGR_F16, false>), g, dim3(256), 0, s, (const _Float16 *)a, (const _Float16 *)du, (_Float16 *)out, n / 8);
+    }
+    HGR_CHECK_LAUNCH("hgr_quickgelu16");
+    return HGR_OK;
+}
+
+extern "C" int hgr_layernorm_bwd(const void *dy, int dy_f32, const float *x, const float *gamma, float *dx, float *dgamma, float *dbeta, float *scratch,
+                                 int rows, int W, int64_t row_mul, const int32_t *row_idx, float eps, int dtype, void *stream) {
+    HGR_REQUIRE(dy && x && gamma && dx && dgamma && dbeta && scratch, "hgr_layernorm_bwd: null operand");
+    HGR_REQUIRE(rows >= 1 && W >= 4 && W % 4 == 0 && W <= 4096 && row_mul >= 1, "hgr_layernorm_bwd: rows=%d W=%d unsupported", rows, W);
+    DT_OK("hgr_layernorm_bwd");
+    const int blocks = rows < 4 * 512 ? (rows + 3) / 4 : 512;          // <= 2048 waves, each leaves one partial row
+    const int nw = blocks * 4;
+    float *pg = scratch, *pb = scratch + (int64_t)nw * W;
+    float *cs = pb + (int64_t)nw * W;                                   // colsum scratch: ceil(nw/512) * W floats
+    hipStream_t s = (hipStream_t)stream;
+    const int nvl = (W / 4 + 63) / 64;
+#define HGR_LNB(NVV)                                                                                                             \
+    do {                                                                                                                         \
+        if (dy_f32) hipLaunchKernelGGL((layernorm_bwd<HGR_BF16, true, NVV>), dim3(blocks), dim3(256), 0, s, dy, x, gamma, dx, pg, pb, rows, W, row_mul, row_idx, eps); \
+        else if (dtype == HGR_BF16) hipLaunchKernelGGL((layernorm_bwd<HGR_BF16, false, NVV>), dim3(blocks), dim3(256), 0, s, dy, x, gamma, dx, pg, pb, rows, W, row_mul, row_idx, eps); \
+        else hipLaunchKernelGGL((layernorm_bwd<HGR_F16, false, NVV>), dim3(blocks), dim3(256), 0, s, dy, x, gamma, dx, pg, pb, rows, W, row_mul, row_idx, eps); \
+    } while (0)
+    if (nvl <= 1) HGR_LNB(1); else if (nvl <= 2) HGR_LNB(2); else if (nvl <= 4) HGR_LNB(4); else if (nvl <= 8) HGR_LNB(8); else HGR_LNB(16);
+#undef HGR_LNB
+    HGR_CHECK_LAUNCH("hgr_layernorm_bwd");
+    int rc = hgr_colsum(pg, W, nw, W, 1, HGR_BF16, dgamma, 1, 1.0f, cs, stream);
+    if (rc) return rc;
+    return hgr_colsum(pb, W, nw, W, 1, HGR_BF16, dbeta, 1, 1.0f, cs, stream);
+}
+
+extern "C" int64_t hgr_layernorm_bwd_scratch_floats(int rows, int W) {
+    const int blocks = rows < 4 * 512 ? (rows + 3) / 4 : 512;
+    const int64_t nw = (int64_t)blocks * 4;
+    return 2 * nw * W + ((nw + 511) / 512) * W;
+}
+
+extern "C" int hgr_mha_bwd(const void *qkv, const void *dout, void *dqkv, int B, int L, int heads, int causal, int dtype, void *stream) {
+    HGR_REQUIRE(qkv && dout && dqkv && B >= 1 && heads >= 1, "hgr_mha_bwd: bad arguments");
+    HGR_REQUIRE(L >= 1 && L <= 64, "hgr_mha_bwd: L=%d unsupported (this round: L <= 64)", L);
+    DT_OK("hgr_mha_bwd");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 g(B * heads);
+    if (dtype == HGR_BF16) {
+        if (causal) hipLaunchKernelGGL((mha_bwd64<HGR_BF16, true>), g, dim3(256), 0, s, (const __bf16 *)qkv, (const __bf16 *)dout, (__bf16 *)dqkv, L, heads);
+        else hipLaunchKernelGGL((mha_bwd64<HGR_BF16, false>), g, dim3(256), 0, s, (const __bf16 *)qkv, (const __bf16 *)dout, (__bf16 *)dqkv, L, heads);
+    } else {
+        if (causal) hipLaunchKernelGGL((mha_bwd64<HGR_F16, true>), g, dim3(256), 0, s, (const _Float16 *)qkv, (const _Float16 *)dout, (_Float16 *)dqkv, L, heads);
+        else hipLaunchKernelGGL((mha_bwd64<HGR_F16, false>), g, dim3(256), 0, s, (const _Float16 *)qkv, (const _Float16 *)dout, (_Float16 *)dqkv, L, heads);
+    }
+    HGR_CHECK_LAUNCH("hgr_mha_bwd");
+    return HGR_OK;
+}
+
+extern "C" int hgr_ce_rows(const float *logits, int64_t ld, const int32_t *labels, int rows, int n, float gscale, float *loss_rows, float *dlogits, int64_t ldd, void *stream) {
+    HGR_REQUIRE(logits && labels && loss_rows && rows >= 1 && n >= 1 && ld >= n && (!dlogits || ldd >= n), "hgr_ce_rows: bad arguments");
+    hipLaunchKernelGGL(ce_rows, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, ld, labels, rows, n, gscale, loss_rows, dlogits, ldd);
+    HGR_CHECK_LAUNCH("hgr_ce_rows");
+    return HGR_OK;
+}
+
+extern "C" int hgr_l2norm_bwd(const float *x, const float *dy, float *dx, int rows, int D, int accumulate, void *stream) {
+    HGR_REQUIRE(x && dy && dx && rows >= 1 && D >= 1, "hgr_l2norm_bwd: bad arguments");
+    hipLaunchKernelGGL(l2norm_bwd, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, dy, dx, rows, D, accumulate);
+    HGR_CHECK_LAUNCH("hgr_l2norm_bwd");
+    return HGR_OK;
+}
+
+extern "C" int hgr_matmul_f32(const float *A, int64_t sam, int64_t sak, const float *B, int64_t sbk, int64_t sbn, float *C, int64_t ldc,
+                              int M, int N, int K, float alpha, int accumulate, void *stream) {
+    HGR_REQUIRE(A && B && C && M >= 1 && N >= 1 && K >= 1 && ldc >= N, "hgr_matmul_f32: bad arguments");
+    hipLaunchKernelGGL(matmul_f32, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, (hipStream_t)stream, A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, alpha, accumulate);
+    HGR_CHECK_LAUNCH("hgr_matmul_f32");
+    return HGR_OK;
+}
+
+extern "C" int hgr_embed_scatter_add(const int64_t *tokens, int64_t ld_tokens, const float *dx, float *dtable, int n, int L, int W, int vocab, void *stream) {
+    HGR_REQUIRE(tokens && dx && dtable && n >= 1 && L >= 1 && W >= 1 && vocab >= 1 && ld_tokens >= L, "hgr_embed_scatter_add: bad arguments");
+    hipLaunchKernelGGL(embed_scatter_add, dim3(grid1((int64_t)n * L * W)), dim3(256), 0, (hipStream_t)stream, tokens, ld_tokens, dx, dtable, n, L, W, vocab);
+    HGR_CHECK_LAUNCH("hgr_embed_scatter_add");
+    return HGR_OK;
+}
+
+extern "C" int hgr_sumsq(const float *x, int64_t n, float *out, void *stream) {
+    HGR_REQUIRE(x && out && n >= 1, "hgr_sumsq: bad arguments");
+    hipLaunchKernelGGL(sumsq, dim3(grid1(n, 256, 1024)), dim3(256), 0, (hipStream_t)stream, x, n, out);
+    HGR_CHECK_LAUNCH("hgr_sumsq");
+    return HGR_OK;
+}
+
+extern "C" int hgr_adamw(float *p, const float *g, float *m, float *v, int64_t n, float lr, float beta1, float beta2, float eps, float wd,
+                         int step, const float *sumsq_total, float max_norm, void *stream) {
+    HGR_REQUIRE(p && g && m && v && n >= 1 && step >= 1, "hgr_adamw: bad arguments");
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adamw, dim3(grid1(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps, wd, bc1, bc2, sumsq_total, max_norm);
+    HGR_CHECK_LAUNCH("hgr_adamw");
+    return HGR_OK;
+}
+
+extern "C" int hgr_rows_axpy(float *dst, int64_t dst_mul, const int32_t *dst_idx, const float *src, int rows, int W, float alpha, void *stream) {
+    HGR_REQUIRE(dst && src && rows >= 1 && W >= 1 && dst_mul >= 1, "hgr_rows_axpy: bad arguments");
+    hipLaunchKernelGGL(rows_axpy, dim3(grid1((int64_t)rows * W)), dim3(256), 0, (hipStream_t)stream, dst, dst_mul, dst_idx, src, rows, W, alpha);
+    HGR_CHECK_LAUNCH("hgr_rows_axpy");
+    return HGR_OK;
+}

@@ -8,8 +8,8 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import (EPI_BIAS, EPI_BIAS_ADD16_RELU, EPI_BIAS_QUICKGELU, EPI_BIAS_RELU, EPI_BIAS_RESIDUAL, EPI_NONE, HGR_BF16,
-                   HGR_F16)
+from ._lib import (EPI_ACCUM, EPI_BIAS, EPI_BIAS_ADD16_RELU, EPI_BIAS_QUICKGELU, EPI_BIAS_RELU, EPI_BIAS_RESIDUAL, EPI_NONE,
+                   HGR_BF16, HGR_F16)
 
 # when a list, every gemm_nt call appends (name, start_event, end_event, algorithmic flops, algorithmic bytes);
 # events are recorded on the launch stream (torch's current stream).  Used by bench.py's roofline pass only.
@@ -165,3 +165,98 @@ def attnpool_attend(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torc
     assert q.dtype == torch.float32 and q.is_contiguous() and k.is_contiguous() and v.is_contiguous()
     _lib.call("hgr_attnpool_attend", _dev(q), _dev(k), _dev(v), _dev(out), b, l, heads, DT_OF[k.dtype], _stream())
     return out
+
+
+# ---- training: backward / optimizer ------------------------------------------------------------------
+def transpose16(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """out[c, r] = x[r, c]; out is [cols, ld >= rows] (its padding columns must already be zero)."""
+    assert x.dim() == 2 and out.dim() == 2 and x.stride(1) == 1 and out.stride(1) == 1 and x.element_size() == 2 and out.dtype == x.dtype
+    _lib.call("hgr_transpose16", _dev(x), x.stride(0), _dev(out), out.stride(0), x.shape[0], x.shape[1], _stream())
+    return out
+
+
+def colsum(x: torch.Tensor, out: torch.Tensor, scratch: torch.Tensor, accumulate: bool = True, alpha: float = 1.0) -> torch.Tensor:
+    assert x.dim() == 2 and x.stride(1) == 1 and out.dtype == torch.float32 and scratch.dtype == torch.float32
+    rows, cols = x.shape
+    assert scratch.numel() >= (rows + 511) // 512 * cols
+    f32 = x.dtype == torch.float32
+    _lib.call("hgr_colsum", _dev(x), x.stride(0), rows, cols, 1 if f32 else 0, HGR_BF16 if f32 else DT_OF[x.dtype], _dev(out),
+              1 if accumulate else 0, alpha, _dev(scratch), _stream())
+    return out
+
+
+def cast16(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    assert x.dtype == torch.float32 and x.is_contiguous() and out.is_contiguous() and x.numel() == out.numel()
+    _lib.call("hgr_cast16", _dev(x), _dev(out), x.numel(), DT_OF[out.dtype], _stream())
+    return out
+
+
+def quickgelu16(a: torch.Tensor, out: torch.Tensor, du: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """forward: out = a*sigmoid(1.702a); with du: out = du * g'(a)."""
+    assert a.is_contiguous() and out.is_contiguous() and (du is None or du.is_contiguous())
+    _lib.call("hgr_quickgelu16", _dev(a), _dev(du), _dev(out), a.numel(), 0 if du is None else 1, DT_OF[a.dtype], _stream())
+    return out
+
+
+def layernorm_bwd_scratch(rows: int, w: int) -> int:
+    return int(_lib.load().hgr_layernorm_bwd_scratch_floats(rows, w))
+
+
+def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, dx: torch.Tensor, dgamma: torch.Tensor, dbeta: torch.Tensor,
+                  scratch: torch.Tensor, rows: Optional[int] = None, row_mul: int = 1, row_idx: Optional[torch.Tensor] = None, eps: float = 1e-5) -> None:
+    """dx[src rows] += dLN; dgamma += ...; dbeta += ...  (all fp32, accumulate)."""
+    w = x.shape[-1]
+    rows = dy.shape[0] if rows is None else rows
+    f32 = dy.dtype == torch.float32
+    assert scratch.numel() >= layernorm_bwd_scratch(rows, w) and dy.is_contiguous()
+    _lib.call("hgr_layernorm_bwd", _dev(dy), 1 if f32 else 0, _dev(x), _dev(gamma), _dev(dx), _dev(dgamma), _dev(dbeta), _dev(scratch),
+              rows, w, row_mul, _dev(row_idx), eps, HGR_BF16 if f32 else DT_OF[dy.dtype], _stream())
+
+
+def mha_bwd(qkv: torch.Tensor, dout: torch.Tensor, dqkv: torch.Tensor, b: int, l: int, heads: int, causal: bool) -> torch.Tensor:
+    assert qkv.is_contiguous() and dout.is_contiguous() and dqkv.is_contiguous()
+    _lib.call("hgr_mha_bwd", _dev(qkv), _dev(dout), _dev(dqkv), b, l, heads, 1 if causal else 0, DT_OF[qkv.dtype], _stream())
+    return dqkv
+
+
+def ce_rows(logits: torch.Tensor, labels: torch.Tensor, loss_rows: torch.Tensor, dlogits: Optional[torch.Tensor] = None, gscale: float = 1.0) -> None:
+    assert logits.dtype == torch.float32 and logits.stride(1) == 1 and labels.dtype == torch.int32
+    _lib.call("hgr_ce_rows", _dev(logits), logits.stride(0), _dev(labels), logits.shape[0], logits.shape[1], gscale, _dev(loss_rows),
+              _dev(dlogits), dlogits.stride(0) if dlogits is not None else 0, _stream())
+
+
+def l2norm_bwd(x: torch.Tensor, dy: torch.Tensor, dx: torch.Tensor, accumulate: bool = False) -> torch.Tensor:
+    assert x.is_contiguous() and dy.is_contiguous() and dx.is_contiguous() and x.dtype == dy.dtype == dx.dtype == torch.float32
+    _lib.call("hgr_l2norm_bwd", _dev(x), _dev(dy), _dev(dx), x.shape[0], x.shape[1], 1 if accumulate else 0, _stream())
+    return dx
+
+
+def matmul_f32(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, alpha: float = 1.0, accumulate: bool = False) -> torch.Tensor:
+    """out[M,N] (+)= alpha * a[M,K] @ b[K,N] for fp32 2-D tensors with ARBITRARY strides (pass .t() views freely)."""
+    assert a.dtype == b.dtype == out.dtype == torch.float32 and out.stride(1) == 1 and a.shape[1] == b.shape[0]
+    m, k = a.shape
+    n = b.shape[1]
+    _lib.call("hgr_matmul_f32", _dev(a), a.stride(0), a.stride(1), _dev(b), b.stride(0), b.stride(1), _dev(out), out.stride(0), m, n, k,
+              alpha, 1 if accumulate else 0, _stream())
+    return out
+
+
+def embed_scatter_add(tokens: torch.Tensor, dx: torch.Tensor, dtable: torch.Tensor, l: int) -> None:
+    assert tokens.dtype == torch.int64 and tokens.stride(1) == 1 and dx.is_contiguous() and dtable.is_contiguous()
+    _lib.call("hgr_embed_scatter_add", _dev(tokens), tokens.stride(0), _dev(dx), _dev(dtable), tokens.shape[0], l, dtable.shape[1], dtable.shape[0], _stream())
+
+
+def rows_axpy(dst: torch.Tensor, src: torch.Tensor, dst_mul: int = 1, dst_idx: Optional[torch.Tensor] = None, alpha: float = 1.0) -> None:
+    assert dst.dtype == src.dtype == torch.float32 and src.is_contiguous() and dst.is_contiguous()
+    _lib.call("hgr_rows_axpy", _dev(dst), dst_mul, _dev(dst_idx), _dev(src), src.shape[0], src.shape[1], alpha, _stream())
+
+
+def sumsq(x: torch.Tensor, out: torch.Tensor) -> None:
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    _lib.call("hgr_sumsq", _dev(x), x.numel(), _dev(out), _stream())
+
+
+def adamw(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, lr: float, step: int, betas=(0.9, 0.999), eps: float = 1e-8,
+          wd: float = 0.0, sumsq_total: Optional[torch.Tensor] = None, max_norm: float = 1.0) -> None:
+    assert p.is_contiguous() and g.is_contiguous() and p.dtype == g.dtype == m.dtype == v.dtype == torch.float32
+    _lib.call("hgr_adamw", _dev(p), _dev(g), _dev(m), _dev(v), p.numel(), lr, betas[0], betas[1], eps, wd, step, _dev(sumsq_total), max_norm, _stream())

@@ -39,8 +39,9 @@ typedef enum {
     HGR_EPI_BIAS_QUICKGELU = 2, /* C = g(A W^T + bias), g(x) = x*sigmoid(1.702x)  (clip/model.py:162-164,177-180) */
     HGR_EPI_BIAS_RESIDUAL = 3,  /* C = residual + A W^T + bias       (x + attn(..), x + mlp(..): clip/model.py:186-187) */
     HGR_EPI_BIAS_RELU = 4,      /* C = relu(A W^T + bias)            (conv + folded BN + ReLU: clip/model.py:43-44,137-138) */
-    HGR_EPI_BIAS_ADD16_RELU = 5 /* C = relu(A W^T + bias + identity) (bn3(conv3) ; out += identity ; relu: clip/model.py:46-52);
+    HGR_EPI_BIAS_ADD16_RELU = 5,/* C = relu(A W^T + bias + identity) (bn3(conv3) ; out += identity ; relu: clip/model.py:46-52);
                                    `residual` points at 16-bit values [M, ldr], 16-bit output only */
+    HGR_EPI_ACCUM = 6           /* C += A W^T, fp32 C                (weight gradients dW += dY^T X of loss.backward(), clip_tree.py:276) */
 } hgr_epilogue_t;
 
 int hgr_abi_version(void);
@@ -178,6 +179,72 @@ int hgr_attnpool_tokens(const void *x, const float *pos, void *out, int B, int S
  */
 int hgr_attnpool_attend(const float *q, const void *k, const void *v, void *out, int B, int L, int heads,
                         int dtype, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * OM training step (model/clip_tree.py:222-281 `train_batch`, main.py:86-94): backward + optimizer.
+ * GEMM gradients reuse hgr_gemm_nt: dX = dY . W is an NT product against the pre-transposed weight,
+ * dW += dY^T . X an NT product of the transposed operands with HGR_EPI_ACCUM.  Parameter gradients are
+ * fp32 and ACCUMULATE (autograd `.grad +=` semantics, needed by the K.M inner `loss_j.backward()` calls).
+ * ------------------------------------------------------------------------------------------------ */
+
+/* y[c][r] = x[r][c] for 16-bit elements; ldy >= rows (columns r >= rows of y are left untouched). */
+int hgr_transpose16(const void *x, int64_t ldx, void *y, int64_t ldy, int rows, int cols, void *stream);
+
+/* out[c] = (accumulate ? out[c] : 0) + alpha * sum_r x[r][c]  (bias gradients, positional-embedding gradients).
+ * x is fp32 (x_f32) or 16-bit `dtype`; scratch >= ceil(rows/512) * cols floats; summation order is fixed. */
+int hgr_colsum(const void *x, int64_t ldx, int rows, int cols, int x_f32, int dtype, float *out, int accumulate,
+               float alpha, float *scratch, void *stream);
+
+/* y = (16-bit) x, n % 4 == 0. */
+int hgr_cast16(const float *x, void *y, int64_t n, int dtype, void *stream);
+
+/* QuickGELU on 16-bit tensors (clip/model.py:162-164): forward out = a*sigmoid(1.702a); backward out = du * g'(a). */
+int hgr_quickgelu16(const void *a, const void *du, void *out, int64_t n, int backward, int dtype, void *stream);
+
+/*
+ * LayerNorm backward (autograd of clip/model.py:153-159): dx[src(r)] += dLN(dy[r]); dgamma += sum_r dy*xhat;
+ * dbeta += sum_r dy.  dy 16-bit `dtype` or fp32 (dy_f32) [rows, W]; x fp32 (forward input); src(r) as in
+ * hgr_layernorm.  scratch >= hgr_layernorm_bwd_scratch_floats(rows, W) floats.  Bit-reproducible.
+ */
+int hgr_layernorm_bwd(const void *dy, int dy_f32, const float *x, const float *gamma, float *dx, float *dgamma,
+                      float *dbeta, float *scratch, int rows, int W, int64_t row_mul, const int32_t *row_idx,
+                      float eps, int dtype, void *stream);
+int64_t hgr_layernorm_bwd_scratch_floats(int rows, int W);
+
+/* Attention backward for hgr_mha (L <= 64 this round): dqkv [B*L, 3W] from qkv and dout [B*L, W], all 16-bit. */
+int hgr_mha_bwd(const void *qkv, const void *dout, void *dqkv, int B, int L, int heads, int causal, int dtype, void *stream);
+
+/*
+ * Row-wise softmax cross-entropy (nn.CrossEntropyLoss at clip_tree.py:49,275): loss_rows[r] = lse(logits[r]) -
+ * logits[r, labels[r]]; dlogits (optional) = (softmax - onehot) * gscale (gscale = weight / rows for the mean).
+ */
+int hgr_ce_rows(const float *logits, int64_t ld, const int32_t *labels, int rows, int n, float gscale,
+                float *loss_rows, float *dlogits, int64_t ldd, void *stream);
+
+/* Backward of y = x/|x| (clip_tree.py:225,262): dx (+)= (dy - y (y.dy)) / |x|, fp32 rows. */
+int hgr_l2norm_bwd(const float *x, const float *dy, float *dx, int rows, int D, int accumulate, void *stream);
+
+/* Small fp32 product with generic strides: C[m][n] (+)= alpha * sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn]
+ * (the [B, <=257] logits head and the two projections: tiny, kept in fp32 for the loss path). */
+int hgr_matmul_f32(const float *A, int64_t sam, int64_t sak, const float *B, int64_t sbk, int64_t sbn, float *C,
+                   int64_t ldc, int M, int N, int K, float alpha, int accumulate, void *stream);
+
+/* token_embedding gradient: dtable[tokens[i,t]] += dx[i*L + t] (fp32 atomics). */
+int hgr_embed_scatter_add(const int64_t *tokens, int64_t ld_tokens, const float *dx, float *dtable, int n, int L,
+                          int W, int vocab, void *stream);
+
+/* dst[(r*dst_mul + idx[r])] += alpha * src[r]  for W-wide fp32 rows (scatter of EOT / class-token row gradients). */
+int hgr_rows_axpy(float *dst, int64_t dst_mul, const int32_t *dst_idx, const float *src, int rows, int W, float alpha, void *stream);
+
+/* *out += sum x^2 (global gradient norm of clip_grad_norm_, main.py:88). */
+int hgr_sumsq(const float *x, int64_t n, float *out, void *stream);
+
+/*
+ * Fused AdamW step with torch.optim.AdamW semantics (main.py:247,91) on fp32 master parameters; if sumsq_total
+ * is given, gradients are first scaled by min(1, max_norm / (sqrt(*sumsq_total) + 1e-6)) = clip_grad_norm_.
+ */
+int hgr_adamw(float *p, const float *g, float *m, float *v, int64_t n, float lr, float beta1, float beta2, float eps,
+              float wd, int step, const float *sumsq_total, float max_norm, void *stream);
 
 #ifdef __cplusplus
 }
