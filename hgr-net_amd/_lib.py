@@ -24,6 +24,8 @@ _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 SIGNATURES = {
     "hgr_gemm_nt": [_p, _l, _p, _l, _p, _l, _p, _p, _l, _i, _i, _i, _i, _i, _i, _p],
     "hgr_im2col_patches": [_p, _p, _i, _i, _i, _i, _i, _p],
+    "hgr_im2col_patches_ex": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "hgr_vit_assemble": [_p, _p, _p, _i, _i, _i, _p],
     "hgr_vit_embed_ln": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p],
     "hgr_layernorm": [_p, _p, _p, _p, _i, _i, _l, _p, _f, _i, _i, _p],
     "hgr_mha": [_p, _p, _i, _i, _i, _i, _i, _p],

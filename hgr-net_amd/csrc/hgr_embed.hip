@@ -10,7 +10,7 @@ namespace {
 // threads of one patch row write P*2 contiguous bytes of the patch row in `out`.
 template <int DT>
 __global__ __launch_bounds__(256) void im2col_vec8(const float *__restrict__ img, typename T16<DT>::elem *__restrict__ out,
-                                                   int B, int R, int P, int Kp) {
+                                                   int B, int R, int P, int Kp, int rpi, int roff) {
     typedef typename T16<DT>::vec8 vec8;
     typedef typename T16<DT>::elem E;
     const int xr = R >> 3;
@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void im2col_vec8(const float *__restrict__ img
         v[0] = (E)a[0]; v[1] = (E)a[1]; v[2] = (E)a[2]; v[3] = (E)a[3];
         v[4] = (E)d[0]; v[5] = (E)d[1]; v[6] = (E)d[2]; v[7] = (E)d[3];
         const int x = x8 * 8, gy = y / P, py = y - gy * P, gx = x / P, px = x - gx * P;
-        const int64_t row = ((int64_t)b * g + gy) * g + gx;
+        const int64_t row = (int64_t)b * rpi + roff + gy * g + gx;
         *(vec8 *)(out + row * Kp + (c * P + py) * P + px) = v;
     }
 }
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void im2col_vec8(const float *__restrict__ img
 // Generic fallback (P % 8 != 0, e.g. ViT-L/14) and zero fill of the K padding: one thread per output element.
 template <int DT>
 __global__ __launch_bounds__(256) void im2col_scalar(const float *__restrict__ img, typename T16<DT>::elem *__restrict__ out,
-                                                     int B, int R, int P, int Kp, int kfirst) {
+                                                     int B, int R, int P, int Kp, int kfirst, int rpi, int roff) {
     typedef typename T16<DT>::elem E;
     const int g = R / P, K = 3 * P * P, span = Kp - kfirst;
     const int64_t total = (int64_t)B * g * g * span;
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void im2col_scalar(const float *__restrict__ i
             const int c = k / (P * P), rem = k - c * P * P, py = rem / P, px = rem - py * P;
             v = img[(((int64_t)b * 3 + c) * R + gy * P + py) * R + gx * P + px];
         }
-        out[row * Kp + k] = (E)v;
+        out[(((int64_t)(row / ((int64_t)g * g))) * rpi + roff + row % ((int64_t)g * g)) * Kp + k] = (E)v;
     }
 }
 
@@ -90,11 +90,43 @@ __global__ __launch_bounds__(256) void eot_index(const int64_t *__restrict__ tok
     if (lane == 0) eot[row] = bi;
 }
 
+// t[b, l] = pe[b, l] + pos[l] + (l == 0 ? cls : 0) in place on the [B*L, W] patch-GEMM output whose class rows are zero
+__global__ __launch_bounds__(256) void vit_assemble(float *__restrict__ t, const float *__restrict__ cls, const float *__restrict__ pos, int B, int L, int W) {
+    const int nv = W >> 2;
+    const int64_t total = (int64_t)B * L * nv;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % nv);
+        const int l = (int)((i / nv) % L);
+        f32x4 v = ((f32x4 *)t)[i] + ((const f32x4 *)(pos + (int64_t)l * W))[c];
+        if (l == 0) v += ((const f32x4 *)cls)[c];
+        ((f32x4 *)t)[i] = v;
+    }
+}
+
 }  // namespace
 
+extern "C" int hgr_vit_assemble(float *t, const float *class_embedding, const float *positional_embedding, int B, int L, int W, void *stream) {
+    HGR_REQUIRE(t && class_embedding && positional_embedding && B >= 1 && L >= 1 && W >= 4 && W % 4 == 0, "hgr_vit_assemble: bad arguments");
+    const int64_t total = (int64_t)B * L * (W / 4);
+    hipLaunchKernelGGL(vit_assemble, dim3((unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192)), dim3(256), 0, (hipStream_t)stream, t, class_embedding, positional_embedding, B, L, W);
+    HGR_CHECK_LAUNCH("hgr_vit_assemble");
+    return HGR_OK;
+}
+
+namespace {
+}
+
+extern "C" int hgr_im2col_patches_ex(const float *image, void *out, int B, int R, int P, int Kp, int rows_per_image, int row_offset, int dtype, void *stream);
+
 extern "C" int hgr_im2col_patches(const float *image, void *out, int B, int R, int P, int Kp, int dtype, void *stream) {
+    return hgr_im2col_patches_ex(image, out, B, R, P, Kp, (R / (P > 0 ? P : 1)) * (R / (P > 0 ? P : 1)), 0, dtype, stream);
+}
+
+extern "C" int hgr_im2col_patches_ex(const float *image, void *out, int B, int R, int P, int Kp, int rows_per_image, int row_offset, int dtype, void *stream) {
     HGR_REQUIRE(image && out, "hgr_im2col_patches: null operand");
     HGR_REQUIRE(B >= 1 && P >= 1 && R >= P && R % P == 0, "hgr_im2col_patches: B=%d R=%d P=%d unsupported", B, R, P);
+    HGR_REQUIRE(row_offset >= 0 && rows_per_image >= row_offset + (R / P) * (R / P), "hgr_im2col_patches_ex: bad row mapping");
+    const int rpi = rows_per_image, roff = row_offset;
     const int K = 3 * P * P;
     HGR_REQUIRE(Kp >= K && Kp % 64 == 0, "hgr_im2col_patches: Kp=%d must be >= %d and a multiple of 64", Kp, K);
     HGR_REQUIRE(hgr_aligned(image, 16) && hgr_aligned(out, 16), "hgr_im2col_patches: operands must be 16-byte aligned");
@@ -104,15 +136,15 @@ extern "C" int hgr_im2col_patches(const float *image, void *out, int B, int R, i
     if (P % 8 == 0) {
         const int64_t total = (int64_t)B * 3 * R * (R / 8);
         const unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-        if (dtype == HGR_BF16) hipLaunchKernelGGL((im2col_vec8<HGR_BF16>), dim3(blocks), dim3(256), 0, s, image, (__bf16 *)out, B, R, P, Kp);
-        else hipLaunchKernelGGL((im2col_vec8<HGR_F16>), dim3(blocks), dim3(256), 0, s, image, (_Float16 *)out, B, R, P, Kp);
+        if (dtype == HGR_BF16) hipLaunchKernelGGL((im2col_vec8<HGR_BF16>), dim3(blocks), dim3(256), 0, s, image, (__bf16 *)out, B, R, P, Kp, rpi, roff);
+        else hipLaunchKernelGGL((im2col_vec8<HGR_F16>), dim3(blocks), dim3(256), 0, s, image, (_Float16 *)out, B, R, P, Kp, rpi, roff);
     }
     const int kfirst = (P % 8 == 0) ? K : 0;     // scalar kernel: everything, or just the zero padding
     if (Kp > kfirst) {
         const int64_t total = (int64_t)B * g * g * (Kp - kfirst);
         const unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-        if (dtype == HGR_BF16) hipLaunchKernelGGL((im2col_scalar<HGR_BF16>), dim3(blocks), dim3(256), 0, s, image, (__bf16 *)out, B, R, P, Kp, kfirst);
-        else hipLaunchKernelGGL((im2col_scalar<HGR_F16>), dim3(blocks), dim3(256), 0, s, image, (_Float16 *)out, B, R, P, Kp, kfirst);
+        if (dtype == HGR_BF16) hipLaunchKernelGGL((im2col_scalar<HGR_BF16>), dim3(blocks), dim3(256), 0, s, image, (__bf16 *)out, B, R, P, Kp, kfirst, rpi, roff);
+        else hipLaunchKernelGGL((im2col_scalar<HGR_F16>), dim3(blocks), dim3(256), 0, s, image, (_Float16 *)out, B, R, P, Kp, kfirst, rpi, roff);
     }
     HGR_CHECK_LAUNCH("hgr_im2col_patches");
     return HGR_OK;

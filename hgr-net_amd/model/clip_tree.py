@@ -208,4 +208,10 @@ class tree_model(nn.Module):
         return plan
 
     def train_batch(self, inputs, targets, training_method, sample_strategy):
-        raise NotImplementedError("OM training step (backward kernels) is a later scope-table row; see DESIGN.md")
+        """One training step (clip_tree.py:222-316): returns the summed loss as a float and leaves the
+        gradients ACCUMULATED in ``.grad`` of every CLIP parameter, like the reference's autograd calls.
+        Runs on libhgr (hgr_net_amd.training); compute dtype ``opts.train_dtype`` (default bf16)."""
+        if getattr(self, "_trainer", None) is None:
+            from ..training import OMTrainer
+            self._trainer = OMTrainer(self, getattr(self.opts, "train_dtype", "bf16"))
+        return self._trainer.train_batch(inputs, targets, training_method, sample_strategy)

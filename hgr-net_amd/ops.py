@@ -70,6 +70,19 @@ def im2col_patches(image: torch.Tensor, out: torch.Tensor, patch: int) -> torch.
     return out
 
 
+def im2col_patches_tokens(image: torch.Tensor, out: torch.Tensor, patch: int, l: int) -> torch.Tensor:
+    """Patches written straight into the [B, L] token layout (row b*L + 1 + p); class rows stay as they are."""
+    b, c, r, _ = image.shape
+    assert image.dtype == torch.float32 and image.is_contiguous() and out.is_contiguous() and out.shape[0] == b * l
+    _lib.call("hgr_im2col_patches_ex", _dev(image), _dev(out), b, r, patch, out.shape[1], l, 1, DT_OF[out.dtype], _stream())
+    return out
+
+
+def vit_assemble(t: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, b: int, l: int) -> torch.Tensor:
+    _lib.call("hgr_vit_assemble", _dev(t), _dev(cls), _dev(pos), b, l, t.shape[1], _stream())
+    return t
+
+
 def vit_embed_ln(patches, cls, pos, gamma, beta, x, b, g, eps=1e-5):
     _lib.call("hgr_vit_embed_ln", _dev(patches), _dev(cls), _dev(pos), _dev(gamma), _dev(beta), _dev(x), b, g, x.shape[1], eps, _stream())
     return x

@@ -1,0 +1,356 @@
+"""OM / hierarchical training step on libhgr.so: what the reference's ``tree_model.train_batch``
+(model/clip_tree.py:222-316) and the optimiser glue of ``main.train`` (main.py:86-94) compute.
+
+The reference leans on torch autograd; here forward-with-saves and the backward chains are written
+out explicitly and every product / reduction runs in a hand-written kernel:
+
+* towers run with 16-bit MFMA inputs (default bf16, BASELINE configs[4]) on fp32 master weights, an
+  fp32 residual stream and fp32 gradients that ACCUMULATE into ``param.grad`` (autograd semantics - the
+  K x M inner ``loss_j.backward()`` calls of one step all add into the text tower's gradients);
+* per linear layer: dX = dY . W is ``hgr_gemm_nt`` against a weight transposed once per step,
+  dW += dY^T . X is ``hgr_gemm_nt`` on transposed activations with the accumulate epilogue, db is a
+  column sum; LayerNorm / QuickGELU / attention / L2-norm backward are their own kernels;
+* the loss head ([B, <= 257] logits, the two projections) is tiny and stays in fp32 (``hgr_matmul_f32``);
+* like the reference, the image tower is run forward once, the image-side gradient of all inner steps
+  is accumulated on the detached normalised features, and ONE image-tower backward follows
+  (clip_tree.py:224-226,280).
+
+Only the host-side orchestration is Python; ``random`` drives negative sampling exactly as in the
+reference (seed it for reproducibility).  RN towers and sequences longer than 64 tokens (ViT-L/14)
+have no backward kernels yet and raise.
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, List, Optional
+
+import torch
+
+from . import ops
+from ._lib import EPI_ACCUM, EPI_BIAS, EPI_BIAS_RESIDUAL, EPI_NONE, HgrError
+from .clip.model import VisionTransformer
+
+
+def _pad64(n: int) -> int:
+    return (n + 63) // 64 * 64
+
+
+def _grad(p: torch.nn.Parameter) -> torch.Tensor:
+    if p.grad is None:
+        p.grad = torch.zeros_like(p.data, dtype=torch.float32)
+    return p.grad
+
+
+class _Lin:
+    """One nn.Linear-shaped weight in training form: 16-bit copy, its transpose, fp32 bias, grad targets."""
+
+    def __init__(self, weight: torch.nn.Parameter, bias: Optional[torch.nn.Parameter], dt: torch.dtype):
+        w32 = weight.data.reshape(weight.shape[0], -1).contiguous()
+        self.weight, self.bias = weight, bias
+        self.n, self.k = w32.shape
+        self.w16 = torch.empty(w32.shape, dtype=dt, device=w32.device)
+        ops.cast16(w32, self.w16)
+        self.wt16 = torch.zeros(self.k, _pad64(self.n), dtype=dt, device=w32.device)     # [K, N] for dX = dY . W
+        ops.transpose16(self.w16, self.wt16)
+        self.b32 = bias.data if bias is not None else None
+
+
+class _Blk:
+    def __init__(self, blk, dt):
+        self.ln1, self.ln2 = blk.ln_1, blk.ln_2
+        self.w_in = _Lin(blk.attn.in_proj_weight, blk.attn.in_proj_bias, dt)
+        self.w_out = _Lin(blk.attn.out_proj.weight, blk.attn.out_proj.bias, dt)
+        self.w_fc = _Lin(blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, dt)
+        self.w_proj = _Lin(blk.mlp.c_proj.weight, blk.mlp.c_proj.bias, dt)
+
+
+class Engine:
+    """Forward-with-saves / backward for the transformer stacks of one CLIP model."""
+
+    def __init__(self, clip_model, dtype: str = "bf16"):
+        self.m = clip_model
+        self.dt = ops.TORCH16[ops.dtype_code(dtype)]
+        self.dev = next(clip_model.parameters()).device
+        self._scratch = None
+
+    # -- helpers -------------------------------------------------------------------------------
+    def scratch(self, n: int) -> torch.Tensor:
+        if self._scratch is None or self._scratch.numel() < n:
+            self._scratch = torch.empty(max(n, 1 << 22), dtype=torch.float32, device=self.dev)
+        return self._scratch
+
+    def prepare(self):
+        """16-bit weight copies + transposes for this step (weights change every step)."""
+        m, dt = self.m, self.dt
+        if not isinstance(m.visual, VisionTransformer):
+            raise NotImplementedError("training: only ViT image towers have backward kernels this round")
+        self.vblocks = [_Blk(b, dt) for b in m.visual.transformer.resblocks]
+        self.tblocks = [_Blk(b, dt) for b in m.transformer.resblocks]
+        self.conv = _Lin(m.visual.conv1.weight, None, dt)
+
+    def _linear_bwd(self, lin: _Lin, dy16: torch.Tensor, x16: torch.Tensor, m: int, need_dx: bool = True) -> Optional[torch.Tensor]:
+        """dW += dY^T X, db += colsum(dY); returns dX = dY W (16-bit) if wanted.  dy16 [m, n], x16 [m, k]."""
+        dev, dt = self.dev, self.dt
+        mp = _pad64(m)
+        dyt = torch.zeros(lin.n, mp, dtype=dt, device=dev)
+        xt = torch.zeros(lin.k, mp, dtype=dt, device=dev)
+        ops.transpose16(dy16, dyt)
+        ops.transpose16(x16, xt)
+        gw = _grad(lin.weight).view(lin.n, lin.k)
+        ops.gemm_nt(dyt, xt, gw, epilogue=EPI_ACCUM)
+        if lin.bias is not None:
+            ops.colsum(dy16, _grad(lin.bias), self.scratch(((m + 511) // 512) * lin.n), accumulate=True)
+        if not need_dx:
+            return None
+        dx = torch.empty(m, lin.k, dtype=dt, device=dev)
+        if lin.n % 64:
+            raise HgrError("backward GEMM needs the output width to be a multiple of 64")
+        ops.gemm_nt(dy16, lin.wt16[:, : lin.n] if lin.wt16.shape[1] == lin.n else lin.wt16, dx, n=lin.k)
+        return dx
+
+    # -- transformer stack ---------------------------------------------------------------------
+    def blocks_fwd(self, x: torch.Tensor, blocks: List[_Blk], heads: int, b: int, l: int, causal: bool):
+        """Returns (x_out, saves).  Same arithmetic as clip.model._run_blocks, out of place, keeping what backward needs."""
+        if l > 64:
+            raise NotImplementedError("training: attention backward supports sequences up to 64 tokens this round")
+        m, w = x.shape
+        dt, dev = self.dt, self.dev
+        saves = []
+        for k in blocks:
+            h1 = torch.empty(m, w, dtype=dt, device=dev)
+            ops.layernorm(x, k.ln1.weight.data, k.ln1.bias.data, h1)
+            qkv = torch.empty(m, 3 * w, dtype=dt, device=dev)
+            ops.gemm_nt(h1, k.w_in.w16, qkv, bias=k.w_in.b32, epilogue=EPI_BIAS)
+            att = torch.empty(m, w, dtype=dt, device=dev)
+            ops.mha(qkv, att, b, l, heads, causal)
+            x1 = torch.empty_like(x)
+            ops.gemm_nt(att, k.w_out.w16, x1, bias=k.w_out.b32, residual=x, epilogue=EPI_BIAS_RESIDUAL)
+            h2 = torch.empty(m, w, dtype=dt, device=dev)
+            ops.layernorm(x1, k.ln2.weight.data, k.ln2.bias.data, h2)
+            a = torch.empty(m, 4 * w, dtype=dt, device=dev)
+            ops.gemm_nt(h2, k.w_fc.w16, a, bias=k.w_fc.b32, epilogue=EPI_BIAS)
+            u = torch.empty_like(a)
+            ops.quickgelu16(a, u)
+            x2 = torch.empty_like(x)
+            ops.gemm_nt(u, k.w_proj.w16, x2, bias=k.w_proj.b32, residual=x1, epilogue=EPI_BIAS_RESIDUAL)
+            saves.append((x, h1, qkv, att, x1, h2, a, u))
+            x = x2
+        return x, saves
+
+    def blocks_bwd(self, dx: torch.Tensor, blocks: List[_Blk], saves, heads: int, b: int, l: int, causal: bool) -> torch.Tensor:
+        """dx: fp32 gradient w.r.t. the stack output (consumed in place); returns the gradient w.r.t. its input."""
+        m, w = dx.shape
+        dt, dev = self.dt, self.dev
+        scr = self.scratch(ops.layernorm_bwd_scratch(m, w))
+        for k, (x0, h1, qkv, att, x1, h2, a, u) in zip(reversed(blocks), reversed(saves)):
+            # x2 = x1 + c_proj(gelu(c_fc(ln_2(x1))))
+            dy = torch.empty(m, w, dtype=dt, device=dev)
+            ops.cast16(dx, dy)
+            du = self._linear_bwd(k.w_proj, dy, u, m)
+            da = torch.empty_like(a)
+            ops.quickgelu16(a, da, du=du)
+            dh2 = self._linear_bwd(k.w_fc, da, h2, m)
+            ops.layernorm_bwd(dh2, x1, k.ln2.weight.data, dx, _grad(k.ln2.weight), _grad(k.ln2.bias), scr)
+            # x1 = x0 + out_proj(attn(in_proj(ln_1(x0))))
+            ops.cast16(dx, dy)
+            datt = self._linear_bwd(k.w_out, dy, att, m)
+            dqkv = torch.empty_like(qkv)
+            ops.mha_bwd(qkv, datt, dqkv, b, l, heads, causal)
+            dh1 = self._linear_bwd(k.w_in, dqkv, h1, m)
+            ops.layernorm_bwd(dh1, x0, k.ln1.weight.data, dx, _grad(k.ln1.weight), _grad(k.ln1.bias), scr)
+        return dx
+
+    # -- image tower (ViT) ----------------------------------------------------------------------
+    def image_fwd(self, image: torch.Tensor):
+        v, dt, dev = self.m.visual, self.dt, self.dev
+        image = image.float().contiguous()
+        b, _, r, _ = image.shape
+        ps = v.patch_size
+        g = r // ps
+        l, w = g * g + 1, v.conv1.weight.shape[0]
+        k = 3 * ps * ps
+        if k % 64:
+            raise NotImplementedError("training: patch size with 3*P*P not a multiple of 64")
+        patches = torch.zeros(b * l, k, dtype=dt, device=dev)            # class rows stay zero
+        ops.im2col_patches_tokens(image, patches, ps, l)
+        t = torch.empty(b * l, w, dtype=torch.float32, device=dev)
+        ops.gemm_nt(patches, self.conv.w16, t)
+        ops.vit_assemble(t, v.class_embedding.data, v.positional_embedding.data, b, l)
+        x = torch.empty_like(t)
+        ops.layernorm(t, v.ln_pre.weight.data, v.ln_pre.bias.data, x)    # fp32 out
+        xl, saves = self.blocks_fwd(x, self.vblocks, w // 64, b, l, False)
+        c32 = torch.empty(b, w, dtype=torch.float32, device=dev)
+        ops.layernorm(xl, v.ln_post.weight.data, v.ln_post.bias.data, c32, rows=b, row_mul=l)
+        feat = torch.empty(b, v.output_dim, dtype=torch.float32, device=dev)
+        ops.matmul_f32(c32, v.proj.data, feat)                            # [B, W] @ [W, D], fp32 head
+        return feat, dict(patches=patches, t=t, xl=xl, saves=saves, c32=c32, b=b, l=l, w=w)
+
+    def image_bwd(self, dfeat: torch.Tensor, s: dict):
+        v, dt, dev = self.m.visual, self.dt, self.dev
+        b, l, w = s["b"], s["l"], s["w"]
+        ops.matmul_f32(s["c32"].t(), dfeat, _grad(v.proj), accumulate=True)                 # dproj += c^T dfeat
+        dc = torch.empty(b, w, dtype=torch.float32, device=dev)
+        ops.matmul_f32(dfeat, v.proj.data.t(), dc)                                          # dc = dfeat proj^T
+        dx = torch.zeros(b * l, w, dtype=torch.float32, device=dev)
+        scr = self.scratch(ops.layernorm_bwd_scratch(b * l, w))
+        ops.layernorm_bwd(dc, s["xl"], v.ln_post.weight.data, dx, _grad(v.ln_post.weight), _grad(v.ln_post.bias), scr, rows=b, row_mul=l)
+        dx = self.blocks_bwd(dx, self.vblocks, s["saves"], w // 64, b, l, False)
+        dt_ = torch.zeros(b * l, w, dtype=torch.float32, device=dev)
+        ops.layernorm_bwd(dx, s["t"], v.ln_pre.weight.data, dt_, _grad(v.ln_pre.weight), _grad(v.ln_pre.bias), scr)
+        # t[b,l] = patch_out[b,l] + pos[l] + (l == 0) cls
+        ops.colsum(dt_.view(b, l * w), _grad(v.positional_embedding).view(-1), self.scratch(((b + 511) // 512) * l * w), accumulate=True)
+        ops.colsum(dt_.view(b, l * w)[:, :w], _grad(v.class_embedding), self.scratch(((b + 511) // 512) * w), accumulate=True)
+        d16 = torch.empty(b * l, w, dtype=dt, device=dev)
+        ops.cast16(dt_, d16)
+        self._linear_bwd(self.conv, d16, s["patches"], b * l, need_dx=False)                # zero class rows add nothing
+
+    # -- text tower -------------------------------------------------------------------------------
+    def text_fwd(self, tokens: torch.Tensor):
+        m, dt, dev = self.m, self.dt, self.dev
+        tokens = tokens.long()
+        n, ctx = tokens.shape
+        w = m.transformer.width
+        eot = torch.empty(n, dtype=torch.int32, device=dev)
+        ops.eot_index(tokens, eot)
+        l = int(eot.max().item()) + 1
+        x = torch.empty(n * l, w, dtype=torch.float32, device=dev)
+        ops.text_embed(tokens, m.token_embedding.weight.data, m.positional_embedding.data, x, l)
+        xl, saves = self.blocks_fwd(x, self.tblocks, w // 64, n, l, True)
+        f32 = torch.empty(n, w, dtype=torch.float32, device=dev)
+        ops.layernorm(xl, m.ln_final.weight.data, m.ln_final.bias.data, f32, rows=n, row_mul=l, row_idx=eot)
+        feat = torch.empty(n, m.text_projection.shape[1], dtype=torch.float32, device=dev)
+        ops.matmul_f32(f32, m.text_projection.data, feat)
+        return feat, dict(tokens=tokens, eot=eot, l=l, n=n, w=w, xl=xl, saves=saves, f32=f32)
+
+    def text_bwd(self, dfeat: torch.Tensor, s: dict):
+        m, dev = self.m, self.dev
+        n, l, w = s["n"], s["l"], s["w"]
+        ops.matmul_f32(s["f32"].t(), dfeat, _grad(m.text_projection), accumulate=True)
+        df = torch.empty(n, w, dtype=torch.float32, device=dev)
+        ops.matmul_f32(dfeat, m.text_projection.data.t(), df)
+        dx = torch.zeros(n * l, w, dtype=torch.float32, device=dev)
+        scr = self.scratch(ops.layernorm_bwd_scratch(n * l, w))
+        ops.layernorm_bwd(df, s["xl"], m.ln_final.weight.data, dx, _grad(m.ln_final.weight), _grad(m.ln_final.bias), scr,
+                          rows=n, row_mul=l, row_idx=s["eot"])
+        dx = self.blocks_bwd(dx, self.tblocks, s["saves"], w // 64, n, l, True)
+        # x[i*l + t] = token_embedding[tok] + positional[t]
+        gp = _grad(m.positional_embedding)
+        ops.colsum(dx.view(n, l * w), gp.view(-1)[: l * w], self.scratch(((n + 511) // 512) * l * w), accumulate=True)
+        ops.embed_scatter_add(s["tokens"], dx, _grad(m.token_embedding.weight), l)
+
+
+class OMTrainer:
+    """``train_batch`` of the reference's tree_model on the Engine above."""
+
+    def __init__(self, tree, dtype: str = "bf16"):
+        self.tree = tree
+        self.engine = Engine(tree.clip_model, dtype)
+        # test hook: force the negative-class lists of the inner steps (list of (ids, label_pos)), else sample
+        self.contra_override: Optional[Callable[[int], tuple]] = None
+        self.last_contra: list = []
+
+    def _head(self, img_n, dimg_n, tfeat, label_pos: int, weight, loss_acc):
+        """logits = img_n tn^T * exp(logit_scale); CE (all rows share the label); gradients of the three inputs."""
+        e, m, dev = self.engine, self.engine.m, self.engine.dev
+        b, d = img_n.shape
+        n = tfeat.shape[0]
+        tn = torch.empty_like(tfeat)
+        ops.l2norm_rows(tfeat, y32=tn)
+        scale = float(m.logit_scale.data.exp())            # one scalar D2H per step would do; kept simple: host scalar
+        logits = torch.empty(b, n, dtype=torch.float32, device=dev)
+        ops.matmul_f32(img_n, tn.t(), logits, alpha=scale)
+        labels = torch.full((b,), label_pos, dtype=torch.int32, device=dev)
+        loss_rows = torch.empty(b, dtype=torch.float32, device=dev)
+        dlog = torch.empty_like(logits)
+        wv = float(weight)
+        ops.ce_rows(logits, labels, loss_rows, dlog, gscale=wv / b)
+        ops.matmul_f32(loss_rows.view(1, b), torch.ones(b, 1, device=dev), loss_acc, alpha=wv / b, accumulate=True)   # loss_j = mean * w
+        ops.matmul_f32(dlog, tn, dimg_n, alpha=scale, accumulate=True)                     # d img_n += s * dlog @ tn
+        dtn = torch.empty_like(tn)
+        ops.matmul_f32(dlog.t(), img_n, dtn, alpha=scale)                                  # d tn = s * dlog^T @ img_n
+        # d logit_scale += sum(dlog * logits)   (logits = cos * exp(ls) => d logits / d ls = logits)
+        ops.matmul_f32(dlog.view(1, b * n), logits.view(b * n, 1), _grad(m.logit_scale).view(1, 1), accumulate=True)
+        dtfeat = torch.empty_like(tfeat)
+        ops.l2norm_bwd(tfeat, dtn, dtfeat)
+        return dtfeat
+
+    @torch.no_grad()
+    def train_batch(self, inputs, targets, training_method: str = "OM", sample_strategy: Optional[str] = None) -> float:
+        tree, e = self.tree, self.engine
+        if not inputs.is_cuda:
+            raise HgrError("train_batch needs device tensors: there is no CPU path")
+        strategy = sample_strategy or tree.opts.sample_strategy
+        e.prepare()
+        feat, isave = e.image_fwd(inputs)
+        img_n = torch.empty_like(feat)
+        ops.l2norm_rows(feat, y32=img_n)
+        dimg_n = torch.zeros_like(img_n)                      # img_feats_.grad of the reference
+        target = int(targets[0].item()) if torch.is_tensor(targets) else int(targets[0])
+        loss_acc = torch.zeros(1, 1, dtype=torch.float32, device=e.dev)
+        self.last_contra = []
+        if training_method == "OM":
+            steps = tree.outer_inner_plan(target)
+        elif training_method == "hierarchical":               # clip_tree.py:283-316
+            parents = list(tree.c2p[target]) + [target]
+            steps = [dict(p_out=target, depth=j, parents_in=parents, k_loop=j, m_loop=0, K=len(parents), M=1, hier=True) for j in range(len(parents))]
+        else:
+            raise NotImplementedError(f"training_method {training_method!r} (the reference implements 'OM' and 'hierarchical' only)")
+        for i, st in enumerate(steps):
+            if self.contra_override is not None:
+                ids, pos = self.contra_override(i)
+            else:
+                ids, pos = tree.get_contra_ids(strategy, st["p_out"], st["depth"], st["parents_in"])
+            self.last_contra.append((list(ids), pos))
+            if st.get("hier"):
+                wgt = tree.get_weights(tree.opts.weights, st["K"])[st["k_loop"]]
+            else:
+                wmode = tree.opts.weighting
+                w_in = tree.get_weights("equal" if wmode == "out" else tree.opts.weights, st["M"])
+                w_out = tree.get_weights("equal" if wmode == "in" else tree.opts.weights, st["K"])
+                wgt = w_in[st["m_loop"]] * w_out[st["k_loop"]]
+            idx = torch.tensor(ids, device=e.dev)
+            tfeat, tsave = e.text_fwd(tree.node_tokens[idx])
+            dtfeat = self._head(img_n, dimg_n, tfeat, pos, wgt, loss_acc)
+            e.text_bwd(dtfeat, tsave)
+        dfeat = torch.empty_like(feat)
+        ops.l2norm_bwd(feat, dimg_n, dfeat)
+        e.image_bwd(dfeat, isave)
+        return float(loss_acc.item())
+
+
+class FusedAdamW:
+    """clip_grad_norm_(params, max_norm) + AdamW.step() of main.py:87-91 as fused kernels on fp32 masters.
+    One `hgr_sumsq` per tensor into a device scalar, then one `hgr_adamw` per tensor that reads the clip
+    factor from device memory: no host synchronisation inside the step."""
+
+    def __init__(self, params, lr: float = 3e-7, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0, max_norm: Optional[float] = 1.0):
+        self.params = [p for p in params]
+        self.param_groups = [dict(lr=lr, params=self.params)]       # so the reference's cosine_lr scheduler can drive it (utils.py:82-95)
+        self.betas, self.eps, self.wd, self.max_norm = betas, eps, weight_decay, max_norm
+        self.step_count = 0
+        self.state = {id(p): (torch.zeros_like(p.data, dtype=torch.float32), torch.zeros_like(p.data, dtype=torch.float32)) for p in self.params}
+        self._tot = None
+
+    @torch.no_grad()
+    def step(self):
+        self.step_count += 1
+        lr = self.param_groups[0]["lr"]
+        live = [p for p in self.params if p.grad is not None]
+        if not live:
+            return
+        tot = None
+        if self.max_norm is not None:
+            if self._tot is None:
+                self._tot = torch.zeros(1, dtype=torch.float32, device=live[0].device)
+            tot = self._tot
+            tot.zero_()
+            for p in live:
+                ops.sumsq(p.grad.contiguous(), tot)
+        for p in live:
+            m, v = self.state[id(p)]
+            ops.adamw(p.data, p.grad.contiguous(), m, v, lr, self.step_count, self.betas, self.eps, self.wd, tot, self.max_norm or 0.0)
+
+    def zero_grad(self):
+        for p in self.params:
+            if p.grad is not None:
+                p.grad.zero_()

@@ -70,6 +70,13 @@ int hgr_gemm_nt(const void *A, int64_t lda, const void *W, int64_t ldw, void *C,
  * `self.conv1(x)` + reshape + permute at clip/model.py:220-222 (kernel = stride = P, no bias).
  */
 int hgr_im2col_patches(const float *image, void *out, int B, int R, int P, int Kp, int dtype, void *stream);
+/* Same, but patch p of image b goes to output row b*rows_per_image + row_offset + p: with (L, 1) the patches land
+ * directly in the [B, L] token layout with the class-token rows left untouched (training keeps them zero). */
+int hgr_im2col_patches_ex(const float *image, void *out, int B, int R, int P, int Kp, int rows_per_image, int row_offset,
+                          int dtype, void *stream);
+/* In place on the [B*L, W] fp32 patch-GEMM output with zero class rows: t[b,l] += positional[l] + (l == 0 ? class : 0)
+ * (clip/model.py:223-224; the un-fused form of hgr_vit_embed_ln, whose pre-LayerNorm sum the backward needs). */
+int hgr_vit_assemble(float *t, const float *class_embedding, const float *positional_embedding, int B, int L, int W, void *stream);
 
 /*
  * ViT token assembly + ln_pre (clip/model.py:223-225): x[b,0] = class_embedding, x[b,1+i] = patch

@@ -192,7 +192,10 @@ def tree_fixture(ref_main_mod, tag, cfg, n_nodes, n_train, n_test, batches, bsz,
         paths.append(dp)
     print(f"[tree] {tag}: main.test -> {metric.strip()}")
     assert st.summary() == metric, (st.summary(), metric)
-    meta = dict(config=cfg, n_nodes=n_nodes, n_train=n_train, n_test=n_test, batches=batches, bsz=bsz,
+    train = None
+    if "vision_patch_size" in cfg and cfg["vision_patch_size"]:
+        train = train_capture(model, o, cfg, h, tag)
+    meta = dict(config=cfg, n_nodes=n_nodes, n_train=n_train, n_test=n_test, batches=batches, bsz=bsz, train=train,
                 dag=dict(depth=8, seed=7, multi_parent=0.08), split_seed=13, image_seed0=100, targets=targets,
                 metric=metric, counters=st.counters(), weights=weights,
                 c2p=h.c2p, p2c=h.p2c, d2n={str(k): v for k, v in h.d2n.items()}, start_up=h.start_up, nodes=h.nodes)
@@ -202,6 +205,50 @@ def tree_fixture(ref_main_mod, tag, cfg, n_nodes, n_train, n_test, batches, bsz,
                         pred_top20=np.stack(preds).astype(np.int32),
                         **{f"dict_path_{i}": p for i, p in enumerate(paths)})
     return model
+
+
+TRAIN_KEEP = ["logit_scale", "ln_final.weight", "ln_final.bias", "text_projection", "positional_embedding", "visual.proj",
+              "visual.class_embedding", "visual.positional_embedding", "visual.ln_pre.weight", "visual.ln_post.bias",
+              "transformer.resblocks.0.attn.in_proj_bias", "transformer.resblocks.1.mlp.c_fc.weight",
+              "visual.transformer.resblocks.0.attn.out_proj.weight", "visual.transformer.resblocks.1.ln_2.weight",
+              "visual.transformer.resblocks.0.mlp.c_proj.bias"]
+
+
+def train_capture(model, o, cfg, h, tag):
+    """One OM step of the reference's tree_model.train_batch (clip_tree.py:222-281) + main.train's clip/AdamW (main.py:86-91)."""
+    import random
+    o.num_compare, o.k, o.sample_strategy, o.weighting, o.out_ratio, o.in_ratio = 8, 1, "topk", "both", 0.5, 0.5
+    bsz = 6
+    test_ids = [int(i) for i in model.test_index.tolist()]
+    target = max(test_ids, key=lambda i: (len(h.c2p[i]), -i))
+    img = synth.images(bsz, cfg["image_resolution"], seed=777)
+    captured = []
+    orig = model.get_contra
+
+    def wrap(method, target, batch_size, depth=None, parents=None):
+        ci, tg = orig(method=method, target=target, batch_size=batch_size, depth=depth, parents=parents)
+        captured.append([ci.tolist(), int(tg[0])])
+        return ci, tg
+
+    model.get_contra = wrap
+    for p_ in model.parameters():
+        p_.grad = None
+    random.seed(123)
+    loss = model.train_batch(img, torch.full((bsz,), target, dtype=torch.long), "OM", "topk")
+    model.get_contra = orig
+    named = dict(model.clip_model.named_parameters())
+    norms = {k: float(v.grad.norm()) for k, v in named.items() if v.grad is not None}
+    keep = {k: named[k].grad.detach().clone() for k in TRAIN_KEEP if k in named}
+    params = [p_ for n_, p_ in model.named_parameters() if p_.requires_grad and n_ != "layer_weight"]
+    total = float(torch.nn.utils.clip_grad_norm_(params, 1.0))
+    opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=0.0)
+    opt.step()
+    after = {k: named[k].detach().clone() for k in TRAIN_KEEP if k in named}
+    np.savez_compressed(GOLD / f"train_{tag}.npz", **{"grad/" + k: v.numpy() for k, v in keep.items()},
+                        **{"after/" + k: v.numpy() for k, v in after.items()})
+    print(f"[train] {tag}: OM step target {target} depth {len(h.c2p[target])}, {len(captured)} inner steps, loss {loss:.6f}, |grad| {total:.4f}")
+    return dict(loss=float(loss), target=int(target), bsz=bsz, image_seed=777, contra=captured, grad_norms=norms, total_norm=total,
+                lr=1e-3, opts=dict(num_compare=8, k=1, sample_strategy="topk", weighting="both", out_ratio=0.5, in_ratio=0.5))
 
 
 def main():
