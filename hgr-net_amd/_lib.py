@@ -51,6 +51,7 @@ SIGNATURES = {
     "hgr_matmul_f32": [_p, _l, _l, _p, _l, _l, _p, _l, _i, _i, _i, _f, _i, _p],
     "hgr_embed_scatter_add": [_p, _l, _p, _p, _i, _i, _i, _i, _p],
     "hgr_rows_axpy": [_p, _l, _p, _p, _i, _i, _f, _p],
+    "hgr_rows_gather": [_p, _p, _p, _i, _i, _p],
     "hgr_sumsq": [_p, _l, _p, _p],
     "hgr_adamw": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _p, _f, _p],
 }

@@ -420,6 +420,13 @@ __global__ __launch_bounds__(256) void rows_axpy(float *__restrict__ dst, int64_
     }
 }
 
+// dst[r] = src[idx[r]] for W-wide fp32 rows
+__global__ __launch_bounds__(256) void rows_gather(float *__restrict__ dst, const float *__restrict__ src, const int32_t *__restrict__ idx, int rows, int W) {
+    const int64_t total = (int64_t)rows * W;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256)
+        dst[i] = src[(int64_t)idx[i / W] * W + i % W];
+}
+
 }  // namespace
 
 #define DT_OK(name) HGR_REQUIRE(dtype == HGR_BF16 || dtype == HGR_F16, name ": bad dtype %d", dtype)
@@ -564,8 +571,15 @@ extern "C" int hgr_adamw(float *p, const float *g, float *m, float *v, int64_t n
 }
 
 extern "C" int hgr_rows_axpy(float *dst, int64_t dst_mul, const int32_t *dst_idx, const float *src, int rows, int W, float alpha, void *stream) {
-    HGR_REQUIRE(dst && src && rows >= 1 && W >= 1 && dst_mul >= 1, "hgr_rows_axpy: bad arguments");
+    HGR_REQUIRE(dst && src && rows >= 1 && W >= 1 && dst_mul >= 0 && (dst_mul >= 1 || dst_idx), "hgr_rows_axpy: bad arguments");
     hipLaunchKernelGGL(rows_axpy, dim3(grid1((int64_t)rows * W)), dim3(256), 0, (hipStream_t)stream, dst, dst_mul, dst_idx, src, rows, W, alpha);
     HGR_CHECK_LAUNCH("hgr_rows_axpy");
+    return HGR_OK;
+}
+
+extern "C" int hgr_rows_gather(float *dst, const float *src, const int32_t *idx, int rows, int W, void *stream) {
+    HGR_REQUIRE(dst && src && idx && rows >= 1 && W >= 1, "hgr_rows_gather: bad arguments");
+    hipLaunchKernelGGL(rows_gather, dim3(grid1((int64_t)rows * W)), dim3(256), 0, (hipStream_t)stream, dst, src, idx, rows, W);
+    HGR_CHECK_LAUNCH("hgr_rows_gather");
     return HGR_OK;
 }

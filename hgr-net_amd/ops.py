@@ -264,6 +264,12 @@ def rows_axpy(dst: torch.Tensor, src: torch.Tensor, dst_mul: int = 1, dst_idx: O
     _lib.call("hgr_rows_axpy", _dev(dst), dst_mul, _dev(dst_idx), _dev(src), src.shape[0], src.shape[1], alpha, _stream())
 
 
+def rows_gather(src: torch.Tensor, idx: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    assert src.dtype == out.dtype == torch.float32 and src.is_contiguous() and out.is_contiguous() and idx.dtype == torch.int32
+    _lib.call("hgr_rows_gather", _dev(out), _dev(src), _dev(idx), out.shape[0], out.shape[1], _stream())
+    return out
+
+
 def sumsq(x: torch.Tensor, out: torch.Tensor) -> None:
     assert x.dtype == torch.float32 and x.is_contiguous()
     _lib.call("hgr_sumsq", _dev(x), x.numel(), _dev(out), _stream())

@@ -68,3 +68,44 @@ def sharded_text_features(clip_model, node_tokens: torch.Tensor, group=None) -> 
 def batches_of_rank(num_batches: int, world: int, rank: int) -> range:
     """Indices of the evaluation batches rank `rank` owns (round-robin keeps class sizes balanced)."""
     return range(rank, num_batches, world)
+
+
+def allreduce_grads(params, group=None, bucket_bytes: int = 64 << 20) -> None:
+    """Average ``.grad`` of `params` over the ranks of `group`: the DP step of OM training.
+
+    The reference has no distributed code; the build shards ONE single-class batch over the ranks with
+    identical sampling seeds (so every rank contrasts against the same negatives); the mean-CE
+    gradient of the global batch is then the average of the per-rank gradients.  Gradients are packed into
+    flat fp32 buckets (default 64 MB: large enough to run RCCL's all-reduce at link rate over xGMI, small
+    enough to pipeline packing / reduction / unpacking) and reduced bucket by bucket with one
+    ``all_reduce(sum)`` each, then scaled by 1/world while unpacking.  Parameters that received no
+    gradient on this rank contribute zeros so that every rank issues the same collectives.
+    """
+    world = dist.get_world_size(group)
+    params = [p for p in params if p.requires_grad]
+    bucket, size = [], 0
+
+    def flush():
+        nonlocal bucket, size
+        if not bucket:
+            return
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p.data)).reshape(-1).float() for p in bucket])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat.mul_(1.0 / world)
+        off = 0
+        for p in bucket:
+            n = p.numel()
+            g = flat[off: off + n].view_as(p.data)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
+            off += n
+        bucket, size = [], 0
+
+    for p in params:
+        bucket.append(p)
+        size += p.numel() * 4
+        if size >= bucket_bytes:
+            flush()
+    flush()

@@ -256,7 +256,7 @@ class OMTrainer:
         n = tfeat.shape[0]
         tn = torch.empty_like(tfeat)
         ops.l2norm_rows(tfeat, y32=tn)
-        scale = float(m.logit_scale.data.exp())            # one scalar D2H per step would do; kept simple: host scalar
+        scale = self._scale
         logits = torch.empty(b, n, dtype=torch.float32, device=dev)
         ops.matmul_f32(img_n, tn.t(), logits, alpha=scale)
         labels = torch.full((b,), label_pos, dtype=torch.int32, device=dev)
@@ -281,13 +281,13 @@ class OMTrainer:
             raise HgrError("train_batch needs device tensors: there is no CPU path")
         strategy = sample_strategy or tree.opts.sample_strategy
         e.prepare()
+        self._scale = float(e.m.logit_scale.data.exp())      # one scalar D2H per step
         feat, isave = e.image_fwd(inputs)
         img_n = torch.empty_like(feat)
         ops.l2norm_rows(feat, y32=img_n)
         dimg_n = torch.zeros_like(img_n)                      # img_feats_.grad of the reference
         target = int(targets[0].item()) if torch.is_tensor(targets) else int(targets[0])
         loss_acc = torch.zeros(1, 1, dtype=torch.float32, device=e.dev)
-        self.last_contra = []
         if training_method == "OM":
             steps = tree.outer_inner_plan(target)
         elif training_method == "hierarchical":               # clip_tree.py:283-316
@@ -295,12 +295,15 @@ class OMTrainer:
             steps = [dict(p_out=target, depth=j, parents_in=parents, k_loop=j, m_loop=0, K=len(parents), M=1, hier=True) for j in range(len(parents))]
         else:
             raise NotImplementedError(f"training_method {training_method!r} (the reference implements 'OM' and 'hierarchical' only)")
+        # negative sampling first (host), then ONE text-tower pass over the de-duplicated prompts of all inner steps:
+        # the weights are constant within a step, so encoding each distinct prompt once and back-propagating the summed
+        # feature gradient once is the same arithmetic as the reference's K x M separate encode_text + backward calls
+        picks = []
         for i, st in enumerate(steps):
             if self.contra_override is not None:
                 ids, pos = self.contra_override(i)
             else:
                 ids, pos = tree.get_contra_ids(strategy, st["p_out"], st["depth"], st["parents_in"])
-            self.last_contra.append((list(ids), pos))
             if st.get("hier"):
                 wgt = tree.get_weights(tree.opts.weights, st["K"])[st["k_loop"]]
             else:
@@ -308,10 +311,19 @@ class OMTrainer:
                 w_in = tree.get_weights("equal" if wmode == "out" else tree.opts.weights, st["M"])
                 w_out = tree.get_weights("equal" if wmode == "in" else tree.opts.weights, st["K"])
                 wgt = w_in[st["m_loop"]] * w_out[st["k_loop"]]
-            idx = torch.tensor(ids, device=e.dev)
-            tfeat, tsave = e.text_fwd(tree.node_tokens[idx])
+            picks.append((list(ids), pos, float(wgt)))
+        self.last_contra = [(ids, pos) for ids, pos, _ in picks]
+        uniq = sorted({i for ids, _, _ in picks for i in ids})
+        where = {nid: j for j, nid in enumerate(uniq)}
+        tfeat_u, tsave = e.text_fwd(tree.node_tokens[torch.tensor(uniq, device=e.dev)])
+        dtfeat_u = torch.zeros_like(tfeat_u)
+        for ids, pos, wgt in picks:
+            loc = torch.tensor([where[i] for i in ids], dtype=torch.int32, device=e.dev)
+            tfeat = torch.empty(len(ids), tfeat_u.shape[1], dtype=torch.float32, device=e.dev)
+            ops.rows_gather(tfeat_u, loc, tfeat)
             dtfeat = self._head(img_n, dimg_n, tfeat, pos, wgt, loss_acc)
-            e.text_bwd(dtfeat, tsave)
+            ops.rows_axpy(dtfeat_u, dtfeat, dst_mul=0, dst_idx=loc)
+        e.text_bwd(dtfeat_u, tsave)
         dfeat = torch.empty_like(feat)
         ops.l2norm_bwd(feat, dimg_n, dfeat)
         e.image_bwd(dfeat, isave)

@@ -240,8 +240,12 @@ int hgr_matmul_f32(const float *A, int64_t sam, int64_t sak, const float *B, int
 int hgr_embed_scatter_add(const int64_t *tokens, int64_t ld_tokens, const float *dx, float *dtable, int n, int L,
                           int W, int vocab, void *stream);
 
-/* dst[(r*dst_mul + idx[r])] += alpha * src[r]  for W-wide fp32 rows (scatter of EOT / class-token row gradients). */
+/* dst[(r*dst_mul + idx[r])] += alpha * src[r]  for W-wide fp32 rows (scatter of EOT / class-token row gradients;
+ * dst_mul = 0 with distinct idx: scatter-add of per-step text-feature gradients into the de-duplicated prompt set). */
 int hgr_rows_axpy(float *dst, int64_t dst_mul, const int32_t *dst_idx, const float *src, int rows, int W, float alpha, void *stream);
+
+/* dst[r] = src[idx[r]]  for W-wide fp32 rows (the text features of one inner step out of the de-duplicated set). */
+int hgr_rows_gather(float *dst, const float *src, const int32_t *idx, int rows, int W, void *stream);
 
 /* *out += sum x^2 (global gradient norm of clip_grad_norm_, main.py:88). */
 int hgr_sumsq(const float *x, int64_t n, float *out, void *stream);

@@ -126,6 +126,14 @@ for b in parallel.batches_of_rank(9, world, rank):
 dist.all_reduce(acc)
 want = sum(torch.arange(len(COUNTERS), dtype=torch.float64) * (b + 1) for b in range(9))
 assert torch.equal(acc, want)
+# bucketed gradient averaging of DP training: rank r holds grad = (r + 1) * base; None grads count as zeros
+ps = [torch.nn.Parameter(torch.zeros(s)) for s in ((300, 7), (5,), (64, 64), (1,))]
+for i, p in enumerate(ps):
+    p.grad = None if (i == 1 and rank == 0) else torch.full_like(p.data, float((rank + 1) * (i + 1)))
+parallel.allreduce_grads(ps, bucket_bytes=4096)
+for i, p in enumerate(ps):
+    contrib = [0.0 if (i == 1 and r == 0) else float((r + 1) * (i + 1)) for r in range(world)]
+    assert torch.allclose(p.grad, torch.full_like(p.data, sum(contrib) / world)), i
 dist.barrier()
 if rank == 0: print("OK")
 dist.destroy_process_group()

@@ -117,10 +117,45 @@ def test_training_is_deterministic_and_accumulates(golden_dir, tmp_path):
     l2, g2 = run(True)
     assert l1 == l2
     for k in g1:
-        if k in ("token_embedding.weight", "logit_scale"):
-            assert torch.allclose(g1[k], g2[k], rtol=1e-4, atol=1e-7)
+        if k == "token_embedding.weight":                      # fp32 atomics: summation order varies
+            assert float((g1[k] - g2[k]).abs().max()) <= 1e-5 * float(g1[k].abs().max())
         else:
             assert torch.equal(g1[k], g2[k]), k
     _, g3 = run(False)                                         # accumulates on top of g2
     k = "visual.transformer.resblocks.0.attn.out_proj.weight"
     assert torch.allclose(g3[k], 2 * g2[k], rtol=1e-2, atol=1e-5)
+
+
+def test_driver_trains_saves_and_evaluates(golden_dir, tmp_path):
+    """hgr_net_amd.main with the reference's flags: 2 epochs x 3 synthetic single-class batches of OM training
+    (loss decreases on a repeated batch), checkpoint in the reference's path / key schema, then test()."""
+    import random
+    from hgr_net_amd import main as drv
+    meta = json.load(open(golden_dir / "tree_tinyvit_n90.json"))
+    z = np.load(golden_dir / "tree_tinyvit_n90.npz")
+    cfg, d = meta["config"], meta["dag"]
+    edges = synth.make_dag(meta["n_nodes"], d["depth"], d["seed"], d["multi_parent"])
+    h = build_hierarchy(edges)
+    splits = synth.make_splits(h.nodes, [len(c) == 0 for c in h.p2c], meta["n_train"], meta["n_test"], meta["split_seed"])
+    (tmp_path / "g.json").write_text(json.dumps(edges))
+    (tmp_path / "s.json").write_text(json.dumps(splits))
+    argv = ["--device", "0", "--folder", str(tmp_path / "run"), "--graph_path", str(tmp_path / "g.json"), "--split_path", str(tmp_path / "s.json"),
+            "--weights", "equal", "--num_compare", "8", "--out_ratio", "0.5", "--epochs", "2", "--synthetic", "3", "--batch_size", "6",
+            "--test_batch_size", "8", "--lr", "1e-4", "--print_freq", "1", "--test_after_train", "--model_train", "all"]
+    opts = drv.build_parser().parse_args(argv)
+    opts.node_tokens = torch.from_numpy(z["node_tokens"].astype(np.int64))
+    opts.clip_model = build_model(synth.clip_state_dict(cfg, 0)).to(DEV)
+    w0 = opts.clip_model.visual.proj.detach().clone()
+    random.seed(0)
+    import os
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        drv.run(opts)
+    finally:
+        os.chdir(cwd)
+    assert not torch.equal(opts.clip_model.visual.proj.detach(), w0)                 # the optimiser moved the weights
+    ck = torch.load(tmp_path / "run" / "HGR" / "equal_0.5_0.5" / "clip_1", map_location="cpu")
+    assert set(ck) == set(synth.clip_state_dict(cfg, 0))                              # reference checkpoint schema
+    log = (tmp_path / "run" / "HGR" / "equal_0.5_0.5" / "arugements.log").read_text()
+    assert "loss:" in log and "Top@1(%)" in log
