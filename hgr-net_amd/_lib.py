@@ -53,7 +53,7 @@ SIGNATURES = {
     "hgr_rows_axpy": [_p, _l, _p, _p, _i, _i, _f, _p],
     "hgr_rows_gather": [_p, _p, _p, _i, _i, _p],
     "hgr_sumsq": [_p, _l, _p, _p],
-    "hgr_adamw": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _p, _f, _p],
+    "hgr_adamw": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _p, _f, _f, _p],
 }
 
 

@@ -305,6 +305,65 @@ __global__ __launch_bounds__(256) void mha_bwd64(const typename T16<DT>::elem *_
             for (int c = 0; c < 4; ++c) dqb[(int64_t)(ti + a) * ld + W + tj + c] = (E)acc[a][c];
 }
 
+// Same arithmetic for short sequences (text prompts are ~8-20 tokens after EOT trimming): LP = 16 or 32 padded
+// positions, 20-45 KB of LDS so several (batch, head) workgroups share a CU, plain per-output loops.
+template <int DT, int LP, bool CAUSAL>
+__global__ __launch_bounds__(256) void mha_bwd_small(const typename T16<DT>::elem *__restrict__ qkv, const typename T16<DT>::elem *__restrict__ dout,
+                                                     typename T16<DT>::elem *__restrict__ dqkv, int L, int H) {
+    typedef typename T16<DT>::elem E;
+    __shared__ float sQ[LP][65], sK[LP][65], sV[LP][65], sO[LP][65], sP[LP][LP + 1], sD[LP][LP + 1];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    const int W = H * 64;
+    const int64_t ld = 3 * (int64_t)W;
+    const E *base = qkv + (int64_t)b * L * ld + h * 64;
+    const E *dob = dout + (int64_t)b * L * W + h * 64;
+    for (int i = tid; i < LP * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        const bool ok = r < L;
+        sQ[r][c] = ok ? (float)base[r * ld + c] : 0.f;
+        sK[r][c] = ok ? (float)base[r * ld + W + c] : 0.f;
+        sV[r][c] = ok ? (float)base[r * ld + 2 * W + c] : 0.f;
+        sO[r][c] = ok ? (float)dob[(int64_t)r * W + c] : 0.f;
+    }
+    __syncthreads();
+    for (int o = tid; o < LP * LP; o += 256) {                        // S and dP
+        const int i = o / LP, j = o - i * LP;
+        float s = 0.f, dp = 0.f;
+#pragma unroll 8
+        for (int d = 0; d < 64; ++d) { s += sQ[i][d] * sK[j][d]; dp += sO[i][d] * sV[j][d]; }
+        sP[i][j] = (j >= L || (CAUSAL && j > i)) ? -INFINITY : s * 0.125f;
+        sD[i][j] = dp;
+    }
+    __syncthreads();
+    if (tid < LP) {                                                   // row softmax and dS, one thread per query row
+        const int i = tid;
+        float mx = -INFINITY;
+        for (int j = 0; j < LP; ++j) mx = fmaxf(mx, sP[i][j]);
+        float sum = 0.f;
+        for (int j = 0; j < LP; ++j) { const float e = __expf(sP[i][j] - mx); sP[i][j] = e; sum += e; }
+        const float inv = (i < L) ? 1.0f / sum : 0.f;
+        float rs = 0.f;
+        for (int j = 0; j < LP; ++j) { sP[i][j] *= inv; rs += sP[i][j] * sD[i][j]; }
+        for (int j = 0; j < LP; ++j) sD[i][j] = sP[i][j] * (sD[i][j] - rs) * 0.125f;
+    }
+    __syncthreads();
+    E *dqb = dqkv + (int64_t)b * L * ld + h * 64;
+    for (int o = tid; o < LP * 64; o += 256) {                        // dQ, dK, dV rows x 64 dims
+        const int r = o >> 6, d = o & 63;
+        if (r >= L) continue;
+        float dq = 0.f, dk = 0.f, dv = 0.f;
+        for (int t = 0; t < L; ++t) {
+            dq += sD[r][t] * sK[t][d];
+            dk += sD[t][r] * sQ[t][d];
+            dv += sP[t][r] * sO[t][d];
+        }
+        dqb[(int64_t)r * ld + d] = (E)dq;
+        dqb[(int64_t)r * ld + W + d] = (E)dk;
+        dqb[(int64_t)r * ld + 2 * W + d] = (E)dv;
+    }
+}
+
 // ---- softmax cross-entropy over rows of fp32 logits: loss_row, dlogits = (softmax - onehot) * gscale ----------
 __global__ __launch_bounds__(256) void ce_rows(const float *__restrict__ logits, int64_t ld, const int32_t *__restrict__ labels, int rows, int n,
                                                float gscale, float *__restrict__ loss_rows, float *__restrict__ dlogits, int64_t ldd) {
@@ -340,33 +399,42 @@ __global__ __launch_bounds__(256) void l2norm_bwd(const float *__restrict__ x, c
     for (int j = lane; j < D; j += 64) o[j] = (accumulate ? o[j] : 0.f) + dr[j] * inv - xr[j] * k;
 }
 
-// ---- small fp32 product C[M,N] = alpha * sum_k A(m,k) B(k,n) (+ C), generic strides (any transposition) ----------
+// ---- fp32 product C[M,N] = alpha * sum_k A(m,k) B(k,n) (+ C), generic strides (any transposition) --------------
+// v_mfma_f32_32x32x2_f32: exact fp32 products and accumulation (a k-ordered fmaf chain), 1/16 of the bf16 MFMA rate -
+// plenty for the loss head and the projections.  One wave owns a 32 x 32 tile and streams its operands straight
+// from global memory (lane l holds A[m0 + (l & 31)][k + (l >> 5)] and B[k + (l >> 5)][n0 + (l & 31)]); 4 waves per
+// block cover 64 x 64.  Out-of-range rows / columns are clamped on load and masked on store.
 __global__ __launch_bounds__(256) void matmul_f32(const float *__restrict__ A, int64_t sam, int64_t sak, const float *__restrict__ B, int64_t sbk, int64_t sbn,
                                                   float *__restrict__ C, int64_t ldc, int M, int N, int K, float alpha, int accumulate) {
-    __shared__ float sA[32][33], sB[32][33];
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
-    float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-    for (int k0 = 0; k0 < K; k0 += 32) {
-        for (int i = threadIdx.x; i < 1024; i += 256) {
-            const int r = i >> 5, c = i & 31;
-            sA[r][c] = (m0 + r < M && k0 + c < K) ? A[(int64_t)(m0 + r) * sam + (int64_t)(k0 + c) * sak] : 0.f;
-            sB[r][c] = (k0 + r < K && n0 + c < N) ? B[(int64_t)(k0 + r) * sbk + (int64_t)(n0 + c) * sbn] : 0.f;
-        }
-        __syncthreads();
-#pragma unroll 8
-        for (int k = 0; k < 32; ++k) {
-            const float a0 = sA[ty * 2][k], a1 = sA[ty * 2 + 1][k], b0 = sB[k][tx * 2], b1 = sB[k][tx * 2 + 1];
-            acc[0][0] += a0 * b0; acc[0][1] += a0 * b1; acc[1][0] += a1 * b0; acc[1][1] += a1 * b1;
-        }
-        __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m0 = blockIdx.y * 64 + (wave >> 1) * 32, n0 = blockIdx.x * 64 + (wave & 1) * 32;
+    if (m0 >= M || n0 >= N) return;                                   // wave-uniform
+    const int r = lane & 31, h = lane >> 5;
+    const float *ap = A + (int64_t)min(m0 + r, M - 1) * sam;
+    const float *bp = B + (int64_t)min(n0 + r, N - 1) * sbn;
+    f32x16 acc = {0.f};
+    int k = 0;
+    for (; k + 8 <= K; k += 8) {                                     // 4 MFMAs per trip, loads issued together
+        float av[4], bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { av[u] = ap[(int64_t)(k + 2 * u + h) * sak]; bv[u] = bp[(int64_t)(k + 2 * u + h) * sbk]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
     }
+    for (; k < K; k += 2) {
+        const bool ok = k + h < K;
+        const float av = ok ? ap[(int64_t)(k + h) * sak] : 0.f, bv = ok ? bp[(int64_t)(k + h) * sbk] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+    const int n = n0 + r;
+    if (n < N)
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int m = m0 + ty * 2 + a, n = n0 + tx * 2 + c;
-            if (m < M && n < N) C[(int64_t)m * ldc + n] = (accumulate ? C[(int64_t)m * ldc + n] : 0.f) + alpha * acc[a][c];
+        for (int i = 0; i < 16; ++i) {
+            const int m = m0 + (i & 3) + 8 * (i >> 2) + 4 * h;           // C/D layout of the 32x32 shapes
+            if (m < M) {
+                float *c = C + (int64_t)m * ldc + n;
+                *c = (accumulate ? *c : 0.f) + alpha * acc[i];
+            }
         }
 }
 
@@ -398,9 +466,9 @@ __global__ __launch_bounds__(256) void sumsq(const float *__restrict__ x, int64_
 // `sumsq_total` (may be NULL) holds the squared global grad norm: grads are scaled by min(1, max_norm/(norm+1e-6))
 // like torch.nn.utils.clip_grad_norm_ (main.py:88).
 __global__ __launch_bounds__(256) void adamw(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v, int64_t n,
-                                             float lr, float b1, float b2, float eps, float wd, float bc1, float bc2, const float *__restrict__ sumsq_total, float max_norm) {
-    float clip = 1.f;
-    if (sumsq_total) { const float norm = sqrtf(*sumsq_total); clip = fminf(1.f, max_norm / (norm + 1e-6f)); }
+                                             float lr, float b1, float b2, float eps, float wd, float bc1, float bc2, const float *__restrict__ sumsq_total, float max_norm, float gscale) {
+    float clip = gscale;                                      // gscale: e.g. 1/world after a sum all-reduce
+    if (sumsq_total) { const float norm = sqrtf(*sumsq_total) * gscale; clip = gscale * fminf(1.f, max_norm / (norm + 1e-6f)); }
     const float rs2 = rsqrtf(bc2);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const float gi = g[i] * clip;
@@ -514,13 +582,15 @@ extern "C" int hgr_mha_bwd(const void *qkv, const void *dout, void *dqkv, int B,
     DT_OK("hgr_mha_bwd");
     hipStream_t s = (hipStream_t)stream;
     const dim3 g(B * heads);
-    if (dtype == HGR_BF16) {
-        if (causal) hipLaunchKernelGGL((mha_bwd64<HGR_BF16, true>), g, dim3(256), 0, s, (const __bf16 *)qkv, (const __bf16 *)dout, (__bf16 *)dqkv, L, heads);
-        else hipLaunchKernelGGL((mha_bwd64<HGR_BF16, false>), g, dim3(256), 0, s, (const __bf16 *)qkv, (const __bf16 *)dout, (__bf16 *)dqkv, L, heads);
-    } else {
-        if (causal) hipLaunchKernelGGL((mha_bwd64<HGR_F16, true>), g, dim3(256), 0, s, (const _Float16 *)qkv, (const _Float16 *)dout, (_Float16 *)dqkv, L, heads);
-        else hipLaunchKernelGGL((mha_bwd64<HGR_F16, false>), g, dim3(256), 0, s, (const _Float16 *)qkv, (const _Float16 *)dout, (_Float16 *)dqkv, L, heads);
-    }
+#define HGR_MB(KERN, ...)                                                                                                         \
+    do {                                                                                                                          \
+        if (dtype == HGR_BF16) hipLaunchKernelGGL((KERN<HGR_BF16, __VA_ARGS__>), g, dim3(256), 0, s, (const __bf16 *)qkv, (const __bf16 *)dout, (__bf16 *)dqkv, L, heads); \
+        else hipLaunchKernelGGL((KERN<HGR_F16, __VA_ARGS__>), g, dim3(256), 0, s, (const _Float16 *)qkv, (const _Float16 *)dout, (_Float16 *)dqkv, L, heads); \
+    } while (0)
+    if (L <= 16) { if (causal) HGR_MB(mha_bwd_small, 16, true); else HGR_MB(mha_bwd_small, 16, false); }
+    else if (L <= 32) { if (causal) HGR_MB(mha_bwd_small, 32, true); else HGR_MB(mha_bwd_small, 32, false); }
+    else { if (causal) HGR_MB(mha_bwd64, true); else HGR_MB(mha_bwd64, false); }
+#undef HGR_MB
     HGR_CHECK_LAUNCH("hgr_mha_bwd");
     return HGR_OK;
 }
@@ -542,7 +612,7 @@ extern "C" int hgr_l2norm_bwd(const float *x, const float *dy, float *dx, int ro
 extern "C" int hgr_matmul_f32(const float *A, int64_t sam, int64_t sak, const float *B, int64_t sbk, int64_t sbn, float *C, int64_t ldc,
                               int M, int N, int K, float alpha, int accumulate, void *stream) {
     HGR_REQUIRE(A && B && C && M >= 1 && N >= 1 && K >= 1 && ldc >= N, "hgr_matmul_f32: bad arguments");
-    hipLaunchKernelGGL(matmul_f32, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, (hipStream_t)stream, A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, alpha, accumulate);
+    hipLaunchKernelGGL(matmul_f32, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, (hipStream_t)stream, A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, alpha, accumulate);
     HGR_CHECK_LAUNCH("hgr_matmul_f32");
     return HGR_OK;
 }
@@ -562,10 +632,10 @@ extern "C" int hgr_sumsq(const float *x, int64_t n, float *out, void *stream) {
 }
 
 extern "C" int hgr_adamw(float *p, const float *g, float *m, float *v, int64_t n, float lr, float beta1, float beta2, float eps, float wd,
-                         int step, const float *sumsq_total, float max_norm, void *stream) {
+                         int step, const float *sumsq_total, float max_norm, float grad_scale, void *stream) {
     HGR_REQUIRE(p && g && m && v && n >= 1 && step >= 1, "hgr_adamw: bad arguments");
     const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
-    hipLaunchKernelGGL(adamw, dim3(grid1(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps, wd, bc1, bc2, sumsq_total, max_norm);
+    hipLaunchKernelGGL(adamw, dim3(grid1(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps, wd, bc1, bc2, sumsq_total, max_norm, grad_scale);
     HGR_CHECK_LAUNCH("hgr_adamw");
     return HGR_OK;
 }

@@ -96,8 +96,7 @@ def train(opts, epoch, model, train_loader, num_batches, optimizer, optimizer2, 
             optimizer.zero_grad()
         loss = model.train_batch(imgs, targets, opts.training_method, opts.sample_strategy)
         if group is not None:
-            from .parallel import allreduce_grads
-            allreduce_grads([p for n, p in model.named_parameters() if p.requires_grad], group)
+            optimizer.allreduce(group)                    # bucketed RCCL all-reduce on the flat gradient buffer
         optimizer.step()                                  # clip_grad_norm_(params, 1.0) + AdamW, main.py:87-91
         if optimizer2 is not None:
             optimizer2.step()

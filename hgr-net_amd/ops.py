@@ -276,6 +276,6 @@ def sumsq(x: torch.Tensor, out: torch.Tensor) -> None:
 
 
 def adamw(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, lr: float, step: int, betas=(0.9, 0.999), eps: float = 1e-8,
-          wd: float = 0.0, sumsq_total: Optional[torch.Tensor] = None, max_norm: float = 1.0) -> None:
+          wd: float = 0.0, sumsq_total: Optional[torch.Tensor] = None, max_norm: float = 1.0, grad_scale: float = 1.0) -> None:
     assert p.is_contiguous() and g.is_contiguous() and p.dtype == g.dtype == m.dtype == v.dtype == torch.float32
-    _lib.call("hgr_adamw", _dev(p), _dev(g), _dev(m), _dev(v), p.numel(), lr, betas[0], betas[1], eps, wd, step, _dev(sumsq_total), max_norm, _stream())
+    _lib.call("hgr_adamw", _dev(p), _dev(g), _dev(m), _dev(v), p.numel(), lr, betas[0], betas[1], eps, wd, step, _dev(sumsq_total), max_norm, grad_scale, _stream())

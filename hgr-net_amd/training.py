@@ -92,8 +92,9 @@ class Engine:
         """dW += dY^T X, db += colsum(dY); returns dX = dY W (16-bit) if wanted.  dy16 [m, n], x16 [m, k]."""
         dev, dt = self.dev, self.dt
         mp = _pad64(m)
-        dyt = torch.zeros(lin.n, mp, dtype=dt, device=dev)
-        xt = torch.zeros(lin.k, mp, dtype=dt, device=dev)
+        alloc = torch.empty if mp == m else torch.zeros           # the pad columns must be zero, the rest is overwritten
+        dyt = alloc(lin.n, mp, dtype=dt, device=dev)
+        xt = alloc(lin.k, mp, dtype=dt, device=dev)
         ops.transpose16(dy16, dyt)
         ops.transpose16(x16, xt)
         gw = _grad(lin.weight).view(lin.n, lin.k)
@@ -332,37 +333,74 @@ class OMTrainer:
 
 class FusedAdamW:
     """clip_grad_norm_(params, max_norm) + AdamW.step() of main.py:87-91 as fused kernels on fp32 masters.
-    One `hgr_sumsq` per tensor into a device scalar, then one `hgr_adamw` per tensor that reads the clip
-    factor from device memory: no host synchronisation inside the step."""
+
+    The parameters and their gradients are re-laid out as views into TWO flat fp32 buffers (256-byte aligned
+    slots), so that one step is ONE `hgr_sumsq` + ONE `hgr_adamw` launch over everything (the clip factor is
+    read from device memory: no host synchronisation), `zero_grad` is one memset and the data-parallel
+    gradient all-reduce runs directly on bucket-sized views of the flat gradient buffer, without packing."""
 
     def __init__(self, params, lr: float = 3e-7, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0, max_norm: Optional[float] = 1.0):
         self.params = [p for p in params]
         self.param_groups = [dict(lr=lr, params=self.params)]       # so the reference's cosine_lr scheduler can drive it (utils.py:82-95)
         self.betas, self.eps, self.wd, self.max_norm = betas, eps, weight_decay, max_norm
         self.step_count = 0
-        self.state = {id(p): (torch.zeros_like(p.data, dtype=torch.float32), torch.zeros_like(p.data, dtype=torch.float32)) for p in self.params}
-        self._tot = None
+        dev = self.params[0].device
+        offs, total = [], 0
+        for p in self.params:
+            offs.append(total)
+            total += (p.numel() + 63) // 64 * 64
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.gflat = torch.zeros(total, dtype=torch.float32, device=dev)
+        for p, off in zip(self.params, offs):
+            n = p.numel()
+            self.flat[off: off + n].copy_(p.data.reshape(-1))
+            p.data = self.flat[off: off + n].view(p.data.shape)
+            g = self.gflat[off: off + n].view(p.data.shape)
+            if p.grad is not None:
+                g.copy_(p.grad)
+            p.grad = g
+        self.m = torch.zeros_like(self.flat)
+        self.v = torch.zeros_like(self.flat)
+        self._tot = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.grad_scale = 1.0
+
+    def _relink(self):
+        """A caller may have dropped gradients (`p.grad = None`): point them back at the flat buffer."""
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            if p.grad is None or p.grad.data_ptr() != self.gflat[off: off + n].data_ptr():
+                g = self.gflat[off: off + n].view(p.data.shape)
+                if p.grad is not None:
+                    g.copy_(p.grad)
+                else:
+                    g.zero_()
+                p.grad = g
+            off += (n + 63) // 64 * 64
+
+    def allreduce(self, group=None, bucket_bytes: int = 64 << 20):
+        """Sum the flat gradient buffer over the ranks, bucket by bucket (RCCL all-reduce on views, no packing);
+        the 1/world average is folded into the next step's `grad_scale`."""
+        import torch.distributed as dist
+        self._relink()
+        step = max(1, bucket_bytes // 4)
+        for lo in range(0, self.gflat.numel(), step):
+            dist.all_reduce(self.gflat[lo: lo + step], op=dist.ReduceOp.SUM, group=group)
+        self.grad_scale = 1.0 / dist.get_world_size(group)
 
     @torch.no_grad()
     def step(self):
         self.step_count += 1
+        self._relink()
         lr = self.param_groups[0]["lr"]
-        live = [p for p in self.params if p.grad is not None]
-        if not live:
-            return
         tot = None
         if self.max_norm is not None:
-            if self._tot is None:
-                self._tot = torch.zeros(1, dtype=torch.float32, device=live[0].device)
             tot = self._tot
             tot.zero_()
-            for p in live:
-                ops.sumsq(p.grad.contiguous(), tot)
-        for p in live:
-            m, v = self.state[id(p)]
-            ops.adamw(p.data, p.grad.contiguous(), m, v, lr, self.step_count, self.betas, self.eps, self.wd, tot, self.max_norm or 0.0)
+            ops.sumsq(self.gflat, tot)
+        ops.adamw(self.flat, self.gflat, self.m, self.v, lr, self.step_count, self.betas, self.eps, self.wd, tot, self.max_norm or 0.0, self.grad_scale)
+        self.grad_scale = 1.0
 
     def zero_grad(self):
-        for p in self.params:
-            if p.grad is not None:
-                p.grad.zero_()
+        self._relink()
+        self.gflat.zero_()

@@ -253,9 +253,10 @@ int hgr_sumsq(const float *x, int64_t n, float *out, void *stream);
 /*
  * Fused AdamW step with torch.optim.AdamW semantics (main.py:247,91) on fp32 master parameters; if sumsq_total
  * is given, gradients are first scaled by min(1, max_norm / (sqrt(*sumsq_total) + 1e-6)) = clip_grad_norm_.
+ * grad_scale multiplies every gradient first (1/world after a sum all-reduce; 1 otherwise).
  */
 int hgr_adamw(float *p, const float *g, float *m, float *v, int64_t n, float lr, float beta1, float beta2, float eps,
-              float wd, int step, const float *sumsq_total, float max_norm, void *stream);
+              float wd, int step, const float *sumsq_total, float max_norm, float grad_scale, void *stream);
 
 #ifdef __cplusplus
 }
