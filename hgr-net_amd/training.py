@@ -250,7 +250,7 @@ class OMTrainer:
         self.contra_override: Optional[Callable[[int], tuple]] = None
         self.last_contra: list = []
 
-    def _head(self, img_n, dimg_n, tfeat, label_pos: int, weight, loss_acc):
+    def _head(self, img_n, dimg_n, tfeat, label_pos: int, weight, loss_acc, ce_out=None):
         """logits = img_n tn^T * exp(logit_scale); CE (all rows share the label); gradients of the three inputs."""
         e, m, dev = self.engine, self.engine.m, self.engine.dev
         b, d = img_n.shape
@@ -266,6 +266,8 @@ class OMTrainer:
         wv = float(weight)
         ops.ce_rows(logits, labels, loss_rows, dlog, gscale=wv / b)
         ops.matmul_f32(loss_rows.view(1, b), torch.ones(b, 1, device=dev), loss_acc, alpha=wv / b, accumulate=True)   # loss_j = mean * w
+        if ce_out is not None:
+            ops.matmul_f32(loss_rows.view(1, b), torch.ones(b, 1, device=dev), ce_out, alpha=1.0 / b)
         ops.matmul_f32(dlog, tn, dimg_n, alpha=scale, accumulate=True)                     # d img_n += s * dlog @ tn
         dtn = torch.empty_like(tn)
         ops.matmul_f32(dlog.t(), img_n, dtn, alpha=scale)                                  # d tn = s * dlog^T @ img_n
@@ -312,19 +314,35 @@ class OMTrainer:
                 w_in = tree.get_weights("equal" if wmode == "out" else tree.opts.weights, st["M"])
                 w_out = tree.get_weights("equal" if wmode == "in" else tree.opts.weights, st["K"])
                 wgt = w_in[st["m_loop"]] * w_out[st["k_loop"]]
-            picks.append((list(ids), pos, float(wgt)))
-        self.last_contra = [(ids, pos) for ids, pos, _ in picks]
-        uniq = sorted({i for ids, _, _ in picks for i in ids})
+            picks.append((list(ids), pos, float(wgt), wgt))
+        self.last_contra = [(ids, pos) for ids, pos, _, _ in picks]
+        uniq = sorted({i for ids, _, _, _ in picks for i in ids})
         where = {nid: j for j, nid in enumerate(uniq)}
         tfeat_u, tsave = e.text_fwd(tree.node_tokens[torch.tensor(uniq, device=e.dev)])
         dtfeat_u = torch.zeros_like(tfeat_u)
-        for ids, pos, wgt in picks:
+        adaptive = tree.opts.weights == "adaptive"
+        ces = torch.zeros(len(picks), 1, dtype=torch.float32, device=e.dev) if adaptive else None
+        for j, (ids, pos, wgt, _) in enumerate(picks):
             loc = torch.tensor([where[i] for i in ids], dtype=torch.int32, device=e.dev)
             tfeat = torch.empty(len(ids), tfeat_u.shape[1], dtype=torch.float32, device=e.dev)
             ops.rows_gather(tfeat_u, loc, tfeat)
-            dtfeat = self._head(img_n, dimg_n, tfeat, pos, wgt, loss_acc)
+            dtfeat = self._head(img_n, dimg_n, tfeat, pos, wgt, loss_acc, ces[j: j + 1] if adaptive else None)
             ops.rows_axpy(dtfeat_u, dtfeat, dst_mul=0, dst_idx=loc)
         e.text_bwd(dtfeat_u, tsave)
+        if adaptive:
+            # loss = sum_j CE_j * w_j(layer_weight): the <= 13-element softmax(100 ** layer_weight) of get_weights is host-level
+            # glue in the reference too (clip_tree.py:209); its gradient comes from autograd over those tiny tensors
+            with torch.enable_grad():
+                ws = []
+                for st in steps:
+                    if st.get("hier"):
+                        ws.append(tree.get_weights("adaptive", st["K"])[st["k_loop"]])
+                    else:
+                        wmode = tree.opts.weighting
+                        w_in = tree.get_weights("equal" if wmode == "out" else "adaptive", st["M"])
+                        w_out = tree.get_weights("equal" if wmode == "in" else "adaptive", st["K"])
+                        ws.append(w_in[st["m_loop"]] * w_out[st["k_loop"]])
+                (torch.stack(ws) * ces.view(-1)).sum().backward()
         dfeat = torch.empty_like(feat)
         ops.l2norm_bwd(feat, dimg_n, dfeat)
         e.image_bwd(dfeat, isave)

@@ -27,7 +27,7 @@ def _cfg(z):
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
-@pytest.mark.parametrize("case", ["tiny-vit", "small-vit", "ViT-B_32", "tiny-rn", "small-rn", "RN50"])
+@pytest.mark.parametrize("case", ["tiny-vit", "small-vit", "ViT-B_32", "ViT-L_14", "tiny-rn", "small-rn", "RN50"])
 def test_towers_vs_reference_fixture(case, dt, golden_dir):
     z = np.load(golden_dir / f"clip_{case}.npz")
     cfg = _cfg(z)

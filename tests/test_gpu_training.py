@@ -159,3 +159,20 @@ def test_driver_trains_saves_and_evaluates(golden_dir, tmp_path):
     assert set(ck) == set(synth.clip_state_dict(cfg, 0))                              # reference checkpoint schema
     log = (tmp_path / "run" / "HGR" / "equal_0.5_0.5" / "arugements.log").read_text()
     assert "loss:" in log and "Top@1(%)" in log
+
+
+def test_adaptive_layer_weight_gets_its_gradient(golden_dir, tmp_path):
+    """--weights adaptive (the reference's default flag): d loss / d layer_weight = sum_j CE_j * d w_j / d layer_weight."""
+    model, meta, cfg = _build("tinyvit_n90", golden_dir, tmp_path, "bf16")
+    t = meta["train"]
+    model.opts.weights = "adaptive"
+    num_layer = [len(model.d2n[layer]) for layer in model.d2n.keys()]
+    model.layer_weight = torch.nn.Parameter(((1.0 / torch.tensor(num_layer, dtype=torch.float32)) * 1.0).to(DEV))
+    img = synth.images(t["bsz"], cfg["image_resolution"], t["image_seed"]).to(DEV)
+    targets = torch.full((t["bsz"],), t["target"], dtype=torch.long, device=DEV)
+    loss = model.train_batch(img, targets, "OM", "topk")
+    g = model.layer_weight.grad
+    assert g is not None and torch.isfinite(g).all() and float(g.abs().sum()) > 0
+    # gradient flows only to the levels that were contrasted in this step
+    assert float(g[model.max_depth + 1:].abs().sum()) == 0 if g.numel() > model.max_depth + 1 else True
+    assert loss > 0

@@ -274,6 +274,7 @@ def main():
         if not a.skip_big:
             clip_fixture(ref_clip, "ViT-B/32", C["ViT-B/32"], 2, 8, tmp)
             clip_fixture(ref_clip, "RN50", C["RN50"], 2, 2, tmp)
+            clip_fixture(ref_clip, "ViT-L/14", C["ViT-L/14"], 1, 2, tmp)
         tv = dict(C["tiny-vit"], vocab_size=49408)   # real BPE ids need the real vocabulary size
         tree_fixture(ref_main, "tinyvit_n90", tv, 90, 30, 40, 3, 8, tmp)
         sv = dict(C["small-vit"], vocab_size=49408)
