@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--image-dtype", default="f16")
     ap.add_argument("--text-dtype", default="f16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pcie", dest="pcie", action="store_false", help="skip the PCIe-inclusive (host uint8 input) measurement")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -185,6 +186,52 @@ def main():
                                    "frac_mfma": round(lg[0][1] / tl / 1e12 / PEAK_TFLOPS_BF16, 4),
                                    "gbps": round(lg[0][2] / tl / 1e9, 1), "frac_hbm": round(lg[0][2] / tl / 8e12, 4)}
 
+    # PCIe-inclusive rate (never `value`): the same step fed from pinned HOST memory with uint8 NHWC crops (what a
+    # JPEG decoder hands over), H2D on a copy stream double-buffered against compute, normalisation fused into the
+    # patch kernel (hgr_im2col_patches_u8).
+    pcie = None
+    if a.pcie and cfg["vision_patch_size"]:
+        r = cfg["image_resolution"]
+        g = torch.Generator().manual_seed(1234 + rank)
+        host = [torch.randint(0, 256, (a.batch, r, r, 3), dtype=torch.uint8, generator=g).pin_memory() for _ in range(2)]
+        dbuf = [torch.empty((a.batch, r, r, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
+        cs = torch.cuda.Stream()
+        ready = [torch.cuda.Event(), torch.cuda.Event()]
+        free = [torch.cuda.Event(), torch.cuda.Event()]
+        for e_ in free:
+            e_.record()
+
+        def prefetch(i):
+            with torch.cuda.stream(cs):
+                cs.wait_event(free[i & 1])
+                dbuf[i & 1].copy_(host[i & 1], non_blocking=True)
+                ready[i & 1].record(cs)
+
+        def ustep(i):
+            prefetch(i + 1)
+            torch.cuda.current_stream().wait_event(ready[i & 1])
+            logits = model(dbuf[i & 1], None)
+            ev.add_batch(logits, targets[i % len(targets)])
+            free[i & 1].record()
+
+        prefetch(0)
+        for i in range(min(3, a.warmup)):
+            ustep(i)
+        fence()
+        base_i = min(3, a.warmup)
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            ustep(base_i + i)
+        fence()
+        el = time.perf_counter() - t0
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        pcie = {"value": round(a.batch * world * a.steps / el, 1), "unit": "images/sec", "ms_per_step": round(el / a.steps * 1e3, 3),
+                "input": f"uint8 NHWC crops in pinned host memory ({a.batch * r * r * 3 / 1e6:.0f} MB/batch), H2D double-buffered on a copy stream"}
+
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(sd, model.zsl_weights.float().cpu())
@@ -198,7 +245,7 @@ def main():
                                        f"+ top-20/top-1/level-argmax metrics (main.py:131-191), N={a.nodes} nodes, batch {a.batch}/GPU",
                            "global_batch": a.batch * world, "parallelism": f"dp{world}", "text_dtype": a.text_dtype,
                            "weights": "random-init (hash-seeded), no checkpoint offline"},
-                "roofline": roof, "cpu_baseline": cpu, "metrics_string": summary.strip()}
+                "roofline": roof, "cpu_baseline": cpu, "pcie_inclusive": pcie, "metrics_string": summary.strip()}
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist

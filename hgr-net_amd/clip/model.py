@@ -337,6 +337,8 @@ class CLIP(nn.Module):
                 wc = torch.zeros(v.conv1.weight.shape[0], kp, dtype=dt, device=v.conv1.weight.device)
                 wc[:, :k] = v.conv1.weight.detach().reshape(v.conv1.weight.shape[0], -1).to(dt)
                 p["conv_w"], p["kp"] = wc, kp
+                # the same weight in (py, px, c) K order for the uint8 NHWC input path (hgr_im2col_patches_u8)
+                p["conv_w_nhwc"] = v.conv1.weight.detach().permute(0, 2, 3, 1).reshape(v.conv1.weight.shape[0], -1).to(dt).contiguous()
                 p["cls"], p["pos"] = _f32(v.class_embedding), _f32(v.positional_embedding)
                 p["ln_pre"] = (_f32(v.ln_pre.weight), _f32(v.ln_pre.bias))
                 p["ln_post"] = (_f32(v.ln_post.weight), _f32(v.ln_post.bias))
@@ -360,8 +362,15 @@ class CLIP(nn.Module):
             raise HgrError("encode_image needs a device tensor: the product path has no CPU fallback")
         p = self._prepared()
         dt, ws, dev = self.image_dtype, self._ws, image.device
-        image = image.float().contiguous()
-        b, _, r, _ = image.shape
+        u8 = image.dtype == torch.uint8                       # [B, R, R, 3] crops straight from the decoder: normalised in the patch kernel
+        if u8:
+            if not isinstance(v, VisionTransformer) or image.dim() != 4 or image.shape[-1] != 3 or (3 * v.patch_size ** 2) % 64:
+                raise NotImplementedError("uint8 NHWC input is implemented for ViT towers with 3*P*P % 64 == 0")
+            image = image.contiguous()
+            b, r = image.shape[0], image.shape[1]
+        else:
+            image = image.float().contiguous()
+            b, _, r, _ = image.shape
         if r != v.input_resolution:
             raise ValueError(f"expected {v.input_resolution}x{v.input_resolution} input, got {r}")
         if not isinstance(v, VisionTransformer):
@@ -370,9 +379,12 @@ class CLIP(nn.Module):
         g = r // ps
         gg, l, w = g * g, g * g + 1, v.conv1.weight.shape[0]
         patches = ws.get("v.patches", (b * gg, p["kp"]), dt, dev)
-        ops.im2col_patches(image, patches, ps)
+        if u8:
+            ops.im2col_patches_u8(image, patches, ps)
+        else:
+            ops.im2col_patches(image, patches, ps)
         pe = ws.get("v.pe", (b * gg, w), torch.float32, dev)
-        ops.gemm_nt(patches, p["conv_w"], pe)
+        ops.gemm_nt(patches, p["conv_w_nhwc"] if u8 else p["conv_w"], pe)
         x = ws.get("v.x", (b * l, w), torch.float32, dev)
         ops.vit_embed_ln(pe, p["cls"], p["pos"], p["ln_pre"][0], p["ln_pre"][1], x, b, gg)
         if taps is not None:

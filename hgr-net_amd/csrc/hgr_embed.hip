@@ -90,6 +90,33 @@ __global__ __launch_bounds__(256) void eot_index(const int64_t *__restrict__ tok
     if (lane == 0) eot[row] = bi;
 }
 
+// uint8 NHWC crops -> normalised 16-bit patch rows in (py, px, c) order: patch row py of patch (gy, gx) is the
+// contiguous 3*P bytes  image[b, gy*P + py, gx*P .. gx*P + P - 1, 0..2];  out = v * a[c] + b[c] with
+// a = 1/(255 std), b = -mean/std (ToTensor + Normalize of clip/clip.py:71-78 folded).  One thread = 4 pixels
+// = 12 bytes in (3 dword loads), 12 values out (24 B).
+template <int DT>
+__global__ __launch_bounds__(256) void im2col_u8(const unsigned char *__restrict__ img, typename T16<DT>::elem *__restrict__ out,
+                                                 int B, int R, int P, int Kp, int rpi, int roff, float a0, float a1, float a2, float b0, float b1, float b2) {
+    typedef typename T16<DT>::elem E;
+    const int g = R / P, q = R / 4;
+    const int64_t total = (int64_t)B * R * q;
+    const float sa[3] = {a0, a1, a2}, sb[3] = {b0, b1, b2};
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int x4 = (int)(i % q);
+        const int y = (int)((i / q) % R);
+        const int b = (int)(i / ((int64_t)q * R));
+        const unsigned int *src = (const unsigned int *)(img + (((int64_t)b * R + y) * R + x4 * 4) * 3);
+        const unsigned int w0 = src[0], w1 = src[1], w2 = src[2];
+        unsigned char px[12];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { px[e] = (w0 >> (8 * e)) & 255; px[4 + e] = (w1 >> (8 * e)) & 255; px[8 + e] = (w2 >> (8 * e)) & 255; }
+        const int x = x4 * 4, gy = y / P, py = y - gy * P, gx = x / P, pxo = x - gx * P;
+        E *o = out + ((int64_t)b * rpi + roff + gy * g + gx) * Kp + (py * P + pxo) * 3;
+#pragma unroll
+        for (int e = 0; e < 12; ++e) o[e] = (E)((float)px[e] * sa[e % 3] + sb[e % 3]);
+    }
+}
+
 // t[b, l] = pe[b, l] + pos[l] + (l == 0 ? cls : 0) in place on the [B*L, W] patch-GEMM output whose class rows are zero
 __global__ __launch_bounds__(256) void vit_assemble(float *__restrict__ t, const float *__restrict__ cls, const float *__restrict__ pos, int B, int L, int W) {
     const int nv = W >> 2;
@@ -167,5 +194,23 @@ extern "C" int hgr_eot_index(const int64_t *tokens, int64_t ld_tokens, int32_t *
     HGR_REQUIRE(n >= 1 && ctx >= 1 && ld_tokens >= ctx, "hgr_eot_index: n=%d ctx=%d ld=%lld unsupported", n, ctx, (long long)ld_tokens);
     hipLaunchKernelGGL(eot_index, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, tokens, ld_tokens, eot, n, ctx);
     HGR_CHECK_LAUNCH("hgr_eot_index");
+    return HGR_OK;
+}
+
+extern "C" int hgr_im2col_patches_u8(const unsigned char *image, void *out, int B, int R, int P, int Kp, int rows_per_image, int row_offset,
+                                     const float *mean3, const float *std3, int dtype, void *stream) {
+    HGR_REQUIRE(image && out && mean3 && std3, "hgr_im2col_patches_u8: null operand");
+    HGR_REQUIRE(B >= 1 && P >= 4 && P % 4 == 0 && R >= P && R % P == 0, "hgr_im2col_patches_u8: B=%d R=%d P=%d unsupported (P %% 4 == 0)", B, R, P);
+    HGR_REQUIRE(Kp == 3 * P * P, "hgr_im2col_patches_u8: Kp must equal 3*P*P (no K padding on this path)");
+    HGR_REQUIRE(row_offset >= 0 && rows_per_image >= row_offset + (R / P) * (R / P), "hgr_im2col_patches_u8: bad row mapping");
+    HGR_REQUIRE(hgr_aligned(image, 4) && hgr_aligned(out, 8), "hgr_im2col_patches_u8: misaligned operand");
+    HGR_REQUIRE(dtype == HGR_BF16 || dtype == HGR_F16, "hgr_im2col_patches_u8: bad dtype %d", dtype);
+    float a[3], b[3];
+    for (int c = 0; c < 3; ++c) { a[c] = 1.0f / (255.0f * std3[c]); b[c] = -mean3[c] / std3[c]; }      // host pointers
+    const int64_t total = (int64_t)B * R * (R / 4);
+    const unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (dtype == HGR_BF16) hipLaunchKernelGGL((im2col_u8<HGR_BF16>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, image, (__bf16 *)out, B, R, P, Kp, rows_per_image, row_offset, a[0], a[1], a[2], b[0], b[1], b[2]);
+    else hipLaunchKernelGGL((im2col_u8<HGR_F16>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, image, (_Float16 *)out, B, R, P, Kp, rows_per_image, row_offset, a[0], a[1], a[2], b[0], b[1], b[2]);
+    HGR_CHECK_LAUNCH("hgr_im2col_patches_u8");
     return HGR_OK;
 }

@@ -78,6 +78,21 @@ def im2col_patches_tokens(image: torch.Tensor, out: torch.Tensor, patch: int, l:
     return out
 
 
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)      # clip/clip.py:77
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def im2col_patches_u8(image: torch.Tensor, out: torch.Tensor, patch: int, mean=CLIP_MEAN, std=CLIP_STD) -> torch.Tensor:
+    """uint8 NHWC [B, R, R, 3] -> normalised 16-bit patch rows in (py, px, c) order."""
+    import ctypes
+    b, r, r2, c = image.shape
+    assert image.dtype == torch.uint8 and c == 3 and r == r2 and image.is_contiguous() and out.is_contiguous()
+    g = r // patch
+    m3, s3 = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
+    _lib.call("hgr_im2col_patches_u8", _dev(image), _dev(out), b, r, patch, out.shape[1], g * g, 0, m3, s3, DT_OF[out.dtype], _stream())
+    return out
+
+
 def vit_assemble(t: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, b: int, l: int) -> torch.Tensor:
     _lib.call("hgr_vit_assemble", _dev(t), _dev(cls), _dev(pos), b, l, t.shape[1], _stream())
     return t

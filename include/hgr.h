@@ -74,6 +74,12 @@ int hgr_im2col_patches(const float *image, void *out, int B, int R, int P, int K
  * directly in the [B, L] token layout with the class-token rows left untouched (training keeps them zero). */
 int hgr_im2col_patches_ex(const float *image, void *out, int B, int R, int P, int Kp, int rows_per_image, int row_offset,
                           int dtype, void *stream);
+/* Input-pipeline form: uint8 NHWC crops [B, R, R, 3] (what PIL / a JPEG decoder hands over) -> normalised 16-bit
+ * patch rows in (py, px, c) order, fusing ToTensor + Normalize(mean, std) of clip/clip.py:71-78 into the patch
+ * extraction.  mean3 / std3 are HOST pointers to 3 floats.  The conv weight must be permuted to the same K order
+ * (weight.permute(0,2,3,1)); a quarter of the bytes of the fp32 path cross PCIe and HBM. */
+int hgr_im2col_patches_u8(const unsigned char *image, void *out, int B, int R, int P, int Kp, int rows_per_image,
+                          int row_offset, const float *mean3, const float *std3, int dtype, void *stream);
 /* In place on the [B*L, W] fp32 patch-GEMM output with zero class rows: t[b,l] += positional[l] + (l == 0 ? class : 0)
  * (clip/model.py:223-224; the un-fused form of hgr_vit_embed_ln, whose pre-LayerNorm sum the backward needs). */
 int hgr_vit_assemble(float *t, const float *class_embedding, const float *positional_embedding, int B, int L, int W, void *stream);

@@ -171,3 +171,17 @@ def test_full_size_properties_vitb32():
     lg3 = torch.empty(b, ld, dtype=torch.float32, device=DEV)
     ops.gemm_nt(f, z, lg3, n=n)
     assert torch.equal(lg3[:, :n], lg[:, :n])
+
+
+def test_uint8_nhwc_input_matches_normalised_float_path():
+    """uint8 crops normalised inside the patch kernel == ToTensor + Normalize (clip/clip.py:71-78) then the fp32 path."""
+    sd = synth.clip_state_dict("small-vit", 0)
+    model = build_model(sd).to(DEV)
+    u8 = torch.from_numpy(synth.randint(4, "u8", 3 * 96 * 96 * 3, 0, 256).astype(np.uint8).reshape(3, 96, 96, 3))
+    mean, std = torch.tensor(ops.CLIP_MEAN).view(1, 3, 1, 1), torch.tensor(ops.CLIP_STD).view(1, 3, 1, 1)
+    x = (u8.permute(0, 3, 1, 2).float() / 255.0 - mean) / std
+    f_u8 = model.encode_image(u8.to(DEV)).cpu()
+    f_fp = model.encode_image(x.to(DEV)).cpu()
+    ref = clip_ref.encode_image(sd, x)
+    assert (f_u8 - f_fp).abs().max() < 2e-3 * max(1.0, float(ref.abs().max()))
+    assert (f_u8 - ref).abs().max() < 6e-3 * max(1.0, float(ref.abs().max()))
