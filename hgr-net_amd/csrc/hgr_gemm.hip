@@ -557,36 +557,61 @@ extern "C" int hgr_gemm_nt(const void *A, int64_t lda, const void *W, int64_t ld
     HGR_REQUIRE(epilogue != HGR_EPI_BIAS_ADD16_RELU || !out_f32, "hgr_gemm_nt: ADD16_RELU writes 16-bit output");
     HGR_REQUIRE(hgr_aligned(C, out_f32 ? 4 : 2), "hgr_gemm_nt: C misaligned");
 
-    GemmArgs a;
-    a.A = (const char *)A; a.lda = lda; a.W = (const char *)W; a.ldw = ldw;
-    a.C = C; a.ldc = ldc; a.bias = bias; a.res = (const float *)residual; a.ldr = ldr;
-    a.M = M; a.N = N; a.K = K;
-    // tile choice: the 256^2 deep-pipelined kernel when its workgroups fill the 256 CUs evenly, otherwise
-    // 128^2 tiles at 2 workgroups per CU (N = 768 outputs: 300 big tiles would run at 59 %; the logits GEMM
-    // with M = 512; small shapes)
-    const int force = hgr_gemm_force_tile();
-    const int64_t t256 = (int64_t)((M + 255) / 256) * ((N + 255) / 256);
-    // one 512-thread workgroup per CU: the launch runs in ceil(t256 / 256) rounds, the last one partly empty
-    const double eff256 = (double)t256 / (double)(((t256 + 255) / 256) * 256);
-    bool big = (K >= 128) && (eff256 >= 0.85);
-    if (force == 128) big = false;
-    if (force == 256 && K >= 128) big = true;
-    const int T = big ? 256 : 128;
-    a.tiles_m = (M + T - 1) / T;
-    a.tiles_n = (N + T - 1) / T;
-    // each XCD owns a contiguous range of tile ids; the operand indexed by the slow tile index is
-    // fetched ~once, the other one once per XCD.  Make the bigger operand the once-fetched one.
-    a.m_fastest = ((int64_t)N * K > (int64_t)M * K) ? 1 : 0;
     bool vec = (ldc % 4 == 0) && hgr_aligned(C, out_f32 ? 16 : 8);
     if (epilogue != HGR_EPI_NONE && epilogue != HGR_EPI_ACCUM) vec = vec && hgr_aligned(bias, 16);
     if (epilogue == HGR_EPI_BIAS_RESIDUAL) vec = vec && (ldr % 4 == 0) && hgr_aligned(residual, 16);
     if (epilogue == HGR_EPI_BIAS_ADD16_RELU) vec = vec && (ldr % 4 == 0) && hgr_aligned(residual, 8);
-    a.vec_ok = vec ? 1 : 0;
-    { static int dbg = -1; if (dbg < 0) { const char *e = getenv("HGR_GEMM_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
-    dim3 grid((unsigned)(a.tiles_m * a.tiles_n));
+    static int dbg = -1, split_env = -1;
+    if (dbg < 0) { const char *e = getenv("HGR_GEMM_DBG"); dbg = e ? atoi(e) : 0; }
+    if (split_env < 0) { const char *e = getenv("HGR_GEMM_SPLIT"); split_env = e ? atoi(e) : 1; }
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == HGR_BF16) launch_dt<HGR_BF16>(a, epilogue, out_f32 != 0, grid, s, big);
-    else launch_dt<HGR_F16>(a, epilogue, out_f32 != 0, grid, s, big);
+    const size_t csz = out_f32 ? 4 : 2, rsz = (epilogue == HGR_EPI_BIAS_ADD16_RELU) ? 2 : 4;
+
+    // launch rows [m_lo, m_lo + m_cnt) with one tile size
+    auto launch = [&](int m_lo, int m_cnt, bool big) {
+        GemmArgs a;
+        a.A = (const char *)A + (size_t)m_lo * lda * 2; a.lda = lda; a.W = (const char *)W; a.ldw = ldw;
+        a.C = (char *)C + (size_t)m_lo * ldc * csz; a.ldc = ldc; a.bias = bias;
+        a.res = residual ? (const float *)((const char *)residual + (size_t)m_lo * ldr * rsz) : nullptr; a.ldr = ldr;
+        a.M = m_cnt; a.N = N; a.K = K;
+        const int T = big ? 256 : 128;
+        a.tiles_m = (m_cnt + T - 1) / T;
+        a.tiles_n = (N + T - 1) / T;
+        // each XCD owns a contiguous range of tile ids; the operand indexed by the slow tile index is fetched ~once,
+        // the other one once per XCD.  Make the bigger operand the once-fetched one.
+        a.m_fastest = ((int64_t)N * K > (int64_t)m_cnt * K) ? 1 : 0;
+        a.vec_ok = vec ? 1 : 0;
+        a.dbg = dbg;
+        dim3 grid((unsigned)(a.tiles_m * a.tiles_n));
+        if (dtype == HGR_BF16) launch_dt<HGR_BF16>(a, epilogue, out_f32 != 0, grid, s, big);
+        else launch_dt<HGR_F16>(a, epilogue, out_f32 != 0, grid, s, big);
+    };
+
+    // Tile choice.  The 256^2 deep-pipelined kernel owns a CU (one 512-thread workgroup), so a launch runs in rounds of
+    // 256 workgroups; 128^2 tiles run 2 workgroups per CU.  Three plans are priced with measured tile times: all big,
+    // all small, or full rounds of big tiles on the first row panels + the remaining panels on the small-tile kernel in a
+    // second launch (pays off at long K, where a mostly empty last big round is expensive: c_proj / patch GEMM).
+    const int force = hgr_gemm_force_tile();
+    const int tn256 = (N + 255) / 256, tm256 = (M + 255) / 256;
+    const int64_t t256 = (int64_t)tm256 * tn256;
+    const int64_t t128 = (int64_t)((M + 127) / 128) * ((N + 127) / 128);
+    // measured tile times on MI355X (us): 256^2 tile ~ 1.75 per K-tile + 14 (prologue + epilogue, nothing overlaps them
+    // at one workgroup per CU); 128^2 tile at 2 per CU ~ 1.08 per K-tile + 9
+    const double Tb = 1.75 * (K / 64) + 14.0, Ts = 1.08 * (K / 64) + 9.0;
+    const double cost_small = (double)((t128 + 511) / 512) * Ts;
+    const double cost_big = (double)((t256 + 255) / 256) * Tb;
+    const int64_t rounds = t256 / 256;
+    const int big_panels = (int)((rounds * 256) / tn256);
+    const int m1 = big_panels * 256;
+    double cost_split = 1e30;
+    if (split_env && rounds >= 1 && m1 > 0 && m1 < M) {
+        const int64_t ts = (int64_t)((M - m1 + 127) / 128) * ((N + 127) / 128);
+        cost_split = (double)rounds * Tb + (double)((ts + 511) / 512) * Ts + 2.0;          // + one kernel boundary
+    }
+    if (force == 128 || K < 128) launch(0, M, false);
+    else if (force == 256) launch(0, M, true);
+    else if (cost_split < cost_big && cost_split < cost_small) { launch(0, m1, true); launch(m1, M - m1, false); }
+    else launch(0, M, cost_big <= cost_small && t256 >= 128);
     HGR_CHECK_LAUNCH("hgr_gemm_nt");
     return HGR_OK;
 }

@@ -281,3 +281,23 @@ def test_stem_im2col_avgpool_attnpool(dt):
     vh = v16.float().view(b, l, heads, 64).transpose(1, 2)
     oref = (torch.softmax(qh @ kh.transpose(-1, -2) * 0.125, -1) @ vh).transpose(1, 2).reshape(b, e)
     assert (o.float().cpu() - oref).abs().max() < (2e-2 if dt == torch.bfloat16 else 2e-3)
+
+
+def test_gemm_race_screen_deep_pipeline():
+    """The 256^2 kernel keeps 5 LDS-DMA pieces in flight across counted waits and raw barriers; a mis-placed wait
+    shows up as rare wrong tiles.  Screen: many launches at several shapes (incl. the split big+small launch),
+    every result bit-identical to the first and correct against an fp32 product of the same 16-bit inputs."""
+    for (m, n, k) in [(25600, 2304, 768), (2560, 3072, 768), (4096, 4096, 1024), (1536, 768, 3072), (777, 1000, 256)]:
+        a = (torch.rand(m, k, device=DEV) * 2 - 1).half()
+        w = ((torch.rand(n, k, device=DEV) * 2 - 1) * 0.05).half()
+        ref = (a.float() @ w.float().t())
+        first = None
+        out = torch.empty(m, n, dtype=torch.float32, device=DEV)
+        for it in range(25):
+            out.fill_(float("nan"))
+            ops.gemm_nt(a, w, out)
+            if first is None:
+                first = out.clone()
+                assert (first - ref).abs().max() < 2e-3 * max(1.0, float(ref.abs().max()))
+            else:
+                assert torch.equal(out, first), (m, n, k, it)
