@@ -77,6 +77,12 @@ def main():
     ap.add_argument("--no-pcie", dest="pcie", action="store_false", help="skip the PCIe-inclusive (host uint8 input) measurement")
     a = ap.parse_args()
 
+    # stdout carries exactly ONE line (the JSON): libraries that print banners to fd 1 (RCCL's version banner does)
+    # are sent to stderr for the whole run, the result is written to the saved original descriptor at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -84,7 +90,7 @@ def main():
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     group = None
-    if world > 1:
+    if world > 1 or os.environ.get("HGR_FORCE_DIST") == "1":              # world 1 under torchrun: exercises the RCCL path on one GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device(dev))     # "nccl" is RCCL on ROCm
@@ -130,7 +136,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if group is not None:
             import torch.distributed as dist
             dist.barrier()
             torch.cuda.synchronize()
@@ -246,8 +252,9 @@ def main():
                            "global_batch": a.batch * world, "parallelism": f"dp{world}", "text_dtype": a.text_dtype,
                            "weights": "random-init (hash-seeded), no checkpoint offline"},
                 "roofline": roof, "cpu_baseline": cpu, "pcie_inclusive": pcie, "metrics_string": summary.strip()}
-        print(json.dumps(line), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
+    if group is not None:
         import torch.distributed as dist
         dist.destroy_process_group()
 
