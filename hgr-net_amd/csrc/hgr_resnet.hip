@@ -122,11 +122,6 @@ unsigned grid_for(int64_t total) { return (unsigned)((total + 255) / 256 < 16384
 
 }  // namespace
 
-#define HGR_DT_DISPATCH(KERNEL, GRID, ...)                                                                   \
-    do {                                                                                                     \
-        if (dtype == HGR_BF16) hipLaunchKernelGGL((KERNEL<HGR_BF16>), GRID, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
-        else hipLaunchKernelGGL((KERNEL<HGR_F16>), GRID, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);    \
-    } while (0)
 
 extern "C" int hgr_stem_im2col(const float *image, void *out, int B, int R, int dtype, void *stream) {
     HGR_REQUIRE(image && out && B >= 1 && R >= 2, "hgr_stem_im2col: bad arguments");
