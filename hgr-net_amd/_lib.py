@@ -46,13 +46,15 @@ SIGNATURES = {
     "hgr_quickgelu16": [_p, _p, _p, _l, _i, _i, _p],
     "hgr_layernorm_bwd": [_p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _l, _p, _f, _i, _p],
     "hgr_layernorm_bwd_scratch_floats": [_i, _i],
-    "hgr_mha_bwd": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "hgr_mha_bwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "hgr_ce_rows": [_p, _l, _p, _i, _i, _f, _p, _p, _l, _p],
     "hgr_l2norm_bwd": [_p, _p, _p, _i, _i, _i, _p],
     "hgr_matmul_f32": [_p, _l, _l, _p, _l, _l, _p, _l, _i, _i, _i, _f, _i, _p],
     "hgr_embed_scatter_add": [_p, _l, _p, _p, _i, _i, _i, _i, _p],
     "hgr_rows_axpy": [_p, _l, _p, _p, _i, _i, _f, _p],
     "hgr_rows_gather": [_p, _p, _p, _i, _i, _p],
+    "hgr_ctx_splice": [_p, _p, _p, _i, _i, _i, _i, _p],
+    "hgr_ctx_splice_bwd": [_p, _p, _i, _i, _i, _i, _p],
     "hgr_sumsq": [_p, _l, _p, _p],
     "hgr_adamw": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _p, _f, _f, _p],
 }

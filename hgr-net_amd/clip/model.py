@@ -397,26 +397,29 @@ class CLIP(nn.Module):
         return out
 
     @torch.no_grad()
-    def encode_text(self, text: torch.Tensor, trim: bool = True) -> torch.Tensor:
+    def encode_text(self, text: torch.Tensor, trim: bool = True, ctx: Optional[torch.Tensor] = None) -> torch.Tensor:
         """fp32 [n, embed_dim] text features (clip/model.py:339-352).  With ``trim`` the blocks run on
-        positions <= max(EOT) only: exact, because the mask is causal and only the EOT row is read."""
+        positions <= max(EOT) only: exact, because the mask is causal and only the EOT row is read.
+        ``ctx`` [n_ctx, W]: CoOp learnable context spliced over token positions 1..n_ctx (model/CoOp.py:98-113)."""
         if not text.is_cuda:
             raise HgrError("encode_text needs a device tensor: the product path has no CPU fallback")
         p = self._prepared()
         dt, ws, dev = self.text_dtype, self._ws, text.device
         text = text.long()
-        n, ctx = text.shape
+        n, ctx_len = text.shape
         w = self.transformer.width
         d = self.text_projection.shape[1]
         out = torch.empty((n, d), dtype=torch.float32, device=dev)
         eot = torch.empty(n, dtype=torch.int32, device=dev)
         ops.eot_index(text, eot)
-        l = int(eot.max().item()) + 1 if trim else ctx
+        l = int(eot.max().item()) + 1 if trim else ctx_len
         for s in range(0, n, self.text_chunk):
             e = min(n, s + self.text_chunk)
             c = e - s
             x = ws.get("t.x", (c * l, w), torch.float32, dev)
             ops.text_embed(text[s:e], p["tok"], p["tpos"], x, l)
+            if ctx is not None:
+                ops.ctx_splice(x, ctx.detach().float().contiguous(), p["tpos"], c, l)
             _run_blocks(x, p["tblocks"], w // 64, c, l, True, dt, ws, "t")
             f16 = ws.get("t.f16", (c, w), dt, dev)
             ops.layernorm(x, p["ln_final"][0], p["ln_final"][1], f16, rows=c, row_mul=l, row_idx=eot[s:e])

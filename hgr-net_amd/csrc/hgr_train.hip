@@ -157,152 +157,169 @@ __global__ __launch_bounds__(256) void layernorm_bwd(const void *__restrict__ dy
     }
 }
 
-// ---- attention backward, L <= 64, d_head 64: one workgroup per (batch, head), fp32 VALU on LDS tiles ---------
-// S = QK^T/8 (+mask), P = softmax(S); dV = P^T dO; dP = dO V^T; dS = P (dP - rowsum(P dP)) / 8; dQ = dS K; dK = dS^T Q
+// ---- attention backward for ANY length (L <= 288 here): tiled, on the exact-fp32 MFMA ---------------------------
+// v_mfma_f32_32x32x2_f32 with operands read from fp32 LDS tiles [64][65]: lane l supplies A(i = l & 31, k = l >> 5)
+// and B(k = l >> 5, j = l & 31) per 2-deep step, so a transposed operand is just a different index function and the
+// five products (S = QK^T, dP = dO V^T, dV = P^T dO, dQ = dS K, dK = dS^T Q) need no transposed copies.  One
+// workgroup (4 waves, each a 32 x 32 quadrant of every 64 x 64 block product) per (batch, head):
+//   sweep 0: row max / sum of exp over all key blocks (online merge) and D = rowsum(dO * O);
+//   sweep 1: per query block, dQ += dS K over the key blocks;   sweep 2: per key block, dK, dV over the query blocks.
+// P is recomputed from the row statistics (flash-attention style), nothing of size L x L is ever stored.
+struct Tile { float (*t)[65]; };
+
+__device__ __forceinline__ void mm64(f32x16 &acc, const float (*A)[65], bool ta, const float (*B)[65], bool tb, int lane, int wr, int wc) {
+    // acc(32x32 quadrant wr, wc) += sum_k A'(i, k) * B'(k, j), A' = ta ? A^T : A, B' = tb ? B^T : B
+    const int r = lane & 31, h = lane >> 5;
+    const int i = wr * 32 + r, j = wc * 32 + r;
+#pragma unroll 8
+    for (int k = 0; k < 64; k += 2) {
+        const float av = ta ? A[k + h][i] : A[i][k + h];
+        const float bv = tb ? B[j][k + h] : B[k + h][j];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+}
+#define HGR_ACC_ROW(reg, h) (((reg) & 3) + 8 * ((reg) >> 2) + 4 * (h))
+
 template <int DT, bool CAUSAL>
-__global__ __launch_bounds__(256) void mha_bwd64(const typename T16<DT>::elem *__restrict__ qkv, const typename T16<DT>::elem *__restrict__ dout,
-                                                 typename T16<DT>::elem *__restrict__ dqkv, int L, int H) {
+__global__ __launch_bounds__(256) void mha_bwd_tiled(const typename T16<DT>::elem *__restrict__ qkv, const typename T16<DT>::elem *__restrict__ outp,
+                                                     const typename T16<DT>::elem *__restrict__ dout, typename T16<DT>::elem *__restrict__ dqkv, int L, int H) {
     typedef typename T16<DT>::elem E;
-    __shared__ float sQ[64][65], sK[64][65], sV[64][65], sO[64][65], sP[64][65];
-    const int tid = threadIdx.x;
+    __shared__ float sQ[64][65], sK[64][65], sV[64][65], sO[64][65], sP[64][65], sD[64][65];
+    __shared__ float rM[320], rLinv[320], rD[320];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    const int r32 = lane & 31, hh = lane >> 5;
     const int b = blockIdx.x / H, h = blockIdx.x - b * H;
     const int W = H * 64;
     const int64_t ld = 3 * (int64_t)W;
     const E *base = qkv + (int64_t)b * L * ld + h * 64;
     const E *dob = dout + (int64_t)b * L * W + h * 64;
-    for (int i = tid; i < 64 * 64; i += 256) {
-        const int r = i >> 6, c = i & 63;
-        const bool ok = r < L;
-        sQ[r][c] = ok ? (float)base[r * ld + c] : 0.f;
-        sK[r][c] = ok ? (float)base[r * ld + W + c] : 0.f;
-        sV[r][c] = ok ? (float)base[r * ld + 2 * W + c] : 0.f;
-        sO[r][c] = ok ? (float)dob[(int64_t)r * W + c] : 0.f;
-    }
-    __syncthreads();
-    const int ti = (tid >> 4) * 4, tj = (tid & 15) * 4;        // this thread's 4 x 4 output block
-    float acc[4][4];
-    auto zero = [&]() {
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[a][c] = 0.f;
-    };
-    // S[i][j] = sum_d Q[i][d] K[j][d]
-    zero();
-    for (int d = 0; d < 64; ++d) {
-        float qa[4], kb[4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) { qa[a] = sQ[ti + a][d]; kb[a] = sK[tj + a][d]; }
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[a][c] += qa[a] * kb[c];
-    }
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int i = ti + a, j = tj + c;
-            sP[i][j] = (j >= L || (CAUSAL && j > i)) ? -INFINITY : acc[a][c] * 0.125f;
-        }
-    __syncthreads();
-    // row softmax: 4 threads per row
-    {
-        const int row = tid >> 2, part = tid & 3;
-        float mx = -INFINITY;
-        for (int j = part; j < 64; j += 4) mx = fmaxf(mx, sP[row][j]);
-        mx = fmaxf(mx, __shfl_xor(mx, 1)); mx = fmaxf(mx, __shfl_xor(mx, 2));
-        float sum = 0.f;
-        for (int j = part; j < 64; j += 4) { const float e = __expf(sP[row][j] - mx); sP[row][j] = e; sum += e; }
-        sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2);
-        const float inv = (row < L) ? 1.0f / sum : 0.f;          // padded query rows contribute nothing
-        for (int j = part; j < 64; j += 4) sP[row][j] *= inv;
-    }
-    __syncthreads();
-    // dV[j][d] = sum_i P[i][j] dO[i][d]   (thread block: j = ti.., d = tj..)
-    zero();
-    for (int i = 0; i < 64; ++i) {
-        float pa[4], ob[4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) { pa[a] = sP[i][ti + a]; ob[a] = sO[i][tj + a]; }
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[a][c] += pa[a] * ob[c];
-    }
+    const E *ob = outp + (int64_t)b * L * W + h * 64;
     E *dqb = dqkv + (int64_t)b * L * ld + h * 64;
+    const int nb = (L + 63) / 64;
+
+    auto load = [&](float (*dst)[65], const E *src, int64_t stride, int r0) {
+        for (int i = tid; i < 64 * 64; i += 256) {
+            const int r = i >> 6, c = i & 63;
+            dst[r][c] = (r0 + r < L) ? (float)src[(int64_t)(r0 + r) * stride + c] : 0.f;
+        }
+    };
+    auto store_acc = [&](float (*dst)[65], const f32x16 &acc) {
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
-        if (ti + a < L)
+        for (int g = 0; g < 16; ++g) dst[wr * 32 + HGR_ACC_ROW(g, hh)][wc * 32 + r32] = acc[g];
+    };
+    auto write_rows = [&](E *dstg, int64_t stride, int r0, const f32x16 &acc) {      // 16-bit global rows from an accumulator quadrant
 #pragma unroll
-            for (int c = 0; c < 4; ++c) dqb[(int64_t)(ti + a) * ld + 2 * W + tj + c] = (E)acc[a][c];
-    // dP[i][j] = sum_d dO[i][d] V[j][d]
-    zero();
-    for (int d = 0; d < 64; ++d) {
-        float oa[4], vb[4];
+        for (int g = 0; g < 16; ++g) {
+            const int row = r0 + wr * 32 + HGR_ACC_ROW(g, hh);
+            if (row < L) dstg[(int64_t)row * stride + wc * 32 + r32] = (E)acc[g];
+        }
+    };
+    // masked, scaled score of (query q, key k) from a raw dot product
+    auto score = [&](float raw, int q, int k) { return (k >= L || (CAUSAL && k > q)) ? -INFINITY : raw * 0.125f; };
+
+    // ---- sweep 0: row statistics ---------------------------------------------------------------------------------------------------------
+    for (int qi = 0; qi < nb; ++qi) {
+        __syncthreads();
+        load(sQ, base, ld, qi * 64);
+        load(sO, dob, W, qi * 64);
+        load(sV, ob, W, qi * 64);                              // forward output O of this query block (in sV for the moment)
+        __syncthreads();
+        {   // D = rowsum(dO * O): 4 threads per row
+            const int row = tid >> 2, part = tid & 3;
+            float acc = 0.f;
+            for (int d = part; d < 64; d += 4) acc += sO[row][d] * sV[row][d];
+            acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2);
+            if (part == 0) { rD[qi * 64 + row] = acc; rM[qi * 64 + row] = -INFINITY; rLinv[qi * 64 + row] = 0.f; }
+        }
+        for (int kj = 0; kj < nb; ++kj) {
+            if (CAUSAL && kj > qi) break;
+            __syncthreads();
+            load(sK, base + W, ld, kj * 64);
+            __syncthreads();
+            f32x16 acc = {0.f};
+            mm64(acc, sQ, false, sK, true, lane, wr, wc);
 #pragma unroll
-        for (int a = 0; a < 4; ++a) { oa[a] = sO[ti + a][d]; vb[a] = sV[tj + a][d]; }
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[a][c] += oa[a] * vb[c];
-    }
-    __syncthreads();                                   // everyone is done reading sO / sV as operands of dV, dP
-    // dS = P * (dP - rowsum(P * dP)) / 8 : row sums need all 16 column-threads of the row -> stage P*dP partials in sO
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        float part = 0.f;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) part += sP[ti + a][tj + c] * acc[a][c];
-        sO[ti + a][tid & 15] = part;
+            for (int g = 0; g < 16; ++g) {
+                const int rr = wr * 32 + HGR_ACC_ROW(g, hh), cc = wc * 32 + r32;
+                sP[rr][cc] = score(acc[g], qi * 64 + rr, kj * 64 + cc);
+            }
+            __syncthreads();
+            const int row = tid >> 2, part = tid & 3;
+            float mb = -INFINITY;
+            for (int c = part; c < 64; c += 4) mb = fmaxf(mb, sP[row][c]);
+            mb = fmaxf(mb, __shfl_xor(mb, 1)); mb = fmaxf(mb, __shfl_xor(mb, 2));
+            const float mo = rM[qi * 64 + row], mn = fmaxf(mo, mb);
+            float sum = 0.f;
+            if (mn > -INFINITY) for (int c = part; c < 64; c += 4) sum += __expf(sP[row][c] - mn);
+            sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2);
+            if (part == 0) {
+                rLinv[qi * 64 + row] = rLinv[qi * 64 + row] * (mo > -INFINITY ? __expf(mo - mn) : 0.f) + sum;   // running sum for now
+                rM[qi * 64 + row] = mn;
+            }
+        }
     }
     __syncthreads();
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        float rs = 0.f;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) rs += sO[ti + a][t];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[a][c] = sP[ti + a][tj + c] * (acc[a][c] - rs) * 0.125f;
-    }
+    for (int i = tid; i < nb * 64; i += 256) rLinv[i] = (i < L && rLinv[i] > 0.f) ? 1.0f / rLinv[i] : 0.f;
     __syncthreads();
+
+    // P and dS quadrant of block (qi, kj) in registers (accumulator layout), operands already staged
+    auto p_and_ds = [&](int qi, int kj, f32x16 &pp, f32x16 &ds) {
+        f32x16 sacc = {0.f}, dp = {0.f};
+        mm64(sacc, sQ, false, sK, true, lane, wr, wc);         // S = Q K^T
+        mm64(dp, sO, false, sV, true, lane, wr, wc);           // dP = dO V^T
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) sV[ti + a][tj + c] = acc[a][c];          // sV now holds dS[i][j]
-    __syncthreads();
-    // dQ[i][d] = sum_j dS[i][j] K[j][d]
-    zero();
-    for (int j = 0; j < 64; ++j) {
-        float sa[4], kb[4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) { sa[a] = sV[ti + a][j]; kb[a] = sK[j][tj + a]; }
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[a][c] += sa[a] * kb[c];
+        for (int g = 0; g < 16; ++g) {
+            const int rr = wr * 32 + HGR_ACC_ROW(g, hh), cc = wc * 32 + r32;
+            const int q = qi * 64 + rr;
+            const float sc = score(sacc[g], q, kj * 64 + cc);
+            const float pv = (sc > -INFINITY) ? __expf(sc - rM[q]) * rLinv[q] : 0.f;
+            pp[g] = pv;
+            ds[g] = pv * (dp[g] - rD[q]) * 0.125f;
+        }
+    };
+
+    // ---- sweep 1: dQ ---------------------------------------------------------------------------------------------------------------------
+    for (int qi = 0; qi < nb; ++qi) {
+        __syncthreads();
+        load(sQ, base, ld, qi * 64);
+        load(sO, dob, W, qi * 64);
+        f32x16 dq = {0.f};
+        for (int kj = 0; kj < nb; ++kj) {
+            if (CAUSAL && kj > qi) break;
+            __syncthreads();
+            load(sK, base + W, ld, kj * 64);
+            load(sV, base + 2 * W, ld, kj * 64);
+            __syncthreads();
+            f32x16 pp, ds;
+            p_and_ds(qi, kj, pp, ds);
+            store_acc(sD, ds);
+            __syncthreads();
+            mm64(dq, sD, false, sK, false, lane, wr, wc);      // dQ += dS K
+        }
+        write_rows(dqb, ld, qi * 64, dq);
     }
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-        if (ti + a < L)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) dqb[(int64_t)(ti + a) * ld + tj + c] = (E)acc[a][c];
-    // dK[j][d] = sum_i dS[i][j] Q[i][d]
-    zero();
-    for (int i = 0; i < 64; ++i) {
-        float sa[4], qb[4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) { sa[a] = sV[i][ti + a]; qb[a] = sQ[i][tj + a]; }
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[a][c] += sa[a] * qb[c];
+    // ---- sweep 2: dK, dV -----------------------------------------------------------------------------------------------------------------
+    for (int kj = 0; kj < nb; ++kj) {
+        __syncthreads();
+        load(sK, base + W, ld, kj * 64);
+        load(sV, base + 2 * W, ld, kj * 64);
+        f32x16 dk = {0.f}, dv = {0.f};
+        for (int qi = CAUSAL ? kj : 0; qi < nb; ++qi) {
+            __syncthreads();
+            load(sQ, base, ld, qi * 64);
+            load(sO, dob, W, qi * 64);
+            __syncthreads();
+            f32x16 pp, ds;
+            p_and_ds(qi, kj, pp, ds);
+            store_acc(sP, pp);
+            store_acc(sD, ds);
+            __syncthreads();
+            mm64(dv, sP, true, sO, false, lane, wr, wc);       // dV += P^T dO
+            mm64(dk, sD, true, sQ, false, lane, wr, wc);       // dK += dS^T Q
+        }
+        write_rows(dqb + W, ld, kj * 64, dk);
+        write_rows(dqb + 2 * W, ld, kj * 64, dv);
     }
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-        if (ti + a < L)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) dqb[(int64_t)(ti + a) * ld + W + tj + c] = (E)acc[a][c];
 }
 
 // Same arithmetic for short sequences (text prompts are ~8-20 tokens after EOT trimming): LP = 16 or 32 padded
@@ -488,6 +505,34 @@ __global__ __launch_bounds__(256) void rows_axpy(float *__restrict__ dst, int64_
     }
 }
 
+// CoOp learnable context (reference model/CoOp.py:98-113): rows 1 .. n_ctx of every prompt are the shared context
+// vectors instead of token embeddings.  x[i*L + 1 + c] = ctx[c] + positional[1 + c].
+__global__ __launch_bounds__(256) void ctx_splice(float *__restrict__ x, const float *__restrict__ ctx, const float *__restrict__ pos, int n, int L, int W, int n_ctx) {
+    const int64_t total = (int64_t)n * n_ctx * W;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % W);
+        const int k = (int)((i / W) % n_ctx);
+        const int64_t pr = i / ((int64_t)W * n_ctx);
+        x[(pr * L + 1 + k) * W + c] = ctx[(int64_t)k * W + c] + pos[(int64_t)(1 + k) * W + c];
+    }
+}
+// backward: dctx[k] += sum_i dx[i*L + 1 + k] in a fixed order (bit-reproducible), and those rows of dx are cleared so the
+// token-embedding scatter that follows gives the placeholder tokens no gradient.  One block per (k, 64-column chunk).
+__global__ __launch_bounds__(256) void ctx_splice_bwd(float *__restrict__ dx, float *__restrict__ dctx, int n, int L, int W, int n_ctx) {
+    __shared__ float s[4][64];
+    const int k = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    float acc = 0.f;
+    if (c < W)
+        for (int i = q; i < n; i += 4) {
+            float *p = dx + ((int64_t)i * L + 1 + k) * W + c;
+            acc += *p;
+            *p = 0.f;
+        }
+    s[q][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (q == 0 && c < W) dctx[(int64_t)k * W + c] += s[0][threadIdx.x] + s[1][threadIdx.x] + s[2][threadIdx.x] + s[3][threadIdx.x];
+}
+
 // dst[r] = src[idx[r]] for W-wide fp32 rows
 __global__ __launch_bounds__(256) void rows_gather(float *__restrict__ dst, const float *__restrict__ src, const int32_t *__restrict__ idx, int rows, int W) {
     const int64_t total = (int64_t)rows * W;
@@ -576,9 +621,9 @@ extern "C" int64_t hgr_layernorm_bwd_scratch_floats(int rows, int W) {
     return 2 * nw * W + ((nw + 511) / 512) * W;
 }
 
-extern "C" int hgr_mha_bwd(const void *qkv, const void *dout, void *dqkv, int B, int L, int heads, int causal, int dtype, void *stream) {
-    HGR_REQUIRE(qkv && dout && dqkv && B >= 1 && heads >= 1, "hgr_mha_bwd: bad arguments");
-    HGR_REQUIRE(L >= 1 && L <= 64, "hgr_mha_bwd: L=%d unsupported (this round: L <= 64)", L);
+extern "C" int hgr_mha_bwd(const void *qkv, const void *out, const void *dout, void *dqkv, int B, int L, int heads, int causal, int dtype, void *stream) {
+    HGR_REQUIRE(qkv && out && dout && dqkv && B >= 1 && heads >= 1, "hgr_mha_bwd: bad arguments");
+    HGR_REQUIRE(L >= 1 && L <= 320, "hgr_mha_bwd: L=%d unsupported (L <= 320)", L);
     DT_OK("hgr_mha_bwd");
     hipStream_t s = (hipStream_t)stream;
     const dim3 g(B * heads);
@@ -589,7 +634,15 @@ extern "C" int hgr_mha_bwd(const void *qkv, const void *dout, void *dqkv, int B,
     } while (0)
     if (L <= 16) { if (causal) HGR_MB(mha_bwd_small, 16, true); else HGR_MB(mha_bwd_small, 16, false); }
     else if (L <= 32) { if (causal) HGR_MB(mha_bwd_small, 32, true); else HGR_MB(mha_bwd_small, 32, false); }
-    else { if (causal) HGR_MB(mha_bwd64, true); else HGR_MB(mha_bwd64, false); }
+    else {
+#define HGR_MT(CAUS)                                                                                                              \
+    do {                                                                                                                          \
+        if (dtype == HGR_BF16) hipLaunchKernelGGL((mha_bwd_tiled<HGR_BF16, CAUS>), g, dim3(256), 0, s, (const __bf16 *)qkv, (const __bf16 *)out, (const __bf16 *)dout, (__bf16 *)dqkv, L, heads); \
+        else hipLaunchKernelGGL((mha_bwd_tiled<HGR_F16, CAUS>), g, dim3(256), 0, s, (const _Float16 *)qkv, (const _Float16 *)out, (const _Float16 *)dout, (_Float16 *)dqkv, L, heads); \
+    } while (0)
+        if (causal) HGR_MT(true); else HGR_MT(false);
+#undef HGR_MT
+    }
 #undef HGR_MB
     HGR_CHECK_LAUNCH("hgr_mha_bwd");
     return HGR_OK;
@@ -651,5 +704,19 @@ extern "C" int hgr_rows_gather(float *dst, const float *src, const int32_t *idx,
     HGR_REQUIRE(dst && src && idx && rows >= 1 && W >= 1, "hgr_rows_gather: bad arguments");
     hipLaunchKernelGGL(rows_gather, dim3(grid1((int64_t)rows * W)), dim3(256), 0, (hipStream_t)stream, dst, src, idx, rows, W);
     HGR_CHECK_LAUNCH("hgr_rows_gather");
+    return HGR_OK;
+}
+
+extern "C" int hgr_ctx_splice(float *x, const float *ctx, const float *positional_embedding, int n, int L, int W, int n_ctx, void *stream) {
+    HGR_REQUIRE(x && ctx && positional_embedding && n >= 1 && n_ctx >= 1 && L >= n_ctx + 2 && W >= 1, "hgr_ctx_splice: bad arguments (L >= n_ctx + 2)");
+    hipLaunchKernelGGL(ctx_splice, dim3(grid1((int64_t)n * n_ctx * W)), dim3(256), 0, (hipStream_t)stream, x, ctx, positional_embedding, n, L, W, n_ctx);
+    HGR_CHECK_LAUNCH("hgr_ctx_splice");
+    return HGR_OK;
+}
+
+extern "C" int hgr_ctx_splice_bwd(float *dx, float *dctx, int n, int L, int W, int n_ctx, void *stream) {
+    HGR_REQUIRE(dx && dctx && n >= 1 && n_ctx >= 1 && L >= n_ctx + 2 && W >= 1, "hgr_ctx_splice_bwd: bad arguments");
+    hipLaunchKernelGGL(ctx_splice_bwd, dim3((W + 63) / 64, n_ctx), dim3(256), 0, (hipStream_t)stream, dx, dctx, n, L, W, n_ctx);
+    HGR_CHECK_LAUNCH("hgr_ctx_splice_bwd");
     return HGR_OK;
 }

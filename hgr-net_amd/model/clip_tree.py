@@ -65,9 +65,17 @@ class tree_model(nn.Module):
             p.requires_grad_(True)
         self.loss = nn.CrossEntropyLoss()
 
-        # prompts -> token ids (clip_tree.py:52-60)
+        # prompts -> token ids (clip_tree.py:52-60).  With opts.n_ctx > 0 the template is CoOp's learnable context
+        # (model/CoOp.py:58-79: "X X ... X {name}." with n_ctx generic context vectors, init N(0, 0.02)); caller-supplied
+        # node_tokens must then carry n_ctx placeholder tokens after SOT.
+        self.n_ctx = int(getattr(opts, "n_ctx", 0) or 0)
         if node_tokens is None:
-            node_tokens = clip.tokenize([TEMPLATE.format(self._wordnet_name(n)) for n in self.nodes])
+            tmpl = (" ".join(["X"] * self.n_ctx) + " {}.") if self.n_ctx else TEMPLATE
+            node_tokens = clip.tokenize([tmpl.format(self._wordnet_name(n)) for n in self.nodes])
+        self.ctx = None
+        if self.n_ctx:
+            wt = self.clip_model.transformer.width
+            self.ctx = nn.Parameter(torch.empty(self.n_ctx, wt, device=self.device).normal_(std=0.02))
         if node_tokens.shape[0] != len(self.nodes):
             raise ValueError(f"node_tokens has {node_tokens.shape[0]} rows for {len(self.nodes)} nodes")
         self.node_tokens = node_tokens.long().to(self.device)
@@ -114,9 +122,9 @@ class tree_model(nn.Module):
         n = len(self.nodes)
         if group is not None:
             from ..parallel import sharded_text_features
-            feats = sharded_text_features(self.clip_model, self.node_tokens, group)
+            feats = sharded_text_features(self.clip_model, self.node_tokens, group, ctx=self.ctx)
         else:
-            feats = self.clip_model.encode_text(self.node_tokens)
+            feats = self.clip_model.encode_text(self.node_tokens, ctx=self.ctx)
         z32 = torch.empty_like(feats)
         z16 = torch.empty(feats.shape, dtype=self.clip_model.image_dtype, device=feats.device)
         ops.l2norm_rows(feats, y16=z16, y32=z32)

@@ -241,9 +241,9 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, dx: to
               rows, w, row_mul, _dev(row_idx), eps, HGR_BF16 if f32 else DT_OF[dy.dtype], _stream())
 
 
-def mha_bwd(qkv: torch.Tensor, dout: torch.Tensor, dqkv: torch.Tensor, b: int, l: int, heads: int, causal: bool) -> torch.Tensor:
-    assert qkv.is_contiguous() and dout.is_contiguous() and dqkv.is_contiguous()
-    _lib.call("hgr_mha_bwd", _dev(qkv), _dev(dout), _dev(dqkv), b, l, heads, 1 if causal else 0, DT_OF[qkv.dtype], _stream())
+def mha_bwd(qkv: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, dqkv: torch.Tensor, b: int, l: int, heads: int, causal: bool) -> torch.Tensor:
+    assert qkv.is_contiguous() and out.is_contiguous() and dout.is_contiguous() and dqkv.is_contiguous()
+    _lib.call("hgr_mha_bwd", _dev(qkv), _dev(out), _dev(dout), _dev(dqkv), b, l, heads, 1 if causal else 0, DT_OF[qkv.dtype], _stream())
     return dqkv
 
 
@@ -277,6 +277,17 @@ def embed_scatter_add(tokens: torch.Tensor, dx: torch.Tensor, dtable: torch.Tens
 def rows_axpy(dst: torch.Tensor, src: torch.Tensor, dst_mul: int = 1, dst_idx: Optional[torch.Tensor] = None, alpha: float = 1.0) -> None:
     assert dst.dtype == src.dtype == torch.float32 and src.is_contiguous() and dst.is_contiguous()
     _lib.call("hgr_rows_axpy", _dev(dst), dst_mul, _dev(dst_idx), _dev(src), src.shape[0], src.shape[1], alpha, _stream())
+
+
+def ctx_splice(x: torch.Tensor, ctx: torch.Tensor, pos: torch.Tensor, n: int, l: int) -> torch.Tensor:
+    assert x.dtype == ctx.dtype == torch.float32 and x.is_contiguous() and ctx.is_contiguous()
+    _lib.call("hgr_ctx_splice", _dev(x), _dev(ctx), _dev(pos), n, l, x.shape[1], ctx.shape[0], _stream())
+    return x
+
+
+def ctx_splice_bwd(dx: torch.Tensor, dctx: torch.Tensor, n: int, l: int) -> None:
+    assert dx.dtype == dctx.dtype == torch.float32 and dx.is_contiguous() and dctx.is_contiguous()
+    _lib.call("hgr_ctx_splice_bwd", _dev(dx), _dev(dctx), n, l, dx.shape[1], dctx.shape[0], _stream())
 
 
 def rows_gather(src: torch.Tensor, idx: torch.Tensor, out: torch.Tensor) -> torch.Tensor:

@@ -60,9 +60,9 @@ def sharded_rows(encode: Callable[[torch.Tensor], torch.Tensor], rows: torch.Ten
     return all_gather_rows(encode(rows[lo:hi]), rows.shape[0], group)
 
 
-def sharded_text_features(clip_model, node_tokens: torch.Tensor, group=None) -> torch.Tensor:
+def sharded_text_features(clip_model, node_tokens: torch.Tensor, group=None, ctx=None) -> torch.Tensor:
     """Text features [N, D] with the prompt rows sharded over the ranks of `group`."""
-    return sharded_rows(clip_model.encode_text, node_tokens, group)
+    return sharded_rows(lambda t: clip_model.encode_text(t, ctx=ctx), node_tokens, group)
 
 
 def batches_of_rank(num_batches: int, world: int, rank: int) -> range:

@@ -270,7 +270,7 @@ def make_dag(n_nodes: int, depth: int = 12, seed: int = 7, multi_parent: float =
 SOT, EOT = 49406, 49407  # clip/simple_tokenizer.py special ids (used when vocab is the real 49408)
 
 
-def make_tokens(n: int, seed: int = 11, vocab_size: int = 49408, context_length: int = 77) -> torch.Tensor:
+def make_tokens(n: int, seed: int = 11, vocab_size: int = 49408, context_length: int = 77, n_ctx: int = 0) -> torch.Tensor:
     """int64 [n, 77] token ids shaped like ``clip.tokenize('a photo of a {name}.')`` (clip.py:188-224).
 
     SOT, 4 template ids, 1-4 name ids, '.', EOT, zero padding.  EOT is the largest id of every row
@@ -279,6 +279,8 @@ def make_tokens(n: int, seed: int = 11, vocab_size: int = 49408, context_length:
     sot, eot = (SOT, EOT) if vocab_size >= 49408 else (vocab_size - 2, vocab_size - 1)
     hi = sot  # ordinary ids are < SOT
     tmpl = [min(320, hi - 1), min(1125, hi - 2), min(539, hi - 3), min(320, hi - 1)]  # 'a photo of a'
+    if n_ctx:
+        tmpl = [min(343, hi - 5)] * n_ctx                       # CoOp: n_ctx 'X' placeholders (model/CoOp.py:70)
     dot = min(269, hi - 4)
     name_len = randint(seed, "tok.len", n, 1, 5)
     name_ids = randint(seed, "tok.ids", n * 4, 1, hi).reshape(n, 4)

@@ -44,12 +44,18 @@ def _grad(p: torch.nn.Parameter) -> torch.Tensor:
 class _Lin:
     """One nn.Linear-shaped weight in training form: 16-bit copy, its transpose, fp32 bias, grad targets."""
 
-    def __init__(self, weight: torch.nn.Parameter, bias: Optional[torch.nn.Parameter], dt: torch.dtype):
+    def __init__(self, weight: torch.nn.Parameter, bias: Optional[torch.nn.Parameter], dt: torch.dtype, kpad: int = 0):
         w32 = weight.data.reshape(weight.shape[0], -1).contiguous()
         self.weight, self.bias = weight, bias
         self.n, self.k = w32.shape
         self.w16 = torch.empty(w32.shape, dtype=dt, device=w32.device)
         ops.cast16(w32, self.w16)
+        if kpad > self.k:                                       # forward operand zero-padded in K (patch 14: 588 -> 640)
+            wp = torch.zeros(self.n, kpad, dtype=dt, device=w32.device)
+            wp[:, : self.k] = self.w16
+            self.w16_fwd = wp
+        else:
+            self.w16_fwd = self.w16
         self.wt16 = torch.zeros(self.k, _pad64(self.n), dtype=dt, device=w32.device)     # [K, N] for dX = dY . W
         ops.transpose16(self.w16, self.wt16)
         self.b32 = bias.data if bias is not None else None
@@ -86,7 +92,8 @@ class Engine:
             raise NotImplementedError("training: only ViT image towers have backward kernels this round")
         self.vblocks = [_Blk(b, dt) for b in m.visual.transformer.resblocks]
         self.tblocks = [_Blk(b, dt) for b in m.transformer.resblocks]
-        self.conv = _Lin(m.visual.conv1.weight, None, dt)
+        ps = m.visual.patch_size
+        self.conv = _Lin(m.visual.conv1.weight, None, dt, kpad=_pad64(3 * ps * ps))
 
     def _linear_bwd(self, lin: _Lin, dy16: torch.Tensor, x16: torch.Tensor, m: int, need_dx: bool = True) -> Optional[torch.Tensor]:
         """dW += dY^T X, db += colsum(dY); returns dX = dY W (16-bit) if wanted.  dy16 [m, n], x16 [m, k]."""
@@ -96,7 +103,7 @@ class Engine:
         dyt = alloc(lin.n, mp, dtype=dt, device=dev)
         xt = alloc(lin.k, mp, dtype=dt, device=dev)
         ops.transpose16(dy16, dyt)
-        ops.transpose16(x16, xt)
+        ops.transpose16(x16[:, : lin.k] if x16.shape[1] != lin.k else x16, xt)
         gw = _grad(lin.weight).view(lin.n, lin.k)
         ops.gemm_nt(dyt, xt, gw, epilogue=EPI_ACCUM)
         if lin.bias is not None:
@@ -112,8 +119,6 @@ class Engine:
     # -- transformer stack ---------------------------------------------------------------------
     def blocks_fwd(self, x: torch.Tensor, blocks: List[_Blk], heads: int, b: int, l: int, causal: bool):
         """Returns (x_out, saves).  Same arithmetic as clip.model._run_blocks, out of place, keeping what backward needs."""
-        if l > 64:
-            raise NotImplementedError("training: attention backward supports sequences up to 64 tokens this round")
         m, w = x.shape
         dt, dev = self.dt, self.dev
         saves = []
@@ -156,7 +161,7 @@ class Engine:
             ops.cast16(dx, dy)
             datt = self._linear_bwd(k.w_out, dy, att, m)
             dqkv = torch.empty_like(qkv)
-            ops.mha_bwd(qkv, datt, dqkv, b, l, heads, causal)
+            ops.mha_bwd(qkv, att, datt, dqkv, b, l, heads, causal)
             dh1 = self._linear_bwd(k.w_in, dqkv, h1, m)
             ops.layernorm_bwd(dh1, x0, k.ln1.weight.data, dx, _grad(k.ln1.weight), _grad(k.ln1.bias), scr)
         return dx
@@ -169,13 +174,11 @@ class Engine:
         ps = v.patch_size
         g = r // ps
         l, w = g * g + 1, v.conv1.weight.shape[0]
-        k = 3 * ps * ps
-        if k % 64:
-            raise NotImplementedError("training: patch size with 3*P*P not a multiple of 64")
-        patches = torch.zeros(b * l, k, dtype=dt, device=dev)            # class rows stay zero
+        kp = _pad64(3 * ps * ps)
+        patches = torch.zeros(b * l, kp, dtype=dt, device=dev)           # class rows (and the K padding) stay zero
         ops.im2col_patches_tokens(image, patches, ps, l)
         t = torch.empty(b * l, w, dtype=torch.float32, device=dev)
-        ops.gemm_nt(patches, self.conv.w16, t)
+        ops.gemm_nt(patches, self.conv.w16_fwd, t)
         ops.vit_assemble(t, v.class_embedding.data, v.positional_embedding.data, b, l)
         x = torch.empty_like(t)
         ops.layernorm(t, v.ln_pre.weight.data, v.ln_pre.bias.data, x)    # fp32 out
@@ -206,22 +209,24 @@ class Engine:
         self._linear_bwd(self.conv, d16, s["patches"], b * l, need_dx=False)                # zero class rows add nothing
 
     # -- text tower -------------------------------------------------------------------------------
-    def text_fwd(self, tokens: torch.Tensor):
+    def text_fwd(self, tokens: torch.Tensor, ctx: Optional[torch.nn.Parameter] = None):
         m, dt, dev = self.m, self.dt, self.dev
         tokens = tokens.long()
-        n, ctx = tokens.shape
+        n = tokens.shape[0]
         w = m.transformer.width
         eot = torch.empty(n, dtype=torch.int32, device=dev)
         ops.eot_index(tokens, eot)
         l = int(eot.max().item()) + 1
         x = torch.empty(n * l, w, dtype=torch.float32, device=dev)
         ops.text_embed(tokens, m.token_embedding.weight.data, m.positional_embedding.data, x, l)
+        if ctx is not None:
+            ops.ctx_splice(x, ctx.data, m.positional_embedding.data, n, l)
         xl, saves = self.blocks_fwd(x, self.tblocks, w // 64, n, l, True)
         f32 = torch.empty(n, w, dtype=torch.float32, device=dev)
         ops.layernorm(xl, m.ln_final.weight.data, m.ln_final.bias.data, f32, rows=n, row_mul=l, row_idx=eot)
         feat = torch.empty(n, m.text_projection.shape[1], dtype=torch.float32, device=dev)
         ops.matmul_f32(f32, m.text_projection.data, feat)
-        return feat, dict(tokens=tokens, eot=eot, l=l, n=n, w=w, xl=xl, saves=saves, f32=f32)
+        return feat, dict(tokens=tokens, eot=eot, l=l, n=n, w=w, xl=xl, saves=saves, f32=f32, ctx=ctx)
 
     def text_bwd(self, dfeat: torch.Tensor, s: dict):
         m, dev = self.m, self.dev
@@ -237,6 +242,8 @@ class Engine:
         # x[i*l + t] = token_embedding[tok] + positional[t]
         gp = _grad(m.positional_embedding)
         ops.colsum(dx.view(n, l * w), gp.view(-1)[: l * w], self.scratch(((n + 511) // 512) * l * w), accumulate=True)
+        if s["ctx"] is not None:                                # CoOp: context gradient; placeholder tokens get none
+            ops.ctx_splice_bwd(dx, _grad(s["ctx"]), n, l)
         ops.embed_scatter_add(s["tokens"], dx, _grad(m.token_embedding.weight), l)
 
 
@@ -318,7 +325,7 @@ class OMTrainer:
         self.last_contra = [(ids, pos) for ids, pos, _, _ in picks]
         uniq = sorted({i for ids, _, _, _ in picks for i in ids})
         where = {nid: j for j, nid in enumerate(uniq)}
-        tfeat_u, tsave = e.text_fwd(tree.node_tokens[torch.tensor(uniq, device=e.dev)])
+        tfeat_u, tsave = e.text_fwd(tree.node_tokens[torch.tensor(uniq, device=e.dev)], getattr(tree, "ctx", None))
         dtfeat_u = torch.zeros_like(tfeat_u)
         adaptive = tree.opts.weights == "adaptive"
         ces = torch.zeros(len(picks), 1, dtype=torch.float32, device=e.dev) if adaptive else None

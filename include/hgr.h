@@ -224,8 +224,10 @@ int hgr_layernorm_bwd(const void *dy, int dy_f32, const float *x, const float *g
                       float eps, int dtype, void *stream);
 int64_t hgr_layernorm_bwd_scratch_floats(int rows, int W);
 
-/* Attention backward for hgr_mha (L <= 64 this round): dqkv [B*L, 3W] from qkv and dout [B*L, W], all 16-bit. */
-int hgr_mha_bwd(const void *qkv, const void *dout, void *dqkv, int B, int L, int heads, int causal, int dtype, void *stream);
+/* Attention backward for hgr_mha (L <= 320): dqkv [B*L, 3W] from qkv, the forward output `out` and dout [B*L, W], all
+ * 16-bit.  Short sequences (L <= 32) use per-output fp32 loops; longer ones a tiled flash-style kernel on the exact-fp32
+ * MFMA that recomputes P from row statistics (nothing L x L is stored). */
+int hgr_mha_bwd(const void *qkv, const void *out, const void *dout, void *dqkv, int B, int L, int heads, int causal, int dtype, void *stream);
 
 /*
  * Row-wise softmax cross-entropy (nn.CrossEntropyLoss at clip_tree.py:49,275): loss_rows[r] = lse(logits[r]) -
@@ -249,6 +251,12 @@ int hgr_embed_scatter_add(const int64_t *tokens, int64_t ld_tokens, const float 
 /* dst[(r*dst_mul + idx[r])] += alpha * src[r]  for W-wide fp32 rows (scatter of EOT / class-token row gradients;
  * dst_mul = 0 with distinct idx: scatter-add of per-step text-feature gradients into the de-duplicated prompt set). */
 int hgr_rows_axpy(float *dst, int64_t dst_mul, const int32_t *dst_idx, const float *src, int rows, int W, float alpha, void *stream);
+
+/* CoOp learnable prompts (reference model/CoOp.py:58-113; BASELINE configs[4]): after hgr_text_embed, rows 1..n_ctx of every
+ * prompt become the shared context vectors: x[i*L + 1 + c] = ctx[c] + positional[1 + c].  Backward: dctx[c] += sum_i
+ * dx[i*L + 1 + c] (fixed order) and those dx rows are cleared, so the placeholder tokens' embeddings get no gradient. */
+int hgr_ctx_splice(float *x, const float *ctx, const float *positional_embedding, int n, int L, int W, int n_ctx, void *stream);
+int hgr_ctx_splice_bwd(float *dx, float *dctx, int n, int L, int W, int n_ctx, void *stream);
 
 /* dst[r] = src[idx[r]]  for W-wide fp32 rows (the text features of one inner step out of the de-duplicated set). */
 int hgr_rows_gather(float *dst, const float *src, const int32_t *idx, int rows, int W, void *stream);

@@ -196,7 +196,7 @@ def encode_image(sd: SD, image: torch.Tensor, rd: Rd = identity, taps: Optional[
     return rn_forward(sd, image)
 
 
-def encode_text(sd: SD, text: torch.Tensor, rd: Rd = identity, trim: bool = False) -> torch.Tensor:
+def encode_text(sd: SD, text: torch.Tensor, rd: Rd = identity, trim: bool = False, ctx: Optional[torch.Tensor] = None) -> torch.Tensor:
     """CLIP.encode_text (clip/model.py:339-352): embedding gather + positional; causal blocks;
     ln_final; row at argmax(token id) (= EOT); @ text_projection.
 
@@ -206,7 +206,10 @@ def encode_text(sd: SD, text: torch.Tensor, rd: Rd = identity, trim: bool = Fals
     if trim:
         text = text[:, : int(eot.max()) + 1]
     l = text.shape[1]
-    x = sd["token_embedding.weight"].float()[text] + sd["positional_embedding"].float()[:l]
+    x = sd["token_embedding.weight"].float()[text]
+    if ctx is not None:
+        x = torch.cat([x[:, :1], ctx.float().unsqueeze(0).expand(x.shape[0], -1, -1), x[:, 1 + ctx.shape[0]:]], dim=1)
+    x = x + sd["positional_embedding"].float()[:l]
     wt = x.shape[-1]
     layers = len({k.split(".")[2] for k in sd if k.startswith("transformer.resblocks")})
     x = transformer(x, sd, "transformer", layers, wt // 64, True, rd)

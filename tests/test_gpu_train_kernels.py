@@ -104,7 +104,7 @@ def test_layernorm_bwd(w):
 
 
 @pytest.mark.parametrize("dt", DTS)
-@pytest.mark.parametrize("L,causal", [(5, True), (16, True), (50, False), (64, False), (37, True)])
+@pytest.mark.parametrize("L,causal", [(5, True), (16, True), (50, False), (64, False), (37, True), (77, True), (65, False), (130, True), (257, False)])
 def test_mha_bwd_vs_autograd(dt, L, causal):
     b, heads = 2, 2
     w = heads * 64
@@ -119,7 +119,7 @@ def test_mha_bwd_vs_autograd(dt, L, causal):
     o = (torch.softmax(s, -1) @ sh(vv)).transpose(1, 2).reshape(b * L, w)
     o.backward(do.float())
     dqkv = torch.empty(b * L, 3 * w, dtype=dt, device=DEV)
-    ops.mha_bwd(qkv.to(DEV), do.to(DEV), dqkv, b, L, heads, causal)
+    ops.mha_bwd(qkv.to(DEV), o.detach().to(dt).to(DEV), do.to(DEV), dqkv, b, L, heads, causal)
     tol = 3e-2 if dt == torch.bfloat16 else 4e-3
     assert (dqkv.float().cpu() - q.grad).abs().max() < tol * max(1.0, float(q.grad.abs().max()))
 

@@ -176,3 +176,68 @@ def test_adaptive_layer_weight_gets_its_gradient(golden_dir, tmp_path):
     # gradient flows only to the levels that were contrasted in this step
     assert float(g[model.max_depth + 1:].abs().sum()) == 0 if g.numel() > model.max_depth + 1 else True
     assert loss > 0
+
+
+def test_coop_context_forward_and_gradient(golden_dir):
+    """CoOp learnable context (BASELINE configs[4]): forward vs the reference fixture, d loss / d ctx vs oracle autograd."""
+    from hgr_net_amd import ops
+    from hgr_net_amd.training import Engine
+    from oracle import clip_ref
+    z = np.load(golden_dir / "coop_tinyvit.npz")
+    cfg = json.loads(str(z["config"]))
+    sd = synth.clip_state_dict(cfg, 0)
+    model = build_model(sd).to(DEV)
+    tok = torch.from_numpy(z["tokens"].astype(np.int64))[torch.from_numpy(z["idx"])]
+    ctx = torch.from_numpy(z["ctx"])
+    f = model.encode_text(tok.to(DEV), ctx=ctx.to(DEV)).cpu().numpy()
+    assert np.abs(f - z["features"]).max() < 6e-3                      # f16 text tower vs the reference's fp32
+    # gradient of sum(features * R) w.r.t. ctx, bf16 engine vs fp32 autograd through the oracle
+    r = torch.from_numpy(synth.normal(3, "R", f.size).astype(np.float32).reshape(f.shape))
+    cref = ctx.clone().requires_grad_(True)
+    (clip_ref.encode_text(sd, tok, trim=True, ctx=cref) * r).sum().backward()
+    e = Engine(model, "bf16")
+    e.prepare()
+    cpar = torch.nn.Parameter(ctx.clone().to(DEV))
+    feat, save = e.text_fwd(tok.to(DEV), cpar)
+    e.text_bwd(r.to(DEV), save)
+    g = cpar.grad.cpu()
+    cos = float((g * cref.grad).sum() / (g.norm() * cref.grad.norm()))
+    assert cos > 0.995 and abs(float(g.norm()) / float(cref.grad.norm()) - 1) < 0.05
+    # the 'X' placeholder token's embedding row got no gradient (its embedding is replaced by ctx)
+    x_id = int(tok[0, 1])
+    assert float(model.token_embedding.weight.grad[x_id].abs().sum()) == 0.0
+
+
+def test_vit_l14_shaped_training_step(tmp_path):
+    """ViT-L/14-shaped geometry end to end in training: patch 14 (K = 588 padded to 640), 26 tokens > short path,
+    CoOp context; loss finite and every parameter (incl. ctx) receives a gradient."""
+    import types
+    from hgr_net_amd.training import FusedAdamW
+    cfg = dict(embed_dim=64, image_resolution=70, vision_layers=2, vision_width=128, vision_patch_size=14, context_length=77,
+               vocab_size=512, transformer_width=64, transformer_heads=1, transformer_layers=2)
+    edges = synth.make_dag(60, depth=6, seed=3, multi_parent=0.05)
+    (tmp_path / "g.json").write_text(json.dumps(edges))
+    h = build_hierarchy(edges)
+    splits = synth.make_splits(h.nodes, [len(c) == 0 for c in h.p2c], 20, 25, 13)
+    o = types.SimpleNamespace(device=DEV, folder=str(tmp_path / "o"), exp_name="HGR", weights="equal", from_epoch=-1, graph_path=str(tmp_path / "g.json"),
+                              arch="x", fetch=False, load=False, load_path="none", scale=1.0, train_dtype="bf16", num_compare=8, k=1,
+                              sample_strategy="topk", weighting="both", out_ratio=0.5, in_ratio=0.5, n_ctx=16)
+    model = tree_model(o, splits["all"], splits["rest"], node_tokens=synth.make_tokens(60, 11, 512, n_ctx=16),
+                       clip_model=build_model(synth.clip_state_dict(cfg, 0)).to(DEV))
+    assert model.ctx.shape == (16, 64)
+    target = max(model.train_index.tolist(), key=lambda i: len(model.c2p[i]))
+    img = synth.images(4, 70, 9).to(DEV)
+    import random
+    random.seed(1)
+    loss = model.train_batch(img, torch.full((4,), target, dtype=torch.long, device=DEV), "OM", "topk")
+    assert np.isfinite(loss) and loss > 0
+    missing = [n for n, p in model.named_parameters() if p.requires_grad and (p.grad is None or not torch.isfinite(p.grad).all())]
+    assert not missing, missing
+    assert float(model.ctx.grad.abs().sum()) > 0 and float(model.clip_model.visual.conv1.weight.grad.abs().sum()) > 0
+    opt = FusedAdamW([p for n, p in model.named_parameters() if p.requires_grad], lr=1e-3)
+    before = model.ctx.detach().clone()
+    opt.step()
+    assert not torch.equal(before, model.ctx.detach())
+    model.update_classifier()                                   # eval path with the learned context
+    lg = model(img, None)
+    assert lg.shape == (4, 60) and torch.isfinite(lg).all()

@@ -122,3 +122,13 @@ def test_bf16_emulation_error_budget():
     ref = tree_ref.forward(sd, img, zsl)
     emu = tree_ref.forward(sd, img, zsl, rd=clip_ref.round_bf16)
     assert float((ref - emu).abs().max()) < 1e-3
+
+
+def test_coop_prompt_path_matches_reference_fixture(golden_dir):
+    """oracle encode_text(ctx=...) vs the reference's PromptLearner + TextEncoder (model/CoOp.py) output."""
+    z = np.load(golden_dir / "coop_tinyvit.npz")
+    cfg = json.loads(str(z["config"]))
+    sd = synth.clip_state_dict(cfg, 0)
+    tok = torch.from_numpy(z["tokens"].astype(np.int64))[torch.from_numpy(z["idx"])]
+    f = clip_ref.encode_text(sd, tok, trim=True, ctx=torch.from_numpy(z["ctx"])).numpy()
+    assert np.abs(f - z["features"]).max() < 1e-5

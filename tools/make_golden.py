@@ -207,6 +207,39 @@ def tree_fixture(ref_main_mod, tag, cfg, n_nodes, n_train, n_test, batches, bsz,
     return model
 
 
+def coop_fixture(ref_clip, tmp):
+    """CoOp prompt learner + text encoder of the reference (model/CoOp.py:31-113) on CPU; its hard-coded .cuda() calls are
+    neutralised for the run.  Pins the oracle's ``encode_text(ctx=...)``."""
+    import importlib
+    cfg = dict(synth.CLIP_CONFIGS["tiny-vit"], vocab_size=49408)
+    sd = synth.clip_state_dict(cfg, 0)
+    p = os.path.join(tmp, "coop_arch.pt")
+    save_sd(sd, p)
+    model, _ = ref_clip.load(name=p, device="cpu")
+    old_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        coop = importlib.import_module("model.CoOp")
+        names = ["great_white_shark", "tabby cat", "kind12 thing3", "zebra finch", "x", "golden retriever puppy"]
+        torch.manual_seed(5)
+        with contextlib.redirect_stdout(io.StringIO()):
+            pl = coop.PromptLearner(names, model)
+        te = coop.TextEncoder(model)
+        idx = torch.tensor([0, 2, 3, 5])
+        with torch.no_grad():
+            feats = te(pl(idx), pl.tokenized_prompts[idx]).float()
+    finally:
+        torch.Tensor.cuda = old_cuda
+    ctx = pl.ctx.detach().float()
+    toks = pl.tokenized_prompts.clone()
+    o = clip_ref.encode_text(sd, toks[idx], ctx=ctx)
+    ot = clip_ref.encode_text(sd, toks[idx], trim=True, ctx=ctx)
+    print(f"[coop] PromptLearner+TextEncoder |ref-oracle| {maxdiff(feats, o):.2e} (trim {maxdiff(feats, ot):.2e}), n_ctx {pl.n_ctx}")
+    assert maxdiff(feats, o) < 1e-5 and maxdiff(feats, ot) < 1e-5
+    np.savez_compressed(GOLD / "coop_tinyvit.npz", config=json.dumps(cfg), ctx=ctx.numpy(), tokens=toks.numpy().astype(np.int32),
+                        idx=idx.numpy(), features=feats.numpy())
+
+
 TRAIN_KEEP = ["logit_scale", "ln_final.weight", "ln_final.bias", "text_projection", "positional_embedding", "visual.proj",
               "visual.class_embedding", "visual.positional_embedding", "visual.ln_pre.weight", "visual.ln_post.bias",
               "transformer.resblocks.0.attn.in_proj_bias", "transformer.resblocks.1.mlp.c_fc.weight",
@@ -275,6 +308,7 @@ def main():
             clip_fixture(ref_clip, "ViT-B/32", C["ViT-B/32"], 2, 8, tmp)
             clip_fixture(ref_clip, "RN50", C["RN50"], 2, 2, tmp)
             clip_fixture(ref_clip, "ViT-L/14", C["ViT-L/14"], 1, 2, tmp)
+        coop_fixture(ref_clip, tmp)
         tv = dict(C["tiny-vit"], vocab_size=49408)   # real BPE ids need the real vocabulary size
         tree_fixture(ref_main, "tinyvit_n90", tv, 90, 30, 40, 3, 8, tmp)
         sv = dict(C["small-vit"], vocab_size=49408)
