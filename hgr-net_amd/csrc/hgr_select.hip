@@ -181,6 +181,159 @@ __global__ __launch_bounds__(256) void level_argmax(const float *__restrict__ lo
     }
 }
 
+// ---- fused evaluation of one logits row (T1 + T2 + T3 of main.py:136-176) ------------------------------------------
+// One workgroup per row, tiny LDS footprint (8 workgroups per CU hide the load latency), the row (<= 160 KB) stays
+// L2-resident between its three sweeps:
+//   * level-segmented arg-max: ONE coalesced sweep over the row; every thread keeps the running best (value, position)
+//     of every depth level in registers (statically unrolled over <= 16 / 32 levels), then one wave-shuffle reduction per
+//     level and 4 partials through LDS.  (Measured alternatives: a row staged in LDS + CSR walk of the levels is bound by
+//     one workgroup per CU and the index loads' latency, 175 us; folding into 12 LDS atomicMax slots serialises in the
+//     per-CU LDS atomic unit, 160 us.)
+//   * the unmasked top-1 = best of the level slots;
+//   * top-k over the test columns with the threshold / candidate algorithm of topk_rows: the slice maxima come out of the
+//     same first sweep, one more coalesced sweep collects the candidates.
+// Both sweeps run over the COLUMNS (fully coalesced) with dense maps column -> subset position (`train_pos`, `test_pos`,
+// -1 = not in the subset; the position only breaks ties); `lvl8[c]` = depth of node c; `filler_pos[l]` = first train
+// position NOT at depth l (-1 if none): the reference fills those columns with -1 before its arg-max, so the filler
+// competes (main.py:170-173).
+constexpr int EV_NT = 1024;                 // threads per row: 16 waves, so 512 rows keep 8 waves per SIMD busy chip-wide
+constexpr int EV_NW = EV_NT / 64;
+
+__device__ __forceinline__ Best block_best16(Best b, float *s_v, int *s_p, int tid) {
+    const Best w = wave_best(b);
+    __syncthreads();
+    if ((tid & 63) == 0) { s_v[tid >> 6] = w.v; s_p[tid >> 6] = w.p; }
+    __syncthreads();
+    Best r = {s_v[0], s_p[0]};
+    for (int i = 1; i < EV_NW; ++i)
+        if (better(s_v[i], s_p[i], r.v, r.p)) { r.v = s_v[i]; r.p = s_p[i]; }
+    return r;
+}
+
+template <int NLV>
+__global__ __launch_bounds__(EV_NT) void eval_rows(const float *__restrict__ logits, int64_t ld, int n_nodes, const unsigned char *__restrict__ lvl8,
+                                                 const int32_t *__restrict__ train_pos, const int32_t *__restrict__ train_cols, int n_train, int n_levels,
+                                                 const int32_t *__restrict__ filler_pos, const int32_t *__restrict__ test_pos, const int32_t *__restrict__ test_cols,
+                                                 int n_test, int k, int32_t *__restrict__ out_level, int32_t *__restrict__ out_top1, int32_t *__restrict__ out_topk) {
+    __shared__ float s_lv[EV_NW][NLV];
+    __shared__ int s_lp[EV_NW][NLV];
+    __shared__ float s_v[EV_NW];
+    __shared__ int s_p[EV_NW];
+    __shared__ float s_mv[256];
+    __shared__ int s_mp[256];
+    __shared__ float s_cv[TOPK_CAND];
+    __shared__ int s_cp[TOPK_CAND];
+    __shared__ float s_t;
+    __shared__ int s_tp, s_cnt;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = blockIdx.x;
+    const float *lr = logits + (int64_t)r * ld;
+    if (tid == 0) s_cnt = 0;
+    // sweep 1 (coalesced over the columns): per-thread running best of every level (registers, statically unrolled) and
+    // this thread's best test element
+    float bv[NLV];
+    int bp[NLV];
+#pragma unroll
+    for (int l = 0; l < NLV; ++l) { bv[l] = -INFINITY; bp[l] = 0x7fffffff; }
+    Best mine = {-INFINITY, 0x7fffffff};
+    for (int c = tid; c < n_nodes; c += EV_NT) {
+        const float v = lr[c] + 0.0f;
+        const int tp = train_pos[c];
+        const int lv = tp >= 0 ? (int)lvl8[c] : -1;
+#pragma unroll
+        for (int l = 0; l < NLV; ++l)
+            if (lv == l && better(v, tp, bv[l], bp[l])) { bv[l] = v; bp[l] = tp; }
+        if (k > 0) {
+            const int te = test_pos[c];
+            if (te >= 0 && better(v, te, mine.v, mine.p)) { mine.v = v; mine.p = te; }
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < NLV; ++l) {
+        Best b = {bv[l], bp[l]};
+        b = wave_best(b);
+        if (lane == 0) { s_lv[wave][l] = b.v; s_lp[wave][l] = b.p; }
+    }
+    // 256 slice maxima for the top-k threshold: best of each group of 4 consecutive threads
+    {
+        Best gmx = mine;
+#pragma unroll
+        for (int o = 1; o <= 2; o <<= 1) {
+            const float ov = __shfl_xor(gmx.v, o);
+            const int op = __shfl_xor(gmx.p, o);
+            if (better(ov, op, gmx.v, gmx.p)) { gmx.v = ov; gmx.p = op; }
+        }
+        if ((tid & 3) == 0) { s_mv[tid >> 2] = gmx.v; s_mp[tid >> 2] = gmx.p; }
+    }
+    __syncthreads();
+    if (wave == 0) {                                        // lane l < n_levels finishes level l; the whole wave takes part in the shuffles
+        const int l = lane;
+        Best b = {-INFINITY, 0x7fffffff};
+        if (l < n_levels) {
+            b = Best{s_lv[0][l], s_lp[0][l]};
+            for (int i = 1; i < EV_NW; ++i)
+                if (better(s_lv[i][l], s_lp[i][l], b.v, b.p)) { b.v = s_lv[i][l]; b.p = s_lp[i][l]; }
+            const int fo = filler_pos[l];
+            const bool has_c = b.p < n_train, has_f = fo >= 0;
+            int win;
+            if (has_c && (!has_f || b.v > -1.0f || (b.v == -1.0f && b.p < fo))) win = b.p;
+            else win = has_f ? fo : b.p;
+            out_level[(int64_t)r * n_levels + l] = train_cols[win];
+        }
+        const Best top = wave_best(b);                      // unmasked top-1 = best of the level bests
+        if (lane == 0 && out_top1) out_top1[r] = top.p < n_train ? train_cols[top.p] : -1;
+    }
+    if (k <= 0) return;
+    // top-k over the test subset: threshold = k-th best of the 256 slice maxima, then sweep 2 collects the candidates
+    if (tid < 256) {
+        const float mv = s_mv[tid]; const int mp = s_mp[tid];
+        int rank = 0, nonempty = 0;
+        for (int j = 0; j < 256; ++j) { rank += better(s_mv[j], s_mp[j], mv, mp) ? 1 : 0; nonempty += s_mp[j] != 0x7fffffff ? 1 : 0; }
+        // k distinct elements >= t are guaranteed only if at least k slices are non-empty (clustered / tiny test sets can
+        // put several test columns into one slice); otherwise every test element is a candidate
+        if (nonempty < k) { if (tid == 0) { s_t = -INFINITY; s_tp = 0x7fffffff; } }
+        else if (rank == k - 1) { s_t = mv; s_tp = mp; }
+    }
+    __syncthreads();
+    const float t = s_t; const int tp0 = s_tp;
+    for (int c = tid; c < n_nodes; c += EV_NT) {
+        const int te = test_pos[c];
+        if (te < 0) continue;
+        const float v = lr[c] + 0.0f;
+        if (!better(t, tp0, v, te)) {
+            const int slot = atomicAdd(&s_cnt, 1);
+            if (slot < TOPK_CAND) { s_cv[slot] = v; s_cp[slot] = te; }
+        }
+    }
+    __syncthreads();
+    const int cnt = s_cnt;
+    if (cnt <= TOPK_CAND) {
+        for (int c = tid; c < cnt; c += EV_NT) {
+            const float v = s_cv[c]; const int p = s_cp[c];
+            int rk = 0;
+            for (int j = 0; j < cnt; ++j) rk += better(s_cv[j], s_cp[j], v, p) ? 1 : 0;
+            if (rk < k) out_topk[(int64_t)r * k + rk] = test_cols[p];
+        }
+    } else {
+        // heavily duplicated data: k rounds of block arg-max; an element is "removed" by requiring it to be worse than the
+        // previous winner in (value, position) order, so nothing has to be written back
+        Best last = {INFINITY, -1};
+        for (int j = 0; j < k; ++j) {
+            Best b = {-INFINITY, 0x7fffffff};
+            for (int c = tid; c < n_nodes; c += EV_NT) {
+                const int te = test_pos[c];
+                if (te < 0) continue;
+                const float v = lr[c] + 0.0f;
+                if (better(last.v, last.p, v, te) && better(v, te, b.v, b.p)) { b.v = v; b.p = te; }
+            }
+            b = block_best16(b, s_v, s_p, tid);
+            if (tid == 0) out_topk[(int64_t)r * k + j] = b.p < n_test ? test_cols[b.p] : -1;
+            last = b;
+            __syncthreads();
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int hgr_topk_rows(const float *logits, int64_t ld, const int32_t *cols, int n_cols, int k,
@@ -209,5 +362,20 @@ extern "C" int hgr_level_argmax(const float *logits, int64_t ld, const int32_t *
     if (n_levels <= 16) hipLaunchKernelGGL((level_argmax<16>), dim3(rows), dim3(256), 0, s, logits, ld, cols, n_cols, depth, n_levels, out, out_top1);
     else hipLaunchKernelGGL((level_argmax<32>), dim3(rows), dim3(256), 0, s, logits, ld, cols, n_cols, depth, n_levels, out, out_top1);
     HGR_CHECK_LAUNCH("hgr_level_argmax");
+    return HGR_OK;
+}
+
+extern "C" int hgr_eval_rows(const float *logits, int64_t ld, int n_nodes, const unsigned char *lvl8, const int32_t *train_pos,
+                             const int32_t *train_cols, int n_train, int n_levels, const int32_t *filler_pos, const int32_t *test_pos,
+                             const int32_t *test_cols, int n_test, int k, int32_t *out_level, int32_t *out_top1, int32_t *out_topk,
+                             int rows, void *stream) {
+    HGR_REQUIRE(logits && lvl8 && train_pos && train_cols && filler_pos && out_level, "hgr_eval_rows: null operand");
+    HGR_REQUIRE(rows >= 1 && n_nodes >= 1 && ld >= n_nodes && n_train >= 1 && n_levels >= 1 && n_levels <= 32, "hgr_eval_rows: bad sizes (n_levels <= 32)");
+    HGR_REQUIRE(k == 0 || (out_topk && test_pos && test_cols && k >= 1 && k <= 32 && n_test >= k), "hgr_eval_rows: bad top-k arguments");
+    if (n_levels <= 16) hipLaunchKernelGGL((eval_rows<16>), dim3(rows), dim3(EV_NT), 0, (hipStream_t)stream, logits, ld, n_nodes, lvl8, train_pos, train_cols, n_train,
+                                           n_levels, filler_pos, test_pos, test_cols, n_test, k, out_level, out_top1, out_topk);
+    else hipLaunchKernelGGL((eval_rows<32>), dim3(rows), dim3(EV_NT), 0, (hipStream_t)stream, logits, ld, n_nodes, lvl8, train_pos, train_cols, n_train,
+                            n_levels, filler_pos, test_pos, test_cols, n_test, k, out_level, out_top1, out_topk);
+    HGR_CHECK_LAUNCH("hgr_eval_rows");
     return HGR_OK;
 }

@@ -28,6 +28,7 @@ class Evaluator:
         dev = model.train_index.device
         self.acc = torch.zeros(len(COUNTERS), dtype=torch.float64, device=dev)
         self.n_levels = model.max_depth + 1
+        self.index = ops.EvalIndex(model.depth32, model.train_index32, model.test_index32, self.n_levels)   # dense per-column maps, built once
         self._parents_cache: Dict[int, tuple] = {}
 
     def _parents(self, target: int):
@@ -47,12 +48,12 @@ class Evaluator:
         (every batch is one group).  Returns (pred_top20, dict_path) int32 tensors."""
         m = self.model
         b = logits.shape[0]
-        pred = ops.topk_rows(logits, max(TOPK), cols=m.test_index32)                 # T1 main.py:136-139
+        # T1 (top-20 over the test columns, main.py:136-139), T2 (top-1 over the train columns, :157) and T3 (arg-max per
+        # depth level, :162-176) in one fused kernel (hgr_eval_rows)
+        lv, p1, pred = ops.eval_rows(logits, self.index, max(TOPK))
         correct = pred == (targets.to(torch.int32).view(-1, 1) if targets is not None else target)
         csum = correct.cumsum(dim=1).sum(dim=0).to(torch.float64)                    # hits for every k at once
         parents, levels, L = self._parents(target)
-        # T3 main.py:162-176 (every level in one pass) and T2 main.py:157 (top-1 = best of the level bests)
-        lv, p1 = ops.level_argmax(logits, m.depth32, self.n_levels, cols=m.train_index32, want_top1=True)
         hits_all = (p1 == parents.view(1, -1)).sum().to(torch.float64)
         dict_path = lv[:, levels]                                                    # [B, L]
         match = dict_path == parents.view(1, -1)                                     # T4 main.py:177-191

@@ -163,6 +163,58 @@ def level_argmax(logits: torch.Tensor, depth: torch.Tensor, n_levels: int, cols:
     return (out, top1) if want_top1 else out
 
 
+class EvalIndex:
+    """Dense per-column maps for the fused evaluation kernel (built once per model on the host): depth of every node,
+    column -> position in the train / test subsets (-1 = absent), position -> node id, and the reference's -1-filler
+    position per level."""
+
+    def __init__(self, depth: torch.Tensor, train_cols: torch.Tensor, test_cols: Optional[torch.Tensor], n_levels: int):
+        import numpy as np
+        d = depth.cpu().numpy()
+        n = len(d)
+        tr = train_cols.cpu().numpy().astype(np.int64)
+        assert d.min() >= 0 and n_levels <= 32 and d[tr].max() < n_levels, "a subset node lies deeper than n_levels"
+        assert len(set(tr.tolist())) == len(tr), "train columns must be distinct"
+        lv = d[tr]
+        filler = np.full(n_levels, -1, dtype=np.int32)
+        for l in range(n_levels):
+            other = np.nonzero(lv != l)[0]
+            if other.size:
+                filler[l] = int(other[0])
+        tpos = np.full(n, -1, dtype=np.int32)
+        tpos[tr] = np.arange(len(tr), dtype=np.int32)
+        dev = depth.device
+        self.n_nodes, self.n_levels, self.n_train = n, n_levels, len(tr)
+        self.lvl8 = torch.from_numpy(np.minimum(d, 255).astype(np.uint8)).to(dev)
+        self.train_pos = torch.from_numpy(tpos).to(dev)
+        self.train_cols = train_cols.to(torch.int32).contiguous()
+        self.filler = torch.from_numpy(filler).to(dev)
+        self.test_pos = self.test_cols = None
+        self.n_test = 0
+        if test_cols is not None:
+            te = test_cols.cpu().numpy().astype(np.int64)
+            assert len(set(te.tolist())) == len(te), "test columns must be distinct"
+            epos = np.full(n, -1, dtype=np.int32)
+            epos[te] = np.arange(len(te), dtype=np.int32)
+            self.test_pos = torch.from_numpy(epos).to(dev)
+            self.test_cols = test_cols.to(torch.int32).contiguous()
+            self.n_test = len(te)
+
+
+def eval_rows(logits: torch.Tensor, index: EvalIndex, k: int):
+    """(level arg-max [rows, n_levels], top-1 [rows, 1], top-k [rows, k]) int32 node ids from one fused kernel."""
+    assert logits.dtype == torch.float32 and logits.stride(1) == 1 and logits.shape[1] >= index.n_nodes
+    rows = logits.shape[0]
+    dev = logits.device
+    lvl = torch.empty((rows, index.n_levels), dtype=torch.int32, device=dev)
+    top1 = torch.empty((rows, 1), dtype=torch.int32, device=dev)
+    topk = torch.empty((rows, max(k, 1)), dtype=torch.int32, device=dev)
+    _lib.call("hgr_eval_rows", _dev(logits), logits.stride(0), index.n_nodes, _dev(index.lvl8), _dev(index.train_pos), _dev(index.train_cols),
+              index.n_train, index.n_levels, _dev(index.filler), _dev(index.test_pos), _dev(index.test_cols), index.n_test, k,
+              _dev(lvl), _dev(top1), _dev(topk), rows, _stream())
+    return lvl, top1, topk
+
+
 # ---- ModifiedResNet (RN) tower -------------------------------------------------------------------
 def conv3x3_nhwc(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out: torch.Tensor, b: int, h: int, wd: int, c: int,
                  stride: int = 1) -> torch.Tensor:

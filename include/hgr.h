@@ -151,6 +151,23 @@ int hgr_topk_rows(const float *logits, int64_t ld, const int32_t *cols, int n_co
 int hgr_level_argmax(const float *logits, int64_t ld, const int32_t *cols, int n_cols,
                      const int32_t *depth, int n_levels, int32_t *out, int32_t *out_top1, int rows, void *stream);
 
+/*
+ * Fused per-row evaluation = hgr_level_argmax + its top-1 + hgr_topk_rows in one kernel (main.py:136-176).  Two fully
+ * coalesced sweeps over the logits row (HBM once, L2 once), driven by dense per-column maps built once per model:
+ *   lvl8 uint8 [n_nodes] depth of node c;  train_pos / test_pos int32 [n_nodes] = position of column c in the train / test
+ *   subset or -1 (positions only break ties, like `logits[:, index].topk`);  train_cols / test_cols int32 = position ->
+ *   node id;  filler_pos int32 [n_levels] = first train position NOT at depth l (or -1): the reference's -1 fill competes.
+ *   - sweep 1 keeps, per thread, the running best of every depth level in registers (the segments of the reduce are the
+ *     levels) plus the thread's best test element, then one shuffle reduction per level; out_level [rows, n_levels],
+ *     out_top1 [rows] (may be NULL) = best of the level bests;
+ *   - sweep 2 collects the top-k candidates (>= the k-th best slice maximum), ranked by brute force: out_topk [rows, k]
+ *     (k = 0 skips it).  Exact for any data, ties to the lowest subset position; n_levels <= 32.
+ */
+int hgr_eval_rows(const float *logits, int64_t ld, int n_nodes, const unsigned char *lvl8, const int32_t *train_pos,
+                  const int32_t *train_cols, int n_train, int n_levels, const int32_t *filler_pos, const int32_t *test_pos,
+                  const int32_t *test_cols, int n_test, int k, int32_t *out_level, int32_t *out_top1, int32_t *out_topk,
+                  int rows, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * ModifiedResNet (RN50) tower, clip/model.py:93-150.  Activations are NHWC 16-bit ([B, H, W, C] =
  * a row-major [B*H*W, C] matrix), so every 1x1 convolution IS hgr_gemm_nt; inference BatchNorm

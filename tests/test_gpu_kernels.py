@@ -301,3 +301,34 @@ def test_gemm_race_screen_deep_pipeline():
                 assert (first - ref).abs().max() < 2e-3 * max(1.0, float(ref.abs().max()))
             else:
                 assert torch.equal(out, first), (m, n, k, it)
+
+
+@pytest.mark.parametrize("n,levels,dup", [(90, 8, False), (48, 5, False), (3000, 12, False), (21841, 12, False), (5000, 6, True)])
+def test_eval_rows_fused_exact(n, levels, dup):
+    """hgr_eval_rows (LDS-atomic level-segmented arg-max + top-1 + top-k) == the oracle's per-level masking / top-k, bit-exact."""
+    rows, k = 4, 20
+    lg = _rand((rows, n), 70 + n, 0.05)
+    if dup:                                                  # heavy duplication: exercises tie order and the in-kernel fallback
+        lg = torch.from_numpy(synth.randint(5, "dupv", rows * n, 0, 3).astype(np.float32).reshape(rows, n)) * 0.1
+    lg[0, 3] = lg[0, 17]
+    depth = synth.randint(2, "depth", n, 0, levels).astype(np.int32)
+    if levels >= 12:
+        depth[depth == 5] = 4                                # an empty level
+    perm = np.argsort(synth.uniform(2, "perm", n), kind="stable").astype(np.int32)
+    train = perm[: n - n // 3]
+    test = np.sort(perm[n - n // 2:])
+    ld = (n + 63) // 64 * 64
+    buf = torch.zeros(rows, ld, dtype=torch.float32, device=DEV)
+    buf[:, :n] = lg.to(DEV)
+    test = perm[n - n // 2:]                                  # unsorted: tie order must follow the subset positions
+    if n == 48:
+        test = np.arange(8, 32, dtype=np.int32)[::-1].copy()  # 24 clustered test columns: several share one slice
+    index = ops.EvalIndex(torch.from_numpy(depth).to(DEV), torch.from_numpy(train).to(DEV), torch.from_numpy(test).to(DEV), levels)
+    lvl, top1, topk = ops.eval_rows(buf[:, :n], index, k)
+    tr = train.astype(np.int64)
+    for l in range(levels):
+        same = [int(i) for i in np.nonzero(depth == l)[0]]
+        assert np.array_equal(lvl[:, l].cpu().numpy(), tree_ref.level_argmax(lg.numpy(), tr, same, n)), l
+    for r in range(rows):
+        assert int(top1[r, 0]) == tr[tree_ref.topk_desc(lg[r, torch.from_numpy(tr)].numpy(), 1)[0]]
+        assert np.array_equal(topk[r].cpu().numpy(), test[tree_ref.topk_desc(lg[r, torch.from_numpy(test.astype(np.int64))].numpy(), k)])
