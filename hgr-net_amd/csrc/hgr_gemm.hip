@@ -95,6 +95,39 @@ __device__ __forceinline__ void store_quad(const GemmArgs &p, f32x4 v, int m, in
     }
 }
 
+// Interior-tile forms (the caller guarantees vec_ok and that the whole quad is inside C).  The quad's second addend
+// (fp32 residual, 16-bit identity or the old C for ACCUM) is loaded by load_addend() and handed to store_quad_full():
+// callers fetch a batch of addends, then store the batch.  Interleaved load / store pairs serialise completely -
+// residual and C may alias, so hipcc keeps every load behind the previous store with a vmcnt(0) between them.
+template <int DT, int EPI>
+__device__ __forceinline__ f32x4 load_addend(const GemmArgs &p, int m, int n) {
+    typedef typename T16<DT>::elem E;
+    if (EPI == HGR_EPI_ACCUM) return *(const f32x4 *)((const float *)p.C + (int64_t)m * p.ldc + n);
+    if (EPI == HGR_EPI_BIAS_RESIDUAL) return *(const f32x4 *)(p.res + (int64_t)m * p.ldr + n);
+    if (EPI == HGR_EPI_BIAS_ADD16_RELU) {
+        const typename T16<DT>::vec4 idn = *(const typename T16<DT>::vec4 *)((const E *)(const void *)p.res + (int64_t)m * p.ldr + n);
+        return (f32x4){(float)idn[0], (float)idn[1], (float)idn[2], (float)idn[3]};
+    }
+    return (f32x4){0.f, 0.f, 0.f, 0.f};
+}
+
+template <int DT, int EPI, bool OUT32>
+__device__ __forceinline__ void store_quad_full(const GemmArgs &p, f32x4 v, f32x4 bq, f32x4 addend, int m, int n) {
+    typedef typename T16<DT>::elem E;
+    if (EPI != HGR_EPI_NONE && EPI != HGR_EPI_ACCUM) v += bq;
+    if (EPI == HGR_EPI_BIAS_QUICKGELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
+    }
+    if (EPI == HGR_EPI_ACCUM || EPI == HGR_EPI_BIAS_RESIDUAL || EPI == HGR_EPI_BIAS_ADD16_RELU) v += addend;
+    if (EPI == HGR_EPI_BIAS_RELU || EPI == HGR_EPI_BIAS_ADD16_RELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    if (OUT32) *(f32x4 *)((float *)p.C + (int64_t)m * p.ldc + n) = v;
+    else *(typename T16<DT>::vec4 *)((E *)p.C + (int64_t)m * p.ldc + n) = cvt4<DT>(v[0], v[1], v[2], v[3]);
+}
+
 template <int DT, int EPI, bool OUT32, bool CONV = false>
 __global__ __launch_bounds__(NT) void gemm_nt_128(GemmArgs p) {
     typedef typename T16<DT>::vec8 vec8;
@@ -224,6 +257,29 @@ __global__ __launch_bounds__(NT) void gemm_nt_128(GemmArgs p) {
 
     // epilogue: lane holds, for tile (i, j), C[m][n .. n+3] with
     //   m = m0 + wm*64 + j*16 + r,   n = n0 + wn*64 + i*16 + g*4
+    if (p.vec_ok && m0 + BM <= p.M && n0 + BN <= p.N) {
+        // interior tile: unguarded loads and stores, bias quads fetched once
+        f32x4 bq[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bq[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (EPI != HGR_EPI_NONE && EPI != HGR_EPI_ACCUM) bq[i] = *(const f32x4 *)(p.bias + n0 + wn * 64 + i * 16 + g * 4);
+        }
+#pragma unroll
+        for (int jh = 0; jh < 2; ++jh) {       // batches of 8 quads: all addend loads first, then the stores
+            f32x4 ad[2][4];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ad[j][i] = load_addend<DT, EPI>(p, m0 + wm * 64 + (jh * 2 + j) * 16 + r, n0 + wn * 64 + i * 16 + g * 4);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    store_quad_full<DT, EPI, OUT32>(p, acc[i][jh * 2 + j], bq[i], ad[j][i], m0 + wm * 64 + (jh * 2 + j) * 16 + r, n0 + wn * 64 + i * 16 + g * 4);
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int m = m0 + wm * 64 + j * 16 + r;
@@ -274,7 +330,7 @@ constexpr int PIECE = 16384;
 #define HGR_MBAR() do { __builtin_amdgcn_sched_barrier(0); \
     asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
-template <int DT, int EPI, bool OUT32>
+template <int DT, int EPI, bool OUT32, bool CONV = false>
 __global__ __launch_bounds__(NT256) void gemm_nt_256(GemmArgs p) {
     typedef typename T16<DT>::vec8 vec8;
     typedef typename T16<DT>::elem E;
@@ -305,22 +361,55 @@ __global__ __launch_bounds__(NT256) void gemm_nt_256(GemmArgs p) {
 
     // piece kinds in issue order: 0 = A0, 1 = W0, 2 = W1, 3 = A1.  Each thread moves 2 x 16 B per piece.
     const char *src[4][2];
+    int cchunk[2];              // CONV: this lane's logical 16-B chunk (8 input channels) inside a K-tile
+    unsigned vmask[2][2];       // CONV: [A0 / A1][j]: bit t set = tap t of that output pixel is inside the image
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int id = (j * 8 + wave) * 64 + lane;       // 16-B chunk id inside the 128-row piece
         const int pr = id >> 3, c = (id & 7) ^ (pr & 7); // piece row, swizzled source chunk
         const int ra0 = pr + (pr >= 64 ? 64 : 0);        // A row of piece row (m-half 0 of wave row pr/64)
         const int rw0 = (pr >> 5) * 64 + (pr & 31);      // W row of piece row (n-half 0 of wave col pr/32)
-        src[0][j] = p.A + ((int64_t)min(m0 + ra0, p.M - 1) * p.lda + c * 8) * 2;
-        src[3][j] = p.A + ((int64_t)min(m0 + ra0 + 64, p.M - 1) * p.lda + c * 8) * 2;
         src[1][j] = p.W + ((int64_t)min(n0 + rw0, p.N - 1) * p.ldw + c * 8) * 2;
         src[2][j] = p.W + ((int64_t)min(n0 + rw0 + 32, p.N - 1) * p.ldw + c * 8) * 2;
+        if (CONV) {
+            cchunk[j] = c;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int gm = min(m0 + ra0 + half * 64, p.M - 1);
+                const int wo = gm % p.cWo, t1 = gm / p.cWo, ho = t1 % p.cHo, b = t1 / p.cHo;
+                const int hi0 = ho * p.cStride - 1, wi0 = wo * p.cStride - 1;
+                unsigned vm = 0;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int hi = hi0 + t / 3, wi = wi0 + t % 3;
+                    if (hi >= 0 && hi < p.cH && wi >= 0 && wi < p.cW) vm |= 1u << t;
+                }
+                vmask[half][j] = vm;
+                src[half ? 3 : 0][j] = p.A + (((int64_t)b * p.cH + hi0) * p.cW + wi0) * p.cC * 2;   // tap (0,0), channel 0
+            }
+        } else {
+            src[0][j] = p.A + ((int64_t)min(m0 + ra0, p.M - 1) * p.lda + c * 8) * 2;
+            src[3][j] = p.A + ((int64_t)min(m0 + ra0 + 64, p.M - 1) * p.lda + c * 8) * 2;
+        }
     }
     const bool do_mma = p.dbg != 1, do_ld = p.dbg != 2;
     auto issue = [&](int kind, int t) {
         if (!do_ld) return;
         char *dst = smem + (t & 1) * (4 * PIECE) + kind * PIECE + wave * 1024;
         const int64_t koff = (int64_t)t * 128;
+        if (CONV && (kind == 0 || kind == 3)) {
+            // implicit im2col (see gemm_nt_128): K index = tap * C + channel, 8 channels per 16-B chunk, OOB taps -> zero page
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int kq = t * 64 + cchunk[j] * 8;
+                const int tap = kq >> p.cLog2C, cin = kq & (p.cC - 1);
+                const int ky = (tap * 11) >> 5, kx = tap - ky * 3;
+                const bool ok = tap < 9 && ((vmask[kind == 3][j] >> tap) & 1u);
+                const char *sp = ok ? src[kind][j] + ((int64_t)(ky * p.cW + kx) * p.cC + cin) * 2 : (const char *)hgr_zero_page;
+                __builtin_amdgcn_global_load_lds((const AS1 void *)sp, (AS3 void *)(dst + j * 8192), 16, 0, 0);
+            }
+            return;
+        }
         __builtin_amdgcn_global_load_lds((const AS1 void *)(src[kind][0] + koff), (AS3 void *)dst, 16, 0, 0);
         __builtin_amdgcn_global_load_lds((const AS1 void *)(src[kind][1] + koff), (AS3 void *)(dst + 8192), 16, 0, 0);
     };
@@ -436,58 +525,102 @@ __global__ __launch_bounds__(NT256) void gemm_nt_256(GemmArgs p) {
 
     // tile (a, b, i, j) of this lane holds C[m][n .. n+3],
     //   m = m0 + wm*128 + a*64 + i*16 + r,   n = n0 + wn*64 + b*32 + j*16 + g*4
-    if (!OUT32 && p.vec_ok && (p.ldc & 7) == 0 && EPI <= HGR_EPI_BIAS_QUICKGELU) {
+    if (!OUT32 && p.vec_ok && (p.ldc & 7) == 0 && (EPI <= HGR_EPI_BIAS_QUICKGELU || EPI == HGR_EPI_BIAS_RELU)) {
         // 16-bit output: transpose the wave's 128 x 64 tile through its private LDS slice (rows of 128 B
         // + 16 B pad) and write full 128-byte lines with 16-byte stores (8 lanes per row, 8 rows per
         // instruction) instead of 32-byte fragments of 16 different lines per instruction.
         constexpr int RS = 144;
         char *my = smem + wave * (128 * RS);
-        // the lane's 4 bias quads depend on (b, j) only: fetch them once (scalar-guarded at the N edge)
+        // FULL = the whole 256 x 256 tile is inside C: no guards, so the 4 bias loads and the 16 stores are independent
+        // (guarded loads make hipcc wait vmcnt(0) behind every one of them: 4 serial L2 round trips per tile)
+        auto staged = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
+            f32x4 bq[2][2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + wn * 64 + b * 32 + j * 16 + g * 4;
+                bq[b][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (EPI != HGR_EPI_NONE && EPI != HGR_EPI_ACCUM) {
+                    if (FULL || n + 3 < p.N) bq[b][j] = *(const f32x4 *)(p.bias + n);
+                    else
+                        for (int e = 0; e < 4; ++e) if (n + e < p.N) bq[b][j][e] = p.bias[n + e];
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x4 v = acc[a][b][i][j] + bq[b][j];
+                if (EPI == HGR_EPI_BIAS_QUICKGELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
+                }
+                if (EPI == HGR_EPI_BIAS_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                *(typename T16<DT>::vec4 *)(my + (a * 64 + i * 16 + r) * RS + (b * 32 + j * 16 + g * 4) * 2) = cvt4<DT>(v[0], v[1], v[2], v[3]);
+            }
+            // LDS ops of one wave complete in order, and the slice is private to the wave: no barrier needed
+            const int ch = lane & 7, rr = lane >> 3;
+            const int nb = n0 + wn * 64 + ch * 8;
+            E *dst0 = (E *)p.C + (int64_t)(m0 + wm * 128 + rr) * p.ldc + nb;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int row = q * 8 + rr;
+                const int m = m0 + wm * 128 + row;
+                const u32x4 v = *(const u32x4 *)(my + row * RS + ch * 16);
+                if (p.dbg == 4) { if (v[0] == 0x12345678u) ((float *)p.C)[0] = 1.f; continue; }
+                E *dst = dst0 + (int64_t)q * 8 * p.ldc;
+                if (FULL) *(u32x4 *)dst = v;
+                else if (m < p.M) {
+                    if (nb + 7 < p.N) *(u32x4 *)dst = v;
+                    else {
+                        const E *ve = (const E *)&v;
+                        for (int e = 0; e < 8 && nb + e < p.N; ++e) dst[e] = ve[e];
+                    }
+                }
+            }
+        };
+        if (m0 + 256 <= p.M && n0 + 256 <= p.N) staged(std::true_type());
+        else staged(std::false_type());
+        return;
+    }
+    if (p.vec_ok && m0 + 256 <= p.M && n0 + 256 <= p.N) {
         f32x4 bq[2][2];
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int n = n0 + wn * 64 + b * 32 + j * 16 + g * 4;
             bq[b][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (EPI != HGR_EPI_NONE && EPI != HGR_EPI_ACCUM) {
-                if (n + 3 < p.N) bq[b][j] = *(const f32x4 *)(p.bias + n);
-                else
-                    for (int e = 0; e < 4; ++e) if (n + e < p.N) bq[b][j][e] = p.bias[n + e];
-            }
+            if (EPI != HGR_EPI_NONE && EPI != HGR_EPI_ACCUM) bq[b][j] = *(const f32x4 *)(p.bias + n0 + wn * 64 + b * 32 + j * 16 + g * 4);
         }
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int ih = 0; ih < 2; ++ih) {       // batches of 8 quads: all addend loads first, then the stores
+            f32x4 ad[2][2][2];
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            f32x4 v = acc[a][b][i][j] + bq[b][j];
-            if (EPI == HGR_EPI_BIAS_QUICKGELU) {
+            for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
-            }
-            *(typename T16<DT>::vec4 *)(my + (a * 64 + i * 16 + r) * RS + (b * 32 + j * 16 + g * 4) * 2) = cvt4<DT>(v[0], v[1], v[2], v[3]);
-        }
-        // LDS ops of one wave complete in order, and the slice is private to the wave: no barrier needed
-        const int ch = lane & 7, rr = lane >> 3;
-        const int nb = n0 + wn * 64 + ch * 8;
+            for (int j = 0; j < 2; ++j)
+                ad[i][b][j] = load_addend<DT, EPI>(p, m0 + wm * 128 + a * 64 + (ih * 2 + i) * 16 + r, n0 + wn * 64 + b * 32 + j * 16 + g * 4);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int row = q * 8 + rr;
-            const int m = m0 + wm * 128 + row;
-            const u32x4 v = *(const u32x4 *)(my + row * RS + ch * 16);
-            if (p.dbg == 4) { if (v[0] == 0x12345678u) ((float *)p.C)[0] = 1.f; continue; }
-            if (m < p.M) {
-                E *dst = (E *)p.C + (int64_t)m * p.ldc + nb;
-                if (nb + 7 < p.N) *(u32x4 *)dst = v;
-                else {
-                    const E *ve = (const E *)&v;
-                    for (int e = 0; e < 8 && nb + e < p.N; ++e) dst[e] = ve[e];
-                }
-            }
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                store_quad_full<DT, EPI, OUT32>(p, acc[a][b][ih * 2 + i][j], bq[b][j], ad[i][b][j],
+                                                m0 + wm * 128 + a * 64 + (ih * 2 + i) * 16 + r, n0 + wn * 64 + b * 32 + j * 16 + g * 4);
         }
         return;
     }
@@ -636,9 +769,19 @@ extern "C" int hgr_conv3x3_nhwc(const void *x, const void *w, const float *bias,
     a.cH = H; a.cW = W; a.cC = C; a.cStride = stride; a.cHo = Ho; a.cWo = Wo;
     int l2 = 0; while ((1 << l2) < C) ++l2;
     a.cLog2C = l2;
-    dim3 grid((unsigned)(a.tiles_m * a.tiles_n));
-    if (dtype == HGR_BF16) hipLaunchKernelGGL((gemm_nt_128<HGR_BF16, HGR_EPI_BIAS_RELU, false, true>), grid, dim3(NT), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((gemm_nt_128<HGR_F16, HGR_EPI_BIAS_RELU, false, true>), grid, dim3(NT), 0, (hipStream_t)stream, a);
+    // big tiles when the output is at least 256 wide-ish and the launch fills >= 4 rounds of 256 workgroups (M is huge here)
+    const int64_t t256 = (int64_t)((a.M + 255) / 256) * ((Cout + 255) / 256);
+    const bool big = hgr_gemm_force_tile() != 128 && Kp >= 128 && Cout >= 128 && t256 >= 1024;
+    if (big) {
+        a.tiles_m = (a.M + 255) / 256; a.tiles_n = (Cout + 255) / 256;
+        dim3 grid((unsigned)(a.tiles_m * a.tiles_n));
+        if (dtype == HGR_BF16) hipLaunchKernelGGL((gemm_nt_256<HGR_BF16, HGR_EPI_BIAS_RELU, false, true>), grid, dim3(NT256), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((gemm_nt_256<HGR_F16, HGR_EPI_BIAS_RELU, false, true>), grid, dim3(NT256), 0, (hipStream_t)stream, a);
+    } else {
+        dim3 grid((unsigned)(a.tiles_m * a.tiles_n));
+        if (dtype == HGR_BF16) hipLaunchKernelGGL((gemm_nt_128<HGR_BF16, HGR_EPI_BIAS_RELU, false, true>), grid, dim3(NT), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((gemm_nt_128<HGR_F16, HGR_EPI_BIAS_RELU, false, true>), grid, dim3(NT), 0, (hipStream_t)stream, a);
+    }
     HGR_CHECK_LAUNCH("hgr_conv3x3_nhwc");
     return HGR_OK;
 }

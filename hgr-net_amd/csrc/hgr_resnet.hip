@@ -5,28 +5,36 @@
 
 namespace {
 
-// one thread per (output pixel, tap): 3 channels of one tap -> out[row][tap*3 .. tap*3+2]; taps 9.. write the zero padding
+// one thread per output pixel: its 27 taps (ky, kx, c order) + zero padding are assembled in registers and written as
+// eight 16-byte stores (a full 128-byte row per thread); the image reads are served from L1/L2 (each pixel is touched
+// by up to 4 neighbouring outputs)
 template <int DT>
 __global__ __launch_bounds__(256) void stem_im2col(const float *__restrict__ img, typename T16<DT>::elem *__restrict__ out, int B, int R) {
     typedef typename T16<DT>::elem E;
+    typedef typename T16<DT>::vec8 vec8;
     const int Ho = (R - 1) / 2 + 1;
-    const int64_t total = (int64_t)B * Ho * Ho * 16;          // 16 slots per pixel: 9 taps + 7 slots of padding work
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int slot = (int)(i & 15);
-        const int64_t row = i >> 4;
+    const int64_t total = (int64_t)B * Ho * Ho;
+    for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < total; row += (int64_t)gridDim.x * 256) {
         const int wo = (int)(row % Ho), ho = (int)((row / Ho) % Ho), b = (int)(row / ((int64_t)Ho * Ho));
-        E *o = out + row * 64;
-        if (slot < 9) {
-            const int ky = slot / 3, kx = slot - ky * 3;
+        vec8 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[q][e] = (E)0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int ky = t / 3, kx = t % 3;
             const int hi = ho * 2 - 1 + ky, wi = wo * 2 - 1 + kx;
             const bool ok = hi >= 0 && hi < R && wi >= 0 && wi < R;
 #pragma unroll
-            for (int c = 0; c < 3; ++c)
-                o[slot * 3 + c] = (E)(ok ? img[(((int64_t)b * 3 + c) * R + hi) * R + wi] : 0.f);
-        } else {
-            // 37 padding columns 27..63 spread over slots 9..15
-            for (int k = 27 + (slot - 9); k < 64; k += 7) o[k] = (E)0.f;
+            for (int c = 0; c < 3; ++c) {
+                const int k = t * 3 + c;
+                v[k >> 3][k & 7] = (E)(ok ? img[(((int64_t)b * 3 + c) * R + hi) * R + wi] : 0.f);
+            }
         }
+        vec8 *o = (vec8 *)(out + row * 64);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] = v[q];
     }
 }
 
@@ -127,7 +135,7 @@ extern "C" int hgr_stem_im2col(const float *image, void *out, int B, int R, int 
     HGR_REQUIRE(image && out && B >= 1 && R >= 2, "hgr_stem_im2col: bad arguments");
     HGR_REQUIRE(dtype == HGR_BF16 || dtype == HGR_F16, "hgr_stem_im2col: bad dtype %d", dtype);
     const int Ho = (R - 1) / 2 + 1;
-    const int64_t total = (int64_t)B * Ho * Ho * 16;
+    const int64_t total = (int64_t)B * Ho * Ho;
     if (dtype == HGR_BF16) hipLaunchKernelGGL((stem_im2col<HGR_BF16>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, image, (__bf16 *)out, B, R);
     else hipLaunchKernelGGL((stem_im2col<HGR_F16>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, image, (_Float16 *)out, B, R);
     HGR_CHECK_LAUNCH("hgr_stem_im2col");
