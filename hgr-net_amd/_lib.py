@@ -23,6 +23,7 @@ _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 # name -> argtypes, exactly the prototypes of include/hgr.h
 SIGNATURES = {
     "hgr_gemm_nt": [_p, _l, _p, _l, _p, _l, _p, _p, _l, _i, _i, _i, _i, _i, _i, _p],
+    "hgr_gemm_set_tile": [_i],
     "hgr_im2col_patches": [_p, _p, _i, _i, _i, _i, _i, _p],
     "hgr_im2col_patches_ex": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "hgr_vit_assemble": [_p, _p, _p, _i, _i, _i, _p],

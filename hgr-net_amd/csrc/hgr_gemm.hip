@@ -664,14 +664,21 @@ void launch_dt(const GemmArgs &a, int epi, bool out32, dim3 grid, hipStream_t s,
     }
 }
 
-// HGR_GEMM_TILE=128|256 pins the tile (tests exercise both kernels on every shape); unset = heuristic
+// tile plan override (hgr_gemm_set_tile); HGR_GEMM_TILE=128|256 sets the initial value
+int g_force_tile = -1;
 int hgr_gemm_force_tile() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("HGR_GEMM_TILE"); v = e ? atoi(e) : 0; }
-    return v;
+    if (g_force_tile < 0) { const char *e = getenv("HGR_GEMM_TILE"); g_force_tile = e ? atoi(e) : 0; }
+    return g_force_tile;
 }
 
 }  // namespace
+
+extern "C" int hgr_gemm_set_tile(int tile) {
+    HGR_REQUIRE(tile == 0 || tile == 128 || tile == 256, "hgr_gemm_set_tile: tile must be 0, 128 or 256, got %d", tile);
+    const int prev = hgr_gemm_force_tile();
+    g_force_tile = tile;
+    return prev;
+}
 
 extern "C" int hgr_gemm_nt(const void *A, int64_t lda, const void *W, int64_t ldw, void *C, int64_t ldc,
                            const float *bias, const void *residual, int64_t ldr,

@@ -63,6 +63,15 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias: Optional[
     return out
 
 
+def gemm_set_tile(tile: int) -> int:
+    """Pin hgr_gemm_nt's tile plan (0 = cost model, 128, 256); returns the previous setting."""
+    lib = _lib.load()
+    prev = lib.hgr_gemm_set_tile(int(tile))
+    if prev < 0:
+        raise _lib.HgrError(f"hgr_gemm_set_tile failed ({prev}): {lib.hgr_last_error().decode()}")
+    return prev
+
+
 def im2col_patches(image: torch.Tensor, out: torch.Tensor, patch: int) -> torch.Tensor:
     b, c, r, r2 = image.shape
     assert c == 3 and r == r2 and image.dtype == torch.float32 and image.is_contiguous() and out.is_contiguous()

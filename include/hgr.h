@@ -64,6 +64,14 @@ int hgr_gemm_nt(const void *A, int64_t lda, const void *W, int64_t ldw, void *C,
                 int M, int N, int K, int dtype, int epilogue, int out_f32, void *stream);
 
 /*
+ * Tile plan override for hgr_gemm_nt: 0 = cost model (default), 128 = the 128x128 kernel only, 256 = the 256x256
+ * kernel wherever it is legal (K >= 128).  Process-wide; the HGR_GEMM_TILE environment variable sets the
+ * initial value.  Results do not depend on the plan (every tile sums K in the same order); parity tests run every
+ * shape under each plan.  Returns the previous value, or a negative HGR_E* code for any other argument.
+ */
+int hgr_gemm_set_tile(int tile);
+
+/*
  * Patch extraction for the ViT stem: image fp32 NCHW [B,3,R,R] -> rows [B*g*g, Kp] of 16-bit
  * values, g = R/P, row (b, gy, gx) holds the patch in (c, py, px) order = conv1.weight.reshape(W,-1)
  * order, zero-padded from 3*P*P to Kp (Kp % 64 == 0).  With hgr_gemm_nt this replaces

@@ -61,6 +61,47 @@ def test_gemm_epilogues(dt):
     assert torch.allclose(x.cpu(), base + res, rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("tile", [0, 128, 256])
+@pytest.mark.parametrize("m,n,k", [(4400, 4200, 256), (8192, 4224, 512), (5120, 3072, 320)])
+def test_gemm_many_tiles_exact(dt, tile, m, n, k):
+    """More 256x256 tiles than CUs (several rounds of workgroups, edge tiles in both dimensions) under every tile
+    plan and epilogue.  Small-integer operands make every sum exact in fp32 and in the
+    16-bit outputs, so the comparison is equality, and a repeat launch must reproduce it."""
+    gen = torch.Generator().manual_seed(m + n + k)
+    a = torch.randint(-2, 3, (m, k), generator=gen).float()
+    w = torch.randint(-1, 2, (n, k), generator=gen).float()
+    bias = torch.randint(-4, 5, (n,), generator=gen).float()
+    res = torch.randint(-8, 9, (m, n), generator=gen).float()
+    ad, wd, bd = a.to(dt).to(DEV), w.to(dt).to(DEV), bias.to(DEV)
+    base = (ad.float() @ wd.float().t())                    # exact: |sum| <= 2 * 512
+    prev = ops.gemm_set_tile(tile)
+    try:
+        for rep in range(2):
+            out32 = torch.empty(m, n, dtype=torch.float32, device=DEV)
+            ops.gemm_nt(ad, wd, out32)
+            assert torch.equal(out32, base)
+            out16 = torch.empty(m, n, dtype=dt, device=DEV)
+            ops.gemm_nt(ad, wd, out16, bias=bd, epilogue=EPI_BIAS)
+            assert torch.equal(out16, (base + bd).to(dt))
+            ops.gemm_nt(ad, wd, out16, bias=bd, epilogue=4)
+            assert torch.equal(out16, torch.relu(base + bd).to(dt))
+            ops.gemm_nt(ad, wd, out16, bias=bd, epilogue=EPI_BIAS_QUICKGELU)
+            ref = clip_ref.quick_gelu(base + bd)
+            assert torch.allclose(out16.float(), ref, rtol=2 ** -7 if dt == torch.bfloat16 else 2 ** -10, atol=1e-3)
+            x = res.to(DEV)
+            ops.gemm_nt(ad, wd, x, bias=bd, residual=x, epilogue=EPI_BIAS_RESIDUAL)
+            assert torch.equal(x, base + bd + res.to(DEV))
+            idn = res.to(dt).to(DEV)
+            ops.gemm_nt(ad, wd, out16, bias=bd, residual=idn, epilogue=5)
+            assert torch.equal(out16, torch.relu(base + bd + idn.float()).to(dt))
+            acc = res.to(DEV)
+            ops.gemm_nt(ad, wd, acc, epilogue=6)
+            assert torch.equal(acc, base + res.to(DEV))
+    finally:
+        ops.gemm_set_tile(prev)
+
+
 def test_gemm_rejects_bad_shapes():
     from hgr_net_amd._lib import HgrError
     a = torch.zeros(8, 96, dtype=torch.bfloat16, device=DEV)
