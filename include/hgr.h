@@ -88,6 +88,23 @@ int hgr_im2col_patches_ex(const float *image, void *out, int B, int R, int P, in
  * (weight.permute(0,2,3,1)); a quarter of the bytes of the fp32 path cross PCIe and HBM. */
 int hgr_im2col_patches_u8(const unsigned char *image, void *out, int B, int R, int P, int Kp, int rows_per_image,
                           int row_offset, const float *mean3, const float *std3, int dtype, void *stream);
+/*
+ * Input pipeline on the device: Resize(n_px, BICUBIC) + CenterCrop(n_px) [+ ToTensor + Normalize] of a batch of decoded
+ * RGB images - the reference's `_transform` (clip/clip.py:71-78 = dataset/imagenet_group.py:27-34), whose resize runs
+ * inside Pillow (libImaging/Resample.c: two-pass separable convolution, 22-bit fixed-point taps, 8-bit clipped
+ * intermediate).  Bit-exact: the taps are computed on the host in double precision (hgr_net_amd.preprocess) and the
+ * device does the integer convolutions.
+ *   src     packed uint8 images; image b = h[b] x w[b] x 3 bytes (row-major HWC, RGB) at src + off[b]
+ *   off     int64 [B] (device);  hw int32 [B, 2] = (h, w) (device)
+ *   xb, yb  int32 [B, R, 2] (device): (first source column / row, tap count) of column / row i of the CROPPED output
+ *   xk, yk  int32 [B, R, KX] / [B, R, KY] (device): the taps, zero padded to the batch maximum
+ *   out_u8  uint8 [B, R, R, 3] or NULL (feeds hgr_im2col_patches_u8);  out_f32 fp32 [B, 3, R, R] or NULL
+ *   mean3, std3  HOST pointers to 3 floats (needed for out_f32)
+ */
+int hgr_preprocess_bicubic(const unsigned char *src, const int64_t *off, const int *hw, const int *xb, const int *xk, int KX,
+                           const int *yb, const int *yk, int KY, unsigned char *out_u8, float *out_f32,
+                           const float *mean3, const float *std3, int B, int R, void *stream);
+
 /* In place on the [B*L, W] fp32 patch-GEMM output with zero class rows: t[b,l] += positional[l] + (l == 0 ? class : 0)
  * (clip/model.py:223-224; the un-fused form of hgr_vit_embed_ln, whose pre-LayerNorm sum the backward needs). */
 int hgr_vit_assemble(float *t, const float *class_embedding, const float *positional_embedding, int B, int L, int W, void *stream);

@@ -168,3 +168,28 @@ def test_tokenizer_matches_reference_ids(golden_dir):
     assert t.shape == (2, 77) and t[0, 0] == 49406 and t[0].max() == 49407 and t[1, 3:].sum() == 0
     with pytest.raises(RuntimeError):
         clip.tokenize(["word " * 200])
+
+
+# ---- input pipeline: host side of the device transform ----------------------------------------------
+def test_resize_taps_match_oracle():
+    """The vectorised tap tables of the product (hgr_net_amd.preprocess) equal the scalar Pillow restatement."""
+    from oracle import resample_ref
+    from hgr_net_amd import preprocess
+    for ins, outs in [(53, 22), (375, 224), (500, 298), (32, 33), (17, 32), (224, 224), (1200, 298), (4000, 224)]:
+        b, k = resample_ref.precompute_coeffs(ins, outs)
+        for start, count in [(0, outs), (outs // 4, outs // 2)]:
+            b2, k2 = preprocess.resize_taps(ins, outs, start, count)
+            assert np.array_equal(b[start:start + count], b2) and np.array_equal(k[start:start + count], k2)
+
+
+def test_resize_and_crop_rules():
+    from oracle import resample_ref
+    from hgr_net_amd import preprocess
+    for w, h in [(500, 375), (375, 500), (224, 224), (225, 224), (640, 427), (333, 1000), (100, 37)]:
+        assert preprocess.resized_size(w, h, 224) == resample_ref.resized_size(w, h, 224)
+        nw, nh = preprocess.resized_size(w, h, 224)
+        assert min(nw, nh) == 224
+        assert preprocess.crop_origin(nw, nh, 224) == resample_ref.crop_origin(nw, nh, 224)
+    assert preprocess.resized_size(500, 375, 224) == (298, 224)
+    assert preprocess.crop_origin(298, 224, 224) == (37, 0)
+    assert preprocess.crop_origin(229, 224, 224) == (2, 0)          # (229 - 224) / 2 = 2.5 rounds half to even

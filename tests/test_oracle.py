@@ -132,3 +132,27 @@ def test_coop_prompt_path_matches_reference_fixture(golden_dir):
     tok = torch.from_numpy(z["tokens"].astype(np.int64))[torch.from_numpy(z["idx"])]
     f = clip_ref.encode_text(sd, tok, trim=True, ctx=torch.from_numpy(z["ctx"])).numpy()
     assert np.abs(f - z["features"]).max() < 1e-5
+
+
+# ---- image transform (oracle/resample_ref.py) -----------------------------------------------------
+def test_resample_oracle_matches_golden(golden_dir):
+    """The Pillow restatement against vectors produced by Pillow + torch (tools/make_golden_preproc.py)."""
+    from oracle import resample_ref
+    g = np.load(golden_dir / "preproc.npz")
+    for i in range(int(g["n_cases"])):
+        n = int(g[f"npx_{i}"])
+        u8 = resample_ref.transform_u8(g[f"in_{i}"], n)
+        assert np.array_equal(u8, g[f"u8_{i}"]), i
+        assert np.array_equal(resample_ref.normalize(u8), g[f"f32_{i}"]), i
+
+
+def test_resample_oracle_matches_pillow_live():
+    """Same check against the Pillow installed next to the tests, on sizes the fixture does not hold."""
+    Image = pytest.importorskip("PIL.Image")
+    from oracle import resample_ref
+    rng = np.random.default_rng(11)
+    for h, w, n in [(375, 500, 224), (500, 333, 224), (97, 61, 48), (48, 48, 64), (31, 400, 32)]:
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        nw, nh = resample_ref.resized_size(w, h, n)
+        ref = np.asarray(Image.fromarray(img).resize((nw, nh), Image.BICUBIC))
+        assert np.array_equal(resample_ref.resize_bicubic(img, nw, nh), ref), (h, w, n)
