@@ -96,8 +96,16 @@ def test(opts, model, device, splits=None, loader: Optional[Iterable] = None, gr
     print("in", opts.in_ratio)
     model.eval()
     model.update_classifier(group=group)
-    if loader is None:
-        raise RuntimeError("pass loader=: the ImageNet-21K group loaders are outside this build's scope (DESIGN.md)")
+    if loader is None:                                   # main.py:111-114
+        print("Loading datasets", flush=True)
+        from .dataset import DataManager_test
+        import os
+        data = DataManager_test(opts=opts, split=opts.data_split_test, node_set=model.nodes, candidates=splits[opts.data_test],
+                                resolution=model.resolution)
+        loader = data.get_data_loader(device=device, rank=int(os.environ.get("RANK", "0")) if group is not None else 0,
+                                      world_size=int(os.environ.get("WORLD_SIZE", "1")) if group is not None else 1,
+                                      workers=getattr(opts, "num_workers", 8))
+        print("number of batches:{}".format(loader.batch_sampler.num_batch))
     print("Running.", flush=True)
     ev = Evaluator(model)
     for data in loader:

@@ -72,6 +72,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--image_dtype", default="f16", type=str)
     p.add_argument("--text_dtype", default="f16", type=str)
     p.add_argument("--train_dtype", default="bf16", type=str)
+    p.add_argument("--split_file", default=None, type=str, help="class -> image paths JSON (default data/{split}_split.json)")
+    p.add_argument("--data_seed", default=None, type=int, help="seed of the loaders' class / image order (all ranks must agree)")
     p.add_argument("--ref_quirks", default=False, action="store_true",
                    help="reproduce the reference's missing zero_grad() (gradients accumulate across steps, SURVEY F11-i)")
     return p
@@ -121,6 +123,12 @@ def run(opts, loader_train=None, loader_test=None, group=None):
                 if k not in ("node_tokens", "clip_model"):
                     f.writelines(k + " : " + str(v) + "\n")
         print("Training.")
+        if opts.synthetic <= 0 and loader_train is None:          # main.py:240-243: the group-batch loaders over the split file
+            print("Loading datasets")
+            from .dataset import DataManager
+            data = DataManager(opts=opts, split=opts.data_split_train, node_set=model.nodes, candidates=splits[opts.data_train],
+                               resolution=model.resolution)
+            loader_train = data.get_data_loader(device=device, rank=rank, world_size=world, workers=opts.num_workers)
         num_batches = opts.synthetic if opts.synthetic > 0 else len(loader_train)
         params = [p for name, p in model.named_parameters() if p.requires_grad and name != "layer_weight"]
         optimizer = FusedAdamW(params, lr=opts.lr, weight_decay=opts.wd, max_norm=1.0)

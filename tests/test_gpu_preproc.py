@@ -58,3 +58,36 @@ def test_rejects_non_rgb_and_oversize():
         pre([np.zeros((40, 40), np.uint8)])
     with pytest.raises(ValueError):
         pre([np.zeros((2000, 2000, 3), np.uint8)])
+
+
+def test_eval_loader_tensors_match_reference(tmp_path):
+    """DataManager_test end to end (PNG files -> decode threads -> device transform) against the tensors the
+    reference's DataManager_test + torchvision-equivalent transform produced for the same files."""
+    import json
+    import types
+    from PIL import Image
+    from hgr_net_amd import dataset as ds
+    gold = Path(__file__).parent / "golden"
+    meta = json.load(open(gold / "loader.json"))
+    imgs = np.load(gold / "loader_imgs.npz")
+    split = {}
+    for cls, names in meta["classes"].items():
+        split[cls] = []
+        for name in names:
+            Image.fromarray(imgs["src_" + name]).save(tmp_path / name)
+            split[cls].append(str(tmp_path / name))
+    json.dump(split, open(tmp_path / "val_split.json", "w"))
+    t = meta["test"]
+    opts = types.SimpleNamespace(split_file=str(tmp_path / "val_split.json"), test_batch_size=t["batch_size"], device=0)
+    loader = ds.DataManager_test(opts, "val", t["node_set"], candidates=t["candidates"], resolution=meta["n_px"]).get_data_loader()
+    n = 0
+    for i, b in enumerate(loader):
+        ref = imgs[f"batch_{i}"]
+        assert b["img"].is_cuda and tuple(b["img"].shape) == ref.shape == tuple(t["batches"][i]["img_shape"])
+        assert np.array_equal(b["img"].cpu().numpy(), ref)
+        assert b["label"][0].tolist() == t["batches"][i]["label"]
+        n += 1
+    assert n == t["num_batch"]
+    # uint8 NHWC output for the fused ViT path carries the same pixels
+    u8 = next(iter(ds.DataManager_test(opts, "val", t["node_set"], candidates=t["candidates"], resolution=meta["n_px"]).get_data_loader(output="u8")))
+    assert u8["img"].dtype == torch.uint8 and tuple(u8["img"].shape) == (1, 2, meta["n_px"], meta["n_px"], 3)

@@ -241,3 +241,66 @@ def test_vit_l14_shaped_training_step(tmp_path):
     model.update_classifier()                                   # eval path with the learned context
     lg = model(img, None)
     assert lg.shape == (4, 60) and torch.isfinite(lg).all()
+
+
+def test_driver_over_image_files(golden_dir, tmp_path):
+    """hgr_net_amd.main end to end on files: split JSON -> group loaders (PIL decode threads) -> device transform ->
+    one OM epoch -> checkpoint -> evaluation.  The evaluation summary must equal the one obtained by pushing the
+    oracle-transformed tensors of the same files through test(loader=...) with the same weights."""
+    import os
+    import random
+    from PIL import Image
+    from hgr_net_amd import evaluate, main as drv
+    from oracle import resample_ref
+    meta = json.load(open(golden_dir / "tree_tinyvit_n90.json"))
+    z = np.load(golden_dir / "tree_tinyvit_n90.npz")
+    cfg, d = meta["config"], meta["dag"]
+    res = cfg["image_resolution"]
+    edges = synth.make_dag(meta["n_nodes"], d["depth"], d["seed"], d["multi_parent"])
+    h = build_hierarchy(edges)
+    splits = synth.make_splits(h.nodes, [len(c) == 0 for c in h.p2c], meta["n_train"], meta["n_test"], meta["split_seed"])
+    rng = np.random.default_rng(3)
+    files, arrays = {}, {}
+    for cls in splits["train"][:4] + splits["rest"][:5]:
+        files[cls] = []
+        for j in range(3):
+            hh, ww = int(rng.integers(res, 3 * res)), int(rng.integers(res, 3 * res))
+            a = rng.integers(0, 256, (hh, ww, 3), dtype=np.uint8)
+            pth = tmp_path / f"{cls}_{j}.png"
+            Image.fromarray(a).save(pth)
+            files[cls].append(str(pth)); arrays[str(pth)] = a
+    for cls in h.nodes:
+        files.setdefault(cls, [])
+    (tmp_path / "g.json").write_text(json.dumps(edges))
+    (tmp_path / "s.json").write_text(json.dumps(splits))
+    (tmp_path / "split.json").write_text(json.dumps(files))
+    argv = ["--device", "0", "--folder", str(tmp_path / "run"), "--graph_path", str(tmp_path / "g.json"), "--split_path", str(tmp_path / "s.json"),
+            "--split_file", str(tmp_path / "split.json"), "--weights", "equal", "--num_compare", "8", "--epochs", "1", "--batch_size", "2",
+            "--test_batch_size", "2", "--lr", "1e-5", "--print_freq", "1", "--test_after_train", "--n_episodes", "3", "--data_seed", "4",
+            "--num_workers", "2"]
+    opts = drv.build_parser().parse_args(argv)
+    opts.node_tokens = torch.from_numpy(z["node_tokens"].astype(np.int64))
+    opts.clip_model = build_model(synth.clip_state_dict(cfg, 0)).to(DEV)
+    random.seed(0)
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        drv.run(opts)
+        run_dir = tmp_path / "run" / "HGR" / "equal_0.25_0.5"
+        log = (run_dir / "arugements.log").read_text()
+        assert log.count("loss:") >= 3 and "Top@1(%)" in log
+        got = log[log.index("Top@1(%)"):].strip()
+        # same weights, tensors built by the oracle transform, fed through the loader= entry point
+        model = tree_model(opts, splits[opts.model_train], splits[opts.model_test], node_tokens=opts.node_tokens, clip_model=opts.clip_model)
+
+        def batches():
+            for cls in splits["rest"]:
+                paths = files[cls]
+                for i in range(0, len(paths), 2):
+                    x = np.stack([resample_ref.transform(arrays[p], res) for p in paths[i:i + 2]])
+                    yield {"img": torch.from_numpy(x)[None], "label": torch.full((1, len(x)), model.nodes.index(cls), dtype=torch.long)}
+
+        want = evaluate.test(opts, model, "cuda:0", splits, loader=batches(), log=False)
+    finally:
+        os.chdir(cwd)
+    assert got.splitlines()[0] == want.strip().splitlines()[0] and got == want.strip()
