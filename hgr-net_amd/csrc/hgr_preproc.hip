@@ -19,13 +19,39 @@ constexpr int PB = 22;      // Resample.c PRECISION_BITS = 32 - 8 - 2
 
 __device__ __forceinline__ int clip8(int v) { return min(max(v >> PB, 0), 255); }
 
+// horizontal taps of one (source row, output column): the row's bytes are fetched as aligned dwords and realigned with
+// v_alignbyte (12 bytes = 3 dwords = 4 RGB taps per step) instead of 3 byte loads per tap.  The tap table is zero padded
+// to a multiple of 4 (host), so the bytes read past the last live tap - at most 15, inside the caller's slack - are
+// multiplied by 0.
+__device__ __forceinline__ void hconv(const unsigned char *p, const int *kx, int xn, int &h0, int &h1, int &h2) {
+    const uintptr_t addr = (uintptr_t)p;
+    const unsigned *q = (const unsigned *)(addr & ~(uintptr_t)3);
+    const unsigned sh = (unsigned)(addr & 3);
+    unsigned carry = q[0];
+    for (int t = 0; t < xn; t += 4) {
+        const unsigned w1 = q[1], w2 = q[2], w3 = q[3];
+        const int4 k = *(const int4 *)(kx + t);
+        // 12 bytes starting at p + 3 t
+        const unsigned d0 = __builtin_amdgcn_alignbyte(w1, carry, sh);
+        const unsigned d1 = __builtin_amdgcn_alignbyte(w2, w1, sh);
+        const unsigned d2 = __builtin_amdgcn_alignbyte(w3, w2, sh);
+        h0 += (int)(d0 & 255u) * k.x;         h1 += (int)((d0 >> 8) & 255u) * k.x;  h2 += (int)((d0 >> 16) & 255u) * k.x;
+        h0 += (int)(d0 >> 24) * k.y;          h1 += (int)(d1 & 255u) * k.y;         h2 += (int)((d1 >> 8) & 255u) * k.y;
+        h0 += (int)((d1 >> 16) & 255u) * k.z; h1 += (int)(d1 >> 24) * k.z;          h2 += (int)(d2 & 255u) * k.z;
+        h0 += (int)((d2 >> 8) & 255u) * k.w;  h1 += (int)((d2 >> 16) & 255u) * k.w; h2 += (int)(d2 >> 24) * k.w;
+        carry = w3; q += 3;
+    }
+}
+
+constexpr int CH = 32;      // source rows per chunk: two (row, column) items per thread in the horizontal pass
+
 __global__ __launch_bounds__(256) void preprocess_bicubic(const unsigned char *__restrict__ src, const int64_t *__restrict__ off,
                                                           const int *__restrict__ hw, const int *__restrict__ xb,
                                                           const int *__restrict__ xk, int KX, const int *__restrict__ yb,
                                                           const int *__restrict__ yk, int KY, unsigned char *__restrict__ out_u8,
                                                           float *__restrict__ out_f32, float m0, float m1, float m2, float s0,
                                                           float s1, float s2, int R, int tiles) {
-    __shared__ int hrow[16][16][3];
+    __shared__ int hrow[CH][16][3];
     const int b = blockIdx.y;
     const int ty0 = (blockIdx.x / tiles) * 16, tx0 = (blockIdx.x % tiles) * 16;
     const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
@@ -41,19 +67,18 @@ __global__ __launch_bounds__(256) void preprocess_bicubic(const unsigned char *_
     const int r1 = yb[((int64_t)b * R + ylast) * 2] + yb[((int64_t)b * R + ylast) * 2 + 1];
 
     int a0 = 1 << (PB - 1), a1 = a0, a2 = a0;
-    for (int rc = r0; rc < r1; rc += 16) {
-        const int row = rc + ly;
-        if (row < r1) {
-            const unsigned char *p = img + ((int64_t)row * w + xmin) * 3;
-            int h0 = 1 << (PB - 1), h1 = h0, h2 = h0;
-            for (int t = 0; t < xn; ++t) {
-                const int k = kx[t];
-                h0 += p[t * 3 + 0] * k; h1 += p[t * 3 + 1] * k; h2 += p[t * 3 + 2] * k;
+    for (int rc = r0; rc < r1; rc += CH) {
+#pragma unroll
+        for (int half = 0; half < CH / 16; ++half) {
+            const int row = rc + half * 16 + ly;
+            if (row < r1) {
+                int h0 = 1 << (PB - 1), h1 = h0, h2 = h0;
+                hconv(img + ((int64_t)row * w + xmin) * 3, kx, xn, h0, h1, h2);
+                hrow[half * 16 + ly][lx][0] = clip8(h0); hrow[half * 16 + ly][lx][1] = clip8(h1); hrow[half * 16 + ly][lx][2] = clip8(h2);
             }
-            hrow[ly][lx][0] = clip8(h0); hrow[ly][lx][1] = clip8(h1); hrow[ly][lx][2] = clip8(h2);
         }
         __syncthreads();
-        const int lo = max(rc, ymin), hi = min(min(rc + 16, r1), ymin + yn);
+        const int lo = max(rc, ymin), hi = min(min(rc + CH, r1), ymin + yn);
         for (int rr = lo; rr < hi; ++rr) {
             const int k = ky[rr - ymin];
             a0 += hrow[rr - rc][lx][0] * k; a1 += hrow[rr - rc][lx][1] * k; a2 += hrow[rr - rc][lx][2] * k;
@@ -85,6 +110,7 @@ extern "C" int hgr_preprocess_bicubic(const unsigned char *src, const int64_t *o
     HGR_REQUIRE(out_u8 || out_f32, "hgr_preprocess_bicubic: no output requested");
     HGR_REQUIRE(B >= 1 && R >= 1 && KX >= 1 && KY >= 1, "hgr_preprocess_bicubic: bad shape B=%d R=%d KX=%d KY=%d", B, R, KX, KY);
     HGR_REQUIRE(B <= 65535, "hgr_preprocess_bicubic: B=%d exceeds the grid limit", B);
+    HGR_REQUIRE(KX % 4 == 0 && hgr_aligned(xk, 16), "hgr_preprocess_bicubic: KX=%d must be a multiple of 4 and xk 16-byte aligned", KX);
     HGR_REQUIRE(!out_f32 || (mean3 && std3), "hgr_preprocess_bicubic: fp32 output needs mean and std");
     const int tiles = (R + 15) / 16;
     const float m0 = mean3 ? mean3[0] : 0.f, m1 = mean3 ? mean3[1] : 0.f, m2 = mean3 ? mean3[2] : 0.f;

@@ -96,6 +96,13 @@ class BatchPreprocessor:
         self.n_px, self.device = int(n_px), torch.device(device)
         self.mean, self.std = tuple(mean), tuple(std)
         self._pin: Optional[torch.Tensor] = None
+        self._threads = None
+
+    def _pool(self):
+        if self._threads is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._threads = ThreadPoolExecutor(8)
+        return self._threads
 
     def _pinned(self, nbytes: int) -> torch.Tensor:
         if self._pin is None or self._pin.numel() < nbytes:
@@ -111,6 +118,7 @@ class BatchPreprocessor:
                 raise ValueError(f"expected uint8 [H, W, 3] RGB arrays, got {im.dtype} {im.shape}")
             tabs.append(image_tables(im.shape[1], im.shape[0], r))
         kx, ky = max(t[1].shape[1] for t in tabs), max(t[3].shape[1] for t in tabs)
+        kx = (kx + 3) // 4 * 4                                   # the kernel consumes 4 horizontal taps per step
         if max(kx, ky) > MAX_TAPS:
             raise ValueError(f"an image is more than {MAX_TAPS // 4 - 1}x larger than the crop: reduce it on the host first")
         sizes = np.array([im.shape[0] * im.shape[1] * 3 for im in images], np.int64)
@@ -118,20 +126,26 @@ class BatchPreprocessor:
         off[1:] = np.cumsum((sizes[:-1] + 15) // 16 * 16)                      # 16-byte aligned starts
         total = int(off[-1] + sizes[-1])
         # one pinned staging buffer: [image bytes | off | hw | xb | yb | xk | yk], one H2D copy
-        meta_i32 = b * 2 + 2 * b * r * 2 + b * r * kx + b * r * ky
+        meta_i32 = b * 2 + 2 * b * r * 2 + b * r * kx + b * r * ky + 4       # + pad so that xk starts 16-byte aligned
         base_meta = (total + 15) // 16 * 16
-        nbytes = base_meta + b * 8 + meta_i32 * 4
+        nbytes = base_meta + (b * 8 + 15) // 16 * 16 + meta_i32 * 4
         pin = self._pinned(nbytes)
         host = pin.numpy()
-        for im, o, s in zip(images, off, sizes):
-            host[o:o + s] = np.ascontiguousarray(im).reshape(-1)
+        def put(k):                                              # numpy copies release the GIL: pack with a few threads
+            host[off[k]:off[k] + sizes[k]] = np.ascontiguousarray(images[k]).reshape(-1)
+        if total > (8 << 20):
+            list(self._pool().map(put, range(b)))
+        else:
+            for k in range(b):
+                put(k)
         p = base_meta
-        host[p:p + b * 8].view(np.int64)[:] = off; o_off = p; p += b * 8
+        host[p:p + b * 8].view(np.int64)[:] = off; o_off = p; p += (b * 8 + 15) // 16 * 16
         i32 = host[p:p + meta_i32 * 4].view(np.int32)
         q = 0
         hw = i32[q:q + b * 2].reshape(b, 2); q_hw = q; q += b * 2
         xb = i32[q:q + b * r * 2].reshape(b, r, 2); q_xb = q; q += b * r * 2
         yb = i32[q:q + b * r * 2].reshape(b, r, 2); q_yb = q; q += b * r * 2
+        q = (q + 3) // 4 * 4                                   # base_meta and b * 8 are multiples of 16 when b is even; see below
         xk = i32[q:q + b * r * kx].reshape(b, r, kx); q_xk = q; q += b * r * kx
         yk = i32[q:q + b * r * ky].reshape(b, r, ky); q_yk = q; q += b * r * ky
         xk[:] = 0; yk[:] = 0

@@ -97,7 +97,8 @@ int hgr_im2col_patches_u8(const unsigned char *image, void *out, int B, int R, i
  *   src     packed uint8 images; image b = h[b] x w[b] x 3 bytes (row-major HWC, RGB) at src + off[b]
  *   off     int64 [B] (device);  hw int32 [B, 2] = (h, w) (device)
  *   xb, yb  int32 [B, R, 2] (device): (first source column / row, tap count) of column / row i of the CROPPED output
- *   xk, yk  int32 [B, R, KX] / [B, R, KY] (device): the taps, zero padded to the batch maximum
+ *   xk, yk  int32 [B, R, KX] / [B, R, KY] (device): the taps, zero padded to the batch maximum; KX % 4 == 0 and xk
+ *           16-byte aligned (a row's bytes are fetched 12 at a time: `src` needs 32 readable bytes past its last image)
  *   out_u8  uint8 [B, R, R, 3] or NULL (feeds hgr_im2col_patches_u8);  out_f32 fp32 [B, 3, R, R] or NULL
  *   mean3, std3  HOST pointers to 3 floats (needed for out_f32)
  */
