@@ -177,12 +177,13 @@ def main():
             # (FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 FETCH x2 correction; tools/pmc_summary.py) - PMC
             # counters cannot be read from inside the process, so the committed summary is quoted when it matches.
             traffic = None
-            pmc = ROOT / "profiles" / "r01_vitb32_pmc_summary.json"
+            cands = sorted((ROOT / "profiles").glob("r*_pmc_summary.json"))      # newest round / letter last
+            pmc = cands[-1] if cands else ROOT / "profiles" / "none"
             if pmc.is_file() and a.arch == ARCH and a.batch == BATCH and a.nodes == N_NODES:
                 traffic = json.load(open(pmc))["tower_gemm"]["hbm_bytes_per_launch"]
             roof = {"kernel": "gemm_nt_256 / gemm_nt_128 (image-tower GEMMs: qkv, out, fc, proj, patch)", "bound": "mfma",
                     "achieved": round(ach, 1), "peak": PEAK_TFLOPS_BF16, "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS_BF16, 4),
-                    "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_vitb32_pmc_summary.json)",
+                    "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/%s)" % pmc.name,
                     "algorithmic_bytes_per_launch": round(sum(b for _, _, b in tower) / len(tower)),
                     "launches": len(tower), "avg_launch_us": round(tsum / len(tower) * 1e6, 1)}
         lg = [(s.elapsed_time(e) * 1e-3, fl, by) for (name, s, e, fl, by) in recs if name == "gemm_nt" and by > 4e7 and fl < 2e10]

@@ -26,7 +26,7 @@ f, w = counters(fetch), counters(write)
 rows = []
 for r in csv.DictReader(open(stats)):
     k = short(r["Name"])
-    if not k.startswith(("gemm_nt", "layernorm", "mha_fwd", "im2col", "topk", "level_argmax", "vit_embed", "l2norm", "text_embed")):
+    if not k.startswith(("gemm_nt", "layernorm", "mha_fwd", "im2col", "topk", "level_argmax", "eval_rows", "vit_embed", "l2norm", "text_embed")):
         continue
     fv, wv = f.get(k, []), w.get(k, [])
     fetch_b = 2 * 1024 * sum(fv) / len(fv) if fv else None
