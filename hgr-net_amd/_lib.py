@@ -59,6 +59,7 @@ SIGNATURES = {
     "hgr_ctx_splice": [_p, _p, _p, _i, _i, _i, _i, _p],
     "hgr_ctx_splice_bwd": [_p, _p, _i, _i, _i, _i, _p],
     "hgr_sumsq": [_p, _l, _p, _p],
+    "hgr_csr_group_aggregate": [_p, _l, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _p, _p, _l, _i, _f, _i, _p],
     "hgr_adamw": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _p, _f, _f, _p],
 }
 

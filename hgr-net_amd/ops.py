@@ -344,6 +344,20 @@ def matmul_f32(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, alpha: float
     return out
 
 
+def csr_group_aggregate(support: torch.Tensor, op, att: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor,
+                        slope: float = 1.0, normalize: bool = False) -> torch.Tensor:
+    """DGP graph propagation step: out[i] = act(sum_e att[grp_e] / deg_e * (support[col_e] + bias)); `op` carries the
+    merged CSR and the work-item tables (hgr_net_amd.baseline.dgp.GraphOperator)."""
+    assert support.dtype == out.dtype == att.dtype == torch.float32 and support.stride(1) == 1 and out.stride(1) == 1
+    assert support.shape[0] == out.shape[0] == op.n and support.shape[1] == out.shape[1] and att.numel() == op.D
+    c = support.shape[1]
+    _lib.call("hgr_csr_group_aggregate", _dev(support), support.stride(0), _dev(op.item_row), _dev(op.item_e0), _dev(op.item_e1),
+              _dev(op.item_slot), op.item_row.numel(), _dev(op.col), _dev(op.inv_deg), _dev(op.grp), _dev(att), op.D, _dev(bias),
+              _dev(op.split_row), _dev(op.split_slot0), _dev(op.split_n), op.split_row.numel(), _dev(op.partial(c)), _dev(out),
+              out.stride(0), c, slope, 1 if normalize else 0, _stream())
+    return out
+
+
 def embed_scatter_add(tokens: torch.Tensor, dx: torch.Tensor, dtable: torch.Tensor, l: int) -> None:
     assert tokens.dtype == torch.int64 and tokens.stride(1) == 1 and dx.is_contiguous() and dtable.is_contiguous()
     _lib.call("hgr_embed_scatter_add", _dev(tokens), tokens.stride(0), _dev(dx), _dev(dtable), tokens.shape[0], l, dtable.shape[1], dtable.shape[0], _stream())

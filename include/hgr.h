@@ -273,6 +273,24 @@ int64_t hgr_layernorm_bwd_scratch_floats(int rows, int W);
 int hgr_mha_bwd(const void *qkv, const void *out, const void *dout, void *dqkv, int B, int L, int heads, int causal, int dtype, void *stream);
 
 /*
+ * DGP baseline graph propagation (baseline/DGP/models/gcn_dense_att.py:31-46 `GraphConv.forward` after the dense
+ * `support = x W + b`): out[i] = act( sum_e att[grp[e]] * inv_deg[e] * (support[col[e]] + bias) ) over the edges of row
+ * i in a CSR that merges the D distance-grouped, in-degree-normalised operators (baseline/DGP/utils.py:56-65;
+ * grouping: materials/make_dense_grouped_graph.py:25-38).  act = LeakyReLU(slope) (slope 1 = identity), then an optional
+ * row L2 normalisation (`F.normalize`, gcn_dense_att.py:115).
+ *   work items  item_row / item_e0 / item_e1 / item_slot int32 [n_items]: edges [e0, e1) of `row`; slot < 0 = the row's
+ *               only item (finished in place), else the index of its fp32 partial in `partial` [n_slots, C]
+ *   split rows  split_row / split_slot0 / split_n int32 [n_split]: rows cut into several items, summed in slot order
+ *   col int32 [nnz], inv_deg fp32 [nnz], grp uint8 [nnz], att fp32 [D] (already soft-maxed), bias fp32 [C] or NULL
+ *   support fp32 [n, ld_support], out fp32 [n, ld_out]; C % 4 == 0, C <= 4096; every row of `out` needs an item
+ */
+int hgr_csr_group_aggregate(const float *support, int64_t ld_support, const int *item_row, const int *item_e0,
+                            const int *item_e1, const int *item_slot, int n_items, const int *col, const float *inv_deg,
+                            const unsigned char *grp, const float *att, int D, const float *bias,
+                            const int *split_row, const int *split_slot0, const int *split_n, int n_split,
+                            float *partial, float *out, int64_t ld_out, int C, float slope, int normalize, void *stream);
+
+/*
  * Row-wise softmax cross-entropy (nn.CrossEntropyLoss at clip_tree.py:49,275): loss_rows[r] = lse(logits[r]) -
  * logits[r, labels[r]]; dlogits (optional) = (softmax - onehot) * gscale (gscale = weight / rows for the mean).
  */
