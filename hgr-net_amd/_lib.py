@@ -59,6 +59,15 @@ SIGNATURES = {
     "hgr_ctx_splice": [_p, _p, _p, _i, _i, _i, _i, _p],
     "hgr_ctx_splice_bwd": [_p, _p, _i, _i, _i, _i, _p],
     "hgr_sumsq": [_p, _l, _p, _p],
+    "hgr_conv3x3_nhwc_plain": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "hgr_gemm_nt_splitk": [_p, _l, _p, _l, _p, _l, _i, _i, _i, _i, _i, _p],
+    "hgr_relu_bwd16": [_p, _p, _p, _l, _i, _p],
+    "hgr_add16": [_p, _p, _p, _l, _i, _p],
+    "hgr_avgpool2_bwd_nhwc": [_p, _p, _i, _i, _i, _i, _i, _p],
+    "hgr_attnpool_tokens_bwd": [_p, _p, _i, _i, _i, _i, _p],
+    "hgr_im2col3x3_t": [_p, _p, _i, _i, _i, _i, _l, _i, _p],
+    "hgr_bn_fold": [_p, _p, _p, _p, _p, _f, _p, _p, _i, _i, _i, _i, _i, _p],
+    "hgr_bn_unfold_grad": [_p, _l, _p, _p, _p, _p, _p, _f, _p, _p, _p, _i, _i, _i, _p],
     "hgr_csr_group_aggregate": [_p, _l, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _p, _p, _l, _i, _f, _i, _p],
     "hgr_adamw": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _p, _f, _f, _p],
 }

@@ -44,6 +44,9 @@ struct GemmArgs {
     int dbg;         // diagnostics only (HGR_GEMM_DBG): 1 = skip MFMAs, 2 = skip LDS-DMA issue, 3 = skip epilogue
     // implicit-GEMM 3x3 convolution (CONV kernels only): A is an NHWC image [B, H, W, C], pad 1
     int cH, cW, cC, cLog2C, cStride, cHo, cWo;
+    // split-K (gemm_nt_128 only): blockIdx.y = split s works on K columns [s * kc, min(K, (s + 1) * kc)) and writes its own
+    // fp32 partial C + s * csplit elements; 0 = off
+    int kc; int64_t csplit;
 };
 
 // 16 zero bytes every out-of-bounds conv tap (and the K padding) is loaded from
@@ -132,6 +135,12 @@ template <int DT, int EPI, bool OUT32, bool CONV = false>
 __global__ __launch_bounds__(NT) void gemm_nt_128(GemmArgs p) {
     typedef typename T16<DT>::vec8 vec8;
     __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE_BYTES];
+    if (p.kc) {                                   // split-K: this workgroup's slice of the reduction, its own partial output
+        const int sp = blockIdx.y;
+        p.A += (int64_t)sp * p.kc * 2; p.W += (int64_t)sp * p.kc * 2;
+        p.C = (char *)p.C + (int64_t)sp * p.csplit * 4;
+        p.K = min(p.kc, p.K - sp * p.kc);
+    }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -721,7 +730,7 @@ extern "C" int hgr_gemm_nt(const void *A, int64_t lda, const void *W, int64_t ld
         // the other one once per XCD.  Make the bigger operand the once-fetched one.
         a.m_fastest = ((int64_t)N * K > (int64_t)m_cnt * K) ? 1 : 0;
         a.vec_ok = vec ? 1 : 0;
-        a.dbg = dbg;
+        a.dbg = dbg; a.kc = 0; a.csplit = 0;
         dim3 grid((unsigned)(a.tiles_m * a.tiles_n));
         if (dtype == HGR_BF16) launch_dt<HGR_BF16>(a, epilogue, out_f32 != 0, grid, s, big);
         else launch_dt<HGR_F16>(a, epilogue, out_f32 != 0, grid, s, big);
@@ -756,13 +765,13 @@ extern "C" int hgr_gemm_nt(const void *A, int64_t lda, const void *W, int64_t ld
     return HGR_OK;
 }
 
-extern "C" int hgr_conv3x3_nhwc(const void *x, const void *w, const float *bias, void *out,
-                                int B, int H, int W, int C, int Cout, int stride, int Kp, int dtype, void *stream) {
-    HGR_REQUIRE(x && w && bias && out, "hgr_conv3x3_nhwc: null operand");
+static int conv3x3_launch(const void *x, const void *w, const float *bias, void *out,
+                          int B, int H, int W, int C, int Cout, int stride, int Kp, int dtype, bool relu, void *stream) {
+    HGR_REQUIRE(x && w && out && (bias || !relu), "hgr_conv3x3_nhwc: null operand");
     HGR_REQUIRE(B >= 1 && H >= 1 && W >= 1 && Cout >= 1 && (stride == 1 || stride == 2), "hgr_conv3x3_nhwc: bad geometry B=%d H=%d W=%d Cout=%d stride=%d", B, H, W, Cout, stride);
     HGR_REQUIRE(C >= 8 && (C & (C - 1)) == 0, "hgr_conv3x3_nhwc: C=%d must be a power of two >= 8", C);
     HGR_REQUIRE(Kp >= 9 * C && Kp % BK == 0, "hgr_conv3x3_nhwc: Kp=%d must be >= 9*C and a multiple of %d", Kp, BK);
-    HGR_REQUIRE(hgr_aligned(x, 16) && hgr_aligned(w, 16) && hgr_aligned(out, 8) && hgr_aligned(bias, 16) && Cout % 4 == 0, "hgr_conv3x3_nhwc: misaligned operand / Cout %% 4 != 0");
+    HGR_REQUIRE(hgr_aligned(x, 16) && hgr_aligned(w, 16) && hgr_aligned(out, 8) && (!bias || hgr_aligned(bias, 16)) && Cout % 4 == 0, "hgr_conv3x3_nhwc: misaligned operand / Cout %% 4 != 0");
     HGR_REQUIRE(dtype == HGR_BF16 || dtype == HGR_F16, "hgr_conv3x3_nhwc: bad dtype %d", dtype);
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     const int64_t M64 = (int64_t)B * Ho * Wo;
@@ -772,13 +781,13 @@ extern "C" int hgr_conv3x3_nhwc(const void *x, const void *w, const float *bias,
     a.C = out; a.ldc = Cout; a.bias = bias; a.res = nullptr; a.ldr = 0;
     a.M = (int)M64; a.N = Cout; a.K = Kp;
     a.tiles_m = (a.M + BM - 1) / BM; a.tiles_n = (Cout + BN - 1) / BN;
-    a.m_fastest = 0; a.vec_ok = 1; a.dbg = 0;
+    a.m_fastest = 0; a.vec_ok = 1; a.dbg = 0; a.kc = 0; a.csplit = 0;
     a.cH = H; a.cW = W; a.cC = C; a.cStride = stride; a.cHo = Ho; a.cWo = Wo;
     int l2 = 0; while ((1 << l2) < C) ++l2;
     a.cLog2C = l2;
     // big tiles when the output is at least 256 wide-ish and the launch fills >= 4 rounds of 256 workgroups (M is huge here)
     const int64_t t256 = (int64_t)((a.M + 255) / 256) * ((Cout + 255) / 256);
-    const bool big = hgr_gemm_force_tile() != 128 && Kp >= 128 && Cout >= 128 && t256 >= 1024;
+    const bool big = relu && hgr_gemm_force_tile() != 128 && Kp >= 128 && Cout >= 128 && t256 >= 1024;
     if (big) {
         a.tiles_m = (a.M + 255) / 256; a.tiles_n = (Cout + 255) / 256;
         dim3 grid((unsigned)(a.tiles_m * a.tiles_n));
@@ -786,9 +795,47 @@ extern "C" int hgr_conv3x3_nhwc(const void *x, const void *w, const float *bias,
         else hipLaunchKernelGGL((gemm_nt_256<HGR_F16, HGR_EPI_BIAS_RELU, false, true>), grid, dim3(NT256), 0, (hipStream_t)stream, a);
     } else {
         dim3 grid((unsigned)(a.tiles_m * a.tiles_n));
-        if (dtype == HGR_BF16) hipLaunchKernelGGL((gemm_nt_128<HGR_BF16, HGR_EPI_BIAS_RELU, false, true>), grid, dim3(NT), 0, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL((gemm_nt_128<HGR_F16, HGR_EPI_BIAS_RELU, false, true>), grid, dim3(NT), 0, (hipStream_t)stream, a);
+        if (relu) {
+            if (dtype == HGR_BF16) hipLaunchKernelGGL((gemm_nt_128<HGR_BF16, HGR_EPI_BIAS_RELU, false, true>), grid, dim3(NT), 0, (hipStream_t)stream, a);
+            else hipLaunchKernelGGL((gemm_nt_128<HGR_F16, HGR_EPI_BIAS_RELU, false, true>), grid, dim3(NT), 0, (hipStream_t)stream, a);
+        } else {
+            if (dtype == HGR_BF16) hipLaunchKernelGGL((gemm_nt_128<HGR_BF16, HGR_EPI_NONE, false, true>), grid, dim3(NT), 0, (hipStream_t)stream, a);
+            else hipLaunchKernelGGL((gemm_nt_128<HGR_F16, HGR_EPI_NONE, false, true>), grid, dim3(NT), 0, (hipStream_t)stream, a);
+        }
     }
     HGR_CHECK_LAUNCH("hgr_conv3x3_nhwc");
+    return HGR_OK;
+}
+
+extern "C" int hgr_conv3x3_nhwc(const void *x, const void *w, const float *bias, void *out,
+                                int B, int H, int W, int C, int Cout, int stride, int Kp, int dtype, void *stream) {
+    return conv3x3_launch(x, w, bias, out, B, H, W, C, Cout, stride, Kp, dtype, true, stream);
+}
+
+extern "C" int hgr_conv3x3_nhwc_plain(const void *x, const void *w, void *out, int B, int H, int W, int C, int Cout, int Kp,
+                                      int dtype, void *stream) {
+    return conv3x3_launch(x, w, nullptr, out, B, H, W, C, Cout, 1, Kp, dtype, false, stream);
+}
+
+extern "C" int hgr_gemm_nt_splitk(const void *A, int64_t lda, const void *W, int64_t ldw, float *partial, int64_t ldc,
+                                  int M, int N, int K, int kc, int dtype, void *stream) {
+    HGR_REQUIRE(A && W && partial, "hgr_gemm_nt_splitk: null operand");
+    HGR_REQUIRE(M >= 1 && N >= 1 && K >= BK && K % BK == 0 && kc >= BK && kc % BK == 0, "hgr_gemm_nt_splitk: bad shape M=%d N=%d K=%d kc=%d", M, N, K, kc);
+    HGR_REQUIRE(lda >= K && ldw >= K && lda % 8 == 0 && ldw % 8 == 0 && hgr_aligned(A, 16) && hgr_aligned(W, 16), "hgr_gemm_nt_splitk: operands must be 16-byte aligned with leading dimensions %% 8 == 0");
+    HGR_REQUIRE(ldc >= N && ldc % 4 == 0 && hgr_aligned(partial, 16), "hgr_gemm_nt_splitk: partial must be 16-byte aligned, ldc %% 4 == 0");
+    HGR_REQUIRE(dtype == HGR_BF16 || dtype == HGR_F16, "hgr_gemm_nt_splitk: bad dtype %d", dtype);
+    const int S = (K + kc - 1) / kc;
+    HGR_REQUIRE(S <= 65535, "hgr_gemm_nt_splitk: %d splits exceed the grid limit", S);
+    GemmArgs a;
+    a.A = (const char *)A; a.lda = lda; a.W = (const char *)W; a.ldw = ldw;
+    a.C = partial; a.ldc = ldc; a.bias = nullptr; a.res = nullptr; a.ldr = 0;
+    a.M = M; a.N = N; a.K = K;
+    a.tiles_m = (M + BM - 1) / BM; a.tiles_n = (N + BN - 1) / BN;
+    a.m_fastest = 0; a.vec_ok = 1; a.dbg = 0; a.kc = kc; a.csplit = (int64_t)M * ldc;
+    a.cH = a.cW = a.cC = a.cLog2C = a.cStride = a.cHo = a.cWo = 0;
+    dim3 grid((unsigned)(a.tiles_m * a.tiles_n), (unsigned)S);
+    if (dtype == HGR_BF16) hipLaunchKernelGGL((gemm_nt_128<HGR_BF16, HGR_EPI_NONE, true, false>), grid, dim3(NT), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((gemm_nt_128<HGR_F16, HGR_EPI_NONE, true, false>), grid, dim3(NT), 0, (hipStream_t)stream, a);
+    HGR_CHECK_LAUNCH("hgr_gemm_nt_splitk");
     return HGR_OK;
 }

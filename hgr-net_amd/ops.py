@@ -344,6 +344,74 @@ def matmul_f32(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, alpha: float
     return out
 
 
+# ---- ModifiedResNet tower in training ---------------------------------------------------------------------------
+def conv3x3_plain(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, b: int, h: int, wd: int, c: int) -> torch.Tensor:
+    """out NHWC = conv3x3(x NHWC, pad 1, stride 1) with w [Cout, Kp] in (ky, kx, c) order; no bias, no activation."""
+    assert x.is_contiguous() and w.is_contiguous() and out.is_contiguous() and x.dtype == w.dtype == out.dtype
+    _lib.call("hgr_conv3x3_nhwc_plain", _dev(x), _dev(w), _dev(out), b, h, wd, c, w.shape[0], w.shape[1], DT_OF[x.dtype], _stream())
+    return out
+
+
+def gemm_nt_splitk(a: torch.Tensor, w: torch.Tensor, partial: torch.Tensor, kc: int) -> torch.Tensor:
+    """partial[s] [M, N] fp32 = a[:, s*kc:(s+1)*kc] @ w[:, same]^T for every K slice."""
+    assert a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.stride(1) == 1 and a.dtype == w.dtype and a.shape[1] == w.shape[1]
+    m, k = a.shape
+    n = w.shape[0]
+    s = (k + kc - 1) // kc
+    assert partial.dtype == torch.float32 and partial.is_contiguous() and partial.numel() >= s * m * n
+    _lib.call("hgr_gemm_nt_splitk", _dev(a), a.stride(0), _dev(w), w.stride(0), _dev(partial), n, m, n, k, kc, DT_OF[a.dtype], _stream())
+    return partial
+
+
+def relu_bwd16(dy: torch.Tensor, y: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    out = dy if out is None else out
+    assert dy.is_contiguous() and y.is_contiguous() and out.is_contiguous() and dy.numel() == y.numel() == out.numel()
+    _lib.call("hgr_relu_bwd16", _dev(dy), _dev(y), _dev(out), dy.numel(), DT_OF[dy.dtype], _stream())
+    return out
+
+
+def add16(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    out = a if out is None else out
+    assert a.is_contiguous() and b.is_contiguous() and out.is_contiguous() and a.numel() == b.numel() == out.numel()
+    _lib.call("hgr_add16", _dev(a), _dev(b), _dev(out), a.numel(), DT_OF[a.dtype], _stream())
+    return out
+
+
+def avgpool2_bwd_nhwc(dy: torch.Tensor, dx: torch.Tensor, b: int, h: int, w: int, c: int) -> torch.Tensor:
+    assert dy.is_contiguous() and dx.is_contiguous() and dx.numel() == 4 * dy.numel() == b * h * w * c
+    _lib.call("hgr_avgpool2_bwd_nhwc", _dev(dy), _dev(dx), b, h, w, c, DT_OF[dy.dtype], _stream())
+    return dx
+
+
+def attnpool_tokens_bwd(dtok: torch.Tensor, dx: torch.Tensor, b: int, s: int, c: int) -> torch.Tensor:
+    assert dtok.is_contiguous() and dx.is_contiguous() and dtok.numel() == b * (s + 1) * c and dx.numel() == b * s * c
+    _lib.call("hgr_attnpool_tokens_bwd", _dev(dtok), _dev(dx), b, s, c, DT_OF[dtok.dtype], _stream())
+    return dx
+
+
+def im2col3x3_t(xt: torch.Tensor, out: torch.Tensor, b: int, h: int, w: int) -> torch.Tensor:
+    """xt [C, ld] (transposed NHWC activation) -> out [9C, ld]: the transposed im2col of a 3x3 / pad 1 convolution."""
+    c, ld = xt.shape
+    assert xt.is_contiguous() and out.is_contiguous() and tuple(out.shape) == (9 * c, ld) and ld >= b * h * w
+    _lib.call("hgr_im2col3x3_t", _dev(xt), _dev(out), b, h, w, c, ld, DT_OF[xt.dtype], _stream())
+    return out
+
+
+def bn_fold(w: torch.Tensor, bn, w16: torch.Tensor, bias: torch.Tensor) -> None:
+    """conv weight fp32 [Cout, Cin, kh, kw] + BatchNorm2d (running stats) -> folded w16 [Cout, Kp] ((ky, kx, ci) order), bias."""
+    cout, cin, kh, kw = w.shape
+    assert w.is_contiguous() and w.dtype == torch.float32 and w16.is_contiguous() and bias.dtype == torch.float32
+    _lib.call("hgr_bn_fold", _dev(w), _dev(bn.weight.data), _dev(bn.bias.data), _dev(bn.running_mean), _dev(bn.running_var), float(bn.eps),
+              _dev(w16), _dev(bias), cout, cin, kh * kw, w16.shape[1], DT_OF[w16.dtype], _stream())
+
+
+def bn_unfold_grad(gwf: torch.Tensor, gbf: torch.Tensor, w: torch.Tensor, bn, g_w: torch.Tensor, g_gamma: torch.Tensor, g_beta: torch.Tensor) -> None:
+    cout, cin, kh, kw = w.shape
+    assert gwf.dtype == gbf.dtype == g_w.dtype == torch.float32 and gwf.stride(1) == 1 and g_w.is_contiguous() and w.is_contiguous()
+    _lib.call("hgr_bn_unfold_grad", _dev(gwf), gwf.stride(0), _dev(gbf), _dev(w), _dev(bn.weight.data), _dev(bn.running_mean),
+              _dev(bn.running_var), float(bn.eps), _dev(g_w), _dev(g_gamma), _dev(g_beta), cout, cin, kh * kw, _stream())
+
+
 def csr_group_aggregate(support: torch.Tensor, op, att: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor,
                         slope: float = 1.0, normalize: bool = False) -> torch.Tensor:
     """DGP graph propagation step: out[i] = act(sum_e att[grp_e] / deg_e * (support[col_e] + bias)); `op` carries the

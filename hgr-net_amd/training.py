@@ -16,8 +16,7 @@ out explicitly and every product / reduction runs in a hand-written kernel:
   (clip_tree.py:224-226,280).
 
 Only the host-side orchestration is Python; ``random`` drives negative sampling exactly as in the
-reference (seed it for reproducibility).  RN towers and sequences longer than 64 tokens (ViT-L/14)
-have no backward kernels yet and raise.
+reference (seed it for reproducibility).  ModifiedResNet image towers: training_rn.py.
 """
 from __future__ import annotations
 
@@ -88,10 +87,13 @@ class Engine:
     def prepare(self):
         """16-bit weight copies + transposes for this step (weights change every step)."""
         m, dt = self.m, self.dt
-        if not isinstance(m.visual, VisionTransformer):
-            raise NotImplementedError("training: only ViT image towers have backward kernels this round")
-        self.vblocks = [_Blk(b, dt) for b in m.visual.transformer.resblocks]
         self.tblocks = [_Blk(b, dt) for b in m.transformer.resblocks]
+        self.rn = None
+        if not isinstance(m.visual, VisionTransformer):
+            from .training_rn import RNTower                # ModifiedResNet (the reference's README trains --arch RN50)
+            self.rn = RNTower(m.visual, dt, self.scratch)
+            return
+        self.vblocks = [_Blk(b, dt) for b in m.visual.transformer.resblocks]
         ps = m.visual.patch_size
         self.conv = _Lin(m.visual.conv1.weight, None, dt, kpad=_pad64(3 * ps * ps))
 
@@ -168,6 +170,8 @@ class Engine:
 
     # -- image tower (ViT) ----------------------------------------------------------------------
     def image_fwd(self, image: torch.Tensor):
+        if self.rn is not None:
+            return self.rn.fwd(image)
         v, dt, dev = self.m.visual, self.dt, self.dev
         image = image.float().contiguous()
         b, _, r, _ = image.shape
@@ -190,6 +194,8 @@ class Engine:
         return feat, dict(patches=patches, t=t, xl=xl, saves=saves, c32=c32, b=b, l=l, w=w)
 
     def image_bwd(self, dfeat: torch.Tensor, s: dict):
+        if self.rn is not None:
+            return self.rn.bwd(dfeat, s)
         v, dt, dev = self.m.visual, self.dt, self.dev
         b, l, w = s["b"], s["l"], s["w"]
         ops.matmul_f32(s["c32"].t(), dfeat, _grad(v.proj), accumulate=True)                 # dproj += c^T dfeat

@@ -273,6 +273,40 @@ int64_t hgr_layernorm_bwd_scratch_floats(int rows, int W);
 int hgr_mha_bwd(const void *qkv, const void *out, const void *dout, void *dqkv, int B, int L, int heads, int causal, int dtype, void *stream);
 
 /*
+ * ---- ModifiedResNet tower in training (clip/model.py:10-150 under model/clip_tree.py:222-281; the reference's README
+ * trains --arch RN50).  BatchNorm uses running statistics even in training (clip_tree.py:46), so every conv + BN pair
+ * is one folded convolution; its weight / bias gradients are mapped back to conv.weight, bn.weight, bn.bias. ----
+ */
+/* 3x3 / pad 1 / stride 1 convolution without bias or activation: the data gradient of hgr_conv3x3_nhwc when `w` holds
+ * the spatially flipped, in/out-transposed folded weight [Cin, Kp >= 9*Cout]. */
+int hgr_conv3x3_nhwc_plain(const void *x, const void *w, void *out, int B, int H, int W, int C, int Cout, int Kp,
+                           int dtype, void *stream);
+/* Split-K NT product for weight gradients (tiny output, reduction over all pixels): split s = 0 .. ceil(K/kc)-1 writes
+ * partial[s] [M, ldc] fp32 = A[:, s*kc : (s+1)*kc] . W[:, same]^T; the caller sums the partials (hgr_colsum). */
+int hgr_gemm_nt_splitk(const void *A, int64_t lda, const void *W, int64_t ldw, float *partial, int64_t ldc,
+                       int M, int N, int K, int kc, int dtype, void *stream);
+/* out = (y > 0) ? dy : 0 (ReLU backward from the saved output; out may alias dy); n % 8 == 0. */
+int hgr_relu_bwd16(const void *dy, const void *y, void *out, int64_t n, int dtype, void *stream);
+/* out = a + b, 16-bit with an fp32 add (the two gradient branches of a Bottleneck); n % 8 == 0. */
+int hgr_add16(const void *a, const void *b, void *out, int64_t n, int dtype, void *stream);
+/* AvgPool2d(2) backward: dx [B, H, W, C] = dy [B, H/2, W/2, C] / 4 per covered pixel. */
+int hgr_avgpool2_bwd_nhwc(const void *dy, void *dx, int B, int H, int W, int C, int dtype, void *stream);
+/* AttentionPool2d token assembly backward (clip/model.py:67-69): dx [B, S, C] = dtok[:, 1:] + dtok[:, 0] / S. */
+int hgr_attnpool_tokens_bwd(const void *dtok, void *dx, int B, int S, int C, int dtype, void *stream);
+/* Transposed im2col for the 3x3 weight gradient: xt [C, ld] (activation transposed, column = pixel) ->
+ * out [9*C, ld], row (tap, c) = xt row c shifted by the tap, zero outside the image and in the padding columns. */
+int hgr_im2col3x3_t(const void *xt, void *out, int B, int H, int W, int C, int64_t ld, int dtype, void *stream);
+/* Fold inference BatchNorm into its convolution: w16 [Cout, Kp] in (ky, kx, ci) order = conv.weight * gamma/sigma,
+ * bias = beta - mean * gamma/sigma (khw = 1 or 9). */
+int hgr_bn_fold(const float *w, const float *gamma, const float *beta, const float *mean, const float *var, float eps,
+                void *w16, float *bias, int Cout, int Cin, int khw, int Kp, int dtype, void *stream);
+/* Gradients of the folded weight gwf [Cout, ldg] (same K order) and bias gbf [Cout] -> += into the gradients of
+ * conv.weight [Cout, Cin, kh, kw], bn.weight and bn.bias. */
+int hgr_bn_unfold_grad(const float *gwf, int64_t ldg, const float *gbf, const float *w, const float *gamma, const float *mean,
+                       const float *var, float eps, float *g_w, float *g_gamma, float *g_beta, int Cout, int Cin, int khw,
+                       void *stream);
+
+/*
  * DGP baseline graph propagation (baseline/DGP/models/gcn_dense_att.py:31-46 `GraphConv.forward` after the dense
  * `support = x W + b`): out[i] = act( sum_e att[grp[e]] * inv_deg[e] * (support[col[e]] + bias) ) over the edges of row
  * i in a CSR that merges the D distance-grouped, in-degree-normalised operators (baseline/DGP/utils.py:56-65;

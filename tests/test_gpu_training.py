@@ -37,7 +37,7 @@ def _build(case, golden_dir, tmp_path, train_dtype):
     return model, meta, cfg
 
 
-@pytest.mark.parametrize("case", ["tinyvit_n90", "smallvit_n300"])
+@pytest.mark.parametrize("case", ["tinyvit_n90", "smallvit_n300", "tinyrn_n64"])
 def test_om_step_matches_reference(case, golden_dir, tmp_path):
     model, meta, cfg = _build(case, golden_dir, tmp_path, "bf16")
     t = meta["train"]
@@ -69,6 +69,9 @@ def test_om_step_matches_reference(case, golden_dir, tmp_path):
             continue
         gref = torch.from_numpy(gold[key]).flatten()
         ggot = named[key[5:]].grad.detach().cpu().flatten()
+        if float(gref.norm()) < 1e-6:                          # identically zero in exact arithmetic (attention key bias:
+            assert float(ggot.norm()) < 1e-4, key              # softmax is shift invariant); only rounding noise on both sides
+            continue
         cos = float(torch.dot(gref, ggot) / (gref.norm() * ggot.norm() + 1e-30))
         assert cos > 0.99, (key, cos)
     # clip_grad_norm_(1.0) + AdamW(lr) as fused kernels vs the reference's torch optimiser
@@ -89,6 +92,8 @@ def test_om_step_matches_reference(case, golden_dir, tmp_path):
         # (near) zero - e.g. the attention key bias, whose gradient vanishes by softmax shift invariance - so the
         # deltas are compared where the reference gradient is not negligible
         gref = torch.from_numpy(gold["grad/" + name]).to(DEV)
+        if float(gref.norm()) < 1e-6:
+            continue
         mask = gref.abs() > 2e-2 * gref.abs().max()
         assert bool(mask.any()), name
         assert float((step_got - step_ref).abs()[mask].mean()) < 0.1 * t["lr"], name

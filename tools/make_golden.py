@@ -192,9 +192,7 @@ def tree_fixture(ref_main_mod, tag, cfg, n_nodes, n_train, n_test, batches, bsz,
         paths.append(dp)
     print(f"[tree] {tag}: main.test -> {metric.strip()}")
     assert st.summary() == metric, (st.summary(), metric)
-    train = None
-    if "vision_patch_size" in cfg and cfg["vision_patch_size"]:
-        train = train_capture(model, o, cfg, h, tag)
+    train = train_capture(model, o, cfg, h, tag)          # ViT and ModifiedResNet towers alike
     meta = dict(config=cfg, n_nodes=n_nodes, n_train=n_train, n_test=n_test, batches=batches, bsz=bsz, train=train,
                 dag=dict(depth=8, seed=7, multi_parent=0.08), split_seed=13, image_seed0=100, targets=targets,
                 metric=metric, counters=st.counters(), weights=weights,
@@ -244,7 +242,14 @@ TRAIN_KEEP = ["logit_scale", "ln_final.weight", "ln_final.bias", "text_projectio
               "visual.class_embedding", "visual.positional_embedding", "visual.ln_pre.weight", "visual.ln_post.bias",
               "transformer.resblocks.0.attn.in_proj_bias", "transformer.resblocks.1.mlp.c_fc.weight",
               "visual.transformer.resblocks.0.attn.out_proj.weight", "visual.transformer.resblocks.1.ln_2.weight",
-              "visual.transformer.resblocks.0.mlp.c_proj.bias"]
+              "visual.transformer.resblocks.0.mlp.c_proj.bias",
+              # ModifiedResNet towers
+              "visual.conv1.weight", "visual.bn1.weight", "visual.bn1.bias", "visual.conv3.weight", "visual.bn3.weight",
+              "visual.layer1.0.conv2.weight", "visual.layer1.0.bn2.weight", "visual.layer1.0.downsample.1.weight",
+              "visual.layer2.0.downsample.1.weight", "visual.layer2.0.downsample.2.bias", "visual.layer3.0.conv1.weight",
+              "visual.layer4.0.bn3.weight", "visual.layer4.0.bn3.bias", "visual.attnpool.q_proj.bias",
+              "visual.attnpool.k_proj.bias", "visual.attnpool.v_proj.bias", "visual.attnpool.c_proj.weight",
+              "visual.attnpool.c_proj.bias", "visual.attnpool.positional_embedding"]      # (the 2048^2 projections: norms only)
 
 
 def train_capture(model, o, cfg, h, tag):
@@ -287,6 +292,7 @@ def train_capture(model, o, cfg, h, tag):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-big", action="store_true", help="skip the true-dimension ViT-B/32 / RN50 fixtures")
+    ap.add_argument("--only-tree", default=None, help="regenerate one tree/train fixture only (tinyvit_n90 | smallvit_n300 | tinyrn_n64)")
     a = ap.parse_args()
     assert REF.is_dir(), f"{REF} not found: fixtures can only be generated where the reference is mounted"
     GOLD.mkdir(parents=True, exist_ok=True)
@@ -300,6 +306,11 @@ def main():
 
     with tempfile.TemporaryDirectory() as tmp:
         C = synth.CLIP_CONFIGS
+        if a.only_tree:
+            spec = {"tinyvit_n90": ("tiny-vit", 90, 30, 40, 3, 8), "smallvit_n300": ("small-vit", 300, 100, 150, 4, 6),
+                    "tinyrn_n64": ("tiny-rn", 64, 20, 24, 2, 4)}[a.only_tree]
+            tree_fixture(ref_main, a.only_tree, dict(C[spec[0]], vocab_size=49408), *spec[1:], tmp)
+            return
         clip_fixture(ref_clip, "tiny-vit", C["tiny-vit"], 4, 6, tmp)
         clip_fixture(ref_clip, "small-vit", C["small-vit"], 3, 5, tmp)
         clip_fixture(ref_clip, "tiny-rn", C["tiny-rn"], 3, 4, tmp)
