@@ -180,3 +180,109 @@ def test_adamw_and_clip_match_torch():
         ops.sumsq(gd, tot)
         ops.adamw(p, gd, m, v, lr=1e-2, step=step, wd=0.1, sumsq_total=tot, max_norm=1.0)
     assert torch.allclose(p.cpu(), p_ref.detach(), rtol=1e-5, atol=1e-6)
+
+
+# ---- ModifiedResNet tower backward pieces (training_rn.py) ---------------------------------------------------------
+@pytest.mark.parametrize("dt", DTS)
+def test_relu_add_avgpool_attnpool_backward_kernels(dt):
+    g = torch.Generator().manual_seed(1)
+    b, h, c = 2, 6, 64
+    y = torch.randn(b * h * h, c, generator=g).to(dt).to(DEV)
+    dy = torch.randn(b * h * h, c, generator=g).to(dt).to(DEV)
+    out = ops.relu_bwd16(dy.clone(), y)
+    assert torch.equal(out, torch.where(y.float() > 0, dy, torch.zeros_like(dy)))
+    s = ops.add16(dy.clone(), y)
+    assert torch.equal(s, (dy.float() + y.float()).to(dt))
+    # AvgPool2d(2) backward against autograd
+    x = torch.randn(b, c, h, h, generator=g, requires_grad=True)
+    go = torch.randn(b, c, h // 2, h // 2, generator=g).to(dt).float()
+    torch.nn.functional.avg_pool2d(x, 2).backward(go)
+    dx = torch.empty(b * h * h, c, dtype=dt, device=DEV)
+    ops.avgpool2_bwd_nhwc(go.permute(0, 2, 3, 1).reshape(-1, c).to(dt).to(DEV), dx, b, h, h, c)
+    assert torch.equal(dx.float().cpu().view(b, h, h, c), x.grad.permute(0, 2, 3, 1).to(dt).float())
+    # attention-pool token assembly backward: tokens = cat(mean, x) + pos
+    sp = h * h
+    xt = torch.randn(b, sp, c, generator=g, requires_grad=True)
+    tok = torch.cat([xt.mean(1, keepdim=True), xt], 1)
+    gt = torch.randn(b, sp + 1, c, generator=g).to(dt).float()
+    tok.backward(gt)
+    dxx = torch.empty(b * sp, c, dtype=dt, device=DEV)
+    ops.attnpool_tokens_bwd(gt.to(dt).reshape(-1, c).to(DEV), dxx, b, sp, c)
+    assert torch.allclose(dxx.float().cpu().view(b, sp, c), xt.grad, rtol=2 ** -7, atol=1e-3)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_conv3x3_data_and_weight_gradients_vs_autograd(dt):
+    """dX through hgr_conv3x3_nhwc_plain with the flipped weight, dW through transpose + im2col3x3_t + split-K GEMM
+    + column sum, against torch autograd of F.conv2d on the same 16-bit-rounded operands (fp32 math)."""
+    g = torch.Generator().manual_seed(2)
+    b, h, cin, cout = 3, 10, 64, 128
+    x = torch.randn(b, cin, h, h, generator=g).to(dt).float().requires_grad_(True)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.05).to(dt).float().requires_grad_(True)
+    go = torch.randn(b, cout, h, h, generator=g).to(dt).float()
+    torch.nn.functional.conv2d(x, w, padding=1).backward(go)
+    m = b * h * h
+    x16 = x.detach().permute(0, 2, 3, 1).reshape(m, cin).to(dt).to(DEV).contiguous()
+    dy16 = go.permute(0, 2, 3, 1).reshape(m, cout).to(dt).to(DEV).contiguous()
+    w16 = w.detach().permute(0, 2, 3, 1).reshape(cout, 9 * cin).to(dt).to(DEV).contiguous()          # (ky, kx, ci) order
+    # data gradient
+    wflip = w16.view(cout, 3, 3, cin).flip(1, 2).permute(3, 1, 2, 0).reshape(cin, 9 * cout).contiguous()
+    dx = torch.empty(m, cin, dtype=dt, device=DEV)
+    ops.conv3x3_plain(dy16, wflip, dx, b, h, h, cout)
+    ref_dx = x.grad.permute(0, 2, 3, 1).reshape(m, cin)
+    tol = 2 ** -6 if dt == torch.bfloat16 else 2 ** -9
+    assert torch.allclose(dx.float().cpu(), ref_dx, rtol=tol, atol=tol * float(ref_dx.abs().max()))
+    # weight gradient
+    mp = (m + 63) // 64 * 64
+    xt = torch.zeros(cin, mp, dtype=dt, device=DEV)
+    ops.transpose16(x16, xt)
+    colt = torch.empty(9 * cin, mp, dtype=dt, device=DEV)
+    ops.im2col3x3_t(xt, colt, b, h, h)
+    unf = torch.nn.functional.unfold(x.detach(), 3, padding=1)                                   # [b, cin*9, h*h], (ci, ky, kx) order
+    ref_col = unf.view(b, cin, 9, h * h).permute(2, 1, 0, 3).reshape(9 * cin, m)                  # (tap, ci) rows, pixel columns
+    assert torch.equal(colt[:, :m].float().cpu(), ref_col) and not colt[:, m:].any()
+    dyt = torch.zeros(cout, mp, dtype=dt, device=DEV)
+    ops.transpose16(dy16, dyt)
+    for kc in (64, 128, mp):
+        s = (mp + kc - 1) // kc
+        part = torch.empty(s, cout * 9 * cin, dtype=torch.float32, device=DEV)
+        ops.gemm_nt_splitk(dyt, colt, part, kc)
+        gw = part.sum(0).view(cout, 9, cin).permute(0, 2, 1).reshape(cout, cin, 3, 3).cpu()
+        assert torch.allclose(gw, w.grad, rtol=1e-3, atol=1e-3 * float(w.grad.abs().max())), kc
+
+
+def test_bn_fold_and_unfold_vs_autograd():
+    """hgr_bn_fold equals the inference engine's fold; hgr_bn_unfold_grad equals autograd through
+    w' = w * gamma / sigma, b' = beta - mean * gamma / sigma."""
+    from hgr_net_amd.clip.model import _fold
+    g = torch.Generator().manual_seed(3)
+    for cin, k in ((64, 3), (128, 1), (3, 3)):
+        cout = 32
+        conv = torch.nn.Conv2d(cin, cout, k, bias=False)
+        bn = torch.nn.BatchNorm2d(cout)
+        with torch.no_grad():
+            conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * 0.1)
+            bn.weight.copy_(torch.rand(cout, generator=g) + 0.5); bn.bias.copy_(torch.randn(cout, generator=g) * 0.1)
+            bn.running_mean.copy_(torch.randn(cout, generator=g) * 0.2); bn.running_var.copy_(torch.rand(cout, generator=g) + 0.5)
+        conv, bn = conv.to(DEV), bn.to(DEV)
+        ref_w16, ref_b = _fold(conv, bn, torch.float16)
+        kp = ref_w16.shape[1]
+        w16 = torch.empty(cout, kp, dtype=torch.float16, device=DEV)
+        bias = torch.empty(cout, dtype=torch.float32, device=DEV)
+        ops.bn_fold(conv.weight.data.contiguous(), bn, w16, bias)
+        assert torch.allclose(w16.float(), ref_w16.float(), rtol=2e-3, atol=1e-6) and torch.allclose(bias, ref_b, rtol=1e-6, atol=1e-7)
+        # unfold: autograd reference
+        kk = cin * k * k
+        gwf = torch.randn(cout, kp, generator=g).to(DEV)
+        gbf = torch.randn(cout, generator=g).to(DEV)
+        wr = conv.weight.detach().clone().requires_grad_(True)
+        ga = bn.weight.detach().clone().requires_grad_(True)
+        be = bn.bias.detach().clone().requires_grad_(True)
+        sc = ga / torch.sqrt(bn.running_var + bn.eps)
+        wf = (wr * sc.view(-1, 1, 1, 1)).permute(0, 2, 3, 1).reshape(cout, kk)
+        bf = be - bn.running_mean * sc
+        ((wf * gwf[:, :kk]).sum() + (bf * gbf).sum()).backward()
+        g_w, g_g, g_b = torch.zeros_like(wr), torch.zeros(cout, device=DEV), torch.zeros(cout, device=DEV)
+        ops.bn_unfold_grad(gwf, gbf, conv.weight.data.contiguous(), bn, g_w, g_g, g_b)
+        assert torch.allclose(g_w, wr.grad, rtol=1e-5, atol=1e-6)
+        assert torch.allclose(g_g, ga.grad, rtol=1e-4, atol=1e-5) and torch.allclose(g_b, be.grad, rtol=1e-6, atol=1e-7)
