@@ -416,38 +416,88 @@ __global__ __launch_bounds__(256) void l2norm_bwd(const float *__restrict__ x, c
     for (int j = lane; j < D; j += 64) o[j] = (accumulate ? o[j] : 0.f) + dr[j] * inv - xr[j] * k;
 }
 
-// ---- fp32 product C[M,N] = alpha * sum_k A(m,k) B(k,n) (+ C), generic strides (any transposition) --------------
-// v_mfma_f32_32x32x2_f32: exact fp32 products and accumulation (a k-ordered fmaf chain), 1/16 of the bf16 MFMA rate -
-// plenty for the loss head and the projections.  One wave owns a 32 x 32 tile and streams its operands straight
-// from global memory (lane l holds A[m0 + (l & 31)][k + (l >> 5)] and B[k + (l >> 5)][n0 + (l & 31)]); 4 waves per
-// block cover 64 x 64.  Out-of-range rows / columns are clamped on load and masked on store.
+// fp32 product with generic strides on the fp32 matrix cores (v_mfma_f32_32x32x2f32: exact fp32 multiply-add).
+// 64 x 64 output tile per workgroup, 4 waves of 32 x 32, K in steps of 32 through LDS ([k][m] and [k][n] images, so an
+// MFMA operand read is one conflict-free ds_read_b32 per lane), the next K-step's global loads in flight while the
+// current one computes.  An operand tile is fetched with 16-byte loads along whichever of its two dimensions has
+// stride 1 (row-major and transposed views are both common here); anything else, and every edge, falls back to
+// guarded scalar loads.  Used for the loss head / projections of the training step and DGP's dense layers.
+constexpr int MM_BK = 32, MM_LD = 68;
+
+// 8 floats of a [64 (outer) x 32 (k)] operand tile for thread `t` -> regs; `so` = outer stride, `sk` = k stride
+__device__ __forceinline__ void mm_fetch(const float *__restrict__ P, int64_t so, int64_t sk, int o0, int O, int k0, int K, bool vec, int t, float (&v)[8]) {
+    if (sk == 1) {                       // k contiguous: rows t/8 and t/8 + 32, 4 consecutive k
+        const int kk = k0 + (t & 7) * 4;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int o = o0 + (t >> 3) + 32 * j;
+            const float *q = P + (int64_t)o * so + kk;
+            if (vec && o < O && kk + 3 < K) { const f32x4 x = *(const f32x4 *)q; v[4 * j] = x[0]; v[4 * j + 1] = x[1]; v[4 * j + 2] = x[2]; v[4 * j + 3] = x[3]; }
+            else
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 * j + e] = (o < O && kk + e < K) ? q[e] : 0.f;
+        }
+    } else {                             // outer contiguous (or generic): k rows t/16 and t/16 + 16, 4 consecutive outer
+        const int oo = o0 + (t & 15) * 4;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = k0 + (t >> 4) + 16 * j;
+            const float *q = P + (int64_t)k * sk + (int64_t)oo * so;
+            if (vec && so == 1 && k < K && oo + 3 < O) { const f32x4 x = *(const f32x4 *)q; v[4 * j] = x[0]; v[4 * j + 1] = x[1]; v[4 * j + 2] = x[2]; v[4 * j + 3] = x[3]; }
+            else
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 * j + e] = (k < K && oo + e < O) ? q[(int64_t)e * so] : 0.f;
+        }
+    }
+}
+
+__device__ __forceinline__ void mm_stage(float (*S)[MM_LD], int64_t sk, int t, const float (&v)[8]) {
+    if (sk == 1) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) S[(t & 7) * 4 + e][(t >> 3) + 32 * j] = v[4 * j + e];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) *(f32x4 *)&S[(t >> 4) + 16 * j][(t & 15) * 4] = (f32x4){v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]};
+    }
+}
+
 __global__ __launch_bounds__(256) void matmul_f32(const float *__restrict__ A, int64_t sam, int64_t sak, const float *__restrict__ B, int64_t sbk, int64_t sbn,
-                                                  float *__restrict__ C, int64_t ldc, int M, int N, int K, float alpha, int accumulate) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int m0 = blockIdx.y * 64 + (wave >> 1) * 32, n0 = blockIdx.x * 64 + (wave & 1) * 32;
-    if (m0 >= M || n0 >= N) return;                                   // wave-uniform
+                                                  float *__restrict__ C, int64_t ldc, int M, int N, int K, float alpha, int accumulate, int vecA, int vecB) {
+    __shared__ __attribute__((aligned(16))) float As[2][MM_BK][MM_LD], Bs[2][MM_BK][MM_LD];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
     const int r = lane & 31, h = lane >> 5;
-    const float *ap = A + (int64_t)min(m0 + r, M - 1) * sam;
-    const float *bp = B + (int64_t)min(n0 + r, N - 1) * sbn;
+    float ra[8], rb[8];
+    mm_fetch(A, sam, sak, m0, M, 0, K, vecA != 0, t, ra);
+    mm_fetch(B, sbn, sbk, n0, N, 0, K, vecB != 0, t, rb);
+    mm_stage(As[0], sak, t, ra);
+    mm_stage(Bs[0], sbk, t, rb);
+    __syncthreads();
     f32x16 acc = {0.f};
-    int k = 0;
-    for (; k + 8 <= K; k += 8) {                                     // 4 MFMAs per trip, loads issued together
-        float av[4], bv[4];
+    const int nk = (K + MM_BK - 1) / MM_BK;
+    for (int s = 0; s < nk; ++s) {
+        const int cur = s & 1;
+        if (s + 1 < nk) {
+            mm_fetch(A, sam, sak, m0, M, (s + 1) * MM_BK, K, vecA != 0, t, ra);
+            mm_fetch(B, sbn, sbk, n0, N, (s + 1) * MM_BK, K, vecB != 0, t, rb);
+        }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { av[u] = ap[(int64_t)(k + 2 * u + h) * sak]; bv[u] = bp[(int64_t)(k + 2 * u + h) * sbk]; }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+        for (int kk = 0; kk < MM_BK; kk += 2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[cur][kk + h][wm + r], Bs[cur][kk + h][wn + r], acc, 0, 0, 0);
+        if (s + 1 < nk) {
+            mm_stage(As[cur ^ 1], sak, t, ra);
+            mm_stage(Bs[cur ^ 1], sbk, t, rb);
+        }
+        __syncthreads();
     }
-    for (; k < K; k += 2) {
-        const bool ok = k + h < K;
-        const float av = ok ? ap[(int64_t)(k + h) * sak] : 0.f, bv = ok ? bp[(int64_t)(k + h) * sbk] : 0.f;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
-    }
-    const int n = n0 + r;
+    const int n = n0 + wn + r;
     if (n < N)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const int m = m0 + (i & 3) + 8 * (i >> 2) + 4 * h;           // C/D layout of the 32x32 shapes
+            const int m = m0 + wm + (i & 3) + 8 * (i >> 2) + 4 * h;           // C/D layout of the 32x32 shapes
             if (m < M) {
                 float *c = C + (int64_t)m * ldc + n;
                 *c = (accumulate ? *c : 0.f) + alpha * acc[i];
@@ -665,7 +715,10 @@ extern "C" int hgr_l2norm_bwd(const float *x, const float *dy, float *dx, int ro
 extern "C" int hgr_matmul_f32(const float *A, int64_t sam, int64_t sak, const float *B, int64_t sbk, int64_t sbn, float *C, int64_t ldc,
                               int M, int N, int K, float alpha, int accumulate, void *stream) {
     HGR_REQUIRE(A && B && C && M >= 1 && N >= 1 && K >= 1 && ldc >= N, "hgr_matmul_f32: bad arguments");
-    hipLaunchKernelGGL(matmul_f32, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, (hipStream_t)stream, A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, alpha, accumulate);
+    // 16-byte loads need the contiguous dimension's rows to start 16-byte aligned
+    const int vecA = hgr_aligned(A, 16) && ((sak == 1 && sam % 4 == 0) || (sam == 1 && sak % 4 == 0));
+    const int vecB = hgr_aligned(B, 16) && ((sbk == 1 && sbn % 4 == 0) || (sbn == 1 && sbk % 4 == 0));
+    hipLaunchKernelGGL(matmul_f32, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, (hipStream_t)stream, A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, alpha, accumulate, vecA, vecB);
     HGR_CHECK_LAUNCH("hgr_matmul_f32");
     return HGR_OK;
 }
@@ -674,6 +727,32 @@ extern "C" int hgr_embed_scatter_add(const int64_t *tokens, int64_t ld_tokens, c
     HGR_REQUIRE(tokens && dx && dtable && n >= 1 && L >= 1 && W >= 1 && vocab >= 1 && ld_tokens >= L, "hgr_embed_scatter_add: bad arguments");
     hipLaunchKernelGGL(embed_scatter_add, dim3(grid1((int64_t)n * L * W)), dim3(256), 0, (hipStream_t)stream, tokens, ld_tokens, dx, dtable, n, L, W, vocab);
     HGR_CHECK_LAUNCH("hgr_embed_scatter_add");
+    return HGR_OK;
+}
+
+namespace {
+// out (+)= alpha * sum_i a[i] b[i]: ONE workgroup of 1024 threads, fixed summation order (deterministic); meant for
+// vectors of at most a few 100 K elements (d logit_scale = sum(dlogits * logits) of the loss head)
+__global__ __launch_bounds__(1024) void dot_f32(const float *__restrict__ a, const float *__restrict__ b, int64_t n, float *__restrict__ out,
+                                                float alpha, int accumulate) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) s += a[i] * b[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < 16; ++w) t += red[w];
+        *out = (accumulate ? *out : 0.f) + alpha * t;
+    }
+}
+}  // namespace
+
+extern "C" int hgr_dot_f32(const float *a, const float *b, int64_t n, float *out, float alpha, int accumulate, void *stream) {
+    HGR_REQUIRE(a && b && out && n >= 1, "hgr_dot_f32: bad arguments");
+    hipLaunchKernelGGL(dot_f32, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, b, n, out, alpha, accumulate);
+    HGR_CHECK_LAUNCH("hgr_dot_f32");
     return HGR_OK;
 }
 

@@ -426,6 +426,13 @@ def csr_group_aggregate(support: torch.Tensor, op, att: torch.Tensor, bias: Opti
     return out
 
 
+def dot_f32(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, alpha: float = 1.0, accumulate: bool = False) -> torch.Tensor:
+    """out[0] (+)= alpha * sum(a * b) for contiguous fp32 tensors of equal size."""
+    assert a.dtype == b.dtype == out.dtype == torch.float32 and a.is_contiguous() and b.is_contiguous() and a.numel() == b.numel()
+    _lib.call("hgr_dot_f32", _dev(a), _dev(b), a.numel(), _dev(out), alpha, 1 if accumulate else 0, _stream())
+    return out
+
+
 def embed_scatter_add(tokens: torch.Tensor, dx: torch.Tensor, dtable: torch.Tensor, l: int) -> None:
     assert tokens.dtype == torch.int64 and tokens.stride(1) == 1 and dx.is_contiguous() and dtable.is_contiguous()
     _lib.call("hgr_embed_scatter_add", _dev(tokens), tokens.stride(0), _dev(dx), _dev(dtable), tokens.shape[0], l, dtable.shape[1], dtable.shape[0], _stream())

@@ -77,6 +77,7 @@ class Engine:
         self.dt = ops.TORCH16[ops.dtype_code(dtype)]
         self.dev = next(clip_model.parameters()).device
         self._scratch = None
+        self._part = None
 
     # -- helpers -------------------------------------------------------------------------------
     def scratch(self, n: int) -> torch.Tensor:
@@ -107,7 +108,20 @@ class Engine:
         ops.transpose16(dy16, dyt)
         ops.transpose16(x16[:, : lin.k] if x16.shape[1] != lin.k else x16, xt)
         gw = _grad(lin.weight).view(lin.n, lin.k)
-        ops.gemm_nt(dyt, xt, gw, epilogue=EPI_ACCUM)
+        tiles = -(-lin.n // 128) * -(-lin.k // 128)
+        s = min(mp // 64, -(-512 // tiles))
+        if s > 1:
+            # few output tiles, long reduction: slice K over the chip, add the fp32 partials in a fixed order
+            kc = _pad64(-(-mp // s))
+            s = -(-mp // kc)
+            need = s * lin.n * lin.k
+            if self._part is None or self._part.numel() < need:
+                self._part = torch.empty(need, dtype=torch.float32, device=dev)
+            part = self._part[:need].view(s, lin.n * lin.k)
+            ops.gemm_nt_splitk(dyt, xt, part, kc)
+            ops.colsum(part, gw.view(-1), self.scratch(lin.n * lin.k), accumulate=True)
+        else:
+            ops.gemm_nt(dyt, xt, gw, epilogue=EPI_ACCUM)
         if lin.bias is not None:
             ops.colsum(dy16, _grad(lin.bias), self.scratch(((m + 511) // 512) * lin.n), accumulate=True)
         if not need_dx:
@@ -285,7 +299,7 @@ class OMTrainer:
         dtn = torch.empty_like(tn)
         ops.matmul_f32(dlog.t(), img_n, dtn, alpha=scale)                                  # d tn = s * dlog^T @ img_n
         # d logit_scale += sum(dlog * logits)   (logits = cos * exp(ls) => d logits / d ls = logits)
-        ops.matmul_f32(dlog.view(1, b * n), logits.view(b * n, 1), _grad(m.logit_scale).view(1, 1), accumulate=True)
+        ops.dot_f32(dlog, logits, _grad(m.logit_scale).view(1), accumulate=True)
         dtfeat = torch.empty_like(tfeat)
         ops.l2norm_bwd(tfeat, dtn, dtfeat)
         return dtfeat

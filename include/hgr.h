@@ -339,6 +339,9 @@ int hgr_l2norm_bwd(const float *x, const float *dy, float *dx, int rows, int D, 
 int hgr_matmul_f32(const float *A, int64_t sam, int64_t sak, const float *B, int64_t sbk, int64_t sbn, float *C,
                    int64_t ldc, int M, int N, int K, float alpha, int accumulate, void *stream);
 
+/* out (+)= alpha * <a, b> over n fp32 elements, fixed summation order (d logit_scale = sum(dlogits * logits), clip_tree.py:263). */
+int hgr_dot_f32(const float *a, const float *b, int64_t n, float *out, float alpha, int accumulate, void *stream);
+
 /* token_embedding gradient: dtable[tokens[i,t]] += dx[i*L + t] (fp32 atomics). */
 int hgr_embed_scatter_add(const int64_t *tokens, int64_t ld_tokens, const float *dx, float *dtable, int n, int L,
                           int W, int vocab, void *stream);
