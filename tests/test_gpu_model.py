@@ -185,3 +185,75 @@ def test_uint8_nhwc_input_matches_normalised_float_path():
     ref = clip_ref.encode_image(sd, x)
     assert (f_u8 - f_fp).abs().max() < 2e-3 * max(1.0, float(ref.abs().max()))
     assert (f_u8 - ref).abs().max() < 6e-3 * max(1.0, float(ref.abs().max()))
+
+
+# ---- BASELINE.json configs by name ------------------------------------------------------------------------------------
+def test_config0_rn50_n1000_batch32_vs_cpu_oracle(tmp_path):
+    """BASELINE configs[0]: RN50 zero-shot evaluation, 1 000-class subset, batch 32 - the reference's own CPU-runnable
+    case.  True-dimension RN50 (hash-seeded weights), 1 000-node hierarchy, one batch of 32: HIP logits against the
+    fp32 CPU oracle within the north-star's 1e-3, top-1 equal wherever the oracle's margin exceeds the error band."""
+    cfg = synth.CLIP_CONFIGS["RN50"]
+    sd = synth.clip_state_dict(cfg, 0)
+    n = 1000
+    edges = synth.make_dag(n, 8, 7, 0.05)
+    from hgr_net_amd.hierarchy import build_hierarchy
+    h = build_hierarchy(edges)
+    splits = synth.make_splits(h.nodes, [len(c) == 0 for c in h.p2c], 300, 400, 13)
+    tokens = synth.make_tokens(len(h.nodes), 11, vocab_size=cfg["vocab_size"])
+    model = tree_model(_opts(tmp_path, edges), splits["all"], splits["rest"], node_tokens=tokens, clip_model=build_model(sd).to(DEV))
+    model.update_classifier()
+    img = synth.images(32, 224, 1234)
+    lg = model(img.to(DEV), None).cpu().numpy()
+    zsl = tree_ref.update_classifier(sd, tokens, trim=True)
+    assert np.abs(model.zsl_weights.float().cpu().numpy() - zsl.numpy()).max() < 2e-3
+    ref = tree_ref.forward(sd, img, zsl).numpy()
+    err = float(np.abs(lg - ref).max())
+    assert err < 1e-3, err
+    te = model.test_index.cpu().numpy()
+    got = ops.topk_rows(torch.from_numpy(lg).to(DEV), 1, cols=model.test_index32).cpu().numpy()[:, 0]
+    checked = 0
+    for r in range(32):
+        sub = ref[r, te]
+        o = tree_ref.topk_desc(sub, 2)
+        if sub[o[0]] - sub[o[1]] > 2 * err:
+            assert got[r] == te[o[0]]
+            checked += 1
+    assert checked >= 8
+
+
+def test_config2_rn50_hierarchy_full_size_metrics_consistent():
+    """BASELINE configs[2] sizes: N = 20 842 nodes, 7 400 seen / 13 442 unseen.  The fused evaluation kernel
+    (top-20 over the unseen columns, top-1 over the seen ones, per-level arg-max) against the separate kernels on the
+    same full-size logits, and the counters against a host recount."""
+    n, d, b = 20842, 1024, 48
+    edges = synth.make_dag(n, 12, 7, 0.03)
+    from hgr_net_amd.hierarchy import build_hierarchy
+    h = build_hierarchy(edges)
+    nn_ = len(h.nodes)
+    splits = synth.make_splits(h.nodes, [len(c) == 0 for c in h.p2c], 7400, 13442, 13)
+    idx = {w: i for i, w in enumerate(h.nodes)}
+    tr = torch.tensor([idx[w] for w in splits["train"]], dtype=torch.int32, device=DEV)
+    te = torch.tensor([idx[w] for w in splits["rest"]], dtype=torch.int32, device=DEV)
+    assert tr.numel() == 7400 and te.numel() == 13442
+    depth = torch.tensor([len(p) for p in h.c2p], dtype=torch.int32)
+    z = torch.from_numpy(synth.normal(5, "z2", nn_ * d).astype(np.float32).reshape(nn_, d))
+    z = (z / z.norm(dim=-1, keepdim=True)).half().to(DEV)
+    f = torch.from_numpy(synth.normal(6, "f2", b * d).astype(np.float32).reshape(b, d))
+    f = (f / f.norm(dim=-1, keepdim=True)).half().to(DEV)
+    ld = (nn_ + 63) // 64 * 64
+    lg = torch.empty(b, ld, dtype=torch.float32, device=DEV)
+    ops.gemm_nt(f, z, lg, n=nn_)
+    n_levels = int(depth.max()) + 1
+    index = ops.EvalIndex(depth.to(DEV), tr, te, n_levels)
+    lv, p1, pk = ops.eval_rows(lg, index, 20)
+    assert torch.equal(pk, ops.topk_rows(lg, 20, cols=te))
+    lv2, p12 = ops.level_argmax(lg, depth.to(DEV), n_levels, cols=tr, want_top1=True)
+    assert torch.equal(lv, lv2) and torch.equal(p1, p12)
+    # host recount of the top-1 over the seen columns and of one level
+    sub = lg[:, :nn_].cpu()[:, tr.cpu().long()]
+    assert torch.equal(p1.cpu()[:, 0].long(), tr.cpu().long()[sub.argmax(1)])
+    lvl = 5
+    mask = (depth[tr.cpu().long()] == lvl)
+    if bool(mask.any()):
+        cols = tr.cpu().long()[mask]
+        assert torch.equal(lv.cpu()[:, lvl].long(), cols[lg[:, :nn_].cpu()[:, cols].argmax(1)])
