@@ -257,3 +257,33 @@ def test_config2_rn50_hierarchy_full_size_metrics_consistent():
     if bool(mask.any()):
         cols = tr.cpu().long()[mask]
         assert torch.equal(lv.cpu()[:, lvl].long(), cols[lg[:, :nn_].cpu()[:, cols].argmax(1)])
+
+
+def test_graph_replay_equals_eager_and_survives_changes(golden_dir, tmp_path):
+    """forward() as a HIP graph: bit-identical to eager launches; fresh output tensors; new input buffers, a new batch
+    size and a new classifier each start a clean generation; never-repeating addresses fall back to a static buffer."""
+    meta, z, cfg, edges = _tree_case("smallvit_n300", golden_dir)
+    from hgr_net_amd.hierarchy import build_hierarchy
+    h = build_hierarchy(edges)
+    splits = synth.make_splits(h.nodes, [len(c) == 0 for c in h.p2c], meta["n_train"], meta["n_test"], meta["split_seed"])
+    model = tree_model(_opts(tmp_path, edges), splits["all"], splits["rest"], node_tokens=torch.from_numpy(z["node_tokens"].astype(np.int64)),
+                       clip_model=build_model(synth.clip_state_dict(cfg, 0)).to(DEV))
+    model.update_classifier()
+    res = cfg["image_resolution"]
+    imgs = [synth.images(6, res, 50 + i).to(DEV) for i in range(3)]
+    model.use_graph = False
+    eager = [model(x, None).clone() for x in imgs]
+    model.use_graph = True
+    first = model(imgs[0], None)
+    again = model(imgs[0], None)
+    assert torch.equal(first, eager[0]) and torch.equal(again, eager[0]) and first.data_ptr() != again.data_ptr()
+    for x, e in zip(imgs, eager):                                 # other buffers: captured on first sight, replayed after
+        assert torch.equal(model(x, None), e) and torch.equal(model(x, None), e)
+    x2 = synth.images(10, res, 99).to(DEV)                        # another batch size: new generation
+    model.use_graph = False; e2 = model(x2, None).clone(); model.use_graph = True
+    assert torch.equal(model(x2, None), e2) and torch.equal(model(imgs[1], None), eager[1])
+    keep = []
+    for i in range(12):                                           # a loader that never reuses an address
+        keep.append(imgs[i % 3].clone())                          # all clones stay alive: 12 distinct addresses
+        assert torch.equal(model(keep[-1], None), eager[i % 3])
+    assert model._graph_static is not None
