@@ -243,8 +243,16 @@ def conv3x3_nhwc(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out: torc
                  stride: int = 1) -> torch.Tensor:
     """out NHWC = relu(conv3x3(x NHWC, pad 1) + bias); w [Cout, Kp] in (ky, kx, c) order (BN folded)."""
     assert x.is_contiguous() and w.is_contiguous() and out.is_contiguous() and x.dtype == w.dtype == out.dtype
+    prof = PROFILE
+    if prof is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     _lib.call("hgr_conv3x3_nhwc", _dev(x), _dev(w), _dev(bias), _dev(out), b, h, wd, c, w.shape[0], stride, w.shape[1],
               DT_OF[x.dtype], _stream())
+    if prof is not None:
+        ev1.record()
+        mo = out.shape[0]
+        prof.append(("gemm_nt", ev0, ev1, 2.0 * mo * 9 * c * w.shape[0], float(2 * x.numel() + 2 * w.numel() + 2 * out.numel())))
     return out
 
 
