@@ -25,18 +25,21 @@ def available_models() -> List[str]:
 
 
 def _transform(n_px: int):
-    """Bicubic resize -> center crop -> RGB -> [0,1] tensor -> CLIP mean/std (clip/clip.py:71-78)."""
+    """Bicubic resize -> center crop -> RGB -> [0,1] tensor -> CLIP mean/std (clip/clip.py:71-78): the per-image host
+    callable `clip.load` returns, like the reference's.  Batches go through hgr_net_amd.preprocess.BatchPreprocessor
+    (the same arithmetic on the GPU, bit-exact)."""
     mean = torch.tensor((0.48145466, 0.4578275, 0.40821073)).view(3, 1, 1)
     std = torch.tensor((0.26862954, 0.26130258, 0.27577711)).view(3, 1, 1)
 
     def apply(image):
         import numpy as np
         from PIL import Image
+        from ..preprocess import crop_origin, resized_size         # torchvision's Resize(int) / CenterCrop size rules
         w, h = image.size
-        s = n_px / min(w, h)
-        image = image.resize((max(n_px, round(w * s)), max(n_px, round(h * s))), Image.BICUBIC)
+        if (w, h) != resized_size(w, h, n_px):
+            image = image.resize(resized_size(w, h, n_px), Image.BICUBIC)
         w, h = image.size
-        left, top = (w - n_px) // 2, (h - n_px) // 2
+        left, top = crop_origin(w, h, n_px)
         image = image.crop((left, top, left + n_px, top + n_px)).convert("RGB")
         t = torch.from_numpy(np.asarray(image, dtype=np.float32) / 255.0).permute(2, 0, 1)
         return (t - mean) / std

@@ -119,3 +119,15 @@ def test_loader_without_device_refuses_to_transform(tiny_dataset):
     dm = ds.DataManager_test(_opts(tiny_dataset), "val", META["test"]["node_set"], candidates=["n001"], resolution=16)
     with pytest.raises(RuntimeError):
         next(iter(dm.get_data_loader()))
+
+
+def test_clip_load_preprocess_callable_matches_oracle_transform():
+    """The host `preprocess` callable returned by clip.load (the reference's per-image API) = the oracle transform."""
+    from PIL import Image
+    from hgr_net_amd.clip.clip import _transform
+    from oracle import resample_ref
+    rng = np.random.default_rng(8)
+    for h, w, n in [(53, 37, 16), (40, 64, 32), (32, 32, 32), (33, 47, 32)]:
+        a = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        got = _transform(n)(Image.fromarray(a)).numpy()
+        assert np.array_equal(got, resample_ref.transform(a, n)), (h, w, n)
