@@ -58,6 +58,7 @@ def cpu_baseline(sd, zsl_cpu, seconds_target=15.0, arch="ViT-B/32"):
         lg = tree_ref.forward(sd, img, zsl_cpu)
         lg.topk(20, dim=1)
     dt = time.time() - t0
+    cpu_baseline.last = (img, lg)          # the oracle's logits of this batch: checked against the HIP path below
     return {"value": round(bs * iters / dt, 2), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{iters} x batch {bs} of the same {arch} N={zsl_cpu.shape[0]} forward+top20, oracle/ (torch fp32 CPU), "
                       f"host cpu_count={os.cpu_count()}"}
@@ -241,9 +242,22 @@ def main():
         pcie = {"value": round(a.batch * world * a.steps / el, 1), "unit": "images/sec", "ms_per_step": round(el / a.steps * 1e3, 3),
                 "input": f"uint8 NHWC crops in pinned host memory ({a.batch * r * r * 3 / 1e6:.0f} MB/batch), H2D double-buffered on a copy stream"}
 
-    cpu = None
+    cpu = parity = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(sd, model.zsl_weights.float().cpu(), arch=a.arch)
+        # the metric's parity clause at full size: the HIP path on the oracle's batch (same weights, same class matrix)
+        img_c, lg_c = cpu_baseline.last
+        lg_g = model(img_c.to(dev), None).float().cpu()
+        err = float((lg_g - lg_c).abs().max())
+        te = model.test_index.cpu()
+        sub_c, sub_g = lg_c[:, te], lg_g[:, te]
+        top2 = sub_c.topk(2, dim=1)
+        decidable = (top2.values[:, 0] - top2.values[:, 1]) > 2 * err          # outside the error band of the two paths
+        same = sub_g.argmax(1) == top2.indices[:, 0]
+        parity = {"images": int(img_c.shape[0]), "max_abs_logit_err": round(err, 6), "tolerance": 1e-3,
+                  "hit1_equal": int(same.sum()), "hit1_decidable": int(decidable.sum()), "hit1_equal_decidable": int((same & decidable).sum()),
+                  "note": "HIP logits vs the CPU oracle on one batch of the same workload; hit@1 over the test columns; "
+                          "'decidable' = oracle top-1 margin > 2 x max logit error"}
 
     if rank == 0:
         line = {"metric": "images/sec over 21K-class hierarchy, batch 512; hit@1 parity vs reference",
@@ -254,7 +268,7 @@ def main():
                                        f"+ top-20/top-1/level-argmax metrics (main.py:131-191), N={a.nodes} nodes, batch {a.batch}/GPU",
                            "global_batch": a.batch * world, "parallelism": f"dp{world}", "text_dtype": a.text_dtype,
                            "weights": "random-init (hash-seeded), no checkpoint offline"},
-                "roofline": roof, "cpu_baseline": cpu, "pcie_inclusive": pcie, "metrics_string": summary.strip()}
+                "roofline": roof, "cpu_baseline": cpu, "parity": parity, "pcie_inclusive": pcie, "metrics_string": summary.strip()}
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if group is not None:
