@@ -197,7 +197,7 @@ class tree_model(nn.Module):
     # ---------------------------------------------------------------------------------------------
     def get_contra_ids(self, method, target, depth=None, parents=None):
         """Negative-class candidates + position of the target (clip_tree.py:80-196: 'random', 'topk',
-        'brothers').  Returns (list of node ids with the target inside, index of the target)."""
+        'near_simi', 'brothers').  Returns (list of node ids with the target inside, index of the target)."""
         nc = self.opts.num_compare
         if method == "random":
             ids = random.sample(self.train_index.tolist(), nc)
@@ -220,8 +220,27 @@ class tree_model(nn.Module):
                 ids = copy.copy(self.start_up)
             if len(ids) > nc:
                 ids = random.sample(ids, nc)
+        elif method == "near_simi":
+            # clip_tree.py:143-178: the num_compare prompts most similar to the target's (text cosine under the CURRENT
+            # weights) among the nodes within k levels, ancestors and children excluded.  The reference's version slices
+            # the wrong axis (`argsort(...)[:num_compare]` on a [1, n] tensor) and dies building a ragged tensor; this is
+            # its evident intent.  Candidates are walked in ascending node id (the reference iterates a set of ints).
+            low, high = min(self.d2n.keys()), max(self.d2n.keys())
+            low = max(low, depth - self.opts.k)
+            high = min(high, depth + self.opts.k)
+            cand = set()
+            for d in range(low, high + 1):
+                cand.update(self.d2n[d])
+            cand = sorted(cand - set(parents) - set(self.p2c[target]) - {target})
+            nc = min(nc, len(cand))
+            with torch.no_grad():
+                toks = self.node_tokens[torch.tensor([target] + cand, device=self.node_tokens.device)]
+                f = self.clip_model.encode_text(toks, ctx=self.ctx.data if self.ctx is not None else None).float()
+                f = f / f.norm(dim=-1, keepdim=True)
+                order = (f[1:] @ f[0]).argsort(descending=True, stable=True)[:nc].tolist()
+            ids = [cand[i] for i in order]
         else:
-            raise NotImplementedError(f"sample_strategy {method!r}")
+            raise NotImplementedError(f"sample_strategy {method!r} (the reference's 'simi' reads attributes that do not exist)")
         if target not in ids:
             ids.append(target)
         return ids, ids.index(target)

@@ -309,3 +309,29 @@ def test_driver_over_image_files(golden_dir, tmp_path):
     finally:
         os.chdir(cwd)
     assert got.splitlines()[0] == want.strip().splitlines()[0] and got == want.strip()
+
+
+def test_near_simi_sampling_picks_the_most_similar_prompts(golden_dir, tmp_path):
+    """sample_strategy='near_simi' (clip_tree.py:143-178, intent): candidates within k levels minus ancestors and
+    children, ranked by text cosine to the target's prompt - checked against the fp32 oracle's text features."""
+    from oracle import clip_ref
+    model, meta, cfg = _build("tinyvit_n90", golden_dir, tmp_path, "bf16")
+    model.opts.k, model.opts.num_compare = 2, 6
+    target = max(model.test_index.tolist(), key=lambda i: (len(model.c2p[i]), -i))
+    parents = model.c2p[target] + [target]
+    depth = len(model.c2p[target])
+    ids, pos = model.get_contra_ids("near_simi", target, depth=depth, parents=parents)
+    assert ids[pos] == target and len(ids) == 7 and len(set(ids)) == 7
+    lo, hi = max(0, depth - 2), min(max(model.d2n), depth + 2)
+    cand = sorted(set(n for d in range(lo, hi + 1) for n in model.d2n[d]) - set(parents) - set(model.p2c[target]))
+    assert set(ids[:-1]) <= set(cand)
+    sd = {k: v.detach().float().cpu() for k, v in model.clip_model.state_dict().items()}
+    f = clip_ref.encode_text(sd, model.node_tokens[[target] + cand].cpu())
+    f = f / f.norm(dim=-1, keepdim=True)
+    sim = (f[1:] @ f[0])
+    kth = float(sim.sort(descending=True).values[5])
+    assert all(float(sim[cand.index(i)]) >= kth - 2e-3 for i in ids[:-1])       # the 6 most similar, up to 16-bit tower rounding
+    # and an OM step runs with it
+    img = synth.images(4, cfg["image_resolution"], 3).to(DEV)
+    loss = model.train_batch(img, torch.full((4,), target, dtype=torch.long, device=DEV), "OM", "near_simi")
+    assert np.isfinite(loss)
