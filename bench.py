@@ -88,13 +88,22 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
+    # HGR_TEST_ONE_GPU=1 (development only): every rank on cuda:0 with the gloo backend, so the multi-rank control flow
+    # (sharded text encode + all-gather, batch dealing, counter all-reduce, max-over-ranks timing) can be exercised on a
+    # single-GPU box; RCCL itself refuses two ranks on one device.  Never set by the driver.
+    one_gpu = os.environ.get("HGR_TEST_ONE_GPU") == "1"
+    if one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     group = None
     if world > 1 or os.environ.get("HGR_FORCE_DIST") == "1":              # world 1 under torchrun: exercises the RCCL path on one GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(dev))     # "nccl" is RCCL on ROCm
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(dev))     # "nccl" is RCCL on ROCm
         group = dist.group.WORLD
 
     from hgr_net_amd import evaluate, ops, synth
