@@ -27,8 +27,6 @@ namespace {
 int hgr_gemm_force_tile();
 
 constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;       // one operand, one stage: 16 KB
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;   // A + W
 constexpr int NT = 256;
 
 struct GemmArgs {
@@ -131,9 +129,14 @@ __device__ __forceinline__ void store_quad_full(const GemmArgs &p, f32x4 v, f32x
     else *(typename T16<DT>::vec4 *)((E *)p.C + (int64_t)m * p.ldc + n) = cvt4<DT>(v[0], v[1], v[2], v[3]);
 }
 
-template <int DT, int EPI, bool OUT32, bool CONV = false>
+// TALL = the 4 waves stacked along M: a 256 (M) x 64 (N) tile for outputs at most 64 wide (the 64-channel stages of the
+// ResNet towers), where the square tile would spend half of its MFMAs and LDS traffic on columns that do not exist.
+template <int DT, int EPI, bool OUT32, bool CONV = false, bool TALL = false>
 __global__ __launch_bounds__(NT) void gemm_nt_128(GemmArgs p) {
     typedef typename T16<DT>::vec8 vec8;
+    constexpr int BM = TALL ? 256 : 128, BN = TALL ? 64 : 128;
+    constexpr int PA = BM / 32, PW = BN / 32;              // 4 KB LDS-DMA pieces (32 rows of 128 B) per operand: one per wave each
+    constexpr int TILE_A = BM * BK * 2, STAGE_BYTES = (BM + BN) * BK * 2;
     __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE_BYTES];
     if (p.kc) {                                   // split-K: this workgroup's slice of the reduction, its own partial output
         const int sp = blockIdx.y;
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(NT) void gemm_nt_128(GemmArgs p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = TALL ? wave : wave >> 1, wn = TALL ? 0 : wave & 1;
     const int r = lane & 15, g = lane >> 4;
 
     // XCD-aware, bijective remap of the 1-D grid (cdna_hip_programming.md T1)
@@ -169,17 +172,19 @@ __global__ __launch_bounds__(NT) void gemm_nt_128(GemmArgs p) {
     }
     const int m0 = tm * BM, n0 = tn * BN;
 
-    // per-lane source rows of the 4 + 4 LDS-DMA pieces this thread issues per stage
-    const char *srcA[4], *srcW[4];
-    int cchunk[4];              // CONV: this lane's logical 16-B chunk (8 input channels) inside a K-tile
-    unsigned vmask[4];          // CONV: bit t set = tap t of this output pixel is inside the image
+    // per-lane source rows of the PA + PW LDS-DMA pieces this thread issues per stage
+    const char *srcA[PA], *srcW[PW];
+    int cchunk[PA];             // CONV: this lane's logical 16-B chunk (8 input channels) inside a K-tile
+    unsigned vmask[PA];         // CONV: bit t set = tap t of this output pixel is inside the image
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int id = (i * 4 + wave) * 64 + lane;    // 16-B chunk id inside the 128 x 64 tile
+    for (int i = 0; i < PA; ++i) {
+        const int id = (i * 4 + wave) * 64 + lane;    // 16-B chunk id inside the BM x 64 tile
         const int row = id >> 3, c = (id & 7) ^ (row & 7);
         const int gm = min(m0 + row, p.M - 1);        // edge rows: load a valid row, never store it
-        const int gn = min(n0 + row, p.N - 1);
-        srcW[i] = p.W + ((int64_t)gn * p.ldw + c * 8) * 2;
+        if (i < PW) {
+            const int gn = min(n0 + row, p.N - 1);
+            srcW[i] = p.W + ((int64_t)gn * p.ldw + c * 8) * 2;
+        }
         if (CONV) {
             // output pixel (b, ho, wo) of row gm; tap (ky, kx) reads input pixel (ho*s - 1 + ky, wo*s - 1 + kx)
             const int wo = gm % p.cWo, t1 = gm / p.cWo, ho = t1 % p.cHo, b = t1 / p.cHo;
@@ -200,10 +205,10 @@ __global__ __launch_bounds__(NT) void gemm_nt_128(GemmArgs p) {
 
     auto stage = [&](int buf, int kt) {
         char *sA = smem + buf * STAGE_BYTES;
-        char *sW = sA + TILE_BYTES;
+        char *sW = sA + TILE_A;
         const int64_t koff = (int64_t)kt * BK * 2;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < PA; ++i) {
             const char *src;
             if (CONV) {
                 // implicit im2col: K index = tap * C + channel (C a power of two >= 8), 8 channels per chunk
@@ -218,7 +223,7 @@ __global__ __launch_bounds__(NT) void gemm_nt_128(GemmArgs p) {
             __builtin_amdgcn_global_load_lds((const AS1 void *)src, (AS3 void *)(sA + (i * 4 + wave) * 1024), 16, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < PW; ++i)
             __builtin_amdgcn_global_load_lds((const AS1 void *)(srcW[i] + koff),
                                              (AS3 void *)(sW + (i * 4 + wave) * 1024), 16, 0, 0);
     };
@@ -244,7 +249,7 @@ __global__ __launch_bounds__(NT) void gemm_nt_128(GemmArgs p) {
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
         const char *sA = smem + cur * STAGE_BYTES;
-        const char *sW = sA + TILE_BYTES;
+        const char *sW = sA + TILE_A;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int sw = kk ? sw1 : sw0;
@@ -731,6 +736,14 @@ extern "C" int hgr_gemm_nt(const void *A, int64_t lda, const void *W, int64_t ld
         a.m_fastest = ((int64_t)N * K > (int64_t)m_cnt * K) ? 1 : 0;
         a.vec_ok = vec ? 1 : 0;
         a.dbg = dbg; a.kc = 0; a.csplit = 0;
+        // outputs at most 64 wide (1x1 convolutions into the 64-channel ResNet stages): the 256 x 64 arrangement of the small kernel
+        if (!big && N <= 64 && m_cnt >= 1024 && epilogue == HGR_EPI_BIAS_RELU && !out_f32) {
+            a.tiles_m = (m_cnt + 255) / 256; a.tiles_n = 1;
+            dim3 gt((unsigned)a.tiles_m);
+            if (dtype == HGR_BF16) hipLaunchKernelGGL((gemm_nt_128<HGR_BF16, HGR_EPI_BIAS_RELU, false, false, true>), gt, dim3(NT), 0, s, a);
+            else hipLaunchKernelGGL((gemm_nt_128<HGR_F16, HGR_EPI_BIAS_RELU, false, false, true>), gt, dim3(NT), 0, s, a);
+            return;
+        }
         dim3 grid((unsigned)(a.tiles_m * a.tiles_n));
         if (dtype == HGR_BF16) launch_dt<HGR_BF16>(a, epilogue, out_f32 != 0, grid, s, big);
         else launch_dt<HGR_F16>(a, epilogue, out_f32 != 0, grid, s, big);
@@ -794,6 +807,19 @@ static int conv3x3_launch(const void *x, const void *w, const float *bias, void 
         if (dtype == HGR_BF16) hipLaunchKernelGGL((gemm_nt_256<HGR_BF16, HGR_EPI_BIAS_RELU, false, true>), grid, dim3(NT256), 0, (hipStream_t)stream, a);
         else hipLaunchKernelGGL((gemm_nt_256<HGR_F16, HGR_EPI_BIAS_RELU, false, true>), grid, dim3(NT256), 0, (hipStream_t)stream, a);
     } else {
+        if (Cout <= 64 && a.M >= 1024) {              // tall 256 x 64 tiles: no MFMAs spent on columns that do not exist
+            a.tiles_m = (a.M + 255) / 256; a.tiles_n = 1;
+            dim3 gt((unsigned)a.tiles_m);
+            if (relu) {
+                if (dtype == HGR_BF16) hipLaunchKernelGGL((gemm_nt_128<HGR_BF16, HGR_EPI_BIAS_RELU, false, true, true>), gt, dim3(NT), 0, (hipStream_t)stream, a);
+                else hipLaunchKernelGGL((gemm_nt_128<HGR_F16, HGR_EPI_BIAS_RELU, false, true, true>), gt, dim3(NT), 0, (hipStream_t)stream, a);
+            } else {
+                if (dtype == HGR_BF16) hipLaunchKernelGGL((gemm_nt_128<HGR_BF16, HGR_EPI_NONE, false, true, true>), gt, dim3(NT), 0, (hipStream_t)stream, a);
+                else hipLaunchKernelGGL((gemm_nt_128<HGR_F16, HGR_EPI_NONE, false, true, true>), gt, dim3(NT), 0, (hipStream_t)stream, a);
+            }
+            HGR_CHECK_LAUNCH("hgr_conv3x3_nhwc");
+            return HGR_OK;
+        }
         dim3 grid((unsigned)(a.tiles_m * a.tiles_n));
         if (relu) {
             if (dtype == HGR_BF16) hipLaunchKernelGGL((gemm_nt_128<HGR_BF16, HGR_EPI_BIAS_RELU, false, true>), grid, dim3(NT), 0, (hipStream_t)stream, a);

@@ -253,7 +253,10 @@ def test_level_argmax_exact(n, levels):
 # ---- ModifiedResNet kernels ------------------------------------------------------------------------
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("b,h,w,c,cout,stride", [(2, 8, 8, 64, 64, 1), (1, 7, 9, 32, 32, 1), (3, 14, 14, 128, 128, 1),
-                                                  (2, 16, 16, 8, 16, 1), (2, 12, 12, 64, 128, 2), (1, 5, 5, 512, 512, 1)])
+                                                  (2, 16, 16, 8, 16, 1), (2, 12, 12, 64, 128, 2), (1, 5, 5, 512, 512, 1),
+                                                  # >= 1024 output pixels and <= 64 channels: the tall 256 x 64 tile variant
+                                                  (5, 16, 16, 64, 64, 1), (3, 20, 19, 32, 32, 1), (9, 12, 12, 32, 64, 1),
+                                                  (2, 48, 48, 64, 64, 2)])
 def test_conv3x3_implicit_gemm_vs_conv2d(dt, b, h, w, c, cout, stride):
     x = _rand((b, c, h, w), 60).to(dt)                       # NCHW reference layout
     wt = _rand((cout, c, 3, 3), 61, (2.0 / (9 * c)) ** 0.5).to(dt)
@@ -284,6 +287,22 @@ def test_gemm_relu_epilogues(dt):
     assert torch.allclose(out.float().cpu(), torch.relu(base), **tol)
     ops.gemm_nt(a.to(DEV), w.to(DEV), out, bias=bias.to(DEV), residual=idn.to(DEV), epilogue=5)
     assert torch.allclose(out.float().cpu(), torch.relu(base + idn.float()), **tol)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("m,n,k", [(1500, 64, 256), (1024, 40, 64), (4097, 64, 576)])
+def test_gemm_tall_tiles_for_narrow_outputs(dt, m, n, k):
+    """N <= 64 with a fused bias + ReLU (1x1 convolutions into the 64-channel ResNet stages) runs the 256 x 64 tile
+    arrangement: ragged M and N edges, integer operands so that the comparison is exact."""
+    gen = torch.Generator().manual_seed(m + n)
+    a = torch.randint(-2, 3, (m, k), generator=gen).float()
+    w = torch.randint(-1, 2, (n, k), generator=gen).float()
+    bias = torch.randint(-4, 5, (n,), generator=gen).float()
+    ld = (n + 7) // 8 * 8
+    out = torch.full((m, ld), 3.0, dtype=dt, device=DEV)
+    ops.gemm_nt(a.to(dt).to(DEV), w.to(dt).to(DEV), out, bias=bias.to(DEV), epilogue=4, n=n)
+    assert torch.equal(out[:, :n].float().cpu(), torch.relu(a @ w.t() + bias).to(dt).float())
+    assert (out[:, n:] == 3.0).all()
 
 
 @pytest.mark.parametrize("dt", DTS)
