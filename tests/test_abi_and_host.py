@@ -193,3 +193,12 @@ def test_resize_and_crop_rules():
     assert preprocess.resized_size(500, 375, 224) == (298, 224)
     assert preprocess.crop_origin(298, 224, 224) == (37, 0)
     assert preprocess.crop_origin(229, 224, 224) == (2, 0)          # (229 - 224) / 2 = 2.5 rounds half to even
+
+
+def test_product_package_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under the product package may import it."""
+    import re
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent / "hgr-net_amd"
+    offenders = [str(p) for p in root.rglob("*.py") if re.search(r"^\s*(from|import)\s+oracle\b", p.read_text(), re.M)]
+    assert not offenders, offenders
