@@ -19,8 +19,7 @@ _PAT = re.compile(r"""<\|startoftext\|>|<\|endoftext\|>|'s|'t|'re|'ve|'m|'ll|'d|
 
 
 def default_bpe_path() -> str:
-    for cand in (os.environ.get("HGR_BPE_VOCAB"), "clip/bpe_simple_vocab_16e6.txt.gz",
-                 "/root/reference/clip/bpe_simple_vocab_16e6.txt.gz"):
+    for cand in (os.environ.get("HGR_BPE_VOCAB"), "clip/bpe_simple_vocab_16e6.txt.gz"):      # env, or a reference checkout as cwd
         if cand and os.path.isfile(cand):
             return cand
     raise FileNotFoundError("BPE merges file not found: set HGR_BPE_VOCAB to the reference's clip/bpe_simple_vocab_16e6.txt.gz")
