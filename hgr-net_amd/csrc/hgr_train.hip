@@ -167,24 +167,39 @@ __global__ __launch_bounds__(256) void layernorm_bwd(const void *__restrict__ dy
 // P is recomputed from the row statistics (flash-attention style), nothing of size L x L is ever stored.
 struct Tile { float (*t)[65]; };
 
-__device__ __forceinline__ void mm64(f32x16 &acc, const float (*A)[65], bool ta, const float (*B)[65], bool tb, int lane, int wr, int wc) {
-    // acc(32x32 quadrant wr, wc) += sum_k A'(i, k) * B'(k, j), A' = ta ? A^T : A, B' = tb ? B^T : B
-    const int r = lane & 31, h = lane >> 5;
-    const int i = wr * 32 + r, j = wc * 32 + r;
-#pragma unroll 8
-    for (int k = 0; k < 64; k += 2) {
-        const float av = ta ? A[k + h][i] : A[i][k + h];
-        const float bv = tb ? B[j][k + h] : B[k + h][j];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
-    }
-}
+// C/D layout of the 32x32 MFMA shapes: accumulator register g of lane (r32, h) holds row HGR_ACC_ROW(g, h), column r32
 #define HGR_ACC_ROW(reg, h) (((reg) & 3) + 8 * ((reg) >> 2) + 4 * (h))
+
+// ---- attention backward, 32 < L <= 320 (ViT image towers: 50 / 197 / 257 tokens; untrimmed text: 77) --------------------
+// One workgroup per (batch, head), 4 waves, 64 x 64 blocks of the L x L score matrix, every product on the 16-bit matrix
+// cores (v_mfma_f32_32x32x16, fp32 accumulate; a wave owns a 32 x 32 quadrant).  Flash-attention style, two sweeps:
+//   sweep 0   D = rowsum(dO * O) and the softmax statistics (row max, 1 / row sum) by recomputing S = Q K^T block by block;
+//   sweep 1   for every key block j:  for every query block i:  S, dP = dO V^T  ->  P, dS = P (dP - D) / 8 in registers  ->
+//             dV_j += P^T dO_i,  dK_j += dS^T Q_i,  dQ_i += dS K_j.   dQ of ALL query blocks lives in registers (5 x 16 per
+//             lane), so nothing is recomputed a second time and there are no atomics.
+// P and dS are rounded to the 16-bit type before the second products (as the forward's P is); Q, K, V, dO are 16-bit in
+// memory anyway.  An MFMA operand is 8 consecutive k for one row, so a transposed product needs the transposed tile: Q, dO
+// (per query block) and K (per key block) are staged both ways, P^T / dS / dS^T are written from the accumulator layout
+// (4 consecutive rows per lane -> one 8-byte store in the transposed image).  LDS rows are padded to 72 elements: the
+// 16-byte operand reads of 32 consecutive rows are bank-conflict free.
+template <int DT>
+__device__ __forceinline__ void mm16(f32x16 &acc, const typename T16<DT>::elem (*A)[72], int arow, const typename T16<DT>::elem (*B)[72], int brow, int lane) {
+    typedef typename T16<DT>::vec8 vec8;
+    const int r = lane & 31, kh = lane >> 5;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+        acc = T16<DT>::mfma32(*(const vec8 *)&A[arow + r][kk * 16 + kh * 8], *(const vec8 *)&B[brow + r][kk * 16 + kh * 8], acc);
+}
 
 template <int DT, bool CAUSAL>
 __global__ __launch_bounds__(256) void mha_bwd_tiled(const typename T16<DT>::elem *__restrict__ qkv, const typename T16<DT>::elem *__restrict__ outp,
                                                      const typename T16<DT>::elem *__restrict__ dout, typename T16<DT>::elem *__restrict__ dqkv, int L, int H) {
     typedef typename T16<DT>::elem E;
-    __shared__ float sQ[64][65], sK[64][65], sV[64][65], sO[64][65], sP[64][65], sD[64][65];
+    typedef typename T16<DT>::vec8 vec8;
+    typedef typename T16<DT>::vec4 vec4;
+    __shared__ __attribute__((aligned(16))) E sQ[64][72], sQt[64][72], sK[64][72], sKt[64][72], sV[64][72], sO[64][72], sOt[64][72],
+        sDS[64][72], sDSt[64][72], sPt[64][72];
+    __shared__ float sS[64][65];
     __shared__ float rM[320], rLinv[320], rD[320];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
     const int r32 = lane & 31, hh = lane >> 5;
@@ -197,15 +212,22 @@ __global__ __launch_bounds__(256) void mha_bwd_tiled(const typename T16<DT>::ele
     E *dqb = dqkv + (int64_t)b * L * ld + h * 64;
     const int nb = (L + 63) / 64;
 
-    auto load = [&](float (*dst)[65], const E *src, int64_t stride, int r0) {
-        for (int i = tid; i < 64 * 64; i += 256) {
-            const int r = i >> 6, c = i & 63;
-            dst[r][c] = (r0 + r < L) ? (float)src[(int64_t)(r0 + r) * stride + c] : 0.f;
-        }
-    };
-    auto store_acc = [&](float (*dst)[65], const f32x16 &acc) {
+    // 64 x 64 block of 16-bit rows -> LDS row-major (and transposed if dt != nullptr); rows past L are zero
+    auto load = [&](E (*dst)[72], E (*dt)[72], const E *src, int64_t stride, int r0) {
 #pragma unroll
-        for (int g = 0; g < 16; ++g) dst[wr * 32 + HGR_ACC_ROW(g, hh)][wc * 32 + r32] = acc[g];
+        for (int j = 0; j < 2; ++j) {
+            const int id = tid + 256 * j;                  // 512 chunks of 8 elements
+            const int r = id >> 3, c = (id & 7) * 8;
+            vec8 v;
+            if (r0 + r < L) v = *(const vec8 *)(src + (int64_t)(r0 + r) * stride + c);
+            else
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (E)0.f;
+            *(vec8 *)&dst[r][c] = v;
+            if (dt)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dt[c + e][r] = v[e];
+        }
     };
     auto write_rows = [&](E *dstg, int64_t stride, int r0, const f32x16 &acc) {      // 16-bit global rows from an accumulator quadrant
 #pragma unroll
@@ -220,37 +242,37 @@ __global__ __launch_bounds__(256) void mha_bwd_tiled(const typename T16<DT>::ele
     // ---- sweep 0: row statistics ---------------------------------------------------------------------------------------------------------
     for (int qi = 0; qi < nb; ++qi) {
         __syncthreads();
-        load(sQ, base, ld, qi * 64);
-        load(sO, dob, W, qi * 64);
-        load(sV, ob, W, qi * 64);                              // forward output O of this query block (in sV for the moment)
+        load(sQ, nullptr, base, ld, qi * 64);
+        load(sO, nullptr, dob, W, qi * 64);
+        load(sV, nullptr, ob, W, qi * 64);                     // forward output O of this query block (in sV for the moment)
         __syncthreads();
         {   // D = rowsum(dO * O): 4 threads per row
             const int row = tid >> 2, part = tid & 3;
             float acc = 0.f;
-            for (int d = part; d < 64; d += 4) acc += sO[row][d] * sV[row][d];
+            for (int d = part * 16; d < part * 16 + 16; ++d) acc += (float)sO[row][d] * (float)sV[row][d];
             acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2);
             if (part == 0) { rD[qi * 64 + row] = acc; rM[qi * 64 + row] = -INFINITY; rLinv[qi * 64 + row] = 0.f; }
         }
         for (int kj = 0; kj < nb; ++kj) {
             if (CAUSAL && kj > qi) break;
             __syncthreads();
-            load(sK, base + W, ld, kj * 64);
+            load(sK, nullptr, base + W, ld, kj * 64);
             __syncthreads();
             f32x16 acc = {0.f};
-            mm64(acc, sQ, false, sK, true, lane, wr, wc);
+            mm16<DT>(acc, sQ, wr * 32, sK, wc * 32, lane);
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 const int rr = wr * 32 + HGR_ACC_ROW(g, hh), cc = wc * 32 + r32;
-                sP[rr][cc] = score(acc[g], qi * 64 + rr, kj * 64 + cc);
+                sS[rr][cc] = score(acc[g], qi * 64 + rr, kj * 64 + cc);
             }
             __syncthreads();
             const int row = tid >> 2, part = tid & 3;
             float mb = -INFINITY;
-            for (int c = part; c < 64; c += 4) mb = fmaxf(mb, sP[row][c]);
+            for (int c = part; c < 64; c += 4) mb = fmaxf(mb, sS[row][c]);
             mb = fmaxf(mb, __shfl_xor(mb, 1)); mb = fmaxf(mb, __shfl_xor(mb, 2));
             const float mo = rM[qi * 64 + row], mn = fmaxf(mo, mb);
             float sum = 0.f;
-            if (mn > -INFINITY) for (int c = part; c < 64; c += 4) sum += __expf(sP[row][c] - mn);
+            if (mn > -INFINITY) for (int c = part; c < 64; c += 4) sum += __expf(sS[row][c] - mn);
             sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2);
             if (part == 0) {
                 rLinv[qi * 64 + row] = rLinv[qi * 64 + row] * (mo > -INFINITY ? __expf(mo - mn) : 0.f) + sum;   // running sum for now
@@ -262,64 +284,54 @@ __global__ __launch_bounds__(256) void mha_bwd_tiled(const typename T16<DT>::ele
     for (int i = tid; i < nb * 64; i += 256) rLinv[i] = (i < L && rLinv[i] > 0.f) ? 1.0f / rLinv[i] : 0.f;
     __syncthreads();
 
-    // P and dS quadrant of block (qi, kj) in registers (accumulator layout), operands already staged
-    auto p_and_ds = [&](int qi, int kj, f32x16 &pp, f32x16 &ds) {
-        f32x16 sacc = {0.f}, dp = {0.f};
-        mm64(sacc, sQ, false, sK, true, lane, wr, wc);         // S = Q K^T
-        mm64(dp, sO, false, sV, true, lane, wr, wc);           // dP = dO V^T
+    // ---- sweep 1: dK, dV per key block, dQ of every query block accumulated in registers -------------------------------------------------
+    f32x16 dq[5];
 #pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            const int rr = wr * 32 + HGR_ACC_ROW(g, hh), cc = wc * 32 + r32;
-            const int q = qi * 64 + rr;
-            const float sc = score(sacc[g], q, kj * 64 + cc);
-            const float pv = (sc > -INFINITY) ? __expf(sc - rM[q]) * rLinv[q] : 0.f;
-            pp[g] = pv;
-            ds[g] = pv * (dp[g] - rD[q]) * 0.125f;
-        }
-    };
-
-    // ---- sweep 1: dQ ---------------------------------------------------------------------------------------------------------------------
-    for (int qi = 0; qi < nb; ++qi) {
-        __syncthreads();
-        load(sQ, base, ld, qi * 64);
-        load(sO, dob, W, qi * 64);
-        f32x16 dq = {0.f};
-        for (int kj = 0; kj < nb; ++kj) {
-            if (CAUSAL && kj > qi) break;
-            __syncthreads();
-            load(sK, base + W, ld, kj * 64);
-            load(sV, base + 2 * W, ld, kj * 64);
-            __syncthreads();
-            f32x16 pp, ds;
-            p_and_ds(qi, kj, pp, ds);
-            store_acc(sD, ds);
-            __syncthreads();
-            mm64(dq, sD, false, sK, false, lane, wr, wc);      // dQ += dS K
-        }
-        write_rows(dqb, ld, qi * 64, dq);
-    }
-    // ---- sweep 2: dK, dV -----------------------------------------------------------------------------------------------------------------
+    for (int i = 0; i < 5; ++i) dq[i] = (f32x16){0.f};
     for (int kj = 0; kj < nb; ++kj) {
         __syncthreads();
-        load(sK, base + W, ld, kj * 64);
-        load(sV, base + 2 * W, ld, kj * 64);
+        load(sK, sKt, base + W, ld, kj * 64);
+        load(sV, nullptr, base + 2 * W, ld, kj * 64);
         f32x16 dk = {0.f}, dv = {0.f};
-        for (int qi = CAUSAL ? kj : 0; qi < nb; ++qi) {
+#pragma unroll
+        for (int qi = 0; qi < 5; ++qi) {
+            if (qi >= nb || (CAUSAL && qi < kj)) continue;       // block-uniform
             __syncthreads();
-            load(sQ, base, ld, qi * 64);
-            load(sO, dob, W, qi * 64);
+            load(sQ, sQt, base, ld, qi * 64);
+            load(sO, sOt, dob, W, qi * 64);
             __syncthreads();
-            f32x16 pp, ds;
-            p_and_ds(qi, kj, pp, ds);
-            store_acc(sP, pp);
-            store_acc(sD, ds);
+            f32x16 sacc = {0.f}, dp = {0.f};
+            mm16<DT>(sacc, sQ, wr * 32, sK, wc * 32, lane);       // S = Q K^T
+            mm16<DT>(dp, sO, wr * 32, sV, wc * 32, lane);         // dP = dO V^T
+            const int cc = wc * 32 + r32;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {                      // 4 consecutive rows of this lane's column per step
+                vec4 p4, d4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int g = g4 * 4 + e;
+                    const int rr = wr * 32 + HGR_ACC_ROW(g, hh), q = qi * 64 + rr;
+                    const float sc = score(sacc[g], q, kj * 64 + cc);
+                    const float pv = (sc > -INFINITY) ? __expf(sc - rM[q]) * rLinv[q] : 0.f;
+                    const float dsv = pv * (dp[g] - rD[q]) * 0.125f;
+                    p4[e] = (E)pv; d4[e] = (E)dsv;
+                    sDS[rr][cc] = (E)dsv;
+                }
+                const int rr0 = wr * 32 + HGR_ACC_ROW(g4 * 4, hh);
+                *(vec4 *)&sPt[cc][rr0] = p4;                      // transposed images: [key][query]
+                *(vec4 *)&sDSt[cc][rr0] = d4;
+            }
             __syncthreads();
-            mm64(dv, sP, true, sO, false, lane, wr, wc);       // dV += P^T dO
-            mm64(dk, sD, true, sQ, false, lane, wr, wc);       // dK += dS^T Q
+            mm16<DT>(dv, sPt, wr * 32, sOt, wc * 32, lane);       // dV += P^T dO      (rows = keys, columns = d)
+            mm16<DT>(dk, sDSt, wr * 32, sQt, wc * 32, lane);      // dK += dS^T Q
+            mm16<DT>(dq[qi], sDS, wr * 32, sKt, wc * 32, lane);   // dQ_i += dS K
         }
         write_rows(dqb + W, ld, kj * 64, dk);
         write_rows(dqb + 2 * W, ld, kj * 64, dv);
     }
+#pragma unroll
+    for (int qi = 0; qi < 5; ++qi)
+        if (qi < nb) write_rows(dqb, ld, qi * 64, dq[qi]);
 }
 
 // Same arithmetic for short sequences (text prompts are ~8-20 tokens after EOT trimming): LP = 16 or 32 padded
