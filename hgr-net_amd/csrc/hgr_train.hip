@@ -9,7 +9,7 @@ namespace {
 unsigned grid1(int64_t total, int per = 256, int cap = 16384) { int64_t g = (total + per - 1) / per; return (unsigned)(g < cap ? (g > 0 ? g : 1) : cap); }
 
 // ---- y[c][r] = x[r][c], 16-bit, 64 x 64 tiles through LDS ------------------------------------------------
-__global__ __launch_bounds__(256) void transpose16(const unsigned short *__restrict__ x, int64_t ldx, unsigned short *__restrict__ y, int64_t ldy, int rows, int cols) {
+__global__ __launch_bounds__(256) void transpose16_scalar(const unsigned short *__restrict__ x, int64_t ldx, unsigned short *__restrict__ y, int64_t ldy, int rows, int cols) {
     __shared__ unsigned short t[64][66];
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -21,6 +21,41 @@ __global__ __launch_bounds__(256) void transpose16(const unsigned short *__restr
     for (int i = ty; i < 64; i += 4) {
         const int c = c0 + i, r = r0 + tx;
         if (c < cols && r < rows) y[(int64_t)c * ldy + r] = t[tx][i];
+    }
+}
+
+// 64 x 64 tile, 16-byte global loads and stores (8 elements): rows in, rows out; the transposition happens in the LDS
+// reads (8 two-byte reads of one column per thread).  Needs ldx, ldy % 8 == 0 and 16-byte aligned bases; ragged edges
+// are handled element-wise.
+__global__ __launch_bounds__(256) void transpose16(const unsigned short *__restrict__ x, int64_t ldx, unsigned short *__restrict__ y, int64_t ldy, int rows, int cols) {
+    typedef __attribute__((ext_vector_type(8))) unsigned short us8;
+    __shared__ __attribute__((aligned(16))) unsigned short t[64][72];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int id = threadIdx.x + 256 * j;
+        const int r = id >> 3, c = (id & 7) * 8;
+        us8 v;
+        if (r0 + r < rows && c0 + c + 7 < cols) v = *(const us8 *)(x + (int64_t)(r0 + r) * ldx + c0 + c);
+        else
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (r0 + r < rows && c0 + c + e < cols) ? x[(int64_t)(r0 + r) * ldx + c0 + c + e] : (unsigned short)0;
+        *(us8 *)&t[r][c] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int id = threadIdx.x + 256 * j;
+        const int oc = id >> 3, o8 = (id & 7) * 8;          // output row = input column oc; 8 consecutive input rows
+        if (c0 + oc >= cols) continue;
+        us8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = t[o8 + e][oc];
+        unsigned short *dst = y + (int64_t)(c0 + oc) * ldy + r0 + o8;
+        if (r0 + o8 + 7 < rows) *(us8 *)dst = v;
+        else
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (r0 + o8 + e < rows) dst[e] = v[e];
     }
 }
 
@@ -608,7 +643,11 @@ __global__ __launch_bounds__(256) void rows_gather(float *__restrict__ dst, cons
 
 extern "C" int hgr_transpose16(const void *x, int64_t ldx, void *y, int64_t ldy, int rows, int cols, void *stream) {
     HGR_REQUIRE(x && y && rows >= 1 && cols >= 1 && ldx >= cols && ldy >= rows, "hgr_transpose16: bad arguments");
-    hipLaunchKernelGGL(transpose16, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const unsigned short *)x, ldx, (unsigned short *)y, ldy, rows, cols);
+    const dim3 grid((cols + 63) / 64, (rows + 63) / 64);
+    if (ldx % 8 == 0 && ldy % 8 == 0 && hgr_aligned(x, 16) && hgr_aligned(y, 16))
+        hipLaunchKernelGGL(transpose16, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short *)x, ldx, (unsigned short *)y, ldy, rows, cols);
+    else
+        hipLaunchKernelGGL(transpose16_scalar, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short *)x, ldx, (unsigned short *)y, ldy, rows, cols);
     HGR_CHECK_LAUNCH("hgr_transpose16");
     return HGR_OK;
 }
