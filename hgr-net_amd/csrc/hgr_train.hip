@@ -74,6 +74,39 @@ __global__ __launch_bounds__(256) void colsum_partial(const void *__restrict__ x
     __syncthreads();
     if (q == 0 && c < cols) partial[(int64_t)blockIdx.y * cols + c] = s[0][threadIdx.x] + s[1][threadIdx.x] + s[2][threadIdx.x] + s[3][threadIdx.x];
 }
+// 16-byte loads: 8 (16-bit) or 4 (fp32) columns per thread, 64 columns and up to 512 rows per block like colsum_partial;
+// the row groups are combined through LDS in a fixed order.  Needs 16-byte aligned rows (ldx, base) and cols % 64 == 0.
+template <int DT, bool F32>
+__global__ __launch_bounds__(256) void colsum_partial_vec(const void *__restrict__ x, int64_t ldx, int rows, int cols, float *__restrict__ partial) {
+    typedef typename T16<DT>::vec8 vec8;
+    constexpr int CPT = F32 ? 4 : 8, TX = 64 / CPT, TY = 256 / TX;       // columns per thread, threads across, row groups
+    __shared__ float s[TY][64];
+    const int cx = threadIdx.x % TX, ry = threadIdx.x / TX;
+    const int c = blockIdx.x * 64 + cx * CPT;
+    const int r0 = blockIdx.y * 512, r1 = min(rows, r0 + 512);
+    float acc[CPT];
+#pragma unroll
+    for (int e = 0; e < CPT; ++e) acc[e] = 0.f;
+    for (int r = r0 + ry; r < r1; r += TY) {
+        if (F32) {
+            const f32x4 v = *(const f32x4 *)((const float *)x + (int64_t)r * ldx + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += v[e];
+        } else {
+            const vec8 v = *(const vec8 *)((const typename T16<DT>::elem *)x + (int64_t)r * ldx + c);
+#pragma unroll
+            for (int e = 0; e < CPT; ++e) acc[e] += (float)v[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < CPT; ++e) s[ry][cx * CPT + e] = acc[e];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float t = 0.f;
+        for (int g = 0; g < TY; ++g) t += s[g][threadIdx.x];
+        partial[(int64_t)blockIdx.y * cols + blockIdx.x * 64 + threadIdx.x] = t;
+    }
+}
 __global__ __launch_bounds__(256) void colsum_final(const float *__restrict__ partial, int nrb, int cols, float *__restrict__ out, int accumulate, float alpha) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= cols) return;
@@ -658,7 +691,12 @@ extern "C" int hgr_colsum(const void *x, int64_t ldx, int rows, int cols, int x_
     const int nrb = (rows + 511) / 512;
     dim3 g((cols + 63) / 64, nrb);
     hipStream_t s = (hipStream_t)stream;
-    if (x_f32) hipLaunchKernelGGL((colsum_partial<HGR_BF16, true>), g, dim3(256), 0, s, x, ldx, rows, cols, scratch);
+    const bool vec = cols % 64 == 0 && hgr_aligned(x, 16) && ldx % (x_f32 ? 4 : 8) == 0 && rows >= 32;
+    if (vec) {
+        if (x_f32) hipLaunchKernelGGL((colsum_partial_vec<HGR_BF16, true>), g, dim3(256), 0, s, x, ldx, rows, cols, scratch);
+        else if (dtype == HGR_BF16) hipLaunchKernelGGL((colsum_partial_vec<HGR_BF16, false>), g, dim3(256), 0, s, x, ldx, rows, cols, scratch);
+        else hipLaunchKernelGGL((colsum_partial_vec<HGR_F16, false>), g, dim3(256), 0, s, x, ldx, rows, cols, scratch);
+    } else if (x_f32) hipLaunchKernelGGL((colsum_partial<HGR_BF16, true>), g, dim3(256), 0, s, x, ldx, rows, cols, scratch);
     else if (dtype == HGR_BF16) hipLaunchKernelGGL((colsum_partial<HGR_BF16, false>), g, dim3(256), 0, s, x, ldx, rows, cols, scratch);
     else hipLaunchKernelGGL((colsum_partial<HGR_F16, false>), g, dim3(256), 0, s, x, ldx, rows, cols, scratch);
     hipLaunchKernelGGL(colsum_final, dim3((cols + 255) / 256), dim3(256), 0, s, scratch, nrb, cols, out, accumulate, alpha);

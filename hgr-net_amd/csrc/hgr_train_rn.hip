@@ -91,19 +91,25 @@ template <int DT>
 __global__ __launch_bounds__(256) void im2col3x3_t(const typename T16<DT>::elem *__restrict__ xt, typename T16<DT>::elem *__restrict__ out,
                                                    int H, int W, int C, int64_t M, int64_t ld) {
     typedef typename T16<DT>::elem E;
+    typedef typename T16<DT>::vec8 vec8;
     const int row = blockIdx.y;                  // t * C + c
     const int t = row / C, c = row - t * C;
     const int dy = t / 3 - 1, dx = t % 3 - 1;
     const E *src = xt + (int64_t)c * ld;
     E *dst = out + (int64_t)row * ld;
-    for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < ld; m += (int64_t)gridDim.x * 256) {
-        E v = (E)0.f;
-        if (m < M) {
-            const int w = (int)(m % W), h = (int)((m / W) % H);
+    const int64_t shift = (int64_t)dy * W + dx;
+    // 8 consecutive pixels per thread: the shifted source is 2-byte misaligned (scalar loads, served by L1), the store is 16 B
+    for (int64_t m0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8; m0 < ld; m0 += (int64_t)gridDim.x * 2048) {
+        vec8 v;
+        int w = (int)(m0 % W), h = (int)((m0 / W) % H);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int64_t m = m0 + e;
             const int hh = h + dy, ww = w + dx;
-            if (hh >= 0 && hh < H && ww >= 0 && ww < W) v = src[m + (int64_t)dy * W + dx];
+            v[e] = (m < M && hh >= 0 && hh < H && ww >= 0 && ww < W) ? src[m + shift] : (E)0.f;
+            if (++w == W) { w = 0; if (++h == H) h = 0; }
         }
-        dst[m] = v;
+        *(vec8 *)(dst + m0) = v;
     }
 }
 
@@ -199,8 +205,8 @@ extern "C" int hgr_attnpool_tokens_bwd(const void *dtok, void *dx, int B, int S,
 extern "C" int hgr_im2col3x3_t(const void *xt, void *out, int B, int H, int W, int C, int64_t ld, int dtype, void *stream) {
     HGR_REQUIRE(xt && out && B >= 1 && H >= 1 && W >= 1 && C >= 1 && 9 * C <= 65535, "hgr_im2col3x3_t: bad geometry B=%d H=%d W=%d C=%d", B, H, W, C);
     const int64_t M = (int64_t)B * H * W;
-    HGR_REQUIRE(ld >= M && (dtype == HGR_BF16 || dtype == HGR_F16), "hgr_im2col3x3_t: ld=%lld < B*H*W or bad dtype", (long long)ld);
-    const dim3 grid((unsigned)((ld + 255) / 256 < 4096 ? (ld + 255) / 256 : 4096), (unsigned)(9 * C));
+    HGR_REQUIRE(ld >= M && ld % 8 == 0 && hgr_aligned(out, 16) && (dtype == HGR_BF16 || dtype == HGR_F16), "hgr_im2col3x3_t: ld=%lld must be >= B*H*W and a multiple of 8, out 16-byte aligned", (long long)ld);
+    const dim3 grid((unsigned)((ld + 2047) / 2048 < 4096 ? (ld + 2047) / 2048 : 4096), (unsigned)(9 * C));
     if (dtype == HGR_BF16) hipLaunchKernelGGL((im2col3x3_t<HGR_BF16>), grid, dim3(256), 0, (hipStream_t)stream, (const __bf16 *)xt, (__bf16 *)out, H, W, C, M, ld);
     else hipLaunchKernelGGL((im2col3x3_t<HGR_F16>), grid, dim3(256), 0, (hipStream_t)stream, (const _Float16 *)xt, (_Float16 *)out, H, W, C, M, ld);
     HGR_CHECK_LAUNCH("hgr_im2col3x3_t");
