@@ -348,6 +348,12 @@ template <int DT, int EPI, bool OUT32, bool CONV = false>
 __global__ __launch_bounds__(NT256) void gemm_nt_256(GemmArgs p) {
     typedef typename T16<DT>::vec8 vec8;
     typedef typename T16<DT>::elem E;
+    if (p.kc) {                                   // split-K (see gemm_nt_128)
+        const int sp = blockIdx.y;
+        p.A += (int64_t)sp * p.kc * 2; p.W += (int64_t)sp * p.kc * 2;
+        p.C = (char *)p.C + (int64_t)sp * p.csplit * 4;
+        p.K = min(p.kc, p.K - sp * p.kc);
+    }
     __shared__ __attribute__((aligned(1024))) char smem[2 * 4 * PIECE + 8 * 2048];   // + epilogue row padding
 
     const int tid = threadIdx.x;
@@ -859,6 +865,16 @@ extern "C" int hgr_gemm_nt_splitk(const void *A, int64_t lda, const void *W, int
     a.tiles_m = (M + BM - 1) / BM; a.tiles_n = (N + BN - 1) / BN;
     a.m_fastest = 0; a.vec_ok = 1; a.dbg = 0; a.kc = kc; a.csplit = (int64_t)M * ldc;
     a.cH = a.cW = a.cC = a.cLog2C = a.cStride = a.cHo = a.cWo = 0;
+    // every slice at least 2 K-tiles deep and an output of at least one 256^2 tile: the deep-pipelined kernel
+    const bool big = hgr_gemm_force_tile() != 128 && M >= 256 && N >= 256 && kc >= 128 && (K - (S - 1) * kc) >= 128;
+    if (big) {
+        a.tiles_m = (M + 255) / 256; a.tiles_n = (N + 255) / 256;
+        dim3 grid((unsigned)(a.tiles_m * a.tiles_n), (unsigned)S);
+        if (dtype == HGR_BF16) hipLaunchKernelGGL((gemm_nt_256<HGR_BF16, HGR_EPI_NONE, true>), grid, dim3(NT256), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((gemm_nt_256<HGR_F16, HGR_EPI_NONE, true>), grid, dim3(NT256), 0, (hipStream_t)stream, a);
+        HGR_CHECK_LAUNCH("hgr_gemm_nt_splitk");
+        return HGR_OK;
+    }
     dim3 grid((unsigned)(a.tiles_m * a.tiles_n), (unsigned)S);
     if (dtype == HGR_BF16) hipLaunchKernelGGL((gemm_nt_128<HGR_BF16, HGR_EPI_NONE, true, false>), grid, dim3(NT), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((gemm_nt_128<HGR_F16, HGR_EPI_NONE, true, false>), grid, dim3(NT), 0, (hipStream_t)stream, a);

@@ -108,8 +108,12 @@ class Engine:
         ops.transpose16(dy16, dyt)
         ops.transpose16(x16[:, : lin.k] if x16.shape[1] != lin.k else x16, xt)
         gw = _grad(lin.weight).view(lin.n, lin.k)
-        tiles = -(-lin.n // 128) * -(-lin.k // 128)
-        s = min(mp // 64, -(-512 // tiles))
+        if lin.n >= 256 and lin.k >= 256:                     # 256^2 tiles, one workgroup per CU
+            tiles = -(-lin.n // 256) * -(-lin.k // 256)
+            s = min(mp // 128, -(-256 // tiles))
+        else:
+            tiles = -(-lin.n // 128) * -(-lin.k // 128)
+            s = min(mp // 64, -(-512 // tiles))
         if s > 1:
             # few output tiles, long reduction: slice K over the chip, add the fp32 partials in a fixed order
             kc = _pad64(-(-mp // s))

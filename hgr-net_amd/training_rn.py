@@ -130,8 +130,12 @@ class RNTower:
         cout, (k, mp) = dy16.shape[1], xcol_t.shape
         dyt = self._tmp("dyt", (cout, mp), self.dt, zero=mp != m)
         ops.transpose16(dy16, dyt)
-        tiles = -(-cout // 128) * -(-k // 128)
-        s = max(1, min(mp // 64, -(-768 // tiles)))
+        if cout >= 256 and k >= 256:                          # 256^2 tiles, one workgroup per CU
+            tiles = -(-cout // 256) * -(-k // 256)
+            s = max(1, min(mp // 128, -(-256 // tiles)))
+        else:
+            tiles = -(-cout // 128) * -(-k // 128)
+            s = max(1, min(mp // 64, -(-768 // tiles)))
         kc = _pad64(-(-mp // s))
         s = -(-mp // kc)
         part = self._tmp("part", (s, cout * k), torch.float32)

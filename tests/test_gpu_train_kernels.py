@@ -286,3 +286,18 @@ def test_bn_fold_and_unfold_vs_autograd():
         ops.bn_unfold_grad(gwf, gbf, conv.weight.data.contiguous(), bn, g_w, g_g, g_b)
         assert torch.allclose(g_w, wr.grad, rtol=1e-5, atol=1e-6)
         assert torch.allclose(g_g, ga.grad, rtol=1e-4, atol=1e-5) and torch.allclose(g_b, be.grad, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("m,n,k,kc", [(512, 384, 1024, 256), (300, 260, 1984, 512), (128, 576, 640, 64), (2048, 512, 896, 128)])
+def test_gemm_nt_splitk_partials(dt, m, n, k, kc):
+    """Every K slice's partial product (both tile sizes: outputs >= 256 x 256 take the 256^2 kernel), exact on integers."""
+    gen = torch.Generator().manual_seed(m + k)
+    a = torch.randint(-2, 3, (m, k), generator=gen).float().to(dt).to(DEV)
+    w = torch.randint(-1, 2, (n, k), generator=gen).float().to(dt).to(DEV)
+    s = (k + kc - 1) // kc
+    part = torch.full((s, m * n), 7.0, dtype=torch.float32, device=DEV)
+    ops.gemm_nt_splitk(a, w, part, kc)
+    for i in range(s):
+        ref = a[:, i * kc:(i + 1) * kc].float() @ w[:, i * kc:(i + 1) * kc].float().t()
+        assert torch.equal(part[i].view(m, n), ref), i
