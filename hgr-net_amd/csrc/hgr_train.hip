@@ -3,6 +3,7 @@
 // pre-transposed, dW = dY^T . X on transposed activations with the fp32 accumulate epilogue); everything here
 // is the glue around them: streaming element-wise / row-wise kernels (HBM-bound) and small fp32 products.
 #include "hgr_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -404,60 +405,104 @@ __global__ __launch_bounds__(256) void mha_bwd_tiled(const typename T16<DT>::ele
 
 // Same arithmetic for short sequences (text prompts are ~8-20 tokens after EOT trimming): LP = 16 or 32 padded
 // positions, 20-45 KB of LDS so several (batch, head) workgroups share a CU, plain per-output loops.
-template <int DT, int LP, bool CAUSAL>
-__global__ __launch_bounds__(256) void mha_bwd_small(const typename T16<DT>::elem *__restrict__ qkv, const typename T16<DT>::elem *__restrict__ dout,
-                                                     typename T16<DT>::elem *__restrict__ dqkv, int L, int H) {
+// ---- attention backward, L <= 32 (EOT-trimmed prompts of the text tower: thousands of tiny problems per inner step) ----------
+// One WAVE per (batch, head): the whole L x L problem is a single 32 x 32 block, so every product is a chain of 2 or 4
+// v_mfma_f32_32x32x16 with the operands staged once in LDS (rows past L zero-filled): S = Q K^T and dP = dO V^T (k = 64),
+// the row softmax and D = rowsum(P * dP) by shuffles inside the 32-lane halves of the accumulator layout (a lane owns one
+// key column and 16 query rows), then dV = P^T dO, dK = dS^T Q, dQ = dS K (k = 32) on 16-bit P / dS images written from
+// the accumulators.  No barriers (one wave), 41 KB of LDS, 3 waves per CU.
+template <int DT>
+__device__ __forceinline__ void mm16k(f32x16 &acc, const typename T16<DT>::elem *A, int lda, const typename T16<DT>::elem *B, int ldb, int ksteps, int lane) {
+    typedef typename T16<DT>::vec8 vec8;
+    const int r = lane & 31, kh = lane >> 5;
+    for (int kk = 0; kk < ksteps; ++kk)
+        acc = T16<DT>::mfma32(*(const vec8 *)(A + r * lda + kk * 16 + kh * 8), *(const vec8 *)(B + r * ldb + kk * 16 + kh * 8), acc);
+}
+
+template <int DT, bool CAUSAL>
+__global__ __launch_bounds__(64) void mha_bwd_wave(const typename T16<DT>::elem *__restrict__ qkv, const typename T16<DT>::elem *__restrict__ dout,
+                                                   typename T16<DT>::elem *__restrict__ dqkv, int L, int H) {
     typedef typename T16<DT>::elem E;
-    __shared__ float sQ[LP][65], sK[LP][65], sV[LP][65], sO[LP][65], sP[LP][LP + 1], sD[LP][LP + 1];
-    const int tid = threadIdx.x;
+    typedef typename T16<DT>::vec8 vec8;
+    typedef typename T16<DT>::vec4 vec4;
+    constexpr int LR = 72, LT = 40;                 // row strides (elements): [32][72] row images, [64][40] / [32][40] transposed images
+    __shared__ __attribute__((aligned(16))) E sQ[32 * LR], sK[32 * LR], sV[32 * LR], sO[32 * LR], sQt[64 * LT], sKt[64 * LT], sOt[64 * LT],
+        sDS[32 * LT], sDSt[32 * LT], sPt[32 * LT];
+    const int lane = threadIdx.x, r32 = lane & 31, hh = lane >> 5;
     const int b = blockIdx.x / H, h = blockIdx.x - b * H;
     const int W = H * 64;
     const int64_t ld = 3 * (int64_t)W;
     const E *base = qkv + (int64_t)b * L * ld + h * 64;
     const E *dob = dout + (int64_t)b * L * W + h * 64;
-    for (int i = tid; i < LP * 64; i += 256) {
-        const int r = i >> 6, c = i & 63;
-        const bool ok = r < L;
-        sQ[r][c] = ok ? (float)base[r * ld + c] : 0.f;
-        sK[r][c] = ok ? (float)base[r * ld + W + c] : 0.f;
-        sV[r][c] = ok ? (float)base[r * ld + 2 * W + c] : 0.f;
-        sO[r][c] = ok ? (float)dob[(int64_t)r * W + c] : 0.f;
+    // stage Q, K, V, dO (32 x 64 each: 256 chunks of 8 elements, 4 per lane) and the transposed images of Q, K, dO
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int id = lane + 64 * j, r = id >> 3, c = (id & 7) * 8;
+        vec8 q, k, v, o;
+        if (r < L) {
+            q = *(const vec8 *)(base + (int64_t)r * ld + c); k = *(const vec8 *)(base + (int64_t)r * ld + W + c);
+            v = *(const vec8 *)(base + (int64_t)r * ld + 2 * W + c); o = *(const vec8 *)(dob + (int64_t)r * W + c);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { q[e] = (E)0.f; k[e] = (E)0.f; v[e] = (E)0.f; o[e] = (E)0.f; }
+        }
+        *(vec8 *)&sQ[r * LR + c] = q; *(vec8 *)&sK[r * LR + c] = k; *(vec8 *)&sV[r * LR + c] = v; *(vec8 *)&sO[r * LR + c] = o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sQt[(c + e) * LT + r] = q[e]; sKt[(c + e) * LT + r] = k[e]; sOt[(c + e) * LT + r] = o[e]; }
     }
     __syncthreads();
-    for (int o = tid; o < LP * LP; o += 256) {                        // S and dP
-        const int i = o / LP, j = o - i * LP;
-        float s = 0.f, dp = 0.f;
-#pragma unroll 8
-        for (int d = 0; d < 64; ++d) { s += sQ[i][d] * sK[j][d]; dp += sO[i][d] * sV[j][d]; }
-        sP[i][j] = (j >= L || (CAUSAL && j > i)) ? -INFINITY : s * 0.125f;
-        sD[i][j] = dp;
+    f32x16 sacc = {0.f}, dp = {0.f};
+    mm16k<DT>(sacc, sQ, LR, sK, LR, 4, lane);       // S[q][j]
+    mm16k<DT>(dp, sO, LR, sV, LR, 4, lane);         // dP[q][j]
+    // this lane: key column j = r32, query rows HGR_ACC_ROW(g, hh); a row's 32 columns live in the 32 lanes of one half
+    float pv[16];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        const int q = HGR_ACC_ROW(g, hh);
+        const float sc = (r32 >= L || (CAUSAL && r32 > q)) ? -INFINITY : sacc[g] * 0.125f;
+        float mx = sc;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        const float e = (sc > -INFINITY) ? __expf(sc - mx) : 0.f;
+        float sum = e;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        const float p = (q < L && sum > 0.f) ? e / sum : 0.f;
+        float d = p * dp[g];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) d += __shfl_xor(d, o);
+        pv[g] = p;
+        dp[g] = p * (dp[g] - d) * 0.125f;            // dS
     }
-    __syncthreads();
-    if (tid < LP) {                                                   // row softmax and dS, one thread per query row
-        const int i = tid;
-        float mx = -INFINITY;
-        for (int j = 0; j < LP; ++j) mx = fmaxf(mx, sP[i][j]);
-        float sum = 0.f;
-        for (int j = 0; j < LP; ++j) { const float e = __expf(sP[i][j] - mx); sP[i][j] = e; sum += e; }
-        const float inv = (i < L) ? 1.0f / sum : 0.f;
-        float rs = 0.f;
-        for (int j = 0; j < LP; ++j) { sP[i][j] *= inv; rs += sP[i][j] * sD[i][j]; }
-        for (int j = 0; j < LP; ++j) sD[i][j] = sP[i][j] * (sD[i][j] - rs) * 0.125f;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+        vec4 p4, d4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int g = g4 * 4 + e;
+            p4[e] = (E)pv[g]; d4[e] = (E)dp[g];
+            sDS[HGR_ACC_ROW(g, hh) * LT + r32] = (E)dp[g];
+        }
+        const int q0 = HGR_ACC_ROW(g4 * 4, hh);
+        *(vec4 *)&sPt[r32 * LT + q0] = p4;
+        *(vec4 *)&sDSt[r32 * LT + q0] = d4;
     }
     __syncthreads();
     E *dqb = dqkv + (int64_t)b * L * ld + h * 64;
-    for (int o = tid; o < LP * 64; o += 256) {                        // dQ, dK, dV rows x 64 dims
-        const int r = o >> 6, d = o & 63;
-        if (r >= L) continue;
-        float dq = 0.f, dk = 0.f, dv = 0.f;
-        for (int t = 0; t < L; ++t) {
-            dq += sD[r][t] * sK[t][d];
-            dk += sD[t][r] * sQ[t][d];
-            dv += sP[t][r] * sO[t][d];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {          // the 64 head dimensions as two blocks of 32 columns
+        f32x16 dq = {0.f}, dk = {0.f}, dv = {0.f};
+        mm16k<DT>(dq, sDS, LT, sKt + half * 32 * LT, LT, 2, lane);      // dQ[q][d] = sum_j dS[q][j] K[j][d]
+        mm16k<DT>(dk, sDSt, LT, sQt + half * 32 * LT, LT, 2, lane);     // dK[j][d] = sum_q dS[q][j] Q[q][d]
+        mm16k<DT>(dv, sPt, LT, sOt + half * 32 * LT, LT, 2, lane);      // dV[j][d] = sum_q P[q][j] dO[q][d]
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int row = HGR_ACC_ROW(g, hh);
+            if (row < L) {
+                E *o = dqb + (int64_t)row * ld + half * 32 + r32;
+                o[0] = (E)dq[g]; o[W] = (E)dk[g]; o[2 * W] = (E)dv[g];
+            }
         }
-        dqb[(int64_t)r * ld + d] = (E)dq;
-        dqb[(int64_t)r * ld + W + d] = (E)dk;
-        dqb[(int64_t)r * ld + 2 * W + d] = (E)dv;
     }
 }
 
@@ -766,13 +811,15 @@ extern "C" int hgr_mha_bwd(const void *qkv, const void *out, const void *dout, v
     DT_OK("hgr_mha_bwd");
     hipStream_t s = (hipStream_t)stream;
     const dim3 g(B * heads);
-#define HGR_MB(KERN, ...)                                                                                                         \
-    do {                                                                                                                          \
-        if (dtype == HGR_BF16) hipLaunchKernelGGL((KERN<HGR_BF16, __VA_ARGS__>), g, dim3(256), 0, s, (const __bf16 *)qkv, (const __bf16 *)dout, (__bf16 *)dqkv, L, heads); \
-        else hipLaunchKernelGGL((KERN<HGR_F16, __VA_ARGS__>), g, dim3(256), 0, s, (const _Float16 *)qkv, (const _Float16 *)dout, (_Float16 *)dqkv, L, heads); \
-    } while (0)
-    if (L <= 16) { if (causal) HGR_MB(mha_bwd_small, 16, true); else HGR_MB(mha_bwd_small, 16, false); }
-    else if (L <= 32) { if (causal) HGR_MB(mha_bwd_small, 32, true); else HGR_MB(mha_bwd_small, 32, false); }
+    if (L <= 32) {
+        if (dtype == HGR_BF16) {
+            if (causal) hipLaunchKernelGGL((mha_bwd_wave<HGR_BF16, true>), g, dim3(64), 0, s, (const __bf16 *)qkv, (const __bf16 *)dout, (__bf16 *)dqkv, L, heads);
+            else hipLaunchKernelGGL((mha_bwd_wave<HGR_BF16, false>), g, dim3(64), 0, s, (const __bf16 *)qkv, (const __bf16 *)dout, (__bf16 *)dqkv, L, heads);
+        } else {
+            if (causal) hipLaunchKernelGGL((mha_bwd_wave<HGR_F16, true>), g, dim3(64), 0, s, (const _Float16 *)qkv, (const _Float16 *)dout, (_Float16 *)dqkv, L, heads);
+            else hipLaunchKernelGGL((mha_bwd_wave<HGR_F16, false>), g, dim3(64), 0, s, (const _Float16 *)qkv, (const _Float16 *)dout, (_Float16 *)dqkv, L, heads);
+        }
+    }
     else {
 #define HGR_MT(CAUS)                                                                                                              \
     do {                                                                                                                          \
@@ -782,7 +829,6 @@ extern "C" int hgr_mha_bwd(const void *qkv, const void *out, const void *dout, v
         if (causal) HGR_MT(true); else HGR_MT(false);
 #undef HGR_MT
     }
-#undef HGR_MB
     HGR_CHECK_LAUNCH("hgr_mha_bwd");
     return HGR_OK;
 }
