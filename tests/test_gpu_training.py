@@ -335,3 +335,26 @@ def test_near_simi_sampling_picks_the_most_similar_prompts(golden_dir, tmp_path)
     img = synth.images(4, cfg["image_resolution"], 3).to(DEV)
     loss = model.train_batch(img, torch.full((4,), target, dtype=torch.long, device=DEV), "OM", "near_simi")
     assert np.isfinite(loss)
+
+
+def test_hierarchical_step_matches_reference(golden_dir, tmp_path):
+    """training_method='hierarchical' (clip_tree.py:283-316): one loss per level of the target's path, weighted by
+    get_weights over the path length - against the reference's own run (same weights, images, sampled negatives)."""
+    model, meta, cfg = _build("tinyvit_n90", golden_dir, tmp_path, "bf16")
+    t = meta["train_hier"]
+    img = synth.images(t["bsz"], cfg["image_resolution"], t["image_seed"]).to(DEV)
+    targets = torch.full((t["bsz"],), t["target"], dtype=torch.long, device=DEV)
+    model.train_batch(img, targets, "hierarchical", "topk")          # builds the trainer
+    for p in model.parameters():
+        p.grad = None
+    assert len(model.c2p[t["target"]]) + 1 == len(t["contra"])
+    model._trainer.contra_override = lambda i: tuple(t["contra"][i])
+    loss = model.train_batch(img, targets, "hierarchical", "topk")
+    assert abs(loss - t["loss"]) < 2e-2 * abs(t["loss"]), (loss, t["loss"])
+    named = dict(model.clip_model.named_parameters())
+    bad = [(k, float(named[k].grad.norm()), ref) for k, ref in t["grad_norms"].items()
+           if abs(float(named[k].grad.norm()) - ref) > 0.08 * ref + (5e-3 if k == "logit_scale" else 1e-4)]
+    assert not bad, bad[:8]
+    params = [p for n, p in model.named_parameters() if p.requires_grad and n != "layer_weight" and p.grad is not None]
+    total = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in params)))
+    assert abs(total - t["total_norm"]) < 0.05 * t["total_norm"]

@@ -192,8 +192,10 @@ def tree_fixture(ref_main_mod, tag, cfg, n_nodes, n_train, n_test, batches, bsz,
         paths.append(dp)
     print(f"[tree] {tag}: main.test -> {metric.strip()}")
     assert st.summary() == metric, (st.summary(), metric)
+    # the 'hierarchical' capture first: it leaves the weights untouched (no optimiser step), the OM capture ends with AdamW
+    train_hier = train_capture(model, o, cfg, h, tag, method="hierarchical") if tag == "tinyvit_n90" else None
     train = train_capture(model, o, cfg, h, tag)          # ViT and ModifiedResNet towers alike
-    meta = dict(config=cfg, n_nodes=n_nodes, n_train=n_train, n_test=n_test, batches=batches, bsz=bsz, train=train,
+    meta = dict(config=cfg, n_nodes=n_nodes, n_train=n_train, n_test=n_test, batches=batches, bsz=bsz, train=train, train_hier=train_hier,
                 dag=dict(depth=8, seed=7, multi_parent=0.08), split_seed=13, image_seed0=100, targets=targets,
                 metric=metric, counters=st.counters(), weights=weights,
                 c2p=h.c2p, p2c=h.p2c, d2n={str(k): v for k, v in h.d2n.items()}, start_up=h.start_up, nodes=h.nodes)
@@ -252,8 +254,9 @@ TRAIN_KEEP = ["logit_scale", "ln_final.weight", "ln_final.bias", "text_projectio
               "visual.attnpool.c_proj.bias", "visual.attnpool.positional_embedding"]      # (the 2048^2 projections: norms only)
 
 
-def train_capture(model, o, cfg, h, tag):
-    """One OM step of the reference's tree_model.train_batch (clip_tree.py:222-281) + main.train's clip/AdamW (main.py:86-91)."""
+def train_capture(model, o, cfg, h, tag, method="OM"):
+    """One step of the reference's tree_model.train_batch ('OM': clip_tree.py:222-281; 'hierarchical': :283-316) + main.train's
+    clip/AdamW (main.py:86-91).  The 'hierarchical' capture keeps numbers only (loss, negatives, gradient norms)."""
     import random
     o.num_compare, o.k, o.sample_strategy, o.weighting, o.out_ratio, o.in_ratio = 8, 1, "topk", "both", 0.5, 0.5
     bsz = 6
@@ -272,10 +275,16 @@ def train_capture(model, o, cfg, h, tag):
     for p_ in model.parameters():
         p_.grad = None
     random.seed(123)
-    loss = model.train_batch(img, torch.full((bsz,), target, dtype=torch.long), "OM", "topk")
+    loss = model.train_batch(img, torch.full((bsz,), target, dtype=torch.long), method, "topk")
     model.get_contra = orig
     named = dict(model.clip_model.named_parameters())
     norms = {k: float(v.grad.norm()) for k, v in named.items() if v.grad is not None}
+    if method != "OM":
+        params = [p_ for n_, p_ in model.named_parameters() if p_.requires_grad and n_ != "layer_weight"]
+        total = float(torch.sqrt(sum((p_.grad.double() ** 2).sum() for p_ in params if p_.grad is not None)))
+        print(f"[train] {tag}: {method} step target {target}, {len(captured)} levels, loss {loss:.6f}, |grad| {total:.4f}")
+        return dict(loss=float(loss), target=int(target), bsz=bsz, image_seed=777, contra=captured, grad_norms=norms, total_norm=total,
+                    opts=dict(num_compare=8, k=1, sample_strategy="topk", weighting="both", out_ratio=0.5, in_ratio=0.5))
     keep = {k: named[k].grad.detach().clone() for k in TRAIN_KEEP if k in named}
     params = [p_ for n_, p_ in model.named_parameters() if p_.requires_grad and n_ != "layer_weight"]
     total = float(torch.nn.utils.clip_grad_norm_(params, 1.0))
