@@ -358,3 +358,17 @@ def test_hierarchical_step_matches_reference(golden_dir, tmp_path):
     params = [p for n, p in model.named_parameters() if p.requires_grad and n != "layer_weight" and p.grad is not None]
     total = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in params)))
     assert abs(total - t["total_norm"]) < 0.05 * t["total_norm"]
+
+
+def test_negative_sampling_matches_reference(golden_dir, tmp_path):
+    """get_contra_ids ('random', 'topk', 'brothers') under the reference's `random` seeds: same ids in the same order,
+    same label position (clip_tree.py:80-141,180-196)."""
+    import random
+    model, meta, cfg = _build("tinyvit_n90", golden_dir, tmp_path, "bf16")
+    model.opts.num_compare, model.opts.k = 5, 2
+    for smp in meta["contra_samples"]:
+        tgt = smp["target"]
+        parents = list(model.c2p[tgt]) + [tgt]
+        random.seed(smp["seed"])
+        ids, pos = model.get_contra_ids(smp["method"], tgt, depth=smp["depth"], parents=parents)
+        assert ids == smp["ids"] and pos == smp["label"], smp

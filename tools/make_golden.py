@@ -192,10 +192,23 @@ def tree_fixture(ref_main_mod, tag, cfg, n_nodes, n_train, n_test, batches, bsz,
         paths.append(dp)
     print(f"[tree] {tag}: main.test -> {metric.strip()}")
     assert st.summary() == metric, (st.summary(), metric)
+    contra_samples = None
+    if tag == "tinyvit_n90":
+        # host-side negative sampling of the reference (clip_tree.py:80-196) under a fixed `random` seed
+        import random
+        o.num_compare, o.k = 5, 2
+        contra_samples = []
+        for tgt in sorted(int(i) for i in model.test_index.tolist())[:6]:
+            parents = list(h.c2p[tgt]) + [tgt]
+            for method in ("random", "topk", "brothers"):
+                for depth in sorted({0, len(parents) // 2, len(parents) - 1}):
+                    random.seed(1000 + tgt + depth)
+                    ci, tg = model.get_contra(method=method, target=tgt, batch_size=3, depth=depth, parents=parents)
+                    contra_samples.append(dict(method=method, target=tgt, depth=depth, seed=1000 + tgt + depth, ids=ci.tolist(), label=int(tg[0])))
     # the 'hierarchical' capture first: it leaves the weights untouched (no optimiser step), the OM capture ends with AdamW
     train_hier = train_capture(model, o, cfg, h, tag, method="hierarchical") if tag == "tinyvit_n90" else None
     train = train_capture(model, o, cfg, h, tag)          # ViT and ModifiedResNet towers alike
-    meta = dict(config=cfg, n_nodes=n_nodes, n_train=n_train, n_test=n_test, batches=batches, bsz=bsz, train=train, train_hier=train_hier,
+    meta = dict(config=cfg, n_nodes=n_nodes, n_train=n_train, n_test=n_test, batches=batches, bsz=bsz, train=train, train_hier=train_hier, contra_samples=contra_samples,
                 dag=dict(depth=8, seed=7, multi_parent=0.08), split_seed=13, image_seed0=100, targets=targets,
                 metric=metric, counters=st.counters(), weights=weights,
                 c2p=h.c2p, p2c=h.p2c, d2n={str(k): v for k, v in h.d2n.items()}, start_up=h.start_up, nodes=h.nodes)
