@@ -54,7 +54,7 @@ def test_state_dict_schema_roundtrip():
         assert infer_config(out) == {**synth.CLIP_CONFIGS[name]}
 
 
-def test_tree_model_host_logic(tmp_path):
+def test_tree_model_host_logic(tmp_path, golden_dir):
     """ctor attributes, OM schedule and negative sampling follow the reference's rules (clip_tree.py:116-141,228-251)."""
     import random
     from hgr_net_amd import synth
@@ -90,6 +90,10 @@ def test_tree_model_host_logic(tmp_path):
         assert set(ids) - {st["p_out"]} <= allowed
     w = m.get_weights("increasing", 4)
     assert torch.allclose(w, torch.tensor([0.1, 0.2, 0.3, 0.4]))
+    table = json.load(open(golden_dir / "tree_tinyvit_n90.json"))["weights_table"]       # captured from the reference
+    for method, by_depth in table.items():
+        for d, ref in by_depth.items():
+            assert torch.allclose(m.get_weights(method, int(d)).float().cpu(), torch.tensor(ref), rtol=0, atol=1e-7), (method, d)
     assert abs(float(m.get_weights("adaptive", 3).sum()) - 1) < 1e-6
 
 

@@ -205,10 +205,14 @@ def tree_fixture(ref_main_mod, tag, cfg, n_nodes, n_train, n_test, batches, bsz,
                     random.seed(1000 + tgt + depth)
                     ci, tg = model.get_contra(method=method, target=tgt, batch_size=3, depth=depth, parents=parents)
                     contra_samples.append(dict(method=method, target=tgt, depth=depth, seed=1000 + tgt + depth, ids=ci.tolist(), label=int(tg[0])))
+    weights_table = None
+    if tag == "tinyvit_n90":                                   # closed-form layer weights (clip_tree.py:198-219)
+        weights_table = {m_: {str(d): model.get_weights(m_, d).tolist() for d in range(1, 9)}
+                         for m_ in ("equal", "decreasing", "increasing", "nl_increasing", "nl_decreasing")}
     # the 'hierarchical' capture first: it leaves the weights untouched (no optimiser step), the OM capture ends with AdamW
     train_hier = train_capture(model, o, cfg, h, tag, method="hierarchical") if tag == "tinyvit_n90" else None
     train = train_capture(model, o, cfg, h, tag)          # ViT and ModifiedResNet towers alike
-    meta = dict(config=cfg, n_nodes=n_nodes, n_train=n_train, n_test=n_test, batches=batches, bsz=bsz, train=train, train_hier=train_hier, contra_samples=contra_samples,
+    meta = dict(config=cfg, n_nodes=n_nodes, n_train=n_train, n_test=n_test, batches=batches, bsz=bsz, train=train, train_hier=train_hier, contra_samples=contra_samples, weights_table=weights_table,
                 dag=dict(depth=8, seed=7, multi_parent=0.08), split_seed=13, image_seed0=100, targets=targets,
                 metric=metric, counters=st.counters(), weights=weights,
                 c2p=h.c2p, p2c=h.p2c, d2n={str(k): v for k, v in h.d2n.items()}, start_up=h.start_up, nodes=h.nodes)
