@@ -207,3 +207,17 @@ def test_product_package_never_imports_the_oracle():
     root = Path(__file__).resolve().parent.parent / "hgr-net_amd"
     offenders = [str(p) for p in root.rglob("*.py") if re.search(r"^\s*(from|import)\s+oracle\b", p.read_text(), re.M)]
     assert not offenders, offenders
+
+
+def test_cosine_lr_schedule_values():
+    """utils.py:78-95 of the reference: linear warm-up base*(step+1)/warmup, then 0.5*(1+cos(pi*e/es))*base."""
+    import math
+    from hgr_net_amd.utils import cosine_lr
+    opt = types.SimpleNamespace(param_groups=[{"lr": 0.0}, {"lr": 0.0}])
+    sched = cosine_lr(opt, 3e-7, 5, 105)
+    sched(0); assert all(abs(g["lr"] - 3e-7 * 1 / 5) < 1e-20 for g in opt.param_groups)
+    sched(4); assert abs(opt.param_groups[0]["lr"] - 3e-7) < 1e-20
+    sched(55); assert abs(opt.param_groups[1]["lr"] - 0.5 * (1 + math.cos(math.pi * 50 / 100)) * 3e-7) < 1e-20
+    sched(105); assert abs(opt.param_groups[0]["lr"]) < 1e-20
+    sched2 = cosine_lr(opt, [1.0, 2.0], 0, 10)
+    sched2(0); assert [g["lr"] for g in opt.param_groups] == [1.0, 2.0]
