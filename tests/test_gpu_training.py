@@ -372,3 +372,27 @@ def test_negative_sampling_matches_reference(golden_dir, tmp_path):
         random.seed(smp["seed"])
         ids, pos = model.get_contra_ids(smp["method"], tgt, depth=smp["depth"], parents=parents)
         assert ids == smp["ids"] and pos == smp["label"], smp
+
+
+def test_adaptive_weights_om_step_matches_reference(golden_dir, tmp_path):
+    """--weights adaptive, the setting of the reference's README commands: layer weights softmax(100 ** layer_weight[:d])
+    (clip_tree.py:207) inside the OM double loop.  Loss, every CLIP parameter's gradient norm and d loss / d layer_weight
+    against the reference's run (its non-leaf `layer_weight` replaced by the leaf the code intends)."""
+    model, meta, cfg = _build("tinyvit_n90", golden_dir, tmp_path, "bf16")
+    t = meta["train_adaptive"]
+    model.opts.weights = "adaptive"
+    model.layer_weight = torch.nn.Parameter(torch.tensor(t["layer_weight"], dtype=torch.float32, device=DEV))
+    img = synth.images(t["bsz"], cfg["image_resolution"], t["image_seed"]).to(DEV)
+    targets = torch.full((t["bsz"],), t["target"], dtype=torch.long, device=DEV)
+    model.train_batch(img, targets, "OM", "topk")
+    for p in model.parameters():
+        p.grad = None
+    model._trainer.contra_override = lambda i: tuple(t["contra"][i])
+    loss = model.train_batch(img, targets, "OM", "topk")
+    assert abs(loss - t["loss"]) < 2e-2 * abs(t["loss"]), (loss, t["loss"])
+    named = dict(model.clip_model.named_parameters())
+    bad = [(k, float(named[k].grad.norm()), ref) for k, ref in t["grad_norms"].items()
+           if abs(float(named[k].grad.norm()) - ref) > 0.08 * ref + (5e-3 if k == "logit_scale" else 1e-4)]
+    assert not bad, bad[:8]
+    g, ref = model.layer_weight.grad.cpu(), torch.tensor(t["layer_weight_grad"])
+    assert float(torch.dot(g, ref) / (g.norm() * ref.norm())) > 0.999 and abs(float(g.norm() / ref.norm()) - 1) < 0.03, (g, ref)

@@ -209,10 +209,22 @@ def tree_fixture(ref_main_mod, tag, cfg, n_nodes, n_train, n_test, batches, bsz,
     if tag == "tinyvit_n90":                                   # closed-form layer weights (clip_tree.py:198-219)
         weights_table = {m_: {str(d): model.get_weights(m_, d).tolist() for d in range(1, 9)}
                          for m_ in ("equal", "decreasing", "increasing", "nl_increasing", "nl_decreasing")}
+    train_adaptive = None
+    if tag == "tinyvit_n90":
+        # --weights adaptive (the reference README's setting).  The reference builds `layer_weight = nn.Parameter(w) * scale`,
+        # which is not a leaf and never receives a gradient; the harness installs the leaf the code intends.
+        # values chosen so that softmax(100 ** w) is not one-hot (the reference's 1 / len(d2n[level]) init saturates on a toy DAG)
+        model.layer_weight = torch.nn.Parameter(0.1 + 0.02 * torch.arange(len(model.d2n), dtype=torch.float32))
+        o.weights = "adaptive"
+        train_adaptive = train_capture(model, o, cfg, h, tag, method="OM-adaptive")
+        train_adaptive["layer_weight"] = model.layer_weight.detach().tolist()
+        train_adaptive["layer_weight_grad"] = model.layer_weight.grad.tolist()
+        o.weights = weights
+        del model.layer_weight
     # the 'hierarchical' capture first: it leaves the weights untouched (no optimiser step), the OM capture ends with AdamW
     train_hier = train_capture(model, o, cfg, h, tag, method="hierarchical") if tag == "tinyvit_n90" else None
     train = train_capture(model, o, cfg, h, tag)          # ViT and ModifiedResNet towers alike
-    meta = dict(config=cfg, n_nodes=n_nodes, n_train=n_train, n_test=n_test, batches=batches, bsz=bsz, train=train, train_hier=train_hier, contra_samples=contra_samples, weights_table=weights_table,
+    meta = dict(config=cfg, n_nodes=n_nodes, n_train=n_train, n_test=n_test, batches=batches, bsz=bsz, train=train, train_hier=train_hier, contra_samples=contra_samples, weights_table=weights_table, train_adaptive=train_adaptive,
                 dag=dict(depth=8, seed=7, multi_parent=0.08), split_seed=13, image_seed0=100, targets=targets,
                 metric=metric, counters=st.counters(), weights=weights,
                 c2p=h.c2p, p2c=h.p2c, d2n={str(k): v for k, v in h.d2n.items()}, start_up=h.start_up, nodes=h.nodes)
@@ -292,7 +304,7 @@ def train_capture(model, o, cfg, h, tag, method="OM"):
     for p_ in model.parameters():
         p_.grad = None
     random.seed(123)
-    loss = model.train_batch(img, torch.full((bsz,), target, dtype=torch.long), method, "topk")
+    loss = model.train_batch(img, torch.full((bsz,), target, dtype=torch.long), "OM" if method.startswith("OM") else method, "topk")
     model.get_contra = orig
     named = dict(model.clip_model.named_parameters())
     norms = {k: float(v.grad.norm()) for k, v in named.items() if v.grad is not None}
