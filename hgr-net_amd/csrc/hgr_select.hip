@@ -2,6 +2,7 @@
 // level-segmented arg-max of the hierarchy metrics (main.py:162-176).  Index work: results are
 // defined bit-exactly (largest value first, ties to the lowest subset position).
 #include "hgr_common.h"
+#include <stdlib.h>
 #include <math.h>
 
 namespace {
@@ -334,6 +335,158 @@ __global__ __launch_bounds__(EV_NT) void eval_rows(const float *__restrict__ log
     }
 }
 
+// ---- same contract, LDS-private accumulators (n_levels <= 16) -----------------------------------------------------------
+constexpr int EL_NT = 512, EL_NW = EL_NT / 64, EL_NLV = 16;
+
+__device__ __forceinline__ Best block_best8(Best b, float *s_v, int *s_p, int tid) {
+    const Best w = wave_best(b);
+    __syncthreads();
+    if ((tid & 63) == 0) { s_v[tid >> 6] = w.v; s_p[tid >> 6] = w.p; }
+    __syncthreads();
+    Best r = {s_v[0], s_p[0]};
+    for (int i = 1; i < EL_NW; ++i)
+        if (better(s_v[i], s_p[i], r.v, r.p)) { r.v = s_v[i]; r.p = s_p[i]; }
+    return r;
+}
+
+__global__ __launch_bounds__(EL_NT) void eval_rows_lds(const float *__restrict__ logits, int64_t ld, int n_nodes, const unsigned char *__restrict__ lvl8,
+                                                 const int32_t *__restrict__ train_pos, const int32_t *__restrict__ train_cols, int n_train, int n_levels,
+                                                 const int32_t *__restrict__ filler_pos, const int32_t *__restrict__ test_pos, const int32_t *__restrict__ test_cols,
+                                                 int n_test, int k, int32_t *__restrict__ out_level, int32_t *__restrict__ out_top1, int32_t *__restrict__ out_topk) {
+    __shared__ unsigned long long acc[EL_NLV][EL_NT];      // per-thread, per-level running best as one orderable 64-bit key
+    __shared__ unsigned long long s_key[EL_NLV];
+    __shared__ float s_v[EL_NW];
+    __shared__ int s_p[EL_NW];
+    __shared__ float s_mv[256];
+    __shared__ int s_mp[256];
+    __shared__ float s_cv[TOPK_CAND];
+    __shared__ int s_cp[TOPK_CAND];
+    __shared__ float s_t;
+    __shared__ int s_tp, s_cnt;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = blockIdx.x;
+    const float *lr = logits + (int64_t)r * ld;
+    if (tid == 0) s_cnt = 0;
+    // sweep 1 (coalesced over the columns): a column belongs to ONE level, so instead of a 16-way compare chain over register
+    // accumulators each thread keeps its per-level bests in its own LDS column (dynamic index = the level): one 8-byte
+    // read, one 64-bit compare and a rare write per column.  key = (orderable(value) << 32) | (0x7fffffff - position):
+    // unsigned max == "larger value, then smaller position"; 0 = empty.
+#pragma unroll
+    for (int l = 0; l < EL_NLV; ++l) acc[l][tid] = 0ull;
+    Best mine = {-INFINITY, 0x7fffffff};
+    for (int c = tid; c < n_nodes; c += EL_NT) {
+        const float v = lr[c] + 0.0f;
+        const int tp = train_pos[c];
+        if (tp >= 0) {
+            const unsigned u = __float_as_uint(v);
+            const unsigned long long key = ((unsigned long long)(u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u)) << 32) | (unsigned)(0x7fffffff - tp);
+            const int lv = lvl8[c];
+            if (lv < EL_NLV) {                                   // always true for a valid index (depth < n_levels <= 16)
+                unsigned long long *slot = &acc[lv][tid];
+                if (key > *slot) *slot = key;
+            }
+        }
+        if (k > 0) {
+            const int te = test_pos[c];
+            if (te >= 0 && better(v, te, mine.v, mine.p)) { mine.v = v; mine.p = te; }
+        }
+    }
+    // 256 slice maxima for the top-k threshold: best of each pair of consecutive threads
+    {
+        Best gmx = mine;
+#pragma unroll
+        for (int o = 1; o <= 1; o <<= 1) {
+            const float ov = __shfl_xor(gmx.v, o);
+            const int op = __shfl_xor(gmx.p, o);
+            if (better(ov, op, gmx.v, gmx.p)) { gmx.v = ov; gmx.p = op; }
+        }
+        if ((tid & 1) == 0) { s_mv[tid >> 1] = gmx.v; s_mp[tid >> 1] = gmx.p; }
+    }
+    __syncthreads();
+    for (int l = wave; l < EL_NLV; l += EL_NW) {              // wave w reduces levels w, w + 8: 512 keys each
+        unsigned long long m = 0ull;
+#pragma unroll
+        for (int i = 0; i < EL_NT / 64; ++i) { const unsigned long long x = acc[l][lane + 64 * i]; m = x > m ? x : m; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned hi = __shfl_xor((unsigned)(m >> 32), o), lo = __shfl_xor((unsigned)m, o);
+            const unsigned long long x = ((unsigned long long)hi << 32) | lo;
+            m = x > m ? x : m;
+        }
+        if (lane == 0) s_key[l] = m;
+    }
+    __syncthreads();
+    if (wave == 0) {                                        // lane l < n_levels finishes level l; the whole wave takes part in the shuffles
+        const int l = lane;
+        Best b = {-INFINITY, 0x7fffffff};
+        if (l < n_levels) {
+            const unsigned long long m = l < EL_NLV ? s_key[l] : 0ull;
+            if (m) {
+                const unsigned u = (unsigned)(m >> 32);
+                b.v = __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+                b.p = 0x7fffffff - (int)(unsigned)m;
+            }
+            const int fo = filler_pos[l];
+            const bool has_c = b.p < n_train, has_f = fo >= 0;
+            int win;
+            if (has_c && (!has_f || b.v > -1.0f || (b.v == -1.0f && b.p < fo))) win = b.p;
+            else win = has_f ? fo : b.p;
+            out_level[(int64_t)r * n_levels + l] = train_cols[win];
+        }
+        const Best top = wave_best(b);                      // unmasked top-1 = best of the level bests
+        if (lane == 0 && out_top1) out_top1[r] = top.p < n_train ? train_cols[top.p] : -1;
+    }
+    if (k <= 0) return;
+    // top-k over the test subset: threshold = k-th best of the 256 slice maxima, then sweep 2 collects the candidates
+    if (tid < 256) {
+        const float mv = s_mv[tid]; const int mp = s_mp[tid];
+        int rank = 0, nonempty = 0;
+        for (int j = 0; j < 256; ++j) { rank += better(s_mv[j], s_mp[j], mv, mp) ? 1 : 0; nonempty += s_mp[j] != 0x7fffffff ? 1 : 0; }
+        // k distinct elements >= t are guaranteed only if at least k slices are non-empty (clustered / tiny test sets can
+        // put several test columns into one slice); otherwise every test element is a candidate
+        if (nonempty < k) { if (tid == 0) { s_t = -INFINITY; s_tp = 0x7fffffff; } }
+        else if (rank == k - 1) { s_t = mv; s_tp = mp; }
+    }
+    __syncthreads();
+    const float t = s_t; const int tp0 = s_tp;
+    for (int c = tid; c < n_nodes; c += EL_NT) {
+        const int te = test_pos[c];
+        if (te < 0) continue;
+        const float v = lr[c] + 0.0f;
+        if (!better(t, tp0, v, te)) {
+            const int slot = atomicAdd(&s_cnt, 1);
+            if (slot < TOPK_CAND) { s_cv[slot] = v; s_cp[slot] = te; }
+        }
+    }
+    __syncthreads();
+    const int cnt = s_cnt;
+    if (cnt <= TOPK_CAND) {
+        for (int c = tid; c < cnt; c += EL_NT) {
+            const float v = s_cv[c]; const int p = s_cp[c];
+            int rk = 0;
+            for (int j = 0; j < cnt; ++j) rk += better(s_cv[j], s_cp[j], v, p) ? 1 : 0;
+            if (rk < k) out_topk[(int64_t)r * k + rk] = test_cols[p];
+        }
+    } else {
+        // heavily duplicated data: k rounds of block arg-max; an element is "removed" by requiring it to be worse than the
+        // previous winner in (value, position) order, so nothing has to be written back
+        Best last = {INFINITY, -1};
+        for (int j = 0; j < k; ++j) {
+            Best b = {-INFINITY, 0x7fffffff};
+            for (int c = tid; c < n_nodes; c += EL_NT) {
+                const int te = test_pos[c];
+                if (te < 0) continue;
+                const float v = lr[c] + 0.0f;
+                if (better(last.v, last.p, v, te) && better(v, te, b.v, b.p)) { b.v = v; b.p = te; }
+            }
+            b = block_best8(b, s_v, s_p, tid);
+            if (tid == 0) out_topk[(int64_t)r * k + j] = b.p < n_test ? test_cols[b.p] : -1;
+            last = b;
+            __syncthreads();
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int hgr_topk_rows(const float *logits, int64_t ld, const int32_t *cols, int n_cols, int k,
@@ -372,7 +525,10 @@ extern "C" int hgr_eval_rows(const float *logits, int64_t ld, int n_nodes, const
     HGR_REQUIRE(logits && lvl8 && train_pos && train_cols && filler_pos && out_level, "hgr_eval_rows: null operand");
     HGR_REQUIRE(rows >= 1 && n_nodes >= 1 && ld >= n_nodes && n_train >= 1 && n_levels >= 1 && n_levels <= 32, "hgr_eval_rows: bad sizes (n_levels <= 32)");
     HGR_REQUIRE(k == 0 || (out_topk && test_pos && test_cols && k >= 1 && k <= 32 && n_test >= k), "hgr_eval_rows: bad top-k arguments");
-    if (n_levels <= 16) hipLaunchKernelGGL((eval_rows<16>), dim3(rows), dim3(EV_NT), 0, (hipStream_t)stream, logits, ld, n_nodes, lvl8, train_pos, train_cols, n_train,
+    static const bool regs = getenv("HGR_EVAL_REGS") != nullptr;      // diagnostics: the register-accumulator variant
+    if (n_levels <= 16 && !regs) hipLaunchKernelGGL(eval_rows_lds, dim3(rows), dim3(EL_NT), 0, (hipStream_t)stream, logits, ld, n_nodes, lvl8, train_pos, train_cols,
+                                                    n_train, n_levels, filler_pos, test_pos, test_cols, n_test, k, out_level, out_top1, out_topk);
+    else if (n_levels <= 16) hipLaunchKernelGGL((eval_rows<16>), dim3(rows), dim3(EV_NT), 0, (hipStream_t)stream, logits, ld, n_nodes, lvl8, train_pos, train_cols, n_train,
                                            n_levels, filler_pos, test_pos, test_cols, n_test, k, out_level, out_top1, out_topk);
     else hipLaunchKernelGGL((eval_rows<32>), dim3(rows), dim3(EV_NT), 0, (hipStream_t)stream, logits, ld, n_nodes, lvl8, train_pos, train_cols, n_train,
                             n_levels, filler_pos, test_pos, test_cols, n_test, k, out_level, out_top1, out_topk);
