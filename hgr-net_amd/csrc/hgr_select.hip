@@ -374,20 +374,26 @@ __global__ __launch_bounds__(EL_NT) void eval_rows_lds(const float *__restrict__
 #pragma unroll
     for (int l = 0; l < EL_NLV; ++l) acc[l][tid] = 0ull;
     Best mine = {-INFINITY, 0x7fffffff};
-    for (int c = tid; c < n_nodes; c += EL_NT) {
-        const float v = lr[c] + 0.0f;
-        const int tp = train_pos[c];
-        if (tp >= 0) {
-            const unsigned u = __float_as_uint(v);
-            const unsigned long long key = ((unsigned long long)(u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u)) << 32) | (unsigned)(0x7fffffff - tp);
-            const int lv = lvl8[c];
-            if (lv < EL_NLV) {                                   // always true for a valid index (depth < n_levels <= 16)
-                unsigned long long *slot = &acc[lv][tid];
+    // 4 columns per trip, every load issued before the first use (a load under a branch is waited for on the spot)
+    for (int c0 = tid; c0 < n_nodes; c0 += 4 * EL_NT) {
+        float v4[4]; int tp4[4], lv4[4], te4[4];
+#pragma unroll
+        for (int u4 = 0; u4 < 4; ++u4) {
+            const int c = min(c0 + u4 * EL_NT, n_nodes - 1);
+            v4[u4] = lr[c]; tp4[u4] = train_pos[c]; lv4[u4] = lvl8[c]; te4[u4] = k > 0 ? test_pos[c] : -1;
+        }
+#pragma unroll
+        for (int u4 = 0; u4 < 4; ++u4) {
+            if (c0 + u4 * EL_NT >= n_nodes) break;
+            const float v = v4[u4] + 0.0f;
+            const int tp = tp4[u4];
+            if (tp >= 0 && lv4[u4] < EL_NLV) {                  // the level test is always true for a valid index (depth < n_levels <= 16)
+                const unsigned u = __float_as_uint(v);
+                const unsigned long long key = ((unsigned long long)(u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u)) << 32) | (unsigned)(0x7fffffff - tp);
+                unsigned long long *slot = &acc[lv4[u4]][tid];
                 if (key > *slot) *slot = key;
             }
-        }
-        if (k > 0) {
-            const int te = test_pos[c];
+            const int te = te4[u4];
             if (te >= 0 && better(v, te, mine.v, mine.p)) { mine.v = v; mine.p = te; }
         }
     }
@@ -449,13 +455,22 @@ __global__ __launch_bounds__(EL_NT) void eval_rows_lds(const float *__restrict__
     }
     __syncthreads();
     const float t = s_t; const int tp0 = s_tp;
-    for (int c = tid; c < n_nodes; c += EL_NT) {
-        const int te = test_pos[c];
-        if (te < 0) continue;
-        const float v = lr[c] + 0.0f;
-        if (!better(t, tp0, v, te)) {
-            const int slot = atomicAdd(&s_cnt, 1);
-            if (slot < TOPK_CAND) { s_cv[slot] = v; s_cp[slot] = te; }
+    for (int c0 = tid; c0 < n_nodes; c0 += 4 * EL_NT) {
+        float v4[4]; int te4[4];
+#pragma unroll
+        for (int u4 = 0; u4 < 4; ++u4) {
+            const int c = min(c0 + u4 * EL_NT, n_nodes - 1);
+            v4[u4] = lr[c]; te4[u4] = test_pos[c];
+        }
+#pragma unroll
+        for (int u4 = 0; u4 < 4; ++u4) {
+            if (c0 + u4 * EL_NT >= n_nodes) break;
+            const int te = te4[u4];
+            const float v = v4[u4] + 0.0f;
+            if (te >= 0 && !better(t, tp0, v, te)) {
+                const int slot = atomicAdd(&s_cnt, 1);
+                if (slot < TOPK_CAND) { s_cv[slot] = v; s_cp[slot] = te; }
+            }
         }
     }
     __syncthreads();
