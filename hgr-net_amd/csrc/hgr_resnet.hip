@@ -26,10 +26,12 @@ __global__ __launch_bounds__(256) void stem_im2col(const float *__restrict__ img
             const int ky = t / 3, kx = t % 3;
             const int hi = ho * 2 - 1 + ky, wi = wo * 2 - 1 + kx;
             const bool ok = hi >= 0 && hi < R && wi >= 0 && wi < R;
+            const int hc = min(max(hi, 0), R - 1), wc = min(max(wi, 0), R - 1);      // unconditional loads (clamped), then select
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const int k = t * 3 + c;
-                v[k >> 3][k & 7] = (E)(ok ? img[(((int64_t)b * 3 + c) * R + hi) * R + wi] : 0.f);
+                const float x = img[(((int64_t)b * 3 + c) * R + hc) * R + wc];
+                v[k >> 3][k & 7] = (E)(ok ? x : 0.f);
             }
         }
         vec8 *o = (vec8 *)(out + row * 64);
