@@ -41,13 +41,12 @@ __global__ __launch_bounds__(256) void mha_fwd(const typename T16<DT>::elem *__r
     // stage K (swizzled rows) and V^T (zero-filled past L: 0 * garbage must stay 0)
     for (int idx = tid; idx < LP * 8; idx += 256) {
         const int row = idx >> 3, c = idx & 7;
-        vec8 kv, vv;
+        const int rc = min(row, L - 1);                    // unconditional loads (a load under a branch is waited for at once)
+        vec8 kv = *(const vec8 *)(base + rc * ld + W + c * 8);
+        vec8 vv = *(const vec8 *)(base + rc * ld + 2 * W + c * 8);
+        if (row >= L)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { kv[e] = (E)0.f; vv[e] = (E)0.f; }
-        if (row < L) {
-            kv = *(const vec8 *)(base + row * ld + W + c * 8);
-            vv = *(const vec8 *)(base + row * ld + 2 * W + c * 8);
-        }
+            for (int e = 0; e < 8; ++e) { kv[e] = (E)0.f; vv[e] = (E)0.f; }
         *(vec8 *)(sK + row * 128 + ((c ^ (row & 7)) * 16)) = kv;
 #pragma unroll
         for (int e = 0; e < 8; ++e) sVt[(c * 8 + e) * VS + row] = vv[e];
