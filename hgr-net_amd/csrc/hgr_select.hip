@@ -135,14 +135,24 @@ __global__ __launch_bounds__(256) void level_argmax(const float *__restrict__ lo
     for (int l = 0; l < NLV; ++l) { bv[l] = -INFINITY; bp[l] = 0x7fffffff; }
     const int lvl0 = depth[cols ? cols[0] : 0];
     int fd = 0x7fffffff;                                // first position whose level differs from position 0's
-    for (int p = tid; p < n_cols; p += 256) {
-        const int c = cols ? cols[p] : p;
-        const int lv = depth[c];
-        const float v = lr[c];
-        if (lv != lvl0 && p < fd) fd = p;
+    for (int p0 = tid; p0 < n_cols; p0 += 4 * 256) {       // 4 positions per trip: the dependent column -> (depth, logit) loads in two batches
+        int c4[4], lv4[4];
+        float v4[4];
 #pragma unroll
-        for (int l = 0; l < NLV; ++l)
-            if (lv == l && v > bv[l]) { bv[l] = v; bp[l] = p; }
+        for (int u = 0; u < 4; ++u) { const int p = min(p0 + u * 256, n_cols - 1); c4[u] = cols ? cols[p] : p; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { lv4[u] = depth[c4[u]]; v4[u] = lr[c4[u]]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = p0 + u * 256;
+            if (p >= n_cols) break;
+            const int lv = lv4[u];
+            const float v = v4[u];
+            if (lv != lvl0 && p < fd) fd = p;
+#pragma unroll
+            for (int l = 0; l < NLV; ++l)
+                if (lv == l && v > bv[l]) { bv[l] = v; bp[l] = p; }
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) fd = min(fd, __shfl_xor(fd, o));
