@@ -59,6 +59,7 @@ SIGNATURES = {
     "hgr_ctx_splice": [_p, _p, _p, _i, _i, _i, _i, _p],
     "hgr_ctx_splice_bwd": [_p, _p, _i, _i, _i, _i, _p],
     "hgr_sumsq": [_p, _l, _p, _p],
+    "hgr_eval_counters": [_p, _i, _p, _i, _p, _p, _i, _p, _p, _i, _p, _i, _p],
     "hgr_dot_f32": [_p, _p, _l, _p, _f, _i, _p],
     "hgr_conv3x3_nhwc_plain": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "hgr_gemm_nt_splitk": [_p, _l, _p, _l, _p, _l, _i, _i, _i, _i, _i, _p],

@@ -543,6 +543,60 @@ extern "C" int hgr_level_argmax(const float *logits, int64_t ld, const int32_t *
     return HGR_OK;
 }
 
+namespace {
+// T1 / T2 / T4 bookkeeping of one batch (main.py:139-148,157-160,177-191) from the outputs of eval_rows: one block, integer
+// counts reduced in a fixed order, then the nine double-precision counters of the evaluation are advanced in place.
+__global__ __launch_bounds__(256) void eval_counters(const int32_t *__restrict__ pred, int k, const int64_t *__restrict__ targets, int target,
+                                                     const int32_t *__restrict__ top1, const int32_t *__restrict__ lv, int n_levels,
+                                                     const int32_t *__restrict__ parents, const int32_t *__restrict__ levels, int L,
+                                                     double *__restrict__ acc, int B) {
+    __shared__ unsigned s_red[4][8];
+    unsigned cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // hits@1,2,5,10,20, hits_all, edges (or first-level matches when L == 1), points
+    for (int r = threadIdx.x; r < B; r += 256) {
+        const int tgt = targets ? (int)targets[r] : target;
+        int j = k;
+        for (int i = k - 1; i >= 0; --i)
+            if (pred[(int64_t)r * k + i] == tgt) j = i;         // first match (ids are distinct: at most one)
+        cnt[0] += j < 1; cnt[1] += j < 2; cnt[2] += j < 5; cnt[3] += j < 10; cnt[4] += j < 20;
+        const int t1 = top1[r];
+        bool prev = false;
+        for (int i = 0; i < L; ++i) {
+            cnt[5] += t1 == parents[i];
+            const bool m = lv[(int64_t)r * n_levels + levels[i]] == parents[i];
+            cnt[7] += m;
+            if (L == 1) cnt[6] += m;
+            else if (i > 0) cnt[6] += (m && prev);
+            prev = m;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        unsigned v = cnt[c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6][c] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned t[8];
+        for (int c = 0; c < 8; ++c) t[c] = s_red[0][c] + s_red[1][c] + s_red[2][c] + s_red[3][c];
+        for (int c = 0; c < 6; ++c) acc[c] += (double)t[c];
+        acc[6] += L > 1 ? (double)t[6] / (double)(L - 1) : (double)t[6];
+        acc[7] += (double)t[7] / (double)L;
+        acc[8] += (double)B;
+    }
+}
+}  // namespace
+
+extern "C" int hgr_eval_counters(const int32_t *pred, int k, const int64_t *targets, int target, const int32_t *top1, const int32_t *lv,
+                                 int n_levels, const int32_t *parents, const int32_t *levels, int L, double *acc, int rows, void *stream) {
+    HGR_REQUIRE(pred && top1 && lv && parents && levels && acc, "hgr_eval_counters: null operand");
+    HGR_REQUIRE(rows >= 1 && k >= 1 && k <= 32 && L >= 1 && n_levels >= 1, "hgr_eval_counters: bad sizes rows=%d k=%d L=%d", rows, k, L);
+    hipLaunchKernelGGL(eval_counters, dim3(1), dim3(256), 0, (hipStream_t)stream, pred, k, targets, target, top1, lv, n_levels, parents, levels, L, acc, rows);
+    HGR_CHECK_LAUNCH("hgr_eval_counters");
+    return HGR_OK;
+}
+
 extern "C" int hgr_eval_rows(const float *logits, int64_t ld, int n_nodes, const unsigned char *lvl8, const int32_t *train_pos,
                              const int32_t *train_cols, int n_train, int n_levels, const int32_t *filler_pos, const int32_t *test_pos,
                              const int32_t *test_cols, int n_test, int k, int32_t *out_level, int32_t *out_top1, int32_t *out_topk,

@@ -38,34 +38,28 @@ class Evaluator:
             parents = copy.copy(m.c2p[target]) + [target]
             levels = [len(m.c2p[p]) for p in parents]           # main.py:164
             dev = m.train_index.device
-            c = (torch.tensor(parents, dtype=torch.int32, device=dev), torch.tensor(levels, dtype=torch.int64, device=dev), len(parents))
+            c = (torch.tensor(parents, dtype=torch.int32, device=dev), torch.tensor(levels, dtype=torch.int64, device=dev),
+                 torch.tensor(levels, dtype=torch.int32, device=dev), len(parents))
             self._parents_cache[target] = c
         return c
 
     @torch.no_grad()
-    def add_batch(self, logits: torch.Tensor, target: int, targets: Optional[torch.Tensor] = None):
+    def add_batch(self, logits: torch.Tensor, target: int, targets: Optional[torch.Tensor] = None, want_outputs: bool = True):
         """One iteration of main.py:131-191 on device.  ``target`` = the batch's single class
-        (every batch is one group).  Returns (pred_top20, dict_path) int32 tensors."""
-        m = self.model
-        b = logits.shape[0]
-        # T1 (top-20 over the test columns, main.py:136-139), T2 (top-1 over the train columns, :157) and T3 (arg-max per
-        # depth level, :162-176) in one fused kernel (hgr_eval_rows)
+        (every batch is one group).  Two launches: hgr_eval_rows (top-20 over the test columns :136-139,
+        top-1 over the train columns :157, arg-max per depth level :162-176) and hgr_eval_counters (hits, hit / path /
+        point ratios :139-148,157-160,177-191).  Returns (pred_top20, dict_path) int32 tensors unless ``want_outputs``
+        is False (the evaluation loop itself does not need them)."""
         lv, p1, pred = ops.eval_rows(logits, self.index, max(TOPK))
-        correct = pred == (targets.to(torch.int32).view(-1, 1) if targets is not None else target)
-        csum = correct.cumsum(dim=1).sum(dim=0).to(torch.float64)                    # hits for every k at once
-        parents, levels, L = self._parents(target)
-        hits_all = (p1 == parents.view(1, -1)).sum().to(torch.float64)
-        dict_path = lv[:, levels]                                                    # [B, L]
-        match = dict_path == parents.view(1, -1)                                     # T4 main.py:177-191
-        point = match.sum().to(torch.float64)
-        if L > 1:
-            path = (match[:, :-1] & match[:, 1:]).sum().to(torch.float64) / (L - 1)
-        else:
-            path = match[:, 0].sum().to(torch.float64)
-        upd = torch.stack([csum[0], csum[1], csum[4], csum[9], csum[19], hits_all, path, point / L,
-                           torch.tensor(float(b), dtype=torch.float64, device=logits.device)])
-        self.acc += upd
-        return pred, dict_path
+        parents, levels64, levels32, L = self._parents(target)
+        tg = None
+        if targets is not None:
+            tg = targets if targets.dtype == torch.int64 else targets.to(torch.int64)
+            tg = tg.contiguous()
+        ops.eval_counters(pred, tg, int(target), p1.view(-1), lv, parents, levels32, self.acc)
+        if not want_outputs:
+            return None
+        return pred, lv[:, levels64]                                                 # dict_path [B, L]
 
     def counters(self, group=None) -> Dict[str, float]:
         """Read the counters (one D2H copy); with a process group, all-reduce(sum) them first."""
@@ -112,7 +106,7 @@ def test(opts, model, device, splits=None, loader: Optional[Iterable] = None, gr
         imgs, targets = data["img"].to(device, non_blocking=True)[0], data["label"].to(device, non_blocking=True)[0]
         target = int(data["label"][0][0])           # host copy of the label: no device sync in the loop
         logits = model(imgs, targets)
-        ev.add_batch(logits, target, targets)
+        ev.add_batch(logits, target, targets, want_outputs=False)
     print("End of testing.")
     out = ev.summary(group)
     print(out, flush=True)

@@ -238,6 +238,16 @@ def eval_rows(logits: torch.Tensor, index: EvalIndex, k: int):
     return lvl, top1, topk
 
 
+def eval_counters(pred: torch.Tensor, targets: Optional[torch.Tensor], target: int, top1: torch.Tensor, lv: torch.Tensor,
+                  parents: torch.Tensor, levels: torch.Tensor, acc: torch.Tensor) -> None:
+    """Advance the nine float64 evaluation counters with one batch (main.py:139-191) from eval_rows' outputs."""
+    assert pred.dtype == top1.dtype == lv.dtype == parents.dtype == levels.dtype == torch.int32 and acc.dtype == torch.float64
+    assert pred.is_contiguous() and lv.is_contiguous() and top1.is_contiguous() and acc.numel() == 9
+    assert targets is None or (targets.dtype == torch.int64 and targets.is_contiguous() and targets.numel() == pred.shape[0])
+    _lib.call("hgr_eval_counters", _dev(pred), pred.shape[1], _dev(targets), int(target), _dev(top1), _dev(lv), lv.shape[1], _dev(parents),
+              _dev(levels), parents.numel(), _dev(acc), pred.shape[0], _stream())
+
+
 # ---- ModifiedResNet (RN) tower -------------------------------------------------------------------
 def conv3x3_nhwc(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out: torch.Tensor, b: int, h: int, wd: int, c: int,
                  stride: int = 1) -> torch.Tensor:

@@ -194,6 +194,14 @@ int hgr_eval_rows(const float *logits, int64_t ld, int n_nodes, const unsigned c
                   const int32_t *test_cols, int n_test, int k, int32_t *out_level, int32_t *out_top1, int32_t *out_topk,
                   int rows, void *stream);
 
+/* The counters of one evaluation batch (main.py:139-148 top-k hits, :157-160 hit_ratio, :177-191 path / point overlap) from
+ * hgr_eval_rows' outputs: acc[0..4] += rows whose target is inside the top-1/2/5/10/20, acc[5] += top-1 hits on any node of
+ * the target's path, acc[6] += matched consecutive level pairs / (L - 1) (matches when L == 1), acc[7] += matched levels / L,
+ * acc[8] += rows.  targets int64 [rows] or NULL (then `target` for every row); parents / levels int32 [L]: the path's node
+ * ids and their depths; acc double [9] on the device, advanced in place (one block, fixed order). */
+int hgr_eval_counters(const int32_t *pred, int k, const int64_t *targets, int target, const int32_t *top1, const int32_t *lv,
+                      int n_levels, const int32_t *parents, const int32_t *levels, int L, double *acc, int rows, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * ModifiedResNet (RN50) tower, clip/model.py:93-150.  Activations are NHWC 16-bit ([B, H, W, C] =
  * a row-major [B*H*W, C] matrix), so every 1x1 convolution IS hgr_gemm_nt; inference BatchNorm
