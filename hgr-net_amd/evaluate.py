@@ -105,7 +105,7 @@ def test(opts, model, device, splits=None, loader: Optional[Iterable] = None, gr
     for data in loader:
         imgs, targets = data["img"].to(device, non_blocking=True)[0], data["label"].to(device, non_blocking=True)[0]
         target = int(data["label"][0][0])           # host copy of the label: no device sync in the loop
-        logits = model(imgs, targets)
+        logits = model(imgs, targets, static_output=True)     # consumed by add_batch before the next forward
         ev.add_batch(logits, target, targets, want_outputs=False)
     print("End of testing.")
     out = ev.summary(group)

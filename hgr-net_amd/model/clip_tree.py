@@ -134,22 +134,23 @@ class tree_model(nn.Module):
         assert z32.shape[0] == n
 
     @torch.no_grad()
-    def forward(self, inputs, targets=None):
+    def forward(self, inputs, targets=None, static_output: bool = False):
         """logits[B, N] = normalise(encode_image(x)) @ zsl_weights.T, no temperature; ``targets`` is
         ignored as in the reference (clip_tree.py:328-333)."""
         if self._zsl16 is None:
             raise HgrError("call update_classifier() before forward()")
         if self.use_graph and inputs.is_cuda:
-            return self._forward_graphed(inputs)
+            return self._forward_graphed(inputs, static_output)
         return self._forward_eager(inputs)
 
-    def _forward_graphed(self, inputs):
+    def _forward_graphed(self, inputs, static_output: bool = False):
         """The ~100 launches of one forward replayed as a HIP graph: no host launch cost and no inter-kernel gaps
         (+6 % on the ViT-B/32 step).  Same kernels, same bits.  A graph is bound to the buffers it was captured on, so
         graphs live for one generation = (input shape, dtype, classifier, prepared weights): anything else clears them
         (the warm-up run may also have re-allocated workspace buffers older graphs point into).  Inside a generation up
         to 4 graphs are keyed by the input buffer's address - loaders recycle a few buffers; after 8 misses in a row the
-        input is copied into one static buffer instead.  The logits are returned as a fresh tensor."""
+        input is copied into one static buffer instead.  The logits are returned as a fresh tensor unless the caller passes
+        ``static_output=True`` (it consumes them before the next forward: the evaluation loop does)."""
         gen = (tuple(inputs.shape), inputs.dtype, self._zsl16.data_ptr(), self.clip_model._fingerprint())
         if gen != self._graph_gen:
             self._graphs.clear()
@@ -165,14 +166,14 @@ class tree_model(nn.Module):
                 buf, g, out = self._graph_static
                 buf.copy_(inputs)
                 g.replay()
-                return out.clone()
+                return out if static_output else out.clone()
             if len(self._graphs) >= 4:
                 self._graphs.pop(next(iter(self._graphs)))
             ent = self._graphs[inputs.data_ptr()] = self._capture(inputs)
         else:
             self._graph_misses = 0
         ent[0].replay()
-        return ent[1].clone()
+        return ent[1] if static_output else ent[1].clone()
 
     def _capture(self, inputs):
         self._forward_eager(inputs)                             # warm-up: workspace buffers and prepared weights exist
