@@ -1,4 +1,8 @@
-import sys; sys.path.insert(0,'/root/repo')
+#!/usr/bin/env python3
+"""Dev tool: correctness + bandwidth of hgr_transpose16 on the shapes the weight-gradient path uses."""
+import sys
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import torch
 from hgr_net_amd import ops
 for (r,c) in [(16448,1024),(16448,4096),(12800,768),(12800,3072),(802816,64),(3084,512),(300,200),(16448,1000)]:
