@@ -96,7 +96,12 @@ def test(opts, model, device, splits=None, loader: Optional[Iterable] = None, gr
         import os
         data = DataManager_test(opts=opts, split=opts.data_split_test, node_set=model.nodes, candidates=splits[opts.data_test],
                                 resolution=model.resolution)
-        loader = data.get_data_loader(device=device, rank=int(os.environ.get("RANK", "0")) if group is not None else 0,
+        # ViT towers take the uint8 crops directly (normalisation fused into the patch kernel): a quarter of the bytes
+        from .clip.model import VisionTransformer
+        v = model.clip_model.visual
+        u8_ok = isinstance(v, VisionTransformer) and (3 * v.patch_size ** 2) % 64 == 0
+        loader = data.get_data_loader(device=device, output="u8" if u8_ok else "f32",
+                                      rank=int(os.environ.get("RANK", "0")) if group is not None else 0,
                                       world_size=int(os.environ.get("WORLD_SIZE", "1")) if group is not None else 1,
                                       workers=getattr(opts, "num_workers", 8))
         print("number of batches:{}".format(loader.batch_sampler.num_batch))
