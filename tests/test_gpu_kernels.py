@@ -392,3 +392,40 @@ def test_eval_rows_fused_exact(n, levels, dup):
     for r in range(rows):
         assert int(top1[r, 0]) == tr[tree_ref.topk_desc(lg[r, torch.from_numpy(tr)].numpy(), 1)[0]]
         assert np.array_equal(topk[r].cpu().numpy(), test[tree_ref.topk_desc(lg[r, torch.from_numpy(test.astype(np.int64))].numpy(), k)])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_eval_counters_vs_host_recount(seed):
+    """hgr_eval_counters against a literal recount of main.py:139-148 (top-k hits), :157-160 (hit_ratio) and :177-191
+    (path / point overlap) on random predictions: path lengths 1..9, per-row or scalar targets, repeated accumulation."""
+    rng = np.random.default_rng(seed)
+    rows, k, n_levels, n_nodes = int(rng.integers(1, 300)), 20, int(rng.integers(1, 14)), 500
+    L = int(rng.integers(1, min(n_levels, 9) + 1))
+    parents = rng.choice(n_nodes, L, replace=False).astype(np.int32)
+    levels = np.sort(rng.choice(n_levels, L, replace=False)).astype(np.int32)
+    target = int(parents[-1])
+    pred = np.stack([rng.choice(n_nodes, k, replace=False) for _ in range(rows)]).astype(np.int32)
+    pred[rng.random(rows) < 0.4, int(rng.integers(0, k))] = target                 # plant hits at one rank
+    top1 = np.where(rng.random(rows) < 0.5, rng.choice(parents, rows), rng.integers(0, n_nodes, rows)).astype(np.int32)
+    lv = rng.integers(0, n_nodes, (rows, n_levels)).astype(np.int32)
+    for i in range(L):                                                             # plant level matches
+        m = rng.random(rows) < 0.6
+        lv[m, levels[i]] = parents[i]
+    acc = torch.zeros(9, dtype=torch.float64, device=DEV)
+    per_row = seed % 2 == 0
+    tg = torch.full((rows,), target, dtype=torch.int64, device=DEV) if per_row else None
+    for _ in range(2):                                                             # accumulates
+        ops.eval_counters(torch.from_numpy(pred).to(DEV), tg, target, torch.from_numpy(top1).to(DEV), torch.from_numpy(lv).to(DEV),
+                          torch.from_numpy(parents).to(DEV), torch.from_numpy(levels).to(DEV), acc)
+    want = np.zeros(9)
+    for r in range(rows):
+        hit = np.nonzero(pred[r] == target)[0]
+        j = int(hit[0]) if hit.size else k
+        for c, kk in enumerate((1, 2, 5, 10, 20)):
+            want[c] += j < kk
+        want[5] += int((top1[r] == parents).sum())
+        match = lv[r, levels] == parents
+        want[7] += match.sum() / L
+        want[6] += (match[:-1] & match[1:]).sum() / (L - 1) if L > 1 else float(match[0])
+        want[8] += 1
+    assert np.allclose(acc.cpu().numpy(), 2 * want, rtol=0, atol=1e-9)
