@@ -27,7 +27,7 @@ SIGNATURES = {
     "hgr_im2col_patches": [_p, _p, _i, _i, _i, _i, _i, _p],
     "hgr_im2col_patches_ex": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "hgr_vit_assemble": [_p, _p, _p, _i, _i, _i, _p],
-    "hgr_preprocess_bicubic": [_p, _p, _p, _p, _p, _i, _p, _p, _i, _p, _p, C.POINTER(C.c_float), C.POINTER(C.c_float), _i, _i, _p],
+    "hgr_preprocess_bicubic": [_p, _p, _p, _p, _p, _p, _i, _p, _p, _i, _p, _p, C.POINTER(C.c_float), C.POINTER(C.c_float), _i, _i, _p],
     "hgr_im2col_patches_u8": [_p, _p, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _i, _p],
     "hgr_vit_embed_ln": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p],
     "hgr_layernorm": [_p, _p, _p, _p, _i, _i, _l, _p, _f, _i, _i, _p],

@@ -46,25 +46,26 @@ __device__ __forceinline__ void hconv(const unsigned char *p, const int *kx, int
 constexpr int CH = 32;      // source rows per chunk: two (row, column) items per thread in the horizontal pass
 
 __global__ __launch_bounds__(256) void preprocess_bicubic(const unsigned char *__restrict__ src, const int64_t *__restrict__ off,
-                                                          const int *__restrict__ hw, const int *__restrict__ xb,
+                                                          const int *__restrict__ hw, const int *__restrict__ tab, const int *__restrict__ xb,
                                                           const int *__restrict__ xk, int KX, const int *__restrict__ yb,
                                                           const int *__restrict__ yk, int KY, unsigned char *__restrict__ out_u8,
                                                           float *__restrict__ out_f32, float m0, float m1, float m2, float s0,
                                                           float s1, float s2, int R, int tiles) {
     __shared__ int hrow[CH][16][3];
     const int b = blockIdx.y;
+    const int tb = tab ? tab[b] : b;                 // images of one size share one set of tap tables
     const int ty0 = (blockIdx.x / tiles) * 16, tx0 = (blockIdx.x % tiles) * 16;
     const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
     const int ox = min(tx0 + lx, R - 1), oy = min(ty0 + ly, R - 1);          // clamped: edge threads redo a valid pixel
     const int w = hw[b * 2 + 1];
     const unsigned char *img = src + off[b];
-    const int *bx = xb + ((int64_t)b * R + ox) * 2, *by = yb + ((int64_t)b * R + oy) * 2;
+    const int *bx = xb + ((int64_t)tb * R + ox) * 2, *by = yb + ((int64_t)tb * R + oy) * 2;
     const int xmin = bx[0], xn = bx[1], ymin = by[0], yn = by[1];
-    const int *kx = xk + ((int64_t)b * R + ox) * KX, *ky = yk + ((int64_t)b * R + oy) * KY;
+    const int *kx = xk + ((int64_t)tb * R + ox) * KX, *ky = yk + ((int64_t)tb * R + oy) * KY;
     // source rows read by this tile: bounds are non-decreasing in the output row
     const int ylast = min(ty0 + 15, R - 1);
-    const int r0 = yb[((int64_t)b * R + ty0) * 2];
-    const int r1 = yb[((int64_t)b * R + ylast) * 2] + yb[((int64_t)b * R + ylast) * 2 + 1];
+    const int r0 = yb[((int64_t)tb * R + ty0) * 2];
+    const int r1 = yb[((int64_t)tb * R + ylast) * 2] + yb[((int64_t)tb * R + ylast) * 2 + 1];
 
     int a0 = 1 << (PB - 1), a1 = a0, a2 = a0;
     for (int rc = r0; rc < r1; rc += CH) {
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(256) void preprocess_bicubic(const unsigned char *_
 
 }  // namespace
 
-extern "C" int hgr_preprocess_bicubic(const unsigned char *src, const int64_t *off, const int *hw, const int *xb, const int *xk,
+extern "C" int hgr_preprocess_bicubic(const unsigned char *src, const int64_t *off, const int *hw, const int *tab, const int *xb, const int *xk,
                                       int KX, const int *yb, const int *yk, int KY, unsigned char *out_u8, float *out_f32,
                                       const float *mean3, const float *std3, int B, int R, void *stream) {
     HGR_REQUIRE(src && off && hw && xb && xk && yb && yk, "hgr_preprocess_bicubic: null operand");
@@ -115,7 +116,7 @@ extern "C" int hgr_preprocess_bicubic(const unsigned char *src, const int64_t *o
     const int tiles = (R + 15) / 16;
     const float m0 = mean3 ? mean3[0] : 0.f, m1 = mean3 ? mean3[1] : 0.f, m2 = mean3 ? mean3[2] : 0.f;
     const float s0 = std3 ? std3[0] : 1.f, s1 = std3 ? std3[1] : 1.f, s2 = std3 ? std3[2] : 1.f;
-    hipLaunchKernelGGL(preprocess_bicubic, dim3(tiles * tiles, B), dim3(256), 0, (hipStream_t)stream, src, off, hw, xb, xk, KX, yb, yk, KY,
+    hipLaunchKernelGGL(preprocess_bicubic, dim3(tiles * tiles, B), dim3(256), 0, (hipStream_t)stream, src, off, hw, tab, xb, xk, KX, yb, yk, KY,
                        out_u8, out_f32, m0, m1, m2, s0, s1, s2, R, tiles);
     HGR_CHECK_LAUNCH("hgr_preprocess_bicubic");
     return HGR_OK;

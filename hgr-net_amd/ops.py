@@ -102,17 +102,19 @@ def im2col_patches_u8(image: torch.Tensor, out: torch.Tensor, patch: int, mean=C
     return out
 
 
-def preprocess_bicubic(src: torch.Tensor, off: torch.Tensor, hw: torch.Tensor, xb: torch.Tensor, xk: torch.Tensor, kx: int,
+def preprocess_bicubic(src: torch.Tensor, off: torch.Tensor, hw: torch.Tensor, tab: Optional[torch.Tensor], xb: torch.Tensor, xk: torch.Tensor, kx: int,
                        yb: torch.Tensor, yk: torch.Tensor, ky: int, out_u8: Optional[torch.Tensor], out_f32: Optional[torch.Tensor],
                        mean=CLIP_MEAN, std=CLIP_STD, b: int = 0, r: int = 0) -> None:
     """Resize + center crop (+ normalise) of packed uint8 RGB images; tables from hgr_net_amd.preprocess."""
     import ctypes
     assert src.dtype == torch.uint8 and off.dtype == torch.int64 and all(t.dtype == torch.int32 for t in (hw, xb, xk, yb, yk))
-    assert off.numel() == b and hw.numel() == 2 * b and xb.numel() == 2 * b * r and xk.numel() == b * r * kx and yk.numel() == b * r * ky
+    t = xb.numel() // (2 * r)                                  # number of table sets
+    assert off.numel() == b and hw.numel() == 2 * b and xb.numel() == 2 * t * r and xk.numel() == t * r * kx and yk.numel() == t * r * ky
+    assert (tab is None and t == b) or (tab is not None and tab.dtype == torch.int32 and tab.numel() == b)
     assert out_u8 is None or (out_u8.dtype == torch.uint8 and out_u8.is_contiguous() and out_u8.numel() == b * r * r * 3)
     assert out_f32 is None or (out_f32.dtype == torch.float32 and out_f32.is_contiguous() and out_f32.numel() == b * r * r * 3)
     m3, s3 = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
-    _lib.call("hgr_preprocess_bicubic", _dev(src), _dev(off), _dev(hw), _dev(xb), _dev(xk), kx, _dev(yb), _dev(yk), ky,
+    _lib.call("hgr_preprocess_bicubic", _dev(src), _dev(off), _dev(hw), _dev(tab), _dev(xb), _dev(xk), kx, _dev(yb), _dev(yk), ky,
               _dev(out_u8), _dev(out_f32), m3, s3, b, r, _stream())
 
 

@@ -112,54 +112,61 @@ class BatchPreprocessor:
     def __call__(self, images: List[np.ndarray], output: str = "f32") -> torch.Tensor:
         assert output in ("f32", "u8") and len(images) > 0
         r, b = self.n_px, len(images)
-        tabs = []
-        for im in images:
+        # one set of tap tables per distinct image size (a batch of ImageNet files has a handful)
+        sizes_hw, tab = {}, np.empty(b, np.int32)
+        for i, im in enumerate(images):
             if im.dtype != np.uint8 or im.ndim != 3 or im.shape[2] != 3:
                 raise ValueError(f"expected uint8 [H, W, 3] RGB arrays, got {im.dtype} {im.shape}")
-            tabs.append(image_tables(im.shape[1], im.shape[0], r))
-        kx, ky = max(t[1].shape[1] for t in tabs), max(t[3].shape[1] for t in tabs)
+            tab[i] = sizes_hw.setdefault((im.shape[0], im.shape[1]), len(sizes_hw))
+        tabs = [image_tables(w, h, r) for (h, w) in sizes_hw]
+        t = len(tabs)
+        kx, ky = max(x[1].shape[1] for x in tabs), max(x[3].shape[1] for x in tabs)
         kx = (kx + 3) // 4 * 4                                   # the kernel consumes 4 horizontal taps per step
         if max(kx, ky) > MAX_TAPS:
             raise ValueError(f"an image is more than {MAX_TAPS // 4 - 1}x larger than the crop: reduce it on the host first")
-        sizes = np.array([im.shape[0] * im.shape[1] * 3 for im in images], np.int64)
+        nbytes_img = np.array([im.shape[0] * im.shape[1] * 3 for im in images], np.int64)
         off = np.zeros(b, np.int64)
-        off[1:] = np.cumsum((sizes[:-1] + 15) // 16 * 16)                      # 16-byte aligned starts
-        total = int(off[-1] + sizes[-1])
-        # one pinned staging buffer: [image bytes | off | hw | xb | yb | xk | yk], one H2D copy
-        meta_i32 = b * 2 + 2 * b * r * 2 + b * r * kx + b * r * ky + 4       # + pad so that xk starts 16-byte aligned
+        off[1:] = np.cumsum((nbytes_img[:-1] + 15) // 16 * 16)                 # 16-byte aligned starts
+        total = int(off[-1] + nbytes_img[-1])
+        # one pinned staging buffer: [image bytes | off | hw | tab | xb | yb | (pad) xk | yk], one H2D copy
+        n_i32 = b * 2 + b + 2 * t * r * 2
+        n_i32 = (n_i32 + 3) // 4 * 4                             # xk starts 16-byte aligned
+        q_xk = n_i32
+        n_i32 += t * r * kx + t * r * ky
         base_meta = (total + 15) // 16 * 16
-        nbytes = base_meta + (b * 8 + 15) // 16 * 16 + meta_i32 * 4
+        p_i32 = base_meta + (b * 8 + 15) // 16 * 16
+        nbytes = p_i32 + n_i32 * 4 + 32                           # + slack: a row's bytes are fetched 12 at a time
         pin = self._pinned(nbytes)
         host = pin.numpy()
+
         def put(k):                                              # numpy copies release the GIL: pack with a few threads
-            host[off[k]:off[k] + sizes[k]] = np.ascontiguousarray(images[k]).reshape(-1)
+            host[off[k]:off[k] + nbytes_img[k]] = np.ascontiguousarray(images[k]).reshape(-1)
         if total > (8 << 20):
             list(self._pool().map(put, range(b)))
         else:
             for k in range(b):
                 put(k)
-        p = base_meta
-        host[p:p + b * 8].view(np.int64)[:] = off; o_off = p; p += (b * 8 + 15) // 16 * 16
-        i32 = host[p:p + meta_i32 * 4].view(np.int32)
+        host[base_meta:base_meta + b * 8].view(np.int64)[:] = off
+        i32 = host[p_i32:p_i32 + n_i32 * 4].view(np.int32)
         q = 0
-        hw = i32[q:q + b * 2].reshape(b, 2); q_hw = q; q += b * 2
-        xb = i32[q:q + b * r * 2].reshape(b, r, 2); q_xb = q; q += b * r * 2
-        yb = i32[q:q + b * r * 2].reshape(b, r, 2); q_yb = q; q += b * r * 2
-        q = (q + 3) // 4 * 4                                   # base_meta and b * 8 are multiples of 16 when b is even; see below
-        xk = i32[q:q + b * r * kx].reshape(b, r, kx); q_xk = q; q += b * r * kx
-        yk = i32[q:q + b * r * ky].reshape(b, r, ky); q_yk = q; q += b * r * ky
+        i32[q:q + 2 * b].reshape(b, 2)[:] = [im.shape[:2] for im in images]; q_hw = q; q += 2 * b
+        i32[q:q + b] = tab; q_tab = q; q += b
+        xb = i32[q:q + t * r * 2].reshape(t, r, 2); q_xb = q; q += t * r * 2
+        yb = i32[q:q + t * r * 2].reshape(t, r, 2); q_yb = q; q += t * r * 2
+        xk = i32[q_xk:q_xk + t * r * kx].reshape(t, r, kx)
+        q_yk = q_xk + t * r * kx
+        yk = i32[q_yk:q_yk + t * r * ky].reshape(t, r, ky)
         xk[:] = 0; yk[:] = 0
-        for i, (im, t) in enumerate(zip(images, tabs)):
-            hw[i] = im.shape[:2]
-            xb[i] = t[0]; xk[i, :, :t[1].shape[1]] = t[1]
-            yb[i] = t[2]; yk[i, :, :t[3].shape[1]] = t[3]
+        for i, x in enumerate(tabs):
+            xb[i] = x[0]; xk[i, :, :x[1].shape[1]] = x[1]
+            yb[i] = x[2]; yk[i, :, :x[3].shape[1]] = x[3]
         dev = pin[:nbytes].to(self.device, non_blocking=True)
-        d_i32 = dev[p:p + meta_i32 * 4].view(torch.int32)
+        d_i32 = dev[p_i32:p_i32 + n_i32 * 4].view(torch.int32)
         out_u8 = torch.empty((b, r, r, 3), dtype=torch.uint8, device=self.device) if output == "u8" else None
         out_f32 = torch.empty((b, 3, r, r), dtype=torch.float32, device=self.device) if output == "f32" else None
-        ops.preprocess_bicubic(dev, dev[o_off:o_off + b * 8].view(torch.int64), d_i32[q_hw:q_hw + b * 2],
-                               d_i32[q_xb:q_xb + b * r * 2], d_i32[q_xk:q_xk + b * r * kx], kx,
-                               d_i32[q_yb:q_yb + b * r * 2], d_i32[q_yk:q_yk + b * r * ky], ky,
+        ops.preprocess_bicubic(dev, dev[base_meta:base_meta + b * 8].view(torch.int64), d_i32[q_hw:q_hw + 2 * b], d_i32[q_tab:q_tab + b],
+                               d_i32[q_xb:q_xb + t * r * 2], d_i32[q_xk:q_xk + t * r * kx], kx,
+                               d_i32[q_yb:q_yb + t * r * 2], d_i32[q_yk:q_yk + t * r * ky], ky,
                                out_u8, out_f32, self.mean, self.std, b, r)
         # the staging buffer is reused by the next call: the copy must have been consumed before we return to the host
         torch.cuda.current_stream(self.device).synchronize()

@@ -96,13 +96,14 @@ int hgr_im2col_patches_u8(const unsigned char *image, void *out, int B, int R, i
  * device does the integer convolutions.
  *   src     packed uint8 images; image b = h[b] x w[b] x 3 bytes (row-major HWC, RGB) at src + off[b]
  *   off     int64 [B] (device);  hw int32 [B, 2] = (h, w) (device)
- *   xb, yb  int32 [B, R, 2] (device): (first source column / row, tap count) of column / row i of the CROPPED output
- *   xk, yk  int32 [B, R, KX] / [B, R, KY] (device): the taps, zero padded to the batch maximum; KX % 4 == 0 and xk
+ *   tab     int32 [B] (device) or NULL: index of image b's tap tables (images of one size share them); NULL = b
+ *   xb, yb  int32 [T, R, 2] (device): (first source column / row, tap count) of column / row i of the CROPPED output
+ *   xk, yk  int32 [T, R, KX] / [T, R, KY] (device): the taps, zero padded to the batch maximum; KX % 4 == 0 and xk
  *           16-byte aligned (a row's bytes are fetched 12 at a time: `src` needs 32 readable bytes past its last image)
  *   out_u8  uint8 [B, R, R, 3] or NULL (feeds hgr_im2col_patches_u8);  out_f32 fp32 [B, 3, R, R] or NULL
  *   mean3, std3  HOST pointers to 3 floats (needed for out_f32)
  */
-int hgr_preprocess_bicubic(const unsigned char *src, const int64_t *off, const int *hw, const int *xb, const int *xk, int KX,
+int hgr_preprocess_bicubic(const unsigned char *src, const int64_t *off, const int *hw, const int *tab, const int *xb, const int *xk, int KX,
                            const int *yb, const int *yk, int KY, unsigned char *out_u8, float *out_f32,
                            const float *mean3, const float *std3, int B, int R, void *stream);
 
