@@ -287,3 +287,18 @@ def test_graph_replay_equals_eager_and_survives_changes(golden_dir, tmp_path):
         keep.append(imgs[i % 3].clone())                          # all clones stay alive: 12 distinct addresses
         assert torch.equal(model(keep[-1], None), eager[i % 3])
     assert model._graph_static is not None
+
+
+def test_vit_b16_image_tower_vs_oracle():
+    """ViT-B/16 (197 tokens, patch 16: the third ViT geometry besides B/32's 50 and L/14's 257 tokens) against the CPU
+    oracle, whose ViT path is pinned by the reference fixtures of the other two."""
+    cfg = synth.CLIP_CONFIGS["ViT-B/16"]
+    sd = synth.clip_state_dict(cfg, 0)
+    model = build_model(sd).to(DEV)
+    img = synth.images(2, 224, 31)
+    got = model.encode_image(img.to(DEV)).cpu()
+    ref = clip_ref.encode_image(sd, img)
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((got - ref).abs().max()) < 2e-3 * scale
+    gn, rn = got / got.norm(dim=-1, keepdim=True), ref / ref.norm(dim=-1, keepdim=True)
+    assert float((gn - rn).abs().max()) < 1e-3                  # what the logits see
