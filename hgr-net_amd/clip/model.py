@@ -181,30 +181,49 @@ def _run_blocks(x: torch.Tensor, blocks, heads: int, b: int, l: int, causal: boo
 # ------------------------------------------------------------------------------------------------
 # ModifiedResNet engine: NHWC 16-bit activations, BN folded, 1x1 convs = GEMMs, 3x3 = implicit GEMM
 # ------------------------------------------------------------------------------------------------
-def _fold(conv: nn.Conv2d, bn: nn.BatchNorm2d, dt: torch.dtype):
+def _cpad(c: int) -> int:
+    """Channel counts that become a GEMM K (block inputs / planes) are stored padded to a multiple of 64 with zero
+    weights on both sides: RN50/RN101 (64, 128, ...) are untouched, RN50x4 stores 80 -> 128 and 160 -> 192, RN50x16
+    96 -> 128.  The padded activations are exact zeros (zero weight rows, zero bias, ReLU), so results do not change."""
+    return (c + 63) // 64 * 64
+
+
+def _fold(conv: nn.Conv2d, bn: nn.BatchNorm2d, dt: torch.dtype, cin_p: Optional[int] = None, cout_p: Optional[int] = None):
     """Inference BatchNorm folded into the preceding conv (legal: the model is always in eval(),
-    model/clip_tree.py:46).  Returns (w16 [Cout, Kp] in (ky, kx, c) order, bias fp32 [Cout])."""
+    model/clip_tree.py:46).  Returns (w16 [cout_p, Kp] in (ky, kx, c) order with c padded to cin_p, bias fp32 [cout_p])."""
     w = conv.weight.detach().float()
     s = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
     b = bn.bias.detach().float() - bn.running_mean.detach().float() * s
-    w = (w * s.view(-1, 1, 1, 1)).permute(0, 2, 3, 1).reshape(w.shape[0], -1)          # [Cout, kh*kw*Cin]
-    k = w.shape[1]
+    w = (w * s.view(-1, 1, 1, 1)).permute(0, 2, 3, 1)                                   # [Cout, kh, kw, Cin]
+    cout, kh, kw, cin = w.shape
+    cin_p, cout_p = cin_p or cin, cout_p or cout
+    k = kh * kw * cin_p
     kp = (k + 63) // 64 * 64
-    out = torch.zeros(w.shape[0], kp, dtype=dt, device=w.device)
-    out[:, :k] = w.to(dt)
-    return out.contiguous(), b.contiguous()
+    out = torch.zeros(cout_p, kp, dtype=dt, device=w.device)
+    out[:cout, :k].view(cout, kh, kw, cin_p)[..., :cin] = w.to(dt)
+    bias = torch.zeros(cout_p, dtype=torch.float32, device=w.device)
+    bias[:cout] = b
+    return out.contiguous(), bias.contiguous()
 
 
 class _RNBlock16:
     def __init__(self, blk, dt):
-        self.c1, self.c2, self.c3 = _fold(blk.conv1, blk.bn1, dt), _fold(blk.conv2, blk.bn2, dt), _fold(blk.conv3, blk.bn3, dt)
-        self.down = _fold(blk.downsample[1], blk.downsample[2], dt) if blk.downsample is not None else None
+        cin, pl = blk.conv1.weight.shape[1], blk.conv1.weight.shape[0]
+        cin_p, pl_p = _cpad(cin), _cpad(pl)
+        self.c1 = _fold(blk.conv1, blk.bn1, dt, cin_p, pl_p)
+        self.c2 = _fold(blk.conv2, blk.bn2, dt, pl_p, pl_p)
+        self.c3 = _fold(blk.conv3, blk.bn3, dt, pl_p, None)
+        self.down = _fold(blk.downsample[1], blk.downsample[2], dt, cin_p, None) if blk.downsample is not None else None
         self.stride = blk.stride
-        self.planes = blk.conv1.weight.shape[0]
+        self.planes = pl_p                     # stored (padded) width of the block's inner activations
+        self.out = blk.conv3.weight.shape[0]   # 4 * planes, always a multiple of 64
 
 
 def _rn_prepare(v: "ModifiedResNet", dt: torch.dtype) -> dict:
-    p = {"stem": [_fold(v.conv1, v.bn1, dt), _fold(v.conv2, v.bn2, dt), _fold(v.conv3, v.bn3, dt)]}
+    width = v.conv3.weight.shape[0]
+    if width % 16:
+        raise NotImplementedError(f"RN width {width}: channel counts must be multiples of 8 (the stem runs at width / 2)")
+    p = {"stem": [_fold(v.conv1, v.bn1, dt), _fold(v.conv2, v.bn2, dt), _fold(v.conv3, v.bn3, dt, None, _cpad(width))]}
     p["blocks"] = [_RNBlock16(b, dt) for li in (1, 2, 3, 4) for b in getattr(v, f"layer{li}")]
     a = v.attnpool
     p["pos"] = _f32(a.positional_embedding)
@@ -219,9 +238,7 @@ def _rn_forward(v: "ModifiedResNet", p: dict, image: torch.Tensor, dt: torch.dty
     4 stages of Bottlenecks (clip/model.py:40-53) -> AttentionPool2d (clip/model.py:66-90)."""
     dev = image.device
     b, _, r, _ = image.shape
-    width = v.conv3.weight.shape[0]
-    if width % 64 or (width & (width - 1)):
-        raise NotImplementedError(f"RN width {width}: the conv kernels need power-of-two channel counts >= 64 (RN50/RN101)")
+    width = p["stem"][2][0].shape[0]                      # stored width (padded to 64, _cpad)
     h = (r - 1) // 2 + 1
     m = b * h * h
     (w1, b1), (w2, b2), (w3, b3) = p["stem"]
@@ -256,11 +273,11 @@ def _rn_forward(v: "ModifiedResNet", p: dict, image: torch.Tensor, dt: torch.dty
                 ops.avgpool2_nhwc(x, xin, b, h, h, cin)
         idn = xin
         if k.down is not None:
-            idn = ws.get("r.idn", (mo, 4 * pl), dt, dev)
+            idn = ws.get("r.idn", (mo, k.out), dt, dev)
             ops.gemm_nt(xin, k.down[0], idn, bias=k.down[1], epilogue=EPI_BIAS)
-        out = ws.get(f"r.out{flip}", (mo, 4 * pl), dt, dev)
+        out = ws.get(f"r.out{flip}", (mo, k.out), dt, dev)
         ops.gemm_nt(t2, k.c3[0], out, bias=k.c3[1], residual=idn, epilogue=EPI_BIAS_ADD16_RELU)
-        x, cin, h, flip = out, 4 * pl, ho, flip ^ 1
+        x, cin, h, flip = out, k.out, ho, flip ^ 1
     # attention pool: only token 0's query is ever used (the module returns x[0])
     a = v.attnpool
     e, l = cin, h * h + 1

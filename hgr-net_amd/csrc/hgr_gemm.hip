@@ -41,7 +41,8 @@ struct GemmArgs {
     int vec_ok;      // C / residual rows allow 4-element vector access
     int dbg;         // diagnostics only (HGR_GEMM_DBG): 1 = skip MFMAs, 2 = skip LDS-DMA issue, 3 = skip epilogue
     // implicit-GEMM 3x3 convolution (CONV kernels only): A is an NHWC image [B, H, W, C], pad 1
-    int cH, cW, cC, cLog2C, cStride, cHo, cWo;
+    int cH, cW, cC, cStride, cHo, cWo;
+    unsigned cMagic;  // ceil(2^32 / cC): __umulhi(k, cMagic) == k / cC for every k < 9 * cC + 64 (k * cC < 2^32)
     // split-K (gemm_nt_128 only): blockIdx.y = split s works on K columns [s * kc, min(K, (s + 1) * kc)) and writes its own
     // fp32 partial C + s * csplit elements; 0 = off
     int kc; int64_t csplit;
@@ -211,9 +212,9 @@ __global__ __launch_bounds__(NT) void gemm_nt_128(GemmArgs p) {
         for (int i = 0; i < PA; ++i) {
             const char *src;
             if (CONV) {
-                // implicit im2col: K index = tap * C + channel (C a power of two >= 8), 8 channels per chunk
+                // implicit im2col: K index = tap * C + channel (C a multiple of 8), 8 channels per chunk
                 const int kq = kt * BK + cchunk[i] * 8;
-                const int tap = kq >> p.cLog2C, cin = kq & (p.cC - 1);
+                const int tap = (int)__umulhi((unsigned)kq, p.cMagic), cin = kq - tap * p.cC;
                 const int ky = (tap * 11) >> 5, kx = tap - ky * 3;               // tap / 3, tap % 3 for tap < 9
                 const bool ok = tap < 9 && ((vmask[i] >> tap) & 1u);
                 src = ok ? srcA[i] + ((int64_t)(ky * p.cW + kx) * p.cC + cin) * 2 : (const char *)hgr_zero_page;
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(NT256) void gemm_nt_256(GemmArgs p) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int kq = t * 64 + cchunk[j] * 8;
-                const int tap = kq >> p.cLog2C, cin = kq & (p.cC - 1);
+                const int tap = (int)__umulhi((unsigned)kq, p.cMagic), cin = kq - tap * p.cC;
                 const int ky = (tap * 11) >> 5, kx = tap - ky * 3;
                 const bool ok = tap < 9 && ((vmask[kind == 3][j] >> tap) & 1u);
                 const char *sp = ok ? src[kind][j] + ((int64_t)(ky * p.cW + kx) * p.cC + cin) * 2 : (const char *)hgr_zero_page;
@@ -788,7 +789,7 @@ static int conv3x3_launch(const void *x, const void *w, const float *bias, void 
                           int B, int H, int W, int C, int Cout, int stride, int Kp, int dtype, bool relu, void *stream) {
     HGR_REQUIRE(x && w && out && (bias || !relu), "hgr_conv3x3_nhwc: null operand");
     HGR_REQUIRE(B >= 1 && H >= 1 && W >= 1 && Cout >= 1 && (stride == 1 || stride == 2), "hgr_conv3x3_nhwc: bad geometry B=%d H=%d W=%d Cout=%d stride=%d", B, H, W, Cout, stride);
-    HGR_REQUIRE(C >= 8 && (C & (C - 1)) == 0, "hgr_conv3x3_nhwc: C=%d must be a power of two >= 8", C);
+    HGR_REQUIRE(C >= 8 && C % 8 == 0 && C <= 16384, "hgr_conv3x3_nhwc: C=%d must be a multiple of 8 in [8, 16384]", C);
     HGR_REQUIRE(Kp >= 9 * C && Kp % BK == 0, "hgr_conv3x3_nhwc: Kp=%d must be >= 9*C and a multiple of %d", Kp, BK);
     HGR_REQUIRE(hgr_aligned(x, 16) && hgr_aligned(w, 16) && hgr_aligned(out, 8) && (!bias || hgr_aligned(bias, 16)) && Cout % 4 == 0, "hgr_conv3x3_nhwc: misaligned operand / Cout %% 4 != 0");
     HGR_REQUIRE(dtype == HGR_BF16 || dtype == HGR_F16, "hgr_conv3x3_nhwc: bad dtype %d", dtype);
@@ -802,8 +803,7 @@ static int conv3x3_launch(const void *x, const void *w, const float *bias, void 
     a.tiles_m = (a.M + BM - 1) / BM; a.tiles_n = (Cout + BN - 1) / BN;
     a.m_fastest = 0; a.vec_ok = 1; a.dbg = 0; a.kc = 0; a.csplit = 0;
     a.cH = H; a.cW = W; a.cC = C; a.cStride = stride; a.cHo = Ho; a.cWo = Wo;
-    int l2 = 0; while ((1 << l2) < C) ++l2;
-    a.cLog2C = l2;
+    a.cMagic = (unsigned)(((1ull << 32) + (unsigned)C - 1) / (unsigned)C);
     // big tiles when the output is at least 256 wide-ish and the launch fills >= 4 rounds of 256 workgroups (M is huge here)
     const int64_t t256 = (int64_t)((a.M + 255) / 256) * ((Cout + 255) / 256);
     const bool big = relu && hgr_gemm_force_tile() != 128 && Kp >= 128 && Cout >= 128 && t256 >= 1024;
@@ -864,7 +864,7 @@ extern "C" int hgr_gemm_nt_splitk(const void *A, int64_t lda, const void *W, int
     a.M = M; a.N = N; a.K = K;
     a.tiles_m = (M + BM - 1) / BM; a.tiles_n = (N + BN - 1) / BN;
     a.m_fastest = 0; a.vec_ok = 1; a.dbg = 0; a.kc = kc; a.csplit = (int64_t)M * ldc;
-    a.cH = a.cW = a.cC = a.cLog2C = a.cStride = a.cHo = a.cWo = 0;
+    a.cH = a.cW = a.cC = a.cStride = a.cHo = a.cWo = 0; a.cMagic = 0;
     // every slice at least 2 K-tiles deep and an output of at least one 256^2 tile: the deep-pipelined kernel
     const bool big = hgr_gemm_force_tile() != 128 && M >= 256 && N >= 256 && kc >= 128 && (K - (S - 1) * kc) >= 128;
     if (big) {

@@ -92,7 +92,8 @@ __global__ __launch_bounds__(256) void attnpool_tokens(const typename T16<DT>::e
     }
 }
 
-// one wave per (b, head): lane j < L scores key j, wave softmax, then lane d accumulates head dim d
+// one wave per (b, head): lane j scores keys j, j + 64, ... (up to 4 per lane, L <= 256), wave softmax, then lane d
+// accumulates head dim d
 template <int DT>
 __global__ __launch_bounds__(256) void attnpool_attend(const float *__restrict__ q, const typename T16<DT>::elem *__restrict__ k,
                                                        const typename T16<DT>::elem *__restrict__ v, typename T16<DT>::elem *__restrict__ out,
@@ -105,25 +106,43 @@ __global__ __launch_bounds__(256) void attnpool_attend(const float *__restrict__
     const int b = wid / H, h = wid - b * H;
     const int64_t Ew = (int64_t)H * 64;
     const float *qh = q + (int64_t)b * Ew + h * 64;
-    float s = -INFINITY;
-    if (lane < L) {
-        const E *kr = k + ((int64_t)b * L + lane) * Ew + h * 64;
-        float acc = 0.f;
+    const int nq = (L + 63) >> 6;                 // wave-uniform
+    float s[4], pe[4];
+    float mx = -INFINITY;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const vec8 kv = *(const vec8 *)(kr + c * 8);
+    for (int t = 0; t < 4; ++t) {
+        s[t] = -INFINITY;
+        const int j = t * 64 + lane;
+        if (t < nq && j < L) {
+            const E *kr = k + ((int64_t)b * L + j) * Ew + h * 64;
+            float acc = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc += qh[c * 8 + e] * (float)kv[e];
+            for (int c = 0; c < 8; ++c) {
+                const vec8 kv = *(const vec8 *)(kr + c * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc += qh[c * 8 + e] * (float)kv[e];
+            }
+            s[t] = acc * 0.125f;
         }
-        s = acc * 0.125f;
+        mx = fmaxf(mx, s[t]);
     }
-    const float mx = wave_max(s);
-    const float pe = lane < L ? __expf(s - mx) : 0.f;
-    const float inv = 1.0f / wave_sum(pe);
+    mx = wave_max(mx);
+    float ps = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        pe[t] = (t * 64 + lane < L) ? __expf(s[t] - mx) : 0.f;
+        ps += pe[t];
+    }
+    const float inv = 1.0f / wave_sum(ps);
     float o = 0.f;
-    for (int j = 0; j < L; ++j) {
-        const float pj = __shfl(pe, j);
-        o += pj * (float)v[((int64_t)b * L + j) * Ew + h * 64 + lane];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        if (t >= nq) break;
+        const int n = min(64, L - t * 64);
+        for (int j = 0; j < n; ++j) {
+            const float pj = __shfl(pe[t], j);
+            o += pj * (float)v[((int64_t)b * L + t * 64 + j) * Ew + h * 64 + lane];
+        }
     }
     out[(int64_t)b * Ew + h * 64 + lane] = (E)(o * inv);
 }
@@ -167,7 +186,7 @@ extern "C" int hgr_attnpool_tokens(const void *x, const float *pos, void *out, i
 }
 
 extern "C" int hgr_attnpool_attend(const float *q, const void *k, const void *v, void *out, int B, int L, int heads, int dtype, void *stream) {
-    HGR_REQUIRE(q && k && v && out && B >= 1 && heads >= 1 && L >= 1 && L <= 64, "hgr_attnpool_attend: bad arguments (L <= 64)");
+    HGR_REQUIRE(q && k && v && out && B >= 1 && heads >= 1 && L >= 1 && L <= 256, "hgr_attnpool_attend: bad arguments (L <= 256)");
     HGR_REQUIRE(hgr_aligned(k, 16) && hgr_aligned(v, 2) && hgr_aligned(q, 4), "hgr_attnpool_attend: misaligned operand");
     HGR_REQUIRE(dtype == HGR_BF16 || dtype == HGR_F16, "hgr_attnpool_attend: bad dtype %d", dtype);
     const unsigned blocks = (unsigned)(((int64_t)B * heads + 3) / 4);

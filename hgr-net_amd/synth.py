@@ -87,6 +87,15 @@ CLIP_CONFIGS: Dict[str, dict] = {
     "RN50": dict(embed_dim=1024, image_resolution=224, vision_layers=(3, 4, 6, 3), vision_width=64,
                  vision_patch_size=None, context_length=77, vocab_size=49408,
                  transformer_width=512, transformer_heads=8, transformer_layers=12),
+    "RN101": dict(embed_dim=512, image_resolution=224, vision_layers=(3, 4, 23, 3), vision_width=64,
+                  vision_patch_size=None, context_length=77, vocab_size=49408,
+                  transformer_width=512, transformer_heads=8, transformer_layers=12),
+    "RN50x4": dict(embed_dim=640, image_resolution=288, vision_layers=(4, 6, 10, 6), vision_width=80,
+                   vision_patch_size=None, context_length=77, vocab_size=49408,
+                   transformer_width=640, transformer_heads=10, transformer_layers=12),
+    "RN50x16": dict(embed_dim=768, image_resolution=384, vision_layers=(6, 8, 18, 8), vision_width=96,
+                    vision_patch_size=None, context_length=77, vocab_size=49408,
+                    transformer_width=768, transformer_heads=12, transformer_layers=12),
     # small configs for fast parity tests (heads must keep d_head = 64, clip/model.py:259,268,417)
     "tiny-vit": dict(embed_dim=64, image_resolution=64, vision_layers=2, vision_width=128,
                      vision_patch_size=32, context_length=77, vocab_size=512,
@@ -94,10 +103,14 @@ CLIP_CONFIGS: Dict[str, dict] = {
     "small-vit": dict(embed_dim=128, image_resolution=96, vision_layers=3, vision_width=256,
                       vision_patch_size=32, context_length=77, vocab_size=1024,
                       transformer_width=128, transformer_heads=2, transformer_layers=3),
-    # RN widths must be real ones (64): the conv kernels need power-of-two channel counts >= 64 past the stem
+    # width 64 = RN50 / RN101's; the training tower (training_rn.py) needs a power-of-two width >= 64
     "tiny-rn": dict(embed_dim=64, image_resolution=64, vision_layers=(1, 1, 1, 1), vision_width=64,
                     vision_patch_size=None, context_length=77, vocab_size=512,
                     transformer_width=64, transformer_heads=1, transformer_layers=2),
+    # non-power-of-two width (RN50x4 / RN50x16 style): planes 48 / 96 are stored padded to 64 / 128
+    "small-rnx": dict(embed_dim=128, image_resolution=96, vision_layers=(1, 2, 1, 1), vision_width=48,
+                      vision_patch_size=None, context_length=77, vocab_size=512,
+                      transformer_width=64, transformer_heads=1, transformer_layers=2),
     "small-rn": dict(embed_dim=128, image_resolution=96, vision_layers=(2, 1, 2, 1), vision_width=64,
                      vision_patch_size=None, context_length=77, vocab_size=512,
                      transformer_width=64, transformer_heads=1, transformer_layers=2),

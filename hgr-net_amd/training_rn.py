@@ -90,7 +90,8 @@ class RNTower:
         self.dev = visual.conv1.weight.device
         width = visual.conv3.weight.shape[0]
         if width % 64 or (width & (width - 1)):
-            raise NotImplementedError(f"RN width {width}: the conv kernels need power-of-two channel counts >= 64 (RN50/RN101)")
+            raise NotImplementedError(f"RN width {width}: the training tower handles widths that are powers of two >= 64 (RN50 / RN101); "
+                                      "RN50x4 / RN50x16 run the zero-shot path only (clip/model.py pads their channels)")
         self.width = width
         self.stem = [_ConvBN(visual.conv1, visual.bn1, dt), _ConvBN(visual.conv2, visual.bn2, dt), _ConvBN(visual.conv3, visual.bn3, dt)]
         self.blocks = [_Block(b, dt) for li in (1, 2, 3, 4) for b in getattr(visual, f"layer{li}")]

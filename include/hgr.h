@@ -212,7 +212,7 @@ int hgr_eval_counters(const int32_t *pred, int k, const int64_t *targets, int ta
 /*
  * 3x3 convolution, padding 1, stride 1 or 2, + folded BN + ReLU as an IMPLICIT GEMM
  * (conv2 of every Bottleneck and the stem's conv2/conv3: clip/model.py:20-21,43,106-109).
- *   x   NHWC 16-bit [B, H, W, C], C a power of two >= 8
+ *   x   NHWC 16-bit [B, H, W, C], C a multiple of 8 (any of CLIP's RN widths, padded to 8)
  *   w   16-bit [Cout, Kp], K order (ky, kx, c) = weight.permute(0,2,3,1).reshape(Cout, 9C), zero
  *       padded to Kp (multiple of 64);  bias fp32 [Cout];  out NHWC 16-bit [B, Ho, Wo, Cout]
  * No im2col buffer: the LDS-DMA loader gathers the taps, out-of-bounds taps read a zero page.
@@ -240,7 +240,7 @@ int hgr_attnpool_tokens(const void *x, const float *pos, void *out, int B, int S
 /*
  * AttentionPool2d attention for the ONLY query that is used, token 0 (the module returns x[0],
  * clip/model.py:90): out[b, h*64 + d] = sum_j softmax_j(q[b,h] . k[b,j,h] / 8) v[b,j,h,d].
- *   q fp32 [B, E] (projected mean token), k, v 16-bit [B*L, E], out 16-bit [B, E]; E = heads*64, L <= 64.
+ *   q fp32 [B, E] (projected mean token), k, v 16-bit [B*L, E], out 16-bit [B, E]; E = heads*64, L <= 256.
  */
 int hgr_attnpool_attend(const float *q, const void *k, const void *v, void *out, int B, int L, int heads,
                         int dtype, void *stream);

@@ -256,7 +256,13 @@ def test_level_argmax_exact(n, levels):
                                                   (2, 16, 16, 8, 16, 1), (2, 12, 12, 64, 128, 2), (1, 5, 5, 512, 512, 1),
                                                   # >= 1024 output pixels and <= 64 channels: the tall 256 x 64 tile variant
                                                   (5, 16, 16, 64, 64, 1), (3, 20, 19, 32, 32, 1), (9, 12, 12, 32, 64, 1),
-                                                  (2, 48, 48, 64, 64, 2)])
+                                                  (2, 48, 48, 64, 64, 2),
+                                                  # channel counts that are not powers of two (RN50x4 / RN50x16 widths):
+                                                  # the loader's tap / channel split is a multiply-high division
+                                                  (2, 9, 9, 40, 40, 1), (1, 12, 12, 48, 128, 1), (2, 18, 18, 192, 192, 2),
+                                                  (1, 9, 9, 320, 320, 1), (1, 6, 6, 640, 640, 1), (2, 24, 24, 24, 48, 1),
+                                                  # 256^2 tiles with a non-power-of-two C (>= 1024 tiles of 256)
+                                                  (40, 80, 80, 192, 192, 1)])
 def test_conv3x3_implicit_gemm_vs_conv2d(dt, b, h, w, c, cout, stride):
     x = _rand((b, c, h, w), 60).to(dt)                       # NCHW reference layout
     wt = _rand((cout, c, 3, 3), 61, (2.0 / (9 * c)) ** 0.5).to(dt)
@@ -334,6 +340,23 @@ def test_stem_im2col_avgpool_attnpool(dt):
     assert (tok.float().cpu().view(b, l, e) - tref).abs().max() < (3e-2 if dt == torch.bfloat16 else 3e-3)
     q = _rand((b, e), 71)
     k16, v16 = _rand((b * l, e), 72).to(dt), _rand((b * l, e), 73).to(dt)
+    o = torch.empty(b, e, dtype=dt, device=DEV)
+    ops.attnpool_attend(q.to(DEV), k16.to(DEV), v16.to(DEV), o, b, l, heads)
+    qh = q.view(b, 1, heads, 64).transpose(1, 2)
+    kh = k16.float().view(b, l, heads, 64).transpose(1, 2)
+    vh = v16.float().view(b, l, heads, 64).transpose(1, 2)
+    oref = (torch.softmax(qh @ kh.transpose(-1, -2) * 0.125, -1) @ vh).transpose(1, 2).reshape(b, e)
+    assert (o.float().cpu() - oref).abs().max() < (2e-2 if dt == torch.bfloat16 else 2e-3)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("l,heads", [(1, 1), (50, 32), (64, 2), (65, 3), (82, 40), (145, 48), (256, 2)])
+def test_attnpool_attend_long_sequences(dt, l, heads):
+    """Token counts of every CLIP ResNet: 50 (RN50/RN101 at 224), 82 (RN50x4 at 288), 145 (RN50x16 at 384); each lane
+    of the wave scores up to four keys."""
+    b, e = 3, heads * 64
+    q = _rand((b, e), 171)
+    k16, v16 = _rand((b * l, e), 172).to(dt), _rand((b * l, e), 173).to(dt)
     o = torch.empty(b, e, dtype=dt, device=DEV)
     ops.attnpool_attend(q.to(DEV), k16.to(DEV), v16.to(DEV), o, b, l, heads)
     qh = q.view(b, 1, heads, 64).transpose(1, 2)

@@ -10,7 +10,7 @@ from hgr_net_amd import synth
 from hgr_net_amd.hierarchy import build_hierarchy
 from oracle import clip_ref, tree_ref
 
-CLIP_CASES = ["tiny-vit", "small-vit", "tiny-rn", "small-rn", "ViT-B_32", "RN50", "ViT-L_14"]
+CLIP_CASES = ["tiny-vit", "small-vit", "tiny-rn", "small-rn", "small-rnx", "ViT-B_32", "RN50", "RN50x4", "ViT-L_14"]   # RN101 / RN50x16 / ViT-B_16 fixtures: GPU suite only (same oracle code, slow on CPU)
 TREE_CASES = ["tinyvit_n90", "smallvit_n300", "tinyrn_n64"]
 
 

@@ -331,6 +331,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-big", action="store_true", help="skip the true-dimension ViT-B/32 / RN50 fixtures")
     ap.add_argument("--only-tree", default=None, help="regenerate one tree/train fixture only (tinyvit_n90 | smallvit_n300 | tinyrn_n64)")
+    ap.add_argument("--only-clip", default=None, help="comma-separated CLIP_CONFIGS names: regenerate those tower fixtures only (batch 1-3)")
     a = ap.parse_args()
     assert REF.is_dir(), f"{REF} not found: fixtures can only be generated where the reference is mounted"
     GOLD.mkdir(parents=True, exist_ok=True)
@@ -349,11 +350,18 @@ def main():
                     "tinyrn_n64": ("tiny-rn", 64, 20, 24, 2, 4)}[a.only_tree]
             tree_fixture(ref_main, a.only_tree, dict(C[spec[0]], vocab_size=49408), *spec[1:], tmp)
             return
+        if a.only_clip:
+            for name in a.only_clip.split(","):
+                clip_fixture(ref_clip, name, C[name], 3 if name.startswith(("tiny", "small")) else 1, 2, tmp)
+            return
         clip_fixture(ref_clip, "tiny-vit", C["tiny-vit"], 4, 6, tmp)
         clip_fixture(ref_clip, "small-vit", C["small-vit"], 3, 5, tmp)
         clip_fixture(ref_clip, "tiny-rn", C["tiny-rn"], 3, 4, tmp)
         clip_fixture(ref_clip, "small-rn", C["small-rn"], 3, 4, tmp)
+        clip_fixture(ref_clip, "small-rnx", C["small-rnx"], 3, 2, tmp)
         if not a.skip_big:
+            for name in ("RN101", "RN50x4", "RN50x16", "ViT-B/16"):      # the rest of clip._MODELS (clip/clip.py:25-32)
+                clip_fixture(ref_clip, name, C[name], 1, 2, tmp)
             clip_fixture(ref_clip, "ViT-B/32", C["ViT-B/32"], 2, 8, tmp)
             clip_fixture(ref_clip, "RN50", C["RN50"], 2, 2, tmp)
             clip_fixture(ref_clip, "ViT-L/14", C["ViT-L/14"], 1, 2, tmp)
