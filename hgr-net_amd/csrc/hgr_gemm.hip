@@ -132,13 +132,16 @@ __device__ __forceinline__ void store_quad_full(const GemmArgs &p, f32x4 v, f32x
 
 // TALL = the 4 waves stacked along M: a 256 (M) x 64 (N) tile for outputs at most 64 wide (the 64-channel stages of the
 // ResNet towers), where the square tile would spend half of its MFMAs and LDS traffic on columns that do not exist.
-template <int DT, int EPI, bool OUT32, bool CONV = false, bool TALL = false>
+// ONEK = K is a single 64-wide tile (the 1x1 convolutions out of 64-channel stages): no second LDS stage, so the
+// workgroup needs 32 KB instead of 64 KB and 3-4 of them (VGPR-limited) share a CU - these launches are HBM-bound
+// streams whose only latency hiding is other workgroups.
+template <int DT, int EPI, bool OUT32, bool CONV = false, bool TALL = false, bool ONEK = false>
 __global__ __launch_bounds__(NT) void gemm_nt_128(GemmArgs p) {
     typedef typename T16<DT>::vec8 vec8;
     constexpr int BM = TALL ? 256 : 128, BN = TALL ? 64 : 128;
     constexpr int PA = BM / 32, PW = BN / 32;              // 4 KB LDS-DMA pieces (32 rows of 128 B) per operand: one per wave each
     constexpr int TILE_A = BM * BK * 2, STAGE_BYTES = (BM + BN) * BK * 2;
-    __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE_BYTES];
+    __shared__ __attribute__((aligned(1024))) char smem[(ONEK ? 1 : 2) * STAGE_BYTES];
     if (p.kc) {                                   // split-K: this workgroup's slice of the reduction, its own partial output
         const int sp = blockIdx.y;
         p.A += (int64_t)sp * p.kc * 2; p.W += (int64_t)sp * p.kc * 2;
@@ -235,8 +238,26 @@ __global__ __launch_bounds__(NT) void gemm_nt_128(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.K / BK;
+    const int nk = ONEK ? 1 : p.K / BK;
     stage(0, 0);
+    // ONEK: the whole epilogue input (bias quads, 16-bit identity) is requested together with the operands, so a
+    // workgroup waits for memory once instead of three times (operands -> bias -> identity)
+    const bool full = p.vec_ok && m0 + BM <= p.M && n0 + BN <= p.N;
+    typedef typename T16<DT>::vec4 vec4;
+    f32x4 pbq[ONEK ? 4 : 1];
+    vec4 pad[ONEK && EPI == HGR_EPI_BIAS_ADD16_RELU ? 4 : 1][ONEK && EPI == HGR_EPI_BIAS_ADD16_RELU ? 4 : 1];
+    if (ONEK && full) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pbq[i] = *(const f32x4 *)(p.bias + n0 + wn * 64 + i * 16 + g * 4);
+        if (EPI == HGR_EPI_BIAS_ADD16_RELU) {
+            typedef typename T16<DT>::elem E;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    pad[j][i] = *(const vec4 *)((const E *)(const void *)p.res + (int64_t)(m0 + wm * 64 + j * 16 + r) * p.ldr + n0 + wn * 64 + i * 16 + g * 4);
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -248,7 +269,7 @@ __global__ __launch_bounds__(NT) void gemm_nt_128(GemmArgs p) {
 
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        if (!ONEK && kt + 1 < nk) stage(cur ^ 1, kt + 1);
         const char *sA = smem + cur * STAGE_BYTES;
         const char *sW = sA + TILE_A;
 #pragma unroll
@@ -272,7 +293,27 @@ __global__ __launch_bounds__(NT) void gemm_nt_128(GemmArgs p) {
 
     // epilogue: lane holds, for tile (i, j), C[m][n .. n+3] with
     //   m = m0 + wm*64 + j*16 + r,   n = n0 + wn*64 + i*16 + g*4
-    if (p.vec_ok && m0 + BM <= p.M && n0 + BN <= p.N) {
+    if (ONEK && full) {
+        typedef typename T16<DT>::elem E;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x4 v = acc[i][j] + pbq[i];
+                if (EPI == HGR_EPI_BIAS_ADD16_RELU) {
+                    const vec4 idn = pad[j][i];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += (float)idn[e];
+                }
+                if (EPI == HGR_EPI_BIAS_RELU || EPI == HGR_EPI_BIAS_ADD16_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                *(vec4 *)((E *)p.C + (int64_t)(m0 + wm * 64 + j * 16 + r) * p.ldc + n0 + wn * 64 + i * 16 + g * 4) = cvt4<DT>(v[0], v[1], v[2], v[3]);
+            }
+        return;
+    }
+    if (full) {
         // interior tile: unguarded loads and stores, bias quads fetched once
         f32x4 bq[4];
 #pragma unroll
@@ -663,6 +704,12 @@ __global__ __launch_bounds__(NT256) void gemm_nt_256(GemmArgs p) {
 
 template <int DT, int EPI>
 void launch_epi(const GemmArgs &a, bool out32, dim3 grid, hipStream_t s, bool big) {
+    if constexpr (EPI == HGR_EPI_BIAS || EPI == HGR_EPI_BIAS_RELU || EPI == HGR_EPI_BIAS_ADD16_RELU) {
+        if (!big && !out32 && a.K == BK) {
+            hipLaunchKernelGGL((gemm_nt_128<DT, EPI, false, false, false, true>), grid, dim3(NT), 0, s, a);
+            return;
+        }
+    }
     if (big) {
         if (out32) hipLaunchKernelGGL((gemm_nt_256<DT, EPI, true>), grid, dim3(NT256), 0, s, a);
         else hipLaunchKernelGGL((gemm_nt_256<DT, EPI, false>), grid, dim3(NT256), 0, s, a);
@@ -747,6 +794,11 @@ extern "C" int hgr_gemm_nt(const void *A, int64_t lda, const void *W, int64_t ld
         if (!big && N <= 64 && m_cnt >= 1024 && epilogue == HGR_EPI_BIAS_RELU && !out_f32) {
             a.tiles_m = (m_cnt + 255) / 256; a.tiles_n = 1;
             dim3 gt((unsigned)a.tiles_m);
+            if (K == BK) {
+                if (dtype == HGR_BF16) hipLaunchKernelGGL((gemm_nt_128<HGR_BF16, HGR_EPI_BIAS_RELU, false, false, true, true>), gt, dim3(NT), 0, s, a);
+                else hipLaunchKernelGGL((gemm_nt_128<HGR_F16, HGR_EPI_BIAS_RELU, false, false, true, true>), gt, dim3(NT), 0, s, a);
+                return;
+            }
             if (dtype == HGR_BF16) hipLaunchKernelGGL((gemm_nt_128<HGR_BF16, HGR_EPI_BIAS_RELU, false, false, true>), gt, dim3(NT), 0, s, a);
             else hipLaunchKernelGGL((gemm_nt_128<HGR_F16, HGR_EPI_BIAS_RELU, false, false, true>), gt, dim3(NT), 0, s, a);
             return;
