@@ -116,6 +116,30 @@ __global__ __launch_bounds__(256) void colsum_final(const float *__restrict__ pa
     out[c] = (accumulate ? out[c] : 0.f) + alpha * acc;
 }
 
+// Many bands (bias gradients over 10^5..10^6 pixels: rows / 512 bands of a few dozen columns): one thread per column
+// walking every band is a serial chain of thousands of loads.  Here a block owns 64 columns, its 4 waves take bands
+// q, q + 4, ... with 4 independent accumulators each, and the 16 sub-sums are combined in a fixed order.
+__global__ __launch_bounds__(256) void colsum_final_deep(const float *__restrict__ partial, int nrb, int cols, float *__restrict__ out, int accumulate, float alpha) {
+    __shared__ float s[4][64];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (c < cols) {
+        const float *pc = partial + c;
+        int rb = q;
+        for (; rb + 12 < nrb; rb += 16) {
+            a0 += pc[(int64_t)rb * cols];
+            a1 += pc[(int64_t)(rb + 4) * cols];
+            a2 += pc[(int64_t)(rb + 8) * cols];
+            a3 += pc[(int64_t)(rb + 12) * cols];
+        }
+        for (; rb < nrb; rb += 4) a0 += pc[(int64_t)rb * cols];
+    }
+    s[q][lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (q == 0 && c < cols) out[c] = (accumulate ? out[c] : 0.f) + alpha * ((s[0][lane] + s[1][lane]) + (s[2][lane] + s[3][lane]));
+}
+
 template <int DT>
 __global__ __launch_bounds__(256) void cast16(const float *__restrict__ x, typename T16<DT>::elem *__restrict__ y, int64_t n4) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
@@ -744,7 +768,8 @@ extern "C" int hgr_colsum(const void *x, int64_t ldx, int rows, int cols, int x_
     } else if (x_f32) hipLaunchKernelGGL((colsum_partial<HGR_BF16, true>), g, dim3(256), 0, s, x, ldx, rows, cols, scratch);
     else if (dtype == HGR_BF16) hipLaunchKernelGGL((colsum_partial<HGR_BF16, false>), g, dim3(256), 0, s, x, ldx, rows, cols, scratch);
     else hipLaunchKernelGGL((colsum_partial<HGR_F16, false>), g, dim3(256), 0, s, x, ldx, rows, cols, scratch);
-    hipLaunchKernelGGL(colsum_final, dim3((cols + 255) / 256), dim3(256), 0, s, scratch, nrb, cols, out, accumulate, alpha);
+    if (nrb >= 32) hipLaunchKernelGGL(colsum_final_deep, dim3((cols + 63) / 64), dim3(256), 0, s, scratch, nrb, cols, out, accumulate, alpha);
+    else hipLaunchKernelGGL(colsum_final, dim3((cols + 255) / 256), dim3(256), 0, s, scratch, nrb, cols, out, accumulate, alpha);
     HGR_CHECK_LAUNCH("hgr_colsum");
     return HGR_OK;
 }

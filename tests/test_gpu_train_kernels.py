@@ -39,6 +39,24 @@ def test_transpose_colsum_cast(dt):
 
 
 @pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("rows,cols", [(16384, 64), (40000, 40), (70001, 192), (17000, 1024)])
+def test_colsum_many_bands(dt, rows, cols):
+    """Bias gradients over 10^4..10^6 pixels: >= 32 bands of 512 rows take the wave-parallel final stage.  Integer values,
+    so any summation order gives the same fp32 result and the comparison is exact; run twice for reproducibility."""
+    gen = torch.Generator().manual_seed(rows + cols)
+    x = torch.randint(-3, 4, (rows, cols), generator=gen).to(dt)
+    want = x.double().sum(0).float()
+    scratch = torch.empty((rows + 511) // 512 * cols, dtype=torch.float32, device=DEV)
+    out = torch.full((cols,), 2.0, dtype=torch.float32, device=DEV)
+    ops.colsum(x.to(DEV), out, scratch, accumulate=True)
+    assert torch.equal(out.cpu(), want + 2.0)
+    xf = x.float().to(DEV)
+    o2 = torch.empty(cols, dtype=torch.float32, device=DEV)
+    ops.colsum(xf, o2, scratch, accumulate=False, alpha=0.5)
+    assert torch.equal(o2.cpu(), 0.5 * want)
+
+
+@pytest.mark.parametrize("dt", DTS)
 def test_gemm_accumulate_and_backward_forms(dt):
     """dX = dY W and dW += dY^T X through hgr_gemm_nt on transposed operands."""
     m, n, k = 200, 192, 128                         # y[m,n] = x[m,k] w[n,k]^T
