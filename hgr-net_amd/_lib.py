@@ -44,6 +44,7 @@ SIGNATURES = {
     "hgr_attnpool_tokens": [_p, _p, _p, _i, _i, _i, _i, _p],
     "hgr_attnpool_attend": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
     "hgr_transpose16": [_p, _l, _p, _l, _i, _i, _p],
+    "hgr_transpose16_colsum": [_p, _l, _p, _l, _i, _i, _i, _p, _i, _f, _p, _p],
     "hgr_colsum": [_p, _l, _i, _i, _i, _i, _p, _i, _f, _p, _p],
     "hgr_cast16": [_p, _p, _l, _i, _p],
     "hgr_quickgelu16": [_p, _p, _p, _l, _i, _i, _p],

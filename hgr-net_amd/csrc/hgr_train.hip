@@ -28,7 +28,11 @@ __global__ __launch_bounds__(256) void transpose16_scalar(const unsigned short *
 // 64 x 64 tile, 16-byte global loads and stores (8 elements): rows in, rows out; the transposition happens in the LDS
 // reads (8 two-byte reads of one column per thread).  Needs ldx, ldy % 8 == 0 and 16-byte aligned bases; ragged edges
 // are handled element-wise.
-__global__ __launch_bounds__(256) void transpose16(const unsigned short *__restrict__ x, int64_t ldx, unsigned short *__restrict__ y, int64_t ldy, int rows, int cols) {
+// CS = 1 (bf16) / 2 (f16): additionally partial[blockIdx.y][c] = sum of the tile's 64 rows of column c (fp32, rows in
+// order) - the bias gradient rides on the transposition that the weight gradient needs anyway, instead of reading dY again.
+template <int CS>
+__global__ __launch_bounds__(256) void transpose16(const unsigned short *__restrict__ x, int64_t ldx, unsigned short *__restrict__ y, int64_t ldy, int rows, int cols,
+                                                   float *__restrict__ partial) {
     typedef __attribute__((ext_vector_type(8))) unsigned short us8;
     __shared__ __attribute__((aligned(16))) unsigned short t[64][72];
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
@@ -44,6 +48,16 @@ __global__ __launch_bounds__(256) void transpose16(const unsigned short *__restr
         *(us8 *)&t[r][c] = v;
     }
     __syncthreads();
+    if (CS && threadIdx.x < 64 && c0 + threadIdx.x < cols) {          // rows beyond `rows` were staged as zeros
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll 8
+        for (int i = 0; i < 64; i += 2) {
+            const unsigned short u0 = t[i][threadIdx.x], u1 = t[i + 1][threadIdx.x];
+            if (CS == 1) { a0 += __uint_as_float((unsigned)u0 << 16); a1 += __uint_as_float((unsigned)u1 << 16); }
+            else { a0 += (float)__builtin_bit_cast(_Float16, u0); a1 += (float)__builtin_bit_cast(_Float16, u1); }
+        }
+        partial[(int64_t)blockIdx.y * cols + c0 + threadIdx.x] = a0 + a1;
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int id = threadIdx.x + 256 * j;
@@ -116,28 +130,50 @@ __global__ __launch_bounds__(256) void colsum_final(const float *__restrict__ pa
     out[c] = (accumulate ? out[c] : 0.f) + alpha * acc;
 }
 
-// Many bands (bias gradients over 10^5..10^6 pixels: rows / 512 bands of a few dozen columns): one thread per column
-// walking every band is a serial chain of thousands of loads.  Here a block owns 64 columns, its 4 waves take bands
-// q, q + 4, ... with 4 independent accumulators each, and the 16 sub-sums are combined in a fixed order.
-__global__ __launch_bounds__(256) void colsum_final_deep(const float *__restrict__ partial, int nrb, int cols, float *__restrict__ out, int accumulate, float alpha) {
+// Many bands (bias gradients over 10^5..10^6 pixels: thousands of bands of a few dozen columns): one thread per column
+// walking every band is a serial chain of thousands of loads.  Here a block owns 64 columns and the bands
+// [blockIdx.y * chunk, +chunk): its 4 waves take bands q, q + 4, ... with 4 independent accumulators each and the 16
+// sub-sums are combined in a fixed order.  MID: the chunk's sum replaces the chunk's first band in place (every thread
+// only ever touches its own column, and the writer has finished reading); the final pass then walks those bands.
+template <bool MID>
+__global__ __launch_bounds__(256) void colsum_reduce_deep(float *__restrict__ partial, int nrb, int chunk, int64_t bstride, int cols,
+                                                          float *__restrict__ out, int accumulate, float alpha) {
     __shared__ float s[4][64];
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
+    const int b0 = blockIdx.y * chunk, b1 = min(nrb, b0 + chunk);
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     if (c < cols) {
         const float *pc = partial + c;
-        int rb = q;
-        for (; rb + 12 < nrb; rb += 16) {
-            a0 += pc[(int64_t)rb * cols];
-            a1 += pc[(int64_t)(rb + 4) * cols];
-            a2 += pc[(int64_t)(rb + 8) * cols];
-            a3 += pc[(int64_t)(rb + 12) * cols];
+        int rb = b0 + q;
+        for (; rb + 12 < b1; rb += 16) {
+            a0 += pc[(int64_t)rb * bstride];
+            a1 += pc[(int64_t)(rb + 4) * bstride];
+            a2 += pc[(int64_t)(rb + 8) * bstride];
+            a3 += pc[(int64_t)(rb + 12) * bstride];
         }
-        for (; rb < nrb; rb += 4) a0 += pc[(int64_t)rb * cols];
+        for (; rb < b1; rb += 4) a0 += pc[(int64_t)rb * bstride];
     }
     s[q][lane] = (a0 + a1) + (a2 + a3);
     __syncthreads();
-    if (q == 0 && c < cols) out[c] = (accumulate ? out[c] : 0.f) + alpha * ((s[0][lane] + s[1][lane]) + (s[2][lane] + s[3][lane]));
+    if (q == 0 && c < cols) {
+        const float t = (s[0][lane] + s[1][lane]) + (s[2][lane] + s[3][lane]);
+        if (MID) partial[(int64_t)b0 * bstride + c] = t;
+        else out[c] = (accumulate ? out[c] : 0.f) + alpha * t;
+    }
+}
+
+// second stage of every column sum: partial [nrb][cols] -> out
+void colsum_finish(float *partial, int nrb, int cols, float *out, int accumulate, float alpha, hipStream_t s) {
+    if (nrb >= 2048) {
+        const int chunk = 256, n2 = (nrb + chunk - 1) / chunk;
+        hipLaunchKernelGGL(colsum_reduce_deep<true>, dim3((cols + 63) / 64, n2), dim3(256), 0, s, partial, nrb, chunk, (int64_t)cols, cols, out, 0, 1.0f);
+        hipLaunchKernelGGL(colsum_reduce_deep<false>, dim3((cols + 63) / 64, 1), dim3(256), 0, s, partial, n2, n2, (int64_t)chunk * cols, cols, out, accumulate, alpha);
+    } else if (nrb >= 32) {
+        hipLaunchKernelGGL(colsum_reduce_deep<false>, dim3((cols + 63) / 64, 1), dim3(256), 0, s, partial, nrb, nrb, (int64_t)cols, cols, out, accumulate, alpha);
+    } else {
+        hipLaunchKernelGGL(colsum_final, dim3((cols + 255) / 256), dim3(256), 0, s, partial, nrb, cols, out, accumulate, alpha);
+    }
 }
 
 template <int DT>
@@ -747,7 +783,7 @@ extern "C" int hgr_transpose16(const void *x, int64_t ldx, void *y, int64_t ldy,
     HGR_REQUIRE(x && y && rows >= 1 && cols >= 1 && ldx >= cols && ldy >= rows, "hgr_transpose16: bad arguments");
     const dim3 grid((cols + 63) / 64, (rows + 63) / 64);
     if (ldx % 8 == 0 && ldy % 8 == 0 && hgr_aligned(x, 16) && hgr_aligned(y, 16))
-        hipLaunchKernelGGL(transpose16, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short *)x, ldx, (unsigned short *)y, ldy, rows, cols);
+        hipLaunchKernelGGL(transpose16<0>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short *)x, ldx, (unsigned short *)y, ldy, rows, cols, (float *)nullptr);
     else
         hipLaunchKernelGGL(transpose16_scalar, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short *)x, ldx, (unsigned short *)y, ldy, rows, cols);
     HGR_CHECK_LAUNCH("hgr_transpose16");
@@ -768,9 +804,23 @@ extern "C" int hgr_colsum(const void *x, int64_t ldx, int rows, int cols, int x_
     } else if (x_f32) hipLaunchKernelGGL((colsum_partial<HGR_BF16, true>), g, dim3(256), 0, s, x, ldx, rows, cols, scratch);
     else if (dtype == HGR_BF16) hipLaunchKernelGGL((colsum_partial<HGR_BF16, false>), g, dim3(256), 0, s, x, ldx, rows, cols, scratch);
     else hipLaunchKernelGGL((colsum_partial<HGR_F16, false>), g, dim3(256), 0, s, x, ldx, rows, cols, scratch);
-    if (nrb >= 32) hipLaunchKernelGGL(colsum_final_deep, dim3((cols + 63) / 64), dim3(256), 0, s, scratch, nrb, cols, out, accumulate, alpha);
-    else hipLaunchKernelGGL(colsum_final, dim3((cols + 255) / 256), dim3(256), 0, s, scratch, nrb, cols, out, accumulate, alpha);
+    colsum_finish(scratch, nrb, cols, out, accumulate, alpha, s);
     HGR_CHECK_LAUNCH("hgr_colsum");
+    return HGR_OK;
+}
+
+extern "C" int hgr_transpose16_colsum(const void *x, int64_t ldx, void *y, int64_t ldy, int rows, int cols, int dtype,
+                                      float *out, int accumulate, float alpha, float *scratch, void *stream) {
+    HGR_REQUIRE(x && y && out && scratch && rows >= 1 && cols >= 1 && ldx >= cols && ldy >= rows, "hgr_transpose16_colsum: bad arguments");
+    HGR_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && hgr_aligned(x, 16) && hgr_aligned(y, 16), "hgr_transpose16_colsum: 16-byte aligned rows required (ldx, ldy multiples of 8)");
+    DT_OK("hgr_transpose16_colsum");
+    const int nrb = (rows + 63) / 64;
+    dim3 grid((cols + 63) / 64, nrb);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == HGR_BF16) hipLaunchKernelGGL(transpose16<1>, grid, dim3(256), 0, s, (const unsigned short *)x, ldx, (unsigned short *)y, ldy, rows, cols, scratch);
+    else hipLaunchKernelGGL(transpose16<2>, grid, dim3(256), 0, s, (const unsigned short *)x, ldx, (unsigned short *)y, ldy, rows, cols, scratch);
+    colsum_finish(scratch, nrb, cols, out, accumulate, alpha, s);
+    HGR_CHECK_LAUNCH("hgr_transpose16_colsum");
     return HGR_OK;
 }
 

@@ -298,6 +298,18 @@ def transpose16(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def transpose16_colsum(x: torch.Tensor, out_t: torch.Tensor, colsum_out: torch.Tensor, scratch: torch.Tensor, accumulate: bool = True,
+                       alpha: float = 1.0) -> torch.Tensor:
+    """out_t[c][r] = x[r][c] and colsum_out[c] (+)= alpha * sum_r x[r][c] in one pass over x (16-bit)."""
+    assert x.dim() == 2 and x.stride(1) == 1 and out_t.stride(1) == 1 and x.dtype == out_t.dtype and x.dtype in DT_OF
+    assert colsum_out.dtype == torch.float32 and scratch.dtype == torch.float32 and colsum_out.numel() >= x.shape[1]
+    rows, cols = x.shape
+    assert out_t.shape[0] >= cols and out_t.stride(0) >= rows and scratch.numel() >= (rows + 63) // 64 * cols
+    _lib.call("hgr_transpose16_colsum", _dev(x), x.stride(0), _dev(out_t), out_t.stride(0), rows, cols, DT_OF[x.dtype], _dev(colsum_out),
+              1 if accumulate else 0, alpha, _dev(scratch), _stream())
+    return out_t
+
+
 def colsum(x: torch.Tensor, out: torch.Tensor, scratch: torch.Tensor, accumulate: bool = True, alpha: float = 1.0) -> torch.Tensor:
     assert x.dim() == 2 and x.stride(1) == 1 and out.dtype == torch.float32 and scratch.dtype == torch.float32
     rows, cols = x.shape

@@ -105,7 +105,11 @@ class Engine:
         alloc = torch.empty if mp == m else torch.zeros           # the pad columns must be zero, the rest is overwritten
         dyt = alloc(lin.n, mp, dtype=dt, device=dev)
         xt = alloc(lin.k, mp, dtype=dt, device=dev)
-        ops.transpose16(dy16, dyt)
+        fused_bias = lin.bias is not None and dy16.stride(0) % 8 == 0 and dy16.data_ptr() % 16 == 0
+        if fused_bias:      # db rides on the transposition of dY
+            ops.transpose16_colsum(dy16, dyt, _grad(lin.bias), self.scratch(((m + 63) // 64) * lin.n), accumulate=True)
+        else:
+            ops.transpose16(dy16, dyt)
         ops.transpose16(x16[:, : lin.k] if x16.shape[1] != lin.k else x16, xt)
         gw = _grad(lin.weight).view(lin.n, lin.k)
         if lin.n >= 256 and lin.k >= 256:                     # 256^2 tiles, one workgroup per CU
@@ -126,7 +130,7 @@ class Engine:
             ops.colsum(part, gw.view(-1), self.scratch(lin.n * lin.k), accumulate=True)
         else:
             ops.gemm_nt(dyt, xt, gw, epilogue=EPI_ACCUM)
-        if lin.bias is not None:
+        if lin.bias is not None and not fused_bias:
             ops.colsum(dy16, _grad(lin.bias), self.scratch(((m + 511) // 512) * lin.n), accumulate=True)
         if not need_dx:
             return None

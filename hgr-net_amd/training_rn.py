@@ -126,11 +126,17 @@ class RNTower:
             v.zero_()
         return v
 
-    def _wgrad(self, gw: torch.Tensor, dy16: torch.Tensor, xcol_t: torch.Tensor, m: int) -> None:
-        """gw [Cout, >= K] += dy16[:m]^T . xcol_t^T   (xcol_t [K, Mp], zero beyond column m)."""
+    def _wgrad(self, gw: torch.Tensor, dy16: torch.Tensor, xcol_t: torch.Tensor, m: int, gb: Optional[torch.Tensor] = None) -> None:
+        """gw [Cout, >= K] += dy16[:m]^T . xcol_t^T   (xcol_t [K, Mp], zero beyond column m);  gb [Cout] += column sums of dy16
+        from the same pass that transposes it."""
         cout, (k, mp) = dy16.shape[1], xcol_t.shape
         dyt = self._tmp("dyt", (cout, mp), self.dt, zero=mp != m)
-        ops.transpose16(dy16, dyt)
+        if gb is not None and dy16.stride(0) % 8 == 0 and dy16.data_ptr() % 16 == 0:
+            ops.transpose16_colsum(dy16, dyt, gb, self.scratch(((dy16.shape[0] + 63) // 64) * cout), accumulate=True)
+        else:
+            ops.transpose16(dy16, dyt)
+            if gb is not None:
+                self._bias_grad(gb, dy16)
         if cout >= 256 and k >= 256:                          # 256^2 tiles, one workgroup per CU
             tiles = -(-cout // 256) * -(-k // 256)
             s = max(1, min(mp // 128, -(-256 // tiles)))
@@ -157,8 +163,7 @@ class RNTower:
         mp = _pad64(m)
         xt = self._tmp("xt", (c.cin, mp), self.dt, zero=mp != m)
         ops.transpose16(x16, xt)
-        self._wgrad(c.gw, dy16, xt, m)
-        self._bias_grad(c.gb, dy16)
+        self._wgrad(c.gw, dy16, xt, m, c.gb)
         if not need_dx:
             return None
         dx = torch.empty(m, c.cin, dtype=self.dt, device=self.dev)
@@ -173,8 +178,7 @@ class RNTower:
         ops.transpose16(x16, xt)
         col_t = self._tmp("colt", (9 * c.cin, mp), self.dt)
         ops.im2col3x3_t(xt, col_t, b, h, h)
-        self._wgrad(c.gw, dy16, col_t, m)
-        self._bias_grad(c.gb, dy16)
+        self._wgrad(c.gw, dy16, col_t, m, c.gb)
         if not need_dx:
             return None
         dx = torch.empty(m, c.cin, dtype=self.dt, device=self.dev)
@@ -270,9 +274,8 @@ class RNTower:
         tok_t = self._tmp("xt", (e, mp), dt, zero=mp != m)
         ops.transpose16(s["tok"], tok_t)
         gwin = self._tmp("gwin", (3 * e, e), torch.float32, zero=True)
-        self._wgrad(gwin, dqkv, tok_t, m)
         gbin = self._tmp("gbin", (3 * e,), torch.float32, zero=True)
-        self._bias_grad(gbin, dqkv)
+        self._wgrad(gwin, dqkv, tok_t, m, gbin)
         for i, lin in enumerate((a.q_proj, a.k_proj, a.v_proj)):
             _grad(lin.weight).add_(gwin[i * e:(i + 1) * e])
             _grad(lin.bias).add_(gbin[i * e:(i + 1) * e])
@@ -320,8 +323,7 @@ class RNTower:
         mp = _pad64(m)
         col_t = self._tmp("xt", (64, mp), dt, zero=mp != m)
         ops.transpose16(s["col"], col_t)
-        self._wgrad(s1.gw, d_a1, col_t, m)
-        self._bias_grad(s1.gb, d_a1)
+        self._wgrad(s1.gw, d_a1, col_t, m, s1.gb)
         for c in self.stem:
             c.finish()
         for k in self.blocks:

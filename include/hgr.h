@@ -255,6 +255,13 @@ int hgr_attnpool_attend(const float *q, const void *k, const void *v, void *out,
 /* y[c][r] = x[r][c] for 16-bit elements; ldy >= rows (columns r >= rows of y are left untouched). */
 int hgr_transpose16(const void *x, int64_t ldx, void *y, int64_t ldy, int rows, int cols, void *stream);
 
+/* hgr_transpose16 and, from the same pass over x, out[c] = (accumulate ? out[c] : 0) + alpha * sum_r x[r][c]: the
+ * transposed dY that `dW += dY^T X` needs and the bias gradient `db += colsum(dY)` (autograd's Linear / Conv2d backward
+ * behind clip_tree.py:279-280) in one read.  ldx, ldy multiples of 8, 16-byte aligned bases;
+ * scratch >= ceil(rows/64) * cols floats; summation order is fixed. */
+int hgr_transpose16_colsum(const void *x, int64_t ldx, void *y, int64_t ldy, int rows, int cols, int dtype,
+                           float *out, int accumulate, float alpha, float *scratch, void *stream);
+
 /* out[c] = (accumulate ? out[c] : 0) + alpha * sum_r x[r][c]  (bias gradients, positional-embedding gradients).
  * x is fp32 (x_f32) or 16-bit `dtype`; scratch >= ceil(rows/512) * cols floats; summation order is fixed. */
 int hgr_colsum(const void *x, int64_t ldx, int rows, int cols, int x_f32, int dtype, float *out, int accumulate,

@@ -39,7 +39,30 @@ def test_transpose_colsum_cast(dt):
 
 
 @pytest.mark.parametrize("dt", DTS)
-@pytest.mark.parametrize("rows,cols", [(16384, 64), (40000, 40), (70001, 192), (17000, 1024)])
+@pytest.mark.parametrize("rows,cols", [(64, 64), (300, 200), (12800, 768), (5000, 40), (100003, 64), (200000, 256)])
+def test_transpose_with_fused_column_sums(dt, rows, cols):
+    """dY^T for the weight gradient and colsum(dY) for the bias gradient from one pass: the transposition is exact, the
+    sums are exact on integer data (any order) and match an fp64 sum of random data to fp32 rounding."""
+    gen = torch.Generator().manual_seed(rows * 7 + cols)
+    ldc = (cols + 7) // 8 * 8
+    xi = torch.zeros(rows, ldc, dtype=dt)
+    xi[:, :cols] = torch.randint(-3, 4, (rows, cols), generator=gen).to(dt)
+    ld = (rows + 63) // 64 * 64
+    scratch = torch.empty((rows + 63) // 64 * cols, dtype=torch.float32, device=DEV)
+    for x, exact in ((xi, True), (_rand((rows, ldc), 9).to(dt), False)):
+        yt = torch.zeros(cols, ld, dtype=dt, device=DEV)
+        acc = torch.full((cols,), 1.5, dtype=torch.float32, device=DEV)
+        ops.transpose16_colsum(x.to(DEV)[:, :cols], yt, acc, scratch, accumulate=True)
+        assert torch.equal(yt[:, :rows].cpu(), x[:, :cols].t()) and (yt[:, rows:] == 0).all()
+        want = x[:, :cols].double().sum(0)
+        if exact:
+            assert torch.equal(acc.cpu(), (want + 1.5).float())
+        else:
+            assert (acc.cpu().double() - 1.5 - want).abs().max() < 1e-5 * rows ** 0.5 * 4
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("rows,cols", [(16384, 64), (40000, 40), (70001, 192), (17000, 1024), (1605632, 64)])
 def test_colsum_many_bands(dt, rows, cols):
     """Bias gradients over 10^4..10^6 pixels: >= 32 bands of 512 rows take the wave-parallel final stage.  Integer values,
     so any summation order gives the same fp32 result and the comparison is exact; run twice for reproducibility."""
