@@ -64,6 +64,8 @@ SIGNATURES = {
     "hgr_dot_f32": [_p, _p, _l, _p, _f, _i, _p],
     "hgr_conv3x3_nhwc_plain": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "hgr_gemm_nt_splitk": [_p, _l, _p, _l, _p, _l, _i, _i, _i, _i, _i, _p],
+    "hgr_gemm_tn_splitk": [_p, _l, _p, _l, _p, _l, _i, _i, _i, _i, _i, _p],
+    "hgr_conv3x3_wgrad_splitk": [_p, _l, _p, _p, _l, _i, _i, _i, _i, _i, _i, _i, _p],
     "hgr_relu_bwd16": [_p, _p, _p, _l, _i, _p],
     "hgr_add16": [_p, _p, _p, _l, _i, _p],
     "hgr_avgpool2_bwd_nhwc": [_p, _p, _i, _i, _i, _i, _i, _p],

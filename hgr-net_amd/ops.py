@@ -395,6 +395,27 @@ def gemm_nt_splitk(a: torch.Tensor, w: torch.Tensor, partial: torch.Tensor, kc: 
     return partial
 
 
+def gemm_tn_splitk(p: torch.Tensor, q: torch.Tensor, partial: torch.Tensor, kc: int) -> torch.Tensor:
+    """partial[s] [Na, Nb] = p[rows of slice s]^T . q[rows of slice s]; p [M, Na], q [M, Nb] 16-bit row-major."""
+    assert p.dim() == 2 and q.dim() == 2 and p.stride(1) == 1 and q.stride(1) == 1 and p.dtype == q.dtype and p.shape[0] == q.shape[0]
+    m, na = p.shape
+    nb = q.shape[1]
+    s = (m + kc - 1) // kc
+    assert partial.dtype == torch.float32 and partial.is_contiguous() and partial.numel() >= s * na * nb
+    _lib.call("hgr_gemm_tn_splitk", _dev(p), p.stride(0), _dev(q), q.stride(0), _dev(partial), nb, m, na, nb, kc, DT_OF[p.dtype], _stream())
+    return partial
+
+
+def conv3x3_wgrad_splitk(dy: torch.Tensor, x: torch.Tensor, partial: torch.Tensor, b: int, h: int, w: int, c: int, kc: int) -> torch.Tensor:
+    """partial[s] [Cout, 9 C] in (ky, kx, c) order = dy[slice]^T . im2col(x)[slice] for a 3x3 / pad 1 / stride 1 convolution."""
+    assert dy.dim() == 2 and dy.stride(1) == 1 and x.is_contiguous() and dy.dtype == x.dtype and dy.shape[0] == b * h * w
+    cout = dy.shape[1]
+    s = (b * h * w + kc - 1) // kc
+    assert partial.dtype == torch.float32 and partial.is_contiguous() and partial.numel() >= s * cout * 9 * c
+    _lib.call("hgr_conv3x3_wgrad_splitk", _dev(dy), dy.stride(0), _dev(x), _dev(partial), 9 * c, b, h, w, c, cout, kc, DT_OF[dy.dtype], _stream())
+    return partial
+
+
 def relu_bwd16(dy: torch.Tensor, y: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     out = dy if out is None else out
     assert dy.is_contiguous() and y.is_contiguous() and out.is_contiguous() and dy.numel() == y.numel() == out.numel()

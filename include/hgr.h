@@ -252,6 +252,23 @@ int hgr_attnpool_attend(const float *q, const void *k, const void *v, void *out,
  * fp32 and ACCUMULATE (autograd `.grad +=` semantics, needed by the K.M inner `loss_j.backward()` calls).
  * ------------------------------------------------------------------------------------------------ */
 
+/*
+ * Weight gradients with the operands as they lie in memory ("TN": the reduction index m is the ROW index of both):
+ *   partial[s][a][b] = sum over rows m in [s*kc, min(M, (s+1)*kc)) of P[m][a] * Q[m][b]      (fp32, s < ceil(M/kc))
+ * For a Linear / 1x1 convolution dW[n][k] = sum_m dY[m][n] X[m][k] (autograd behind clip_tree.py:279-280): P = dY,
+ * Q = X, no transposed copies.  P [M, ldp], Q [M, ldq] 16-bit; Na, Nb, ldp, ldq multiples of 8; kc a multiple of 64;
+ * partial [S][Na][ldo] (ldo >= Nb, ldo % 4 == 0).  Reduce the S slices with hgr_colsum.
+ */
+int hgr_gemm_tn_splitk(const void *P, int64_t ldp, const void *Q, int64_t ldq, float *partial, int64_t ldo,
+                       int M, int Na, int Nb, int kc, int dtype, void *stream);
+
+/* The same for a 3x3 / pad 1 / stride 1 convolution (every 3x3 of clip/model.py's Bottleneck and stem conv2/conv3):
+ *   partial[s][co][(ky, kx, c)] = sum over pixels m of slice s of dY[m][co] * x[pixel m shifted by (ky-1, kx-1)][c]
+ * x NHWC 16-bit [B, H, W, C] (C a multiple of 8), dy [B*H*W, lddy] with Cout live columns; the loader gathers the taps
+ * (zero outside the image) - no im2col buffer.  partial [S][Cout][ldo], ldo >= 9*C. */
+int hgr_conv3x3_wgrad_splitk(const void *dy, int64_t lddy, const void *x, float *partial, int64_t ldo,
+                             int B, int H, int W, int C, int Cout, int kc, int dtype, void *stream);
+
 /* y[c][r] = x[r][c] for 16-bit elements; ldy >= rows (columns r >= rows of y are left untouched). */
 int hgr_transpose16(const void *x, int64_t ldx, void *y, int64_t ldy, int rows, int cols, void *stream);
 

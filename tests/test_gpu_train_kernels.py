@@ -343,3 +343,42 @@ def test_gemm_nt_splitk_partials(dt, m, n, k, kc):
     for i in range(s):
         ref = a[:, i * kc:(i + 1) * kc].float() @ w[:, i * kc:(i + 1) * kc].float().t()
         assert torch.equal(part[i].view(m, n), ref), i
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("m,na,nb,kc", [(64, 128, 128, 64), (200, 192, 128, 64), (1000, 40, 264, 256), (12800, 768, 768, 1280),
+                                        (777, 136, 72, 128), (4096, 3072, 768, 4096), (130, 8, 8, 64)])
+def test_gemm_tn_splitk_exact(dt, m, na, nb, kc):
+    """Weight gradient with untransposed operands: partial[s] = P[slice]^T . Q[slice].  Small-integer operands, so the
+    fp32 accumulation is exact in any order: every slice must equal the fp64 product bit for bit (ragged M, Na, Nb;
+    strided operands)."""
+    gen = torch.Generator().manual_seed(m + na + nb)
+    pf = torch.zeros(m, na + 8, dtype=dt)
+    pf[:, :na] = torch.randint(-2, 3, (m, na), generator=gen).to(dt)
+    qf = torch.randint(-2, 3, (m, nb), generator=gen).to(dt)
+    s = (m + kc - 1) // kc
+    part = torch.full((s, na, nb), 7.0, dtype=torch.float32, device=DEV)
+    ops.gemm_tn_splitk(pf.to(DEV)[:, :na], qf.to(DEV), part, kc)
+    for i in range(s):
+        want = pf[i * kc:(i + 1) * kc, :na].double().t() @ qf[i * kc:(i + 1) * kc].double()
+        assert torch.equal(part[i].cpu(), want.float()), i
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("b,h,w,c,cout,kc", [(2, 8, 8, 64, 64, 64), (3, 7, 9, 32, 40, 128), (1, 14, 14, 128, 128, 64), (5, 12, 12, 8, 16, 256),
+                                             (2, 9, 9, 40, 80, 64), (4, 28, 28, 64, 64, 1024)])
+def test_conv3x3_wgrad_splitk_vs_autograd(dt, b, h, w, c, cout, kc):
+    """dW of a 3x3 / pad 1 / stride 1 convolution from NHWC x and dY, taps gathered by the loader; against autograd's
+    conv2d weight gradient on the same 16-bit values (integers: exact)."""
+    gen = torch.Generator().manual_seed(b * h + c)
+    x = torch.randint(-2, 3, (b, c, h, w), generator=gen).float()
+    dy = torch.randint(-2, 3, (b, cout, h, w), generator=gen).float()
+    wt = torch.zeros(cout, c, 3, 3, requires_grad=True)
+    torch.nn.functional.conv2d(x, wt, padding=1).backward(dy)
+    want = wt.grad.permute(0, 2, 3, 1).reshape(cout, 9 * c)                      # (ky, kx, c) order
+    xn = x.permute(0, 2, 3, 1).contiguous().to(dt).to(DEV)
+    dyn = dy.permute(0, 2, 3, 1).reshape(b * h * w, cout).contiguous().to(dt).to(DEV)
+    s = (b * h * w + kc - 1) // kc
+    part = torch.empty(s, cout, 9 * c, dtype=torch.float32, device=DEV)
+    ops.conv3x3_wgrad_splitk(dyn, xn, part, b, h, w, c, kc)
+    assert torch.equal(part.sum(0).cpu(), want)
