@@ -395,6 +395,21 @@ def gemm_nt_splitk(a: torch.Tensor, w: torch.Tensor, partial: torch.Tensor, kc: 
     return partial
 
 
+def splitk_slices(tiles: int, m: int, slots: int = 512) -> int:
+    """Number of reduction slices for a split-K weight gradient with `tiles` output tiles over `m` rows: the smallest count
+    that fills >= 85 % of whole rounds of `slots` workgroups (2 per CU), each slice at least 512 rows deep."""
+    smax = max(1, min(m // 512, 4096))
+    best = (0.0, 1)
+    for s in range(1, smax + 1):
+        wgs = tiles * s
+        eff = wgs / (-(-wgs // slots) * slots)
+        if eff >= 0.85:
+            return s
+        if eff > best[0]:
+            best = (eff, s)
+    return best[1]
+
+
 def gemm_tn_splitk(p: torch.Tensor, q: torch.Tensor, partial: torch.Tensor, kc: int) -> torch.Tensor:
     """partial[s] [Na, Nb] = p[rows of slice s]^T . q[rows of slice s]; p [M, Na], q [M, Nb] 16-bit row-major."""
     assert p.dim() == 2 and q.dim() == 2 and p.stride(1) == 1 and q.stride(1) == 1 and p.dtype == q.dtype and p.shape[0] == q.shape[0]

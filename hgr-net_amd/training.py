@@ -30,6 +30,12 @@ from ._lib import EPI_ACCUM, EPI_BIAS, EPI_BIAS_RESIDUAL, EPI_NONE, HgrError
 from .clip.model import VisionTransformer
 
 
+import os
+
+# weight gradients from untransposed operands (hgr_gemm_tn_splitk); HGR_WGRAD=nt keeps the transposing route for A/B runs
+WGRAD_TN = os.environ.get("HGR_WGRAD", "tn") != "nt"
+
+
 def _pad64(n: int) -> int:
     return (n + 63) // 64 * 64
 
@@ -101,6 +107,26 @@ class Engine:
     def _linear_bwd(self, lin: _Lin, dy16: torch.Tensor, x16: torch.Tensor, m: int, need_dx: bool = True) -> Optional[torch.Tensor]:
         """dW += dY^T X, db += colsum(dY); returns dX = dY W (16-bit) if wanted.  dy16 [m, n], x16 [m, k]."""
         dev, dt = self.dev, self.dt
+        xq = x16[:, : lin.k] if x16.shape[1] != lin.k else x16
+        if WGRAD_TN and lin.n % 8 == 0 and lin.k % 8 == 0 and dy16.stride(0) % 8 == 0 and xq.stride(0) % 8 == 0 \
+                and dy16.data_ptr() % 16 == 0 and xq.data_ptr() % 16 == 0:
+            # operands as they lie in memory (hgr_gemm_tn_splitk): no transposed copies of dY and X
+            gw = _grad(lin.weight).view(lin.n, lin.k)
+            s = ops.splitk_slices(-(-lin.n // 128) * -(-lin.k // 128), m)
+            kc = _pad64(-(-m // s))
+            s = -(-m // kc)
+            need = s * lin.n * lin.k
+            if self._part is None or self._part.numel() < need:
+                self._part = torch.empty(need, dtype=torch.float32, device=dev)
+            part = self._part[:need].view(s, lin.n * lin.k)
+            ops.gemm_tn_splitk(dy16, xq, part, kc)
+            if s > 1:
+                ops.colsum(part, gw.view(-1), self.scratch(lin.n * lin.k), accumulate=True)
+            else:
+                gw.view(-1).add_(part[0])
+            if lin.bias is not None:
+                ops.colsum(dy16, _grad(lin.bias), self.scratch(((m + 511) // 512) * lin.n), accumulate=True)
+            return self._linear_dx(lin, dy16, m) if need_dx else None
         mp = _pad64(m)
         alloc = torch.empty if mp == m else torch.zeros           # the pad columns must be zero, the rest is overwritten
         dyt = alloc(lin.n, mp, dtype=dt, device=dev)
@@ -132,9 +158,10 @@ class Engine:
             ops.gemm_nt(dyt, xt, gw, epilogue=EPI_ACCUM)
         if lin.bias is not None and not fused_bias:
             ops.colsum(dy16, _grad(lin.bias), self.scratch(((m + 511) // 512) * lin.n), accumulate=True)
-        if not need_dx:
-            return None
-        dx = torch.empty(m, lin.k, dtype=dt, device=dev)
+        return self._linear_dx(lin, dy16, m) if need_dx else None
+
+    def _linear_dx(self, lin: _Lin, dy16: torch.Tensor, m: int) -> torch.Tensor:
+        dx = torch.empty(m, lin.k, dtype=self.dt, device=self.dev)
         if lin.n % 64:
             raise HgrError("backward GEMM needs the output width to be a multiple of 64")
         ops.gemm_nt(dy16, lin.wt16[:, : lin.n] if lin.wt16.shape[1] == lin.n else lin.wt16, dx, n=lin.k)

@@ -158,12 +158,45 @@ class RNTower:
         m, n = dy16.shape
         ops.colsum(dy16, gb, self.scratch(((m + 511) // 512) * n), accumulate=True)
 
+    def _reduce(self, part: torch.Tensor, s: int, gw: torch.Tensor, cout: int, k: int) -> None:
+        """gw [Cout, >= K] += sum of the s fp32 slices part [s, Cout * K]."""
+        if gw.shape[1] == k and s > 1:
+            ops.colsum(part, gw.view(-1), self.scratch(cout * k), accumulate=True)
+            return
+        if s > 1:
+            red = self._tmp("red", (cout, k), torch.float32)
+            ops.colsum(part, red.view(-1), self.scratch(cout * k), accumulate=False)
+        else:
+            red = part[0].view(cout, k)
+        gw[:, :k].add_(red)
+
+    def _wgrad_tn(self, gw: torch.Tensor, dy16: torch.Tensor, x16: torch.Tensor, gb: Optional[torch.Tensor], conv: Optional[tuple] = None) -> bool:
+        """Weight (and bias) gradient from the operands as stored: dW = dY^T X (1x1) or dY^T im2col(X) (conv = (b, h, c))."""
+        from .training import WGRAD_TN
+        m, cout = dy16.shape
+        k = 9 * conv[2] if conv else x16.shape[1]
+        if not WGRAD_TN or cout % 8 or k % 8 or dy16.stride(0) % 8 or dy16.data_ptr() % 16 or x16.data_ptr() % 16 or not x16.is_contiguous():
+            return False
+        s = ops.splitk_slices(-(-cout // 128) * -(-k // 128), m)
+        kc = _pad64(-(-m // s))
+        s = -(-m // kc)
+        part = self._tmp("part", (s, cout * k), torch.float32)
+        if conv:
+            ops.conv3x3_wgrad_splitk(dy16, x16, part, conv[0], conv[1], conv[1], conv[2], kc)
+        else:
+            ops.gemm_tn_splitk(dy16, x16, part, kc)
+        self._reduce(part, s, gw, cout, k)
+        if gb is not None:
+            self._bias_grad(gb, dy16)
+        return True
+
     def _conv1x1_bwd(self, c: _ConvBN, dy16: torch.Tensor, x16: torch.Tensor, need_dx: bool = True) -> Optional[torch.Tensor]:
         m = dy16.shape[0]
-        mp = _pad64(m)
-        xt = self._tmp("xt", (c.cin, mp), self.dt, zero=mp != m)
-        ops.transpose16(x16, xt)
-        self._wgrad(c.gw, dy16, xt, m, c.gb)
+        if not self._wgrad_tn(c.gw, dy16, x16, c.gb):
+            mp = _pad64(m)
+            xt = self._tmp("xt", (c.cin, mp), self.dt, zero=mp != m)
+            ops.transpose16(x16, xt)
+            self._wgrad(c.gw, dy16, xt, m, c.gb)
         if not need_dx:
             return None
         dx = torch.empty(m, c.cin, dtype=self.dt, device=self.dev)
@@ -173,12 +206,13 @@ class RNTower:
 
     def _conv3x3_bwd(self, c: _ConvBN, dy16: torch.Tensor, x16: torch.Tensor, b: int, h: int, need_dx: bool = True) -> Optional[torch.Tensor]:
         m = dy16.shape[0]
-        mp = _pad64(m)
-        xt = self._tmp("xt", (c.cin, mp), self.dt, zero=mp != m)
-        ops.transpose16(x16, xt)
-        col_t = self._tmp("colt", (9 * c.cin, mp), self.dt)
-        ops.im2col3x3_t(xt, col_t, b, h, h)
-        self._wgrad(c.gw, dy16, col_t, m, c.gb)
+        if not self._wgrad_tn(c.gw, dy16, x16, c.gb, conv=(b, h, c.cin)):
+            mp = _pad64(m)
+            xt = self._tmp("xt", (c.cin, mp), self.dt, zero=mp != m)
+            ops.transpose16(x16, xt)
+            col_t = self._tmp("colt", (9 * c.cin, mp), self.dt)
+            ops.im2col3x3_t(xt, col_t, b, h, h)
+            self._wgrad(c.gw, dy16, col_t, m, c.gb)
         if not need_dx:
             return None
         dx = torch.empty(m, c.cin, dtype=self.dt, device=self.dev)
@@ -271,11 +305,12 @@ class RNTower:
         # in-projection: qkv = tok . Win^T + bin   (q, k, v are separate parameters: scatter the packed gradient)
         m = b * l
         mp = _pad64(m)
-        tok_t = self._tmp("xt", (e, mp), dt, zero=mp != m)
-        ops.transpose16(s["tok"], tok_t)
         gwin = self._tmp("gwin", (3 * e, e), torch.float32, zero=True)
         gbin = self._tmp("gbin", (3 * e,), torch.float32, zero=True)
-        self._wgrad(gwin, dqkv, tok_t, m, gbin)
+        if not self._wgrad_tn(gwin, dqkv, s["tok"], gbin):
+            tok_t = self._tmp("xt", (e, mp), dt, zero=mp != m)
+            ops.transpose16(s["tok"], tok_t)
+            self._wgrad(gwin, dqkv, tok_t, m, gbin)
         for i, lin in enumerate((a.q_proj, a.k_proj, a.v_proj)):
             _grad(lin.weight).add_(gwin[i * e:(i + 1) * e])
             _grad(lin.bias).add_(gbin[i * e:(i + 1) * e])
@@ -321,9 +356,10 @@ class RNTower:
         ops.relu_bwd16(d_a1, s["a1"])
         m = b * hs * hs
         mp = _pad64(m)
-        col_t = self._tmp("xt", (64, mp), dt, zero=mp != m)
-        ops.transpose16(s["col"], col_t)
-        self._wgrad(s1.gw, d_a1, col_t, m, s1.gb)
+        if not self._wgrad_tn(s1.gw, d_a1, s["col"], s1.gb):
+            col_t = self._tmp("xt", (64, mp), dt, zero=mp != m)
+            ops.transpose16(s["col"], col_t)
+            self._wgrad(s1.gw, d_a1, col_t, m, s1.gb)
         for c in self.stem:
             c.finish()
         for k in self.blocks:
