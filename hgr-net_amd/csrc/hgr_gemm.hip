@@ -22,6 +22,9 @@
 #include <stdlib.h>
 #include <type_traits>
 
+int hgr_conv3x3_c32_launch(const void *x, const void *w, const float *bias, void *out, int B, int H, int W, int Cout, int Kp,
+                           int dtype, int relu, void *stream);      // hgr_conv_direct.hip
+
 namespace {
 
 int hgr_gemm_force_tile();
@@ -914,6 +917,11 @@ static int conv3x3_launch(const void *x, const void *w, const float *bias, void 
     HGR_REQUIRE(Kp >= 9 * C && Kp % BK == 0, "hgr_conv3x3_nhwc: Kp=%d must be >= 9*C and a multiple of %d", Kp, BK);
     HGR_REQUIRE(hgr_aligned(x, 16) && hgr_aligned(w, 16) && hgr_aligned(out, 8) && (!bias || hgr_aligned(bias, 16)) && Cout % 4 == 0, "hgr_conv3x3_nhwc: misaligned operand / Cout %% 4 != 0");
     HGR_REQUIRE(dtype == HGR_BF16 || dtype == HGR_F16, "hgr_conv3x3_nhwc: bad dtype %d", dtype);
+    // 32 input channels (the stem at 112 x 112): the direct kernel of hgr_conv_direct.hip; HGR_CONV_DIRECT=0 keeps the implicit GEMM
+    static int direct_env = -1;
+    if (direct_env < 0) { const char *e = getenv("HGR_CONV_DIRECT"); direct_env = e ? atoi(e) : 1; }
+    if (direct_env && C == 32 && stride == 1 && (Cout == 32 || Cout == 64) && Kp >= 288 && hgr_aligned(out, 16))
+        return hgr_conv3x3_c32_launch(x, w, bias, out, B, H, W, Cout, Kp, dtype, relu ? 1 : 0, stream);
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     const int64_t M64 = (int64_t)B * Ho * Wo;
     HGR_REQUIRE(M64 < (1ll << 31), "hgr_conv3x3_nhwc: too many output pixels");

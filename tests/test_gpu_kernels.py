@@ -261,6 +261,8 @@ def test_level_argmax_exact(n, levels):
                                                   # the loader's tap / channel split is a multiply-high division
                                                   (2, 9, 9, 40, 40, 1), (1, 12, 12, 48, 128, 1), (2, 18, 18, 192, 192, 2),
                                                   (1, 9, 9, 320, 320, 1), (1, 6, 6, 640, 640, 1), (2, 24, 24, 24, 48, 1),
+                                                  # 32 input channels, stride 1, 32 / 64 outputs: the direct halo-tile kernel (ragged tiles too)
+                                                  (2, 16, 16, 32, 32, 1), (1, 33, 17, 32, 64, 1), (3, 40, 48, 32, 32, 1), (2, 5, 70, 32, 64, 1),
                                                   # 256^2 tiles with a non-power-of-two C (>= 1024 tiles of 256)
                                                   (40, 80, 80, 192, 192, 1)])
 def test_conv3x3_implicit_gemm_vs_conv2d(dt, b, h, w, c, cout, stride):
