@@ -242,10 +242,13 @@ def _rn_forward(v: "ModifiedResNet", p: dict, image: torch.Tensor, dt: torch.dty
     h = (r - 1) // 2 + 1
     m = b * h * h
     (w1, b1), (w2, b2), (w3, b3) = p["stem"]
-    col = ws.get("r.col", (m, 64), dt, dev)
-    ops.stem_im2col(image, col)
     a1 = ws.get("r.a", (m, w1.shape[0]), dt, dev)
-    ops.gemm_nt(col, w1, a1, bias=b1, epilogue=EPI_BIAS_RELU)
+    if r % 4 == 0 and w1.shape[0] <= 48:
+        ops.stem_conv1(image, w1, b1, a1)                 # conv + BN + ReLU straight from the fp32 image
+    else:
+        col = ws.get("r.col", (m, 64), dt, dev)
+        ops.stem_im2col(image, col)
+        ops.gemm_nt(col, w1, a1, bias=b1, epilogue=EPI_BIAS_RELU)
     a2 = ws.get("r.b", (m, w2.shape[0]), dt, dev)
     ops.conv3x3_nhwc(a1, w2, b2, a2, b, h, h, w1.shape[0])
     a3 = ws.get("r.c", (m, w3.shape[0]), dt, dev)

@@ -120,6 +120,94 @@ __global__ __launch_bounds__(256) void conv3x3_c32(DcArgs p) {
     }
 }
 
+// ---- stem conv1: 3 x 3, stride 2, pad 1 over the fp32 NCHW image, 3 -> Cout channels (+ folded BN + ReLU) ------------------
+// clip/model.py:106 (`relu(bn1(conv1(x)))`).  As a GEMM this is K = 27: the im2col route wrote a [pixels, 64] 16-bit matrix
+// (822 MB at batch 512) and read it back for one k-step of work.  Here a workgroup owns 4 output rows of one image: the 9 x 3
+// input rows they touch are converted to 16 bit into LDS once (coalesced float4 loads), every 16-pixel group builds its
+// MFMA fragment with eight 2-byte LDS reads per lane (K order (ky, kx, c), the 5 columns beyond 27 meet zero weights), one
+// v_mfma_f32_16x16x32 per 16 output channels, and the NHWC rows leave as whole 16-byte chunks through LDS.
+struct StemArgs {
+    const float *img; const char *w; const float *bias; char *out;
+    int B, R, Ho, Cout, Kp, tiles_y;
+};
+
+template <int DT, int NOUT>
+__global__ __launch_bounds__(256) void stem_conv1(StemArgs p) {
+    typedef typename T16<DT>::vec8 vec8;
+    typedef typename T16<DT>::vec4 vec4;
+    typedef typename T16<DT>::elem E;
+    extern __shared__ __attribute__((aligned(16))) char dsm[];
+    const int R = p.R, RS = R + 8;                 // LDS row: 4 pad + R + 4 pad elements (column x at index x + 4)
+    E *tile = (E *)dsm;                            // [3][9][RS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int ty = blockIdx.x % p.tiles_y, b = blockIdx.x / p.tiles_y;
+    const int ho0 = ty * 4, yi0 = 2 * ho0 - 1;     // first input row of the tile
+
+    // ---- stage: 27 rows of R floats -> 16 bit
+    const int r4 = R >> 2;
+    for (int id = tid; id < 27 * r4; id += 256) {
+        const int row = id / r4, q = id - row * r4;          // row = c * 9 + local input row
+        const int c = row / 9, ly = row - c * 9, yi = yi0 + ly;
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (yi >= 0 && yi < R) v = *(const f32x4 *)(p.img + (((int64_t)b * 3 + c) * R + yi) * R + q * 4);
+        *(vec4 *)(tile + row * RS + 4 + q * 4) = cvt4<DT>(v[0], v[1], v[2], v[3]);
+    }
+    for (int row = tid; row < 27; row += 256) {              // the column left of x = 0 and right of x = R - 1
+        tile[row * RS + 3] = (E)0.f;
+        tile[row * RS + 4 + R] = (E)0.f;
+    }
+    // weights: fragment i = output channels i*16 + r, k = 8g .. 8g+7; bias quads
+    vec8 wf[NOUT];
+    f32x4 bq[NOUT];
+#pragma unroll
+    for (int i = 0; i < NOUT; ++i) {
+        const int co = i * 16 + r;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wf[i][e] = (E)0.f;
+        if (co < p.Cout) wf[i] = *(const vec8 *)(p.w + ((int64_t)co * p.Kp + g * 8) * 2);
+        const int cq = i * 16 + g * 4;
+        bq[i] = cq < p.Cout ? *(const f32x4 *)(p.bias + cq) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    // per-lane offsets of the 8 taps k = 8g + e relative to (output row 0 of the tile, output column 0)
+    int koff[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = g * 8 + e, kk = k < 27 ? k : 0;        // k >= 27 multiplies a zero weight
+        const int tap = kk / 3, c = kk - tap * 3, ky = tap / 3, kx = tap - ky * 3;
+        koff[e] = (c * 9 + ky) * RS + kx + 3;
+    }
+    __syncthreads();
+
+    const int nsub = (p.Ho + 15) >> 4;                       // 16-pixel groups per output row
+    const int PXB = p.Cout * 2;
+    char *stg = dsm + ((27 * RS * 2 + 15) & ~15) + wave * (16 * NOUT * 32);   // this wave's 16 px x (NOUT*16 channels) staging
+    for (int sidx = wave; sidx < 4 * nsub; sidx += 4) {
+        const int ly = sidx / nsub, sub = sidx - ly * nsub;
+        const int ho = ho0 + ly, wo = sub * 16 + r;
+        const int base = (2 * ly) * RS + 2 * min(wo, p.Ho - 1);
+        vec8 af;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) af[e] = tile[base + koff[e]];
+#pragma unroll
+        for (int i = 0; i < NOUT; ++i) {
+            f32x4 v = T16<DT>::mfma16(wf[i], af, (f32x4){0.f, 0.f, 0.f, 0.f}) + bq[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            *(vec4 *)(stg + r * (NOUT * 32) + (i * 16 + g * 4) * 2) = cvt4<DT>(v[0], v[1], v[2], v[3]);
+        }
+        // 16 pixels x PXB bytes, contiguous in the NHWC output (row ho, columns sub*16 ..)
+        if (ho < p.Ho) {
+            char *dst = p.out + (((int64_t)b * p.Ho + ho) * p.Ho + sub * 16) * PXB;
+            const int cpp = PXB >> 4;                         // 16-byte chunks per pixel (Cout % 8 == 0)
+            for (int c = lane; c < 16 * cpp; c += 64) {
+                const int px = c / cpp, cc = c - px * cpp;
+                if (sub * 16 + px < p.Ho) *(u32x4 *)(dst + c * 16) = *(const u32x4 *)(stg + px * (NOUT * 32) + cc * 16);
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // Called by hgr_conv3x3_nhwc / hgr_conv3x3_nhwc_plain (hgr_gemm.hip) for C = 32, stride 1, Cout in {32, 64}.
@@ -141,5 +229,32 @@ int hgr_conv3x3_c32_launch(const void *x, const void *w, const float *bias, void
         else hipLaunchKernelGGL((conv3x3_c32<HGR_F16, 4>), grid, dim3(256), 0, s, a);
     }
     HGR_CHECK_LAUNCH("hgr_conv3x3_nhwc");
+    return HGR_OK;
+}
+
+// out NHWC [B, Ho, Ho, Cout] 16-bit = relu(conv1(image fp32 [B, 3, R, R], stride 2, pad 1) + bias); w [Cout, Kp] 16-bit in
+// (ky, kx, c) order, zero beyond column 27 (the folded layout of clip/model.py `_fold`).
+extern "C" int hgr_stem_conv1(const float *image, const void *w, const float *bias, void *out, int B, int R, int Cout, int Kp,
+                              int dtype, void *stream) {
+    HGR_REQUIRE(image && w && bias && out && B >= 1 && R >= 4 && R % 4 == 0 && R <= 1024, "hgr_stem_conv1: bad arguments (R a multiple of 4, <= 1024)");
+    HGR_REQUIRE(Cout >= 8 && Cout % 8 == 0 && Cout <= 48 && Kp >= 32 && Kp % 8 == 0, "hgr_stem_conv1: Cout=%d must be a multiple of 8 up to 48, Kp=%d >= 32", Cout, Kp);
+    HGR_REQUIRE(hgr_aligned(image, 16) && hgr_aligned(w, 16) && hgr_aligned(bias, 16) && hgr_aligned(out, 16), "hgr_stem_conv1: misaligned operand");
+    HGR_REQUIRE(dtype == HGR_BF16 || dtype == HGR_F16, "hgr_stem_conv1: bad dtype %d", dtype);
+    StemArgs a;
+    a.img = image; a.w = (const char *)w; a.bias = bias; a.out = (char *)out;
+    a.B = B; a.R = R; a.Ho = (R - 1) / 2 + 1; a.Cout = Cout; a.Kp = Kp; a.tiles_y = (a.Ho + 3) / 4;
+    const int nout = (Cout + 15) / 16;
+    const size_t lds = (((size_t)27 * (R + 8) * 2 + 15) & ~(size_t)15) + 4 * 16 * nout * 32;
+    HGR_REQUIRE(lds <= 64 * 1024, "hgr_stem_conv1: R=%d needs %zu bytes of LDS", R, lds);
+    dim3 grid((unsigned)(B * a.tiles_y));
+    hipStream_t s = (hipStream_t)stream;
+    if (nout <= 2) {
+        if (dtype == HGR_BF16) hipLaunchKernelGGL((stem_conv1<HGR_BF16, 2>), grid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((stem_conv1<HGR_F16, 2>), grid, dim3(256), lds, s, a);
+    } else {
+        if (dtype == HGR_BF16) hipLaunchKernelGGL((stem_conv1<HGR_BF16, 3>), grid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((stem_conv1<HGR_F16, 3>), grid, dim3(256), lds, s, a);
+    }
+    HGR_CHECK_LAUNCH("hgr_stem_conv1");
     return HGR_OK;
 }

@@ -268,6 +268,15 @@ def conv3x3_nhwc(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out: torc
     return out
 
 
+def stem_conv1(image: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """out NHWC [B*Ho*Ho, Cout] = relu(conv3x3 stride 2 pad 1 (image fp32 NCHW) + bias); w [Cout, Kp] folded, (ky, kx, c) order."""
+    assert image.dtype == torch.float32 and image.is_contiguous() and image.shape[1] == 3 and image.shape[2] == image.shape[3]
+    assert w.is_contiguous() and out.is_contiguous() and w.dtype == out.dtype and out.shape[1] == w.shape[0]
+    _lib.call("hgr_stem_conv1", _dev(image), _dev(w), _dev(bias), _dev(out), image.shape[0], image.shape[2], w.shape[0], w.shape[1],
+              DT_OF[out.dtype], _stream())
+    return out
+
+
 def stem_im2col(image: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
     assert image.dtype == torch.float32 and image.is_contiguous() and out.is_contiguous() and out.shape[1] == 64
     _lib.call("hgr_stem_im2col", _dev(image), _dev(out), image.shape[0], image.shape[2], DT_OF[out.dtype], _stream())

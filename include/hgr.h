@@ -221,6 +221,15 @@ int hgr_conv3x3_nhwc(const void *x, const void *w, const float *bias, void *out,
                      int B, int H, int W, int C, int Cout, int stride, int Kp, int dtype, void *stream);
 
 /*
+ * The stem's first convolution in one kernel (clip/model.py:106 `relu(bn1(conv1(x)))`, 3 x 3, stride 2, pad 1, 3 -> Cout):
+ *   out NHWC 16-bit [B, Ho, Ho, Cout] = relu(conv(image fp32 [B, 3, R, R]) + bias),  Ho = (R - 1) / 2 + 1
+ * w 16-bit [Cout, Kp] in (ky, kx, c) order, zero beyond column 27 (the folded layout); R a multiple of 4, Cout a multiple
+ * of 8 up to 48.  Replaces hgr_stem_im2col + hgr_gemm_nt on the inference path (no [pixels, 64] matrix in HBM).
+ */
+int hgr_stem_conv1(const float *image, const void *w, const float *bias, void *out, int B, int R, int Cout, int Kp,
+                   int dtype, void *stream);
+
+/*
  * im2col of the stem's first convolution (3 -> width/2 channels, 3x3, stride 2, pad 1,
  * clip/model.py:105) straight from the fp32 NCHW image: out 16-bit [B*Ho*Wo, 64], K order
  * (ky, kx, c), 27 values + zero padding.  Followed by hgr_gemm_nt with HGR_EPI_BIAS_RELU.

@@ -284,6 +284,24 @@ def test_conv3x3_implicit_gemm_vs_conv2d(dt, b, h, w, c, cout, stride):
 
 
 @pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("b,r,cout", [(2, 64, 32), (1, 224, 32), (3, 36, 40), (2, 100, 48), (1, 288, 40), (5, 8, 32)])
+def test_stem_conv1_vs_conv2d(dt, b, r, cout):
+    """3x3 / stride 2 / pad 1 from the fp32 NCHW image, bias + ReLU, NHWC out: against conv2d on the same 16-bit values."""
+    img = _rand((b, 3, r, r), 160)
+    wt = _rand((cout, 3, 3, 3), 161, 0.3).to(dt)
+    bias = _rand((cout,), 162, 0.2)
+    ref = torch.relu(torch.nn.functional.conv2d(img.to(dt).float(), wt.float(), bias, stride=2, padding=1))
+    ho = ref.shape[2]
+    w2 = torch.zeros(cout, 64, dtype=dt)
+    w2[:, :27] = wt.permute(0, 2, 3, 1).reshape(cout, 27)
+    out = torch.full((b * ho * ho, cout), 9.0, dtype=dt, device=DEV)
+    ops.stem_conv1(img.to(DEV), w2.to(DEV), bias.to(DEV), out)
+    got = out.float().cpu().view(b, ho, ho, cout).permute(0, 3, 1, 2)
+    tol = 2e-2 if dt == torch.bfloat16 else 3e-3
+    assert (got - ref).abs().max() < tol * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("dt", DTS)
 def test_gemm_relu_epilogues(dt):
     m, n, k = 260, 192, 128
     a, w = _rand((m, k), 63).to(dt), _rand((n, k), 64, 0.1).to(dt)

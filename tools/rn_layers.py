@@ -38,8 +38,8 @@ def wrap(name, shape_of):
 
 wrap("gemm_nt", lambda a, w, out, **k: (a.shape[0], w.shape[0], w.shape[1], k.get("epilogue", 0), 2.0 * a.shape[0] * w.shape[0] * w.shape[1]))
 wrap("conv3x3_nhwc", lambda x, w, bias, out, b, h, wd, c, stride=1: (out.shape[0], w.shape[0], 9 * c, f"s{stride}", 2.0 * out.shape[0] * w.shape[0] * 9 * c))
-for nm in ("stem_im2col", "avgpool2_nhwc", "attnpool_tokens", "attnpool_attend"):
-    wrap(nm, lambda *a, **k: (tuple(a[1].shape) if torch.is_tensor(a[1]) else (), 0.0))
+for nm in ("stem_conv1", "stem_im2col", "avgpool2_nhwc", "attnpool_tokens", "attnpool_attend"):
+    wrap(nm, lambda *a, **k: (tuple(a[-1].shape) if torch.is_tensor(a[-1]) else (tuple(a[1].shape) if torch.is_tensor(a[1]) else ()), 0.0))
 
 for _ in range(3):
     rec.clear()
