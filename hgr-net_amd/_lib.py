@@ -39,6 +39,7 @@ SIGNATURES = {
     "hgr_level_argmax": [_p, _l, _p, _i, _p, _i, _p, _p, _i, _p],
     "hgr_eval_rows": [_p, _l, _i, _p, _p, _p, _i, _i, _p, _p, _p, _i, _i, _p, _p, _p, _i, _p],
     "hgr_conv3x3_nhwc": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "hgr_conv3x3_pool2_nhwc": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "hgr_stem_conv1": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "hgr_stem_im2col": [_p, _p, _i, _i, _i, _p],
     "hgr_avgpool2_nhwc": [_p, _p, _i, _i, _i, _i, _i, _p],

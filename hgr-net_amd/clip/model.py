@@ -251,11 +251,16 @@ def _rn_forward(v: "ModifiedResNet", p: dict, image: torch.Tensor, dt: torch.dty
         ops.gemm_nt(col, w1, a1, bias=b1, epilogue=EPI_BIAS_RELU)
     a2 = ws.get("r.b", (m, w2.shape[0]), dt, dev)
     ops.conv3x3_nhwc(a1, w2, b2, a2, b, h, h, w1.shape[0])
-    a3 = ws.get("r.c", (m, w3.shape[0]), dt, dev)
-    ops.conv3x3_nhwc(a2, w3, b3, a3, b, h, h, w2.shape[0])
-    h //= 2
-    x = ws.get("r.x0", (b * h * h, width), dt, dev)
-    ops.avgpool2_nhwc(a3, x, b, 2 * h, 2 * h, width)
+    if w2.shape[0] == 32 and width == 64 and h % 2 == 0:      # RN50 / RN101: conv3 + BN + ReLU + AvgPool2d(2) in one kernel
+        h //= 2
+        x = ws.get("r.x0", (b * h * h, width), dt, dev)
+        ops.conv3x3_pool2_nhwc(a2, w3, b3, x, b, 2 * h, 2 * h, 32)
+    else:
+        a3 = ws.get("r.c", (m, w3.shape[0]), dt, dev)
+        ops.conv3x3_nhwc(a2, w3, b3, a3, b, h, h, w2.shape[0])
+        h //= 2
+        x = ws.get("r.x0", (b * h * h, width), dt, dev)
+        ops.avgpool2_nhwc(a3, x, b, 2 * h, 2 * h, width)
     cin, flip = width, 0
     for k in p["blocks"]:
         m = b * h * h

@@ -25,7 +25,9 @@ struct DcArgs {
     int B, H, W, Kp, tiles_x, tiles_y, relu;
 };
 
-template <int DT, int NOUT>                    // NOUT = Cout / 16
+// POOL: the 2 x 2 average pool that follows the stem's conv3 (clip/model.py:108-109) is taken from the staged 16-bit tile
+// (same values and the same fp32 average as hgr_avgpool2_nhwc on the stored tensor), so only the pooled tensor is written.
+template <int DT, int NOUT, bool POOL = false>  // NOUT = Cout / 16
 __global__ __launch_bounds__(256) void conv3x3_c32(DcArgs p) {
     typedef typename T16<DT>::vec8 vec8;
     typedef typename T16<DT>::vec4 vec4;
@@ -105,6 +107,25 @@ __global__ __launch_bounds__(256) void conv3x3_c32(DcArgs p) {
             }
             *(vec4 *)(my + (s * 16 + r) * PXB + (i * 16 + g * 4) * 2) = cvt4<DT>(v[0], v[1], v[2], v[3]);
         }
+    if (POOL) {
+        // the wave's 4 rows x 16 px -> 2 pooled rows x 8 px; chunk c of a pooled row = (pixel c / CPP, channels 8 (c % CPP) ..)
+        constexpr int CPP = PXB / 16;
+        const int Hp = p.H >> 1, Wp = p.W >> 1;
+#pragma unroll
+        for (int c0 = 0; c0 < 2 * 8 * CPP; c0 += 64) {
+            const int c = c0 + lane;
+            const int pr = c / (8 * CPP), cr = c - pr * (8 * CPP), px = cr / CPP, cc = cr - px * CPP;
+            const char *s00 = my + ((2 * pr) * 16 + 2 * px) * PXB + cc * 16;
+            const vec8 a = *(const vec8 *)s00, b2 = *(const vec8 *)(s00 + PXB);
+            const vec8 c2 = *(const vec8 *)(s00 + 16 * PXB), d = *(const vec8 *)(s00 + 17 * PXB);
+            vec8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (typename T16<DT>::elem)(((float)a[e] + (float)b2[e] + (float)c2[e] + (float)d[e]) * 0.25f);
+            const int yp = (y0 >> 1) + wave * 2 + pr, xp = (x0 >> 1) + px;
+            if (yp < Hp && xp < Wp) *(vec8 *)(p.out + (((int64_t)b * Hp + yp) * Wp + xp) * PXB + cc * 16) = o;
+        }
+        return;
+    }
     // a row's 16 pixels are 16 * PXB contiguous bytes of the NHWC output: 16-byte chunks, lane-linear
     constexpr int CPR = 16 * PXB / 16;             // chunks per output row of the tile (64 or 128)
 #pragma unroll
@@ -119,6 +140,7 @@ __global__ __launch_bounds__(256) void conv3x3_c32(DcArgs p) {
         }
     }
 }
+
 
 // ---- stem conv1: 3 x 3, stride 2, pad 1 over the fp32 NCHW image, 3 -> Cout channels (+ folded BN + ReLU) ------------------
 // clip/model.py:106 (`relu(bn1(conv1(x)))`).  As a GEMM this is K = 27: the im2col route wrote a [pixels, 64] 16-bit matrix
@@ -212,7 +234,7 @@ __global__ __launch_bounds__(256) void stem_conv1(StemArgs p) {
 
 // Called by hgr_conv3x3_nhwc / hgr_conv3x3_nhwc_plain (hgr_gemm.hip) for C = 32, stride 1, Cout in {32, 64}.
 int hgr_conv3x3_c32_launch(const void *x, const void *w, const float *bias, void *out, int B, int H, int W, int Cout, int Kp,
-                           int dtype, int relu, void *stream) {
+                           int dtype, int relu, void *stream, int pool) {
     DcArgs a;
     a.x = (const char *)x; a.w = (const char *)w; a.bias = bias; a.out = (char *)out;
     a.B = B; a.H = H; a.W = W; a.Kp = Kp; a.relu = relu;
@@ -221,6 +243,17 @@ int hgr_conv3x3_c32_launch(const void *x, const void *w, const float *bias, void
     HGR_REQUIRE(nwg < (1ll << 31), "hgr_conv3x3_nhwc: too many tiles");
     dim3 grid((unsigned)nwg);
     hipStream_t s = (hipStream_t)stream;
+    if (pool) {
+        if (Cout == 32) {
+            if (dtype == HGR_BF16) hipLaunchKernelGGL((conv3x3_c32<HGR_BF16, 2, true>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((conv3x3_c32<HGR_F16, 2, true>), grid, dim3(256), 0, s, a);
+        } else {
+            if (dtype == HGR_BF16) hipLaunchKernelGGL((conv3x3_c32<HGR_BF16, 4, true>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((conv3x3_c32<HGR_F16, 4, true>), grid, dim3(256), 0, s, a);
+        }
+        HGR_CHECK_LAUNCH("hgr_conv3x3_pool2_nhwc");
+        return HGR_OK;
+    }
     if (Cout == 32) {
         if (dtype == HGR_BF16) hipLaunchKernelGGL((conv3x3_c32<HGR_BF16, 2>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((conv3x3_c32<HGR_F16, 2>), grid, dim3(256), 0, s, a);
@@ -257,4 +290,15 @@ extern "C" int hgr_stem_conv1(const float *image, const void *w, const float *bi
     }
     HGR_CHECK_LAUNCH("hgr_stem_conv1");
     return HGR_OK;
+}
+
+// relu(conv3x3(x) + bias) followed by the 2 x 2 average pool, one kernel; x NHWC [B, H, W, 32] (H, W even), out NHWC
+// [B, H/2, W/2, Cout], Cout in {32, 64}: the end of the ModifiedResNet stem (clip/model.py:108-109).
+extern "C" int hgr_conv3x3_pool2_nhwc(const void *x, const void *w, const float *bias, void *out, int B, int H, int W, int C, int Cout,
+                                      int Kp, int dtype, void *stream) {
+    HGR_REQUIRE(x && w && bias && out && B >= 1 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0, "hgr_conv3x3_pool2_nhwc: bad geometry B=%d H=%d W=%d", B, H, W);
+    HGR_REQUIRE(C == 32 && (Cout == 32 || Cout == 64) && Kp >= 288 && Kp % 8 == 0, "hgr_conv3x3_pool2_nhwc: built for C = 32, Cout in {32, 64} (got C=%d Cout=%d Kp=%d)", C, Cout, Kp);
+    HGR_REQUIRE(hgr_aligned(x, 16) && hgr_aligned(w, 16) && hgr_aligned(out, 16) && hgr_aligned(bias, 16), "hgr_conv3x3_pool2_nhwc: misaligned operand");
+    HGR_REQUIRE(dtype == HGR_BF16 || dtype == HGR_F16, "hgr_conv3x3_pool2_nhwc: bad dtype %d", dtype);
+    return hgr_conv3x3_c32_launch(x, w, bias, out, B, H, W, Cout, Kp, dtype, 1, stream, 1);
 }

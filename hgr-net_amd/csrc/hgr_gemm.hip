@@ -23,7 +23,7 @@
 #include <type_traits>
 
 int hgr_conv3x3_c32_launch(const void *x, const void *w, const float *bias, void *out, int B, int H, int W, int Cout, int Kp,
-                           int dtype, int relu, void *stream);      // hgr_conv_direct.hip
+                           int dtype, int relu, void *stream, int pool);      // hgr_conv_direct.hip
 
 namespace {
 
@@ -921,7 +921,7 @@ static int conv3x3_launch(const void *x, const void *w, const float *bias, void 
     static int direct_env = -1;
     if (direct_env < 0) { const char *e = getenv("HGR_CONV_DIRECT"); direct_env = e ? atoi(e) : 1; }
     if (direct_env && C == 32 && stride == 1 && (Cout == 32 || Cout == 64) && Kp >= 288 && hgr_aligned(out, 16))
-        return hgr_conv3x3_c32_launch(x, w, bias, out, B, H, W, Cout, Kp, dtype, relu ? 1 : 0, stream);
+        return hgr_conv3x3_c32_launch(x, w, bias, out, B, H, W, Cout, Kp, dtype, relu ? 1 : 0, stream, 0);
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     const int64_t M64 = (int64_t)B * Ho * Wo;
     HGR_REQUIRE(M64 < (1ll << 31), "hgr_conv3x3_nhwc: too many output pixels");

@@ -268,6 +268,13 @@ def conv3x3_nhwc(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out: torc
     return out
 
 
+def conv3x3_pool2_nhwc(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out: torch.Tensor, b: int, h: int, wd: int, c: int) -> torch.Tensor:
+    """out NHWC [b, h/2, wd/2, Cout] = avgpool2(relu(conv3x3(x NHWC, pad 1) + bias)); C = 32 only (the stem)."""
+    assert x.is_contiguous() and w.is_contiguous() and out.is_contiguous() and x.dtype == w.dtype == out.dtype
+    _lib.call("hgr_conv3x3_pool2_nhwc", _dev(x), _dev(w), _dev(bias), _dev(out), b, h, wd, c, w.shape[0], w.shape[1], DT_OF[x.dtype], _stream())
+    return out
+
+
 def stem_conv1(image: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
     """out NHWC [B*Ho*Ho, Cout] = relu(conv3x3 stride 2 pad 1 (image fp32 NCHW) + bias); w [Cout, Kp] folded, (ky, kx, c) order."""
     assert image.dtype == torch.float32 and image.is_contiguous() and image.shape[1] == 3 and image.shape[2] == image.shape[3]

@@ -221,6 +221,15 @@ int hgr_conv3x3_nhwc(const void *x, const void *w, const float *bias, void *out,
                      int B, int H, int W, int C, int Cout, int stride, int Kp, int dtype, void *stream);
 
 /*
+ * relu(conv3x3(x, pad 1, stride 1) + bias) followed by AvgPool2d(2) in one kernel: the end of the ModifiedResNet stem
+ * (clip/model.py:108-109 `relu(bn3(conv3(x)))`, `avgpool(x)`).  x NHWC 16-bit [B, H, W, 32] (H, W even), w / bias as for
+ * hgr_conv3x3_nhwc, out NHWC [B, H/2, W/2, Cout], Cout in {32, 64}.  Same values as the two separate calls (the pool averages
+ * the 16-bit conv outputs in fp32); the full-resolution tensor is never written.
+ */
+int hgr_conv3x3_pool2_nhwc(const void *x, const void *w, const float *bias, void *out, int B, int H, int W, int C, int Cout,
+                           int Kp, int dtype, void *stream);
+
+/*
  * The stem's first convolution in one kernel (clip/model.py:106 `relu(bn1(conv1(x)))`, 3 x 3, stride 2, pad 1, 3 -> Cout):
  *   out NHWC 16-bit [B, Ho, Ho, Cout] = relu(conv(image fp32 [B, 3, R, R]) + bias),  Ho = (R - 1) / 2 + 1
  * w 16-bit [Cout, Kp] in (ky, kx, c) order, zero beyond column 27 (the folded layout); R a multiple of 4, Cout a multiple

@@ -284,6 +284,25 @@ def test_conv3x3_implicit_gemm_vs_conv2d(dt, b, h, w, c, cout, stride):
 
 
 @pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("b,h,w,cout", [(2, 16, 16, 64), (1, 34, 18, 64), (3, 40, 48, 32), (2, 6, 70, 64)])
+def test_conv3x3_pool2_equals_conv_then_pool(dt, b, h, w, cout):
+    """The fused stem tail must give exactly what the two kernels give (the pool averages the 16-bit conv outputs)."""
+    x = _rand((b * h * w, 32), 150).to(dt).to(DEV)
+    k = 9 * 32
+    kp = (k + 63) // 64 * 64
+    w2 = torch.zeros(cout, kp, dtype=dt)
+    w2[:, :k] = _rand((cout, k), 151, (2.0 / k) ** 0.5).to(dt)
+    bias = _rand((cout,), 152, 0.1).to(DEV)
+    full = torch.empty(b * h * w, cout, dtype=dt, device=DEV)
+    ops.conv3x3_nhwc(x, w2.to(DEV), bias, full, b, h, w, 32)
+    want = torch.empty(b * (h // 2) * (w // 2), cout, dtype=dt, device=DEV)
+    ops.avgpool2_nhwc(full, want, b, h, w, cout)
+    got = torch.full_like(want, 3.0)
+    ops.conv3x3_pool2_nhwc(x, w2.to(DEV), bias, got, b, h, w, 32)
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("b,r,cout", [(2, 64, 32), (1, 224, 32), (3, 36, 40), (2, 100, 48), (1, 288, 40), (5, 8, 32)])
 def test_stem_conv1_vs_conv2d(dt, b, r, cout):
     """3x3 / stride 2 / pad 1 from the fp32 NCHW image, bias + ReLU, NHWC out: against conv2d on the same 16-bit values."""
