@@ -933,12 +933,13 @@ static int conv3x3_launch(const void *x, const void *w, const float *bias, void 
     a.m_fastest = 0; a.vec_ok = 1; a.dbg = 0; a.kc = 0; a.csplit = 0;
     a.cH = H; a.cW = W; a.cC = C; a.cStride = stride; a.cHo = Ho; a.cWo = Wo;
     a.cMagic = (unsigned)(((1ull << 32) + (unsigned)C - 1) / (unsigned)C);
-    // big tiles when the output is at least 256 wide-ish and the launch fills >= 4 rounds of 256 workgroups (M is huge here)
+    // big tiles when the output is at least 256 wide-ish and the launch has >= 160 of them (measured at batch 512: 14x14x256
+    // 160 -> 142 us with 392 tiles, 7x7x512 160 -> 135 us with 196 tiles; K is 2304 / 4608 there, so one round is long)
     const int64_t t256 = (int64_t)((a.M + 255) / 256) * ((Cout + 255) / 256);
     // ... and 256-wide tiles do not waste more columns than 128-wide ones would (Cout = 128: half of every 256^2 tile would be
     // padding - measured 1066 vs 646 us at 56x56x128 and 285 vs 160 us at 28x28x128, batch 512)
     const int waste256 = (Cout + 255) / 256 * 256 - Cout, waste128 = (Cout + 127) / 128 * 128 - Cout;
-    const bool big = relu && hgr_gemm_force_tile() != 128 && Kp >= 128 && Cout >= 128 && t256 >= 1024 && waste256 <= waste128;
+    const bool big = relu && hgr_gemm_force_tile() != 128 && Kp >= 128 && Cout >= 128 && (t256 >= 160 || hgr_gemm_force_tile() == 256) && waste256 <= waste128;
     if (big) {
         a.tiles_m = (a.M + 255) / 256; a.tiles_n = (Cout + 255) / 256;
         dim3 grid((unsigned)(a.tiles_m * a.tiles_n));
