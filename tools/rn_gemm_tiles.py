@@ -8,7 +8,9 @@ import importlib
 importlib.import_module("hgr_net_amd")
 from hgr_net_amd import ops
 SHAPES = [(1605632, 256, 64, 5), (401408, 512, 128, 5), (100352, 1024, 256, 5), (1605632, 64, 256, 4), (1605632, 256, 64, 1),
-          (6422528, 32, 64, 4), (1605632, 128, 256, 4), (401408, 128, 512, 4), (25088, 2048, 512, 5)]
+          (6422528, 32, 64, 4), (1605632, 128, 256, 4), (401408, 128, 512, 4), (25088, 2048, 512, 5),
+          (401408, 512, 256, 1), (100352, 1024, 512, 1), (25088, 2048, 1024, 1), (401408, 256, 512, 4), (100352, 512, 1024, 4), (100352, 256, 1024, 4),
+          (25088, 512, 2048, 4), (25600, 2048, 2048, 1)]
 def timeit(fn, iters=10):
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     fn(); s.record()
