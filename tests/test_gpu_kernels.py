@@ -102,6 +102,38 @@ def test_gemm_many_tiles_exact(dt, tile, m, n, k):
         ops.gemm_set_tile(prev)
 
 
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("m,n,k", [(512, 21841, 512), (200, 5000, 128), (1000, 4099, 192), (1, 4096, 128), (300, 9000, 256), (64, 70000, 64 * 3)])
+def test_gemm_stream_few_rows_many_columns_exact(dt, m, n, k):
+    """The persistent streaming kernel hgr_gemm_nt takes for fp32, epilogue-free products with M <= 1024 and N >= 4096
+    (the class logits, clip_tree.py:331-333): small-integer operands make every sum exact, so the comparison with the fp32
+    product is equality; ragged row panels, ragged column ranges, a panel count that does not divide the XCDs, padded and
+    unpadded ldc; never writes past N; bit-identical to the tiled kernels on random data and from launch to launch."""
+    gen = torch.Generator().manual_seed(m + n + k)
+    a = torch.randint(-2, 3, (m, k), generator=gen).float()
+    w = torch.randint(-1, 2, (n, k), generator=gen).float()
+    ad, wd = a.to(dt).to(DEV), w.to(dt).to(DEV)
+    base = ad.float() @ wd.float().t()
+    for ldc in sorted({(n + 3) // 4 * 4, (n + 63) // 64 * 64 + 64}):
+        out = torch.full((m, ldc), 7.0, dtype=torch.float32, device=DEV)
+        ops.gemm_nt(ad, wd, out, n=n)
+        assert torch.equal(out[:, :n], base)
+        assert (out[:, n:] == 7.0).all()
+    ar, wr = _rand((m, k), 11).to(dt).to(DEV), _rand((n, k), 12, 0.05).to(dt).to(DEV)
+    ld = (n + 63) // 64 * 64
+    o1, o2, o3 = (torch.zeros((m, ld), dtype=torch.float32, device=DEV) for _ in range(3))
+    ops.gemm_nt(ar, wr, o1, n=n)
+    ops.gemm_nt(ar, wr, o2, n=n)
+    prev = ops.gemm_set_tile(128)                            # a pinned tile plan bypasses the streaming kernel
+    try:
+        ops.gemm_nt(ar, wr, o3, n=n)
+    finally:
+        ops.gemm_set_tile(prev)
+    assert torch.equal(o1, o2) and torch.equal(o1, o3)
+    ref = ar.float().cpu() @ wr.float().cpu().t()
+    assert torch.allclose(o1[:, :n].cpu(), ref, rtol=1e-4, atol=2e-4 * k ** 0.5)
+
+
 def test_gemm_rejects_bad_shapes():
     from hgr_net_amd._lib import HgrError
     a = torch.zeros(8, 96, dtype=torch.bfloat16, device=DEV)
