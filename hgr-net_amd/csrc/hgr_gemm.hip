@@ -24,8 +24,6 @@
 
 int hgr_conv3x3_c32_launch(const void *x, const void *w, const float *bias, void *out, int B, int H, int W, int Cout, int Kp,
                            int dtype, int relu, void *stream, int pool);      // hgr_conv_direct.hip
-int hgr_gemm_stream_launch(const void *A, int64_t lda, const void *W, int64_t ldw, float *C, int64_t ldc,
-                           int M, int N, int K, int dtype, void *stream);     // hgr_gemm_stream.hip
 
 namespace {
 
@@ -886,15 +884,6 @@ extern "C" int hgr_gemm_nt(const void *A, int64_t lda, const void *W, int64_t ld
     // all small, or full rounds of big tiles on the first row panels + the remaining panels on the small-tile kernel in a
     // second launch (pays off at long K, where a mostly empty last big round is expensive: c_proj / patch GEMM).
     const int force = hgr_gemm_force_tile();
-    // few rows x many columns, fp32 out, no epilogue (the class logits): the persistent streaming kernel (bit-identical
-    // results); HGR_GEMM_STREAM=0 or a pinned tile plan keeps the tiled kernels
-    static int stream_env = -1;
-    if (stream_env < 0) { const char *e = getenv("HGR_GEMM_STREAM"); stream_env = e ? atoi(e) : 1; }
-    if (stream_env && force == 0 && !dbg && epilogue == HGR_EPI_NONE && out_f32 &&
-        hgr_gemm_stream_launch(A, lda, W, ldw, (float *)C, ldc, M, N, K, dtype, stream)) {
-        HGR_CHECK_LAUNCH("hgr_gemm_nt (stream)");
-        return HGR_OK;
-    }
     const int tn256 = (N + 255) / 256, tm256 = (M + 255) / 256;
     const int64_t t256 = (int64_t)tm256 * tn256;
     const int64_t t128 = (int64_t)((M + 127) / 128) * ((N + 127) / 128);

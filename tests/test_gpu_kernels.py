@@ -104,11 +104,11 @@ def test_gemm_many_tiles_exact(dt, tile, m, n, k):
 
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("m,n,k", [(512, 21841, 512), (200, 5000, 128), (1000, 4099, 192), (1, 4096, 128), (300, 9000, 256), (64, 70000, 64 * 3)])
-def test_gemm_stream_few_rows_many_columns_exact(dt, m, n, k):
-    """The persistent streaming kernel hgr_gemm_nt takes for fp32, epilogue-free products with M <= 1024 and N >= 4096
-    (the class logits, clip_tree.py:331-333): small-integer operands make every sum exact, so the comparison with the fp32
-    product is equality; ragged row panels, ragged column ranges, a panel count that does not divide the XCDs, padded and
-    unpadded ldc; never writes past N; bit-identical to the tiled kernels on random data and from launch to launch."""
+def test_gemm_few_rows_many_columns_exact(dt, m, n, k):
+    """fp32, epilogue-free products with few rows and many columns (the class logits, clip_tree.py:331-333: batch x 21 841):
+    small-integer operands make every sum exact, so the comparison with the fp32 product is equality; ragged rows and
+    columns, padded and unpadded ldc; never writes past N; on random data the cost-model plan and the pinned 128-tile
+    plan agree bit for bit, and so do two launches."""
     gen = torch.Generator().manual_seed(m + n + k)
     a = torch.randint(-2, 3, (m, k), generator=gen).float()
     w = torch.randint(-1, 2, (n, k), generator=gen).float()
@@ -124,7 +124,7 @@ def test_gemm_stream_few_rows_many_columns_exact(dt, m, n, k):
     o1, o2, o3 = (torch.zeros((m, ld), dtype=torch.float32, device=DEV) for _ in range(3))
     ops.gemm_nt(ar, wr, o1, n=n)
     ops.gemm_nt(ar, wr, o2, n=n)
-    prev = ops.gemm_set_tile(128)                            # a pinned tile plan bypasses the streaming kernel
+    prev = ops.gemm_set_tile(128)
     try:
         ops.gemm_nt(ar, wr, o3, n=n)
     finally:
