@@ -38,6 +38,14 @@ __global__ __launch_bounds__(256) void mha_fwd(const typename T16<DT>::elem *__r
     const int64_t ld = 3 * (int64_t)W;
     const E *base = qkv + (int64_t)b * L * ld + h * 64;
 
+    // this wave's first query tile is requested together with K / V: one memory round trip per workgroup, not two (with
+    // L <= 64 - ViT-B/32, the attention pool, trimmed prompts - a wave has exactly one tile and the kernel is one round trip)
+    vec8 q0n, q1n;
+    {
+        const int qrow = min(wave * 16 + r, L - 1);
+        q0n = *(const vec8 *)(base + qrow * ld + g * 8);
+        q1n = *(const vec8 *)(base + qrow * ld + 32 + g * 8);
+    }
     // stage K (swizzled rows) and V^T (zero-filled past L: 0 * garbage must stay 0)
     for (int idx = tid; idx < LP * 8; idx += 256) {
         const int row = idx >> 3, c = idx & 7;
@@ -56,9 +64,12 @@ __global__ __launch_bounds__(256) void mha_fwd(const typename T16<DT>::elem *__r
     const int sw0 = ((0 + g) ^ (r & 7)) * 16, sw1 = ((4 + g) ^ (r & 7)) * 16;
     for (int qt = wave; qt * 16 < L; qt += 4) {
         const int q = qt * 16 + r;
-        const int qrow = min(q, L - 1);
-        const vec8 q0 = *(const vec8 *)(base + qrow * ld + g * 8);
-        const vec8 q1 = *(const vec8 *)(base + qrow * ld + 32 + g * 8);
+        const vec8 q0 = q0n, q1 = q1n;
+        if ((qt + 4) * 16 < L) {                   // the next tile's queries travel while this tile is computed
+            const int qrow = min(q + 64, L - 1);
+            q0n = *(const vec8 *)(base + qrow * ld + g * 8);
+            q1n = *(const vec8 *)(base + qrow * ld + 32 + g * 8);
+        }
 
         f32x4 acc[2 * KT];
 #pragma unroll
