@@ -347,6 +347,7 @@ __global__ __launch_bounds__(EV_NT) void eval_rows(const float *__restrict__ log
 
 // ---- same contract, LDS-private accumulators (n_levels <= 16) -----------------------------------------------------------
 constexpr int EL_NT = 512, EL_NW = EL_NT / 64, EL_NLV = 16;
+constexpr int EL_U = 8;                 // columns per thread per trip of the two sweeps
 
 __device__ __forceinline__ Best block_best8(Best b, float *s_v, int *s_p, int tid) {
     const Best w = wave_best(b);
@@ -384,16 +385,17 @@ __global__ __launch_bounds__(EL_NT) void eval_rows_lds(const float *__restrict__
 #pragma unroll
     for (int l = 0; l < EL_NLV; ++l) acc[l][tid] = 0ull;
     Best mine = {-INFINITY, 0x7fffffff};
-    // 4 columns per trip, every load issued before the first use (a load under a branch is waited for on the spot)
-    for (int c0 = tid; c0 < n_nodes; c0 += 4 * EL_NT) {
-        float v4[4]; int tp4[4], lv4[4], te4[4];
+    // EL_U columns per trip, every load issued before the first use (a load under a branch is waited for on the spot); the sweep is a
+    // chain of memory round trips with 2 workgroups per CU to hide them, so the trip count is what it costs: 11 trips of 4 -> 6 trips of 8
+    for (int c0 = tid; c0 < n_nodes; c0 += EL_U * EL_NT) {
+        float v4[EL_U]; int tp4[EL_U], lv4[EL_U], te4[EL_U];
 #pragma unroll
-        for (int u4 = 0; u4 < 4; ++u4) {
+        for (int u4 = 0; u4 < EL_U; ++u4) {
             const int c = min(c0 + u4 * EL_NT, n_nodes - 1);
             v4[u4] = lr[c]; tp4[u4] = train_pos[c]; lv4[u4] = lvl8[c]; te4[u4] = k > 0 ? test_pos[c] : -1;
         }
 #pragma unroll
-        for (int u4 = 0; u4 < 4; ++u4) {
+        for (int u4 = 0; u4 < EL_U; ++u4) {
             if (c0 + u4 * EL_NT >= n_nodes) break;
             const float v = v4[u4] + 0.0f;
             const int tp = tp4[u4];
@@ -465,15 +467,15 @@ __global__ __launch_bounds__(EL_NT) void eval_rows_lds(const float *__restrict__
     }
     __syncthreads();
     const float t = s_t; const int tp0 = s_tp;
-    for (int c0 = tid; c0 < n_nodes; c0 += 4 * EL_NT) {
-        float v4[4]; int te4[4];
+    for (int c0 = tid; c0 < n_nodes; c0 += EL_U * EL_NT) {
+        float v4[EL_U]; int te4[EL_U];
 #pragma unroll
-        for (int u4 = 0; u4 < 4; ++u4) {
+        for (int u4 = 0; u4 < EL_U; ++u4) {
             const int c = min(c0 + u4 * EL_NT, n_nodes - 1);
             v4[u4] = lr[c]; te4[u4] = test_pos[c];
         }
 #pragma unroll
-        for (int u4 = 0; u4 < 4; ++u4) {
+        for (int u4 = 0; u4 < EL_U; ++u4) {
             if (c0 + u4 * EL_NT >= n_nodes) break;
             const int te = te4[u4];
             const float v = v4[u4] + 0.0f;
