@@ -143,6 +143,7 @@ class _Workspace:
 
     def __init__(self):
         self._b: Dict[str, torch.Tensor] = {}
+        self.epoch = 0          # bumped whenever a buffer is (re)allocated: captured HIP graphs hold the old pointers
 
     def get(self, name: str, shape, dtype, device) -> torch.Tensor:
         n = int(np.prod(shape))
@@ -150,6 +151,7 @@ class _Workspace:
         if t is None or t.numel() < n or t.dtype != dtype or t.device != device:
             t = torch.empty(n, dtype=dtype, device=device)
             self._b[name] = t
+            self.epoch += 1
         return t[:n].view(*shape)
 
 
@@ -346,11 +348,13 @@ class CLIP(nn.Module):
         return self.visual.conv1.weight.dtype
 
     def _fingerprint(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+        """(storage, torch version counter) of every parameter + ops.WEIGHTS_GEN: the fused optimizer writes the flat
+        master buffer through a raw pointer, which moves neither data_ptr nor _version."""
+        return (ops.WEIGHTS_GEN[0],) + tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def _prepared(self) -> dict:
         """16-bit weight copies, rebuilt whenever a parameter was replaced or written in place
-        (optimizer step, load_state_dict, .to())."""
+        (load_state_dict, .to(), a torch optimizer) or a libhgr optimizer step ran (ops.WEIGHTS_GEN)."""
         fp = self._fingerprint()
         if self._prep.get("fp") != fp:
             p: dict = {"fp": fp}

@@ -2,9 +2,10 @@
 ``--train False`` zero-shot evaluation (main.py:104-222) and the OM / hierarchical training loop
 (main.py:72-101,225-267), single GPU or one process per GPU under torch.distributed.run.
 
-The ImageNet-21K group loaders of the reference (dataset/) are outside this build's scope, so batches
-come from ``--synthetic`` (hash-generated images, one class per batch like the reference's
-GroupBatchSampler) or from a user-supplied loader passed to ``run(opts, loader_train, loader_test)``.
+Batches come from the group loaders of ``hgr_net_amd.dataset`` (the reference's dataset/imagenet_group*.py
+contract: split JSON -> one single-class batch per step, device-side resize / crop / normalise), from
+``--synthetic`` (hash-generated images, one class per batch like the reference's GroupBatchSampler) or from
+a user-supplied loader passed to ``run(opts, loader_train, loader_test)``.
 """
 from __future__ import annotations
 
@@ -79,10 +80,19 @@ def build_parser() -> argparse.ArgumentParser:
     return p
 
 
-def synthetic_loader(model, class_ids, n_batches: int, batch: int, seed: int = 0, rank: int = 0, world: int = 1):
-    """Batches shaped like the reference's group loaders: {'img': [1,B,3,R,R], 'label': [1,B]}, one class each."""
-    base = synth.images(batch, model.resolution, seed + 17 * rank)
-    for i in range(rank, n_batches, world):
+def synthetic_loader(model, class_ids, n_batches: int, batch: int, seed: int = 0, rank: int = 0, world: int = 1,
+                     shard_batch: bool = False):
+    """Batches shaped like the reference's group loaders: {'img': [1,B,3,R,R], 'label': [1,B]}, one class each.
+    Evaluation deals whole batches round-robin over the ranks (batch i goes to rank i % world).  Training
+    (``shard_batch``) gives every rank ITS rows of the same single-class global batch at every step - rank r holds rows
+    [r*B, (r+1)*B) of a global batch of world*B images - so that the averaged gradient is the global batch's."""
+    if shard_batch:
+        base = synth.images(batch * world, model.resolution, seed)[rank * batch: (rank + 1) * batch]
+        steps = range(n_batches)
+    else:
+        base = synth.images(batch, model.resolution, seed + 17 * rank)
+        steps = range(rank, n_batches, world)
+    for i in steps:
         label = class_ids[(7 * i + 3) % len(class_ids)]
         yield {"img": base.roll(i, 0)[None], "label": torch.full((1, batch), label, dtype=torch.long)}
 
@@ -96,9 +106,15 @@ def train(opts, epoch, model, train_loader, num_batches, optimizer, optimizer2, 
         imgs, targets = data["img"][0].to(device), data["label"][0].to(device)
         if not opts.ref_quirks:
             optimizer.zero_grad()
+            if optimizer2 is not None:
+                optimizer2.zero_grad()                    # layer_weight.grad follows the same rule as the CLIP gradients
         loss = model.train_batch(imgs, targets, opts.training_method, opts.sample_strategy)
         if group is not None:
             optimizer.allreduce(group)                    # bucketed RCCL all-reduce on the flat gradient buffer
+            if optimizer2 is not None and model.layer_weight.grad is not None:
+                import torch.distributed as dist          # <= 13 floats: keep the ranks' layer weights identical
+                dist.all_reduce(model.layer_weight.grad, op=dist.ReduceOp.SUM, group=group)
+                model.layer_weight.grad.div_(dist.get_world_size(group))
         optimizer.step()                                  # clip_grad_norm_(params, 1.0) + AdamW, main.py:87-91
         if optimizer2 is not None:
             optimizer2.step()
@@ -136,7 +152,7 @@ def run(opts, loader_train=None, loader_test=None, group=None):
         scheduler = cosine_lr(optimizer, opts.lr, opts.warmup_length, opts.epochs * num_batches)
         for epoch in range(opts.from_epoch + 1, opts.epochs):
             ids = model.train_index.tolist()
-            loader = loader_train if opts.synthetic <= 0 else synthetic_loader(model, ids, opts.synthetic, opts.batch_size, epoch, 0, 1)
+            loader = loader_train if opts.synthetic <= 0 else synthetic_loader(model, ids, opts.synthetic, opts.batch_size, epoch, rank, world, shard_batch=True)
             train(opts, epoch, model, loader, num_batches, optimizer, optimizer2, scheduler, device, group)
             if rank == 0:
                 model.save(opts, epoch)

@@ -91,7 +91,9 @@ class tree_model(nn.Module):
             num_layer = [len(self.d2n[layer]) for layer in self.d2n.keys()]
             # a real leaf parameter (the reference multiplies after wrapping, which makes it a
             # non-parameter and breaks SGD([layer_weight]): SURVEY.md F11-ii)
-            self.layer_weight = nn.Parameter((1.0 / torch.tensor(num_layer, dtype=torch.float32)) * opts.scale)
+            # on the model's device: get_weights('adaptive') multiplies it with device-side loss terms (the reference only ever
+            # multiplies 0-dim tensors, which torch allows across devices; a [K] vector it does not)
+            self.layer_weight = nn.Parameter(((1.0 / torch.tensor(num_layer, dtype=torch.float32)) * opts.scale).to(self.device))
 
         # device arrays for the evaluation kernels
         self.train_index32 = self.train_index.to(torch.int32)
@@ -151,10 +153,16 @@ class tree_model(nn.Module):
         to 4 graphs are keyed by the input buffer's address - loaders recycle a few buffers; after 8 misses in a row the
         input is copied into one static buffer instead.  The logits are returned as a fresh tensor unless the caller passes
         ``static_output=True`` (it consumes them before the next forward: the evaluation loop does)."""
-        gen = (tuple(inputs.shape), inputs.dtype, self._zsl16.data_ptr(), self.clip_model._fingerprint())
-        if gen != self._graph_gen:
+        def generation():
+            return (tuple(inputs.shape), inputs.dtype, self._zsl16.data_ptr(), self.clip_model._ws.epoch, self.clip_model._fingerprint())
+
+        if generation() != self._graph_gen:
+            # warm-up BEFORE the key is fixed: it builds the prepared weights and may (re)allocate workspace buffers, both of
+            # which move the key; graphs captured afterwards then see a stable generation.  A direct encode_image call with
+            # a larger batch between two forwards re-allocates the workspace -> epoch moves -> stale graphs are dropped here.
             self._graphs.clear()
-            self._graph_gen, self._graph_misses, self._graph_static = gen, 0, None
+            self._forward_eager(inputs)
+            self._graph_gen, self._graph_misses, self._graph_static = generation(), 0, None
         ent = self._graphs.get(inputs.data_ptr())
         if ent is None:
             self._graph_misses += 1
@@ -190,7 +198,7 @@ class tree_model(nn.Module):
         ops.l2norm_rows(feats, y16=f16)
         ld = (n + 63) // 64 * 64                   # 16-byte aligned rows for the vector stores
         logits = torch.empty((b, ld), dtype=torch.float32, device=feats.device)
-        ops.gemm_nt(f16, self._zsl16, logits, n=n)
+        ops.gemm_nt(f16, self._zsl16, logits, n=n, tag="logits")
         return logits[:, :n]
 
     # ---------------------------------------------------------------------------------------------

@@ -11,9 +11,14 @@ from . import _lib
 from ._lib import (EPI_ACCUM, EPI_BIAS, EPI_BIAS_ADD16_RELU, EPI_BIAS_QUICKGELU, EPI_BIAS_RELU, EPI_BIAS_RESIDUAL, EPI_NONE,
                    HGR_BF16, HGR_F16)
 
-# when a list, every gemm_nt call appends (name, start_event, end_event, algorithmic flops, algorithmic bytes);
+# when a list, every gemm_nt call appends (name, start_event, end_event, algorithmic flops, algorithmic bytes, tag);
 # events are recorded on the launch stream (torch's current stream).  Used by bench.py's roofline pass only.
 PROFILE = None
+
+# bumped by every raw kernel that writes parameter storage behind torch's back (hgr_adamw): tensors written through a
+# ctypes pointer keep their data_ptr and _version, so caches keyed on those (CLIP._prepared, the HIP graphs of
+# tree_model.forward) also key on this counter.
+WEIGHTS_GEN = [0]
 
 TORCH16 = {HGR_BF16: torch.bfloat16, HGR_F16: torch.float16}
 DT_OF = {torch.bfloat16: HGR_BF16, torch.float16: HGR_F16}
@@ -39,8 +44,9 @@ def _dev(t: Optional[torch.Tensor]) -> int:
 
 
 def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias: Optional[torch.Tensor] = None,
-            residual: Optional[torch.Tensor] = None, epilogue: int = EPI_NONE, n: Optional[int] = None) -> torch.Tensor:
-    """out[M, :N] = epilogue(a[M,K] @ w[N,K]^T); `out` fp32 or the operands' 16-bit type (may be wider than N)."""
+            residual: Optional[torch.Tensor] = None, epilogue: int = EPI_NONE, n: Optional[int] = None, tag: str = "") -> torch.Tensor:
+    """out[M, :N] = epilogue(a[M,K] @ w[N,K]^T); `out` fp32 or the operands' 16-bit type (may be wider than N).
+    `tag` only labels the PROFILE record (bench.py's roofline pass)."""
     assert a.dim() == 2 and w.dim() == 2 and out.dim() == 2 and a.dtype == w.dtype and a.stride(1) == 1 and w.stride(1) == 1
     m, k = a.shape
     nn = w.shape[0] if n is None else n
@@ -59,7 +65,7 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias: Optional[
     if prof is not None:
         ev1.record()
         byts = 2 * m * k + 2 * nn * k + (4 if out32 else 2) * m * nn + (4 * m * nn if residual is not None else 0)
-        prof.append(("gemm_nt", ev0, ev1, 2.0 * m * nn * k, float(byts)))
+        prof.append(("gemm_nt", ev0, ev1, 2.0 * m * nn * k, float(byts), tag))
     return out
 
 
@@ -264,7 +270,7 @@ def conv3x3_nhwc(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out: torc
     if prof is not None:
         ev1.record()
         mo = out.shape[0]
-        prof.append(("gemm_nt", ev0, ev1, 2.0 * mo * 9 * c * w.shape[0], float(2 * x.numel() + 2 * w.numel() + 2 * out.numel())))
+        prof.append(("gemm_nt", ev0, ev1, 2.0 * mo * 9 * c * w.shape[0], float(2 * x.numel() + 2 * w.numel() + 2 * out.numel()), "conv3x3"))
     return out
 
 
@@ -552,4 +558,5 @@ def sumsq(x: torch.Tensor, out: torch.Tensor) -> None:
 def adamw(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, lr: float, step: int, betas=(0.9, 0.999), eps: float = 1e-8,
           wd: float = 0.0, sumsq_total: Optional[torch.Tensor] = None, max_norm: float = 1.0, grad_scale: float = 1.0) -> None:
     assert p.is_contiguous() and g.is_contiguous() and p.dtype == g.dtype == m.dtype == v.dtype == torch.float32
+    WEIGHTS_GEN[0] += 1
     _lib.call("hgr_adamw", _dev(p), _dev(g), _dev(m), _dev(v), p.numel(), lr, betas[0], betas[1], eps, wd, step, _dev(sumsq_total), max_norm, grad_scale, _stream())

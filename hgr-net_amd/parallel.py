@@ -11,7 +11,7 @@ shards naturally because evaluation batches are independent single-class units (
 * one all-reduce(sum) of the 9 metric counters at the end (evaluate.Evaluator.counters).
 
 The same functions run on CPU tensors over the "gloo" backend, which is how the sharding logic is
-tested without GPUs (tests/test_parallel.py).
+tested without GPUs (tests/test_abi_and_host.py::test_world_size_2_gloo_sharding; N-rank == 1-rank numerics: tests/test_gpu_multirank.py).
 """
 from __future__ import annotations
 

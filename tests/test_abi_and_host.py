@@ -221,3 +221,33 @@ def test_cosine_lr_schedule_values():
     sched(105); assert abs(opt.param_groups[0]["lr"]) < 1e-20
     sched2 = cosine_lr(opt, [1.0, 2.0], 0, 10)
     sched2(0); assert [g["lr"] for g in opt.param_groups] == [1.0, 2.0]
+
+
+def test_bench_parent_launcher_never_loads_torch(tmp_path, monkeypatch):
+    """`python bench.py --gpus N` (N > 1, no WORLD_SIZE): the parent only builds the torch.distributed.run command line and
+    relays the children's JSON line - it must not import torch (let alone touch the GPU) before or after spawning."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", ROOT / "bench.py")
+    code = (ROOT / "bench.py").read_text()
+    assert "import torch" not in code.split("def launch_ranks")[0]            # nothing heavy at module import
+    fake = tmp_path / "fake_run.py"
+    fake.write_text("import sys, json\nprint('banner noise')\nprint(json.dumps({'ok': 1, 'argv': sys.argv[1:]}))\n")
+    probe = tmp_path / "probe.py"
+    probe.write_text(
+        "import sys, subprocess, importlib.util\n"
+        f"spec = importlib.util.spec_from_file_location('b', r'{ROOT / 'bench.py'}')\n"
+        "b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)\n"
+        "real = subprocess.Popen\n"
+        "def popen(cmd, **kw):\n"
+        "    assert cmd[1:3] == ['-m', 'torch.distributed.run'] and '--nproc-per-node=2' in cmd and '127.0.0.1' in cmd, cmd\n"
+        f"    return real([sys.executable, r'{fake}'] + cmd[cmd.index(str(b.Path(b.__file__).resolve())) + 1:], **kw)\n"
+        "subprocess.Popen = popen\n"
+        "rc = b.launch_ranks(['--gpus', '2', '--steps', '3'], 2)\n"
+        "assert 'torch' not in sys.modules, 'the launcher parent imported torch'\n"
+        "sys.exit(rc)\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, str(probe)], capture_output=True, text=True, env=env, timeout=120)
+    assert p.returncode == 0, p.stderr
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["argv"] == ["--gpus", "2", "--steps", "3"]
+    assert "banner noise" in p.stderr                                          # non-JSON child output goes to stderr

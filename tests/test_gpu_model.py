@@ -306,3 +306,76 @@ def test_vit_b16_image_tower_vs_oracle():
     assert float((got - ref).abs().max()) < 2e-3 * scale
     gn, rn = got / got.norm(dim=-1, keepdim=True), ref / ref.norm(dim=-1, keepdim=True)
     assert float((gn - rn).abs().max()) < 1e-3                  # what the logits see
+
+
+@pytest.mark.parametrize("arch,nodes", [("ViT-B/32", 21841), ("RN50", 20842)])
+def test_batch512_forward_through_graph_vs_oracle_subsample(arch, nodes, tmp_path):
+    """BASELINE configs[1] / configs[2] AT THEIR SIZE through the path the headline number runs: batch 512 (256^2 / split
+    tile plans, 256^2 implicit convolutions), tree_model.forward with HIP-graph replay on - against the fp32 CPU oracle
+    (model/clip_tree.py:328-333; clip/model.py:219-236 / :135-150) on a 48-row subsample.
+      (1) both towers from the oracle on a 2 048-column subsample: |logit - oracle| < 1e-3 (north_star tolerance);
+      (2) image tower from the oracle x the model's own class matrix over ALL columns: < 1e-3, and hit@1 over the test
+          columns equal on every row whose oracle margin exceeds 2 x the measured error (count asserted and printed)."""
+    from hgr_net_amd.hierarchy import build_hierarchy
+    cfg = synth.CLIP_CONFIGS[arch]
+    sd = synth.clip_state_dict(cfg, 0)
+    edges = synth.make_dag(nodes, depth=12, seed=7, multi_parent=0.03)
+    h = build_hierarchy(edges)
+    n_test = int(round(nodes * 13442 / 20842))
+    splits = synth.make_splits(h.nodes, [len(c) == 0 for c in h.p2c], nodes - n_test, n_test, 13)
+    tokens = synth.make_tokens(nodes, 11, cfg["vocab_size"])
+    model = tree_model(_opts(tmp_path, edges), splits["all"], splits["rest"], node_tokens=tokens,
+                       clip_model=build_model(sd, image_dtype="f16", text_dtype="f16").to(DEV))
+    assert model.use_graph
+    model.update_classifier()
+    img = synth.images(512, cfg["image_resolution"], 4321)
+    dimg = img.to(DEV)
+    lg_first = model(dimg, None).clone()                 # captures (warm-up + capture + first replay)
+    assert len(model._graphs) == 1
+    lg = model(dimg, None)                               # pure replay of the captured graph
+    assert torch.equal(lg, lg_first)
+    assert torch.equal(lg, model._forward_eager(dimg))   # and the eager launches give the same bits
+    rows = torch.arange(5, 512, 11)[:48]
+    got = lg[rows.to(DEV)].cpu()
+    # (2) oracle image tower, the model's class matrix
+    ref = tree_ref.forward(sd, img[rows], model.zsl_weights.float().cpu())
+    err = float((got - ref).abs().max())
+    assert err < 1e-3, f"{arch} batch 512: max |logit - oracle| = {err:.3e}"
+    te = model.test_index.cpu()
+    top2 = ref[:, te].topk(2, dim=1)
+    decidable = (top2.values[:, 0] - top2.values[:, 1]) > 2 * err
+    same = got[:, te].argmax(1) == top2.indices[:, 0]
+    assert int(decidable.sum()) >= 24, int(decidable.sum())
+    assert bool(same[decidable].all())
+    # (1) both towers from the oracle on a column subsample
+    cols = torch.randperm(nodes, generator=torch.Generator().manual_seed(3))[:2048]
+    z_ref = tree_ref.update_classifier(sd, tokens[cols], trim=True)
+    ref_full = tree_ref.forward(sd, img[rows], z_ref)
+    err_full = float((got[:, cols] - ref_full).abs().max())
+    assert err_full < 1e-3, f"{arch} batch 512: max |logit - full oracle| = {err_full:.3e}"
+    print(f"\n[batch512 {arch}] max|logit-oracle| {err:.2e} (image oracle x HIP class matrix), {err_full:.2e} (both towers oracle, 2048 cols); "
+          f"hit@1 equal {int(same.sum())}/48, decidable {int(decidable.sum())}, equal&decidable {int((same & decidable).sum())}")
+
+
+def test_graphs_survive_a_workspace_reallocation(golden_dir, tmp_path):
+    """a direct encode_image call with a LARGER batch between two graphed forwards re-allocates the shared
+    workspace; the old graph must not be replayed on the freed buffers (workspace epoch is part of the graph key)."""
+    meta, z, cfg, edges = _tree_case("smallvit_n300", golden_dir)
+    sd = synth.clip_state_dict(cfg, 0)
+    from hgr_net_amd.hierarchy import build_hierarchy
+    h = build_hierarchy(edges)
+    splits = synth.make_splits(h.nodes, [len(c) == 0 for c in h.p2c], meta["n_train"], meta["n_test"], meta["split_seed"])
+    model = tree_model(_opts(tmp_path, edges), splits["all"], splits["rest"],
+                       node_tokens=torch.from_numpy(z["node_tokens"].astype(np.int64)), clip_model=build_model(sd).to(DEV))
+    model.update_classifier()
+    img = synth.images(8, cfg["image_resolution"], 5).to(DEV)
+    a = model(img, None).clone()
+    ep = model.clip_model._ws.epoch
+    big = synth.images(64, cfg["image_resolution"], 6).to(DEV)
+    model.clip_model.encode_image(big)                   # grows every workspace buffer
+    assert model.clip_model._ws.epoch > ep
+    junk = [torch.full((1 << 20,), 7.0, device=DEV) for _ in range(8)]   # recycle the freed blocks
+    b = model(img, None).clone()
+    del junk
+    assert torch.equal(a, b)
+    assert torch.equal(model(img, None), a)

@@ -396,3 +396,143 @@ def test_adaptive_weights_om_step_matches_reference(golden_dir, tmp_path):
     assert not bad, bad[:8]
     g, ref = model.layer_weight.grad.cpu(), torch.tensor(t["layer_weight_grad"])
     assert float(torch.dot(g, ref) / (g.norm() * ref.norm())) > 0.999 and abs(float(g.norm() / ref.norm()) - 1) < 0.03, (g, ref)
+
+
+def test_evaluation_sees_the_weights_the_optimizer_wrote(golden_dir, tmp_path):
+    """FusedAdamW updates the flat master buffer through a raw kernel, which moves neither data_ptr nor
+    torch's version counter; the cached 16-bit inference weights and the HIP graphs must still be rebuilt.  After a step,
+    encode_image / zsl_weights / forward change AND equal the oracle run on the UPDATED state_dict."""
+    from oracle import clip_ref, tree_ref
+    model, meta, cfg = _build("tinyvit_n90", golden_dir, tmp_path, "bf16")
+    t = meta["train"]
+    img = synth.images(t["bsz"], cfg["image_resolution"], t["image_seed"]).to(DEV)
+    targets = torch.full((t["bsz"],), t["target"], dtype=torch.long, device=DEV)
+    params = [p for n, p in model.named_parameters() if p.requires_grad and n != "layer_weight"]
+    opt = FusedAdamW(params, lr=2e-3, weight_decay=0.0, max_norm=1.0)     # large lr: the update must be visible in 16 bit
+    model.update_classifier()
+    f0 = model.clip_model.encode_image(img).clone()
+    z0 = model.zsl_weights.clone()
+    lg0 = model(img, None).clone()                                         # captured graph of the OLD weights
+    for _ in range(2):
+        opt.zero_grad()
+        model.train_batch(img, targets, "OM", "topk")
+        opt.step()
+    f1 = model.clip_model.encode_image(img)
+    assert float((f1 - f0).abs().max()) > 1e-3                             # stale copies would give f1 == f0
+    model.update_classifier()
+    assert float((model.zsl_weights - z0).abs().max()) > 1e-4
+    lg1 = model(img, None)
+    assert float((lg1 - lg0).abs().max()) > 1e-4
+    sd1 = {k: v.detach().float().cpu() for k, v in model.clip_model.state_dict().items()}
+    ref_f = clip_ref.encode_image(sd1, img.cpu())
+    assert float((f1.cpu() - ref_f).abs().max()) < 6e-3 * max(1.0, float(ref_f.abs().max()))
+    zr = tree_ref.update_classifier(sd1, model.node_tokens.cpu(), trim=True)
+    ref_lg = tree_ref.forward(sd1, img.cpu(), zr)
+    assert float((lg1.cpu() - ref_lg).abs().max()) < 1e-3
+
+
+def test_driver_runs_with_the_default_adaptive_weights(golden_dir, tmp_path):
+    """`--weights adaptive` is the parser's default and the reference README's setting; it must run
+    through hgr_net_amd.main with the model's OWN layer_weight (created on the model's device), move it by SGD, and zero
+    its gradient every step like the CLIP gradients."""
+    import os
+    import random
+    from hgr_net_amd import main as drv
+    meta = json.load(open(golden_dir / "tree_tinyvit_n90.json"))
+    z = np.load(golden_dir / "tree_tinyvit_n90.npz")
+    cfg, d = meta["config"], meta["dag"]
+    edges = synth.make_dag(meta["n_nodes"], d["depth"], d["seed"], d["multi_parent"])
+    h = build_hierarchy(edges)
+    splits = synth.make_splits(h.nodes, [len(c) == 0 for c in h.p2c], meta["n_train"], meta["n_test"], meta["split_seed"])
+    (tmp_path / "g.json").write_text(json.dumps(edges))
+    (tmp_path / "s.json").write_text(json.dumps(splits))
+    argv = ["--device", "0", "--folder", str(tmp_path / "run"), "--graph_path", str(tmp_path / "g.json"), "--split_path", str(tmp_path / "s.json"),
+            "--num_compare", "8", "--out_ratio", "0.5", "--epochs", "1", "--synthetic", "3", "--batch_size", "6", "--w_lr", "1e-2",
+            "--test_batch_size", "8", "--lr", "1e-5", "--print_freq", "1", "--model_train", "all"]
+    opts = drv.build_parser().parse_args(argv)
+    assert opts.weights == "adaptive"
+    opts.node_tokens = torch.from_numpy(z["node_tokens"].astype(np.int64))
+    opts.clip_model = build_model(synth.clip_state_dict(cfg, 0)).to(DEV)
+    seen = {}
+    orig = tree_model.train_batch
+
+    def spy(self, *a, **k):                                   # the gradient must be zero on entry of every step
+        g = self.layer_weight.grad
+        seen.setdefault("dev", self.layer_weight.device.type)
+        seen.setdefault("w0", self.layer_weight.detach().clone())
+        seen["entry_grad_zero"] = seen.get("entry_grad_zero", True) and (g is None or float(g.abs().sum()) == 0.0)
+        seen["model"] = self
+        return orig(self, *a, **k)
+
+    tree_model.train_batch = spy
+    random.seed(0)
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        drv.run(opts)
+    finally:
+        os.chdir(cwd)
+        tree_model.train_batch = orig
+    assert seen["dev"] == "cuda" and seen["entry_grad_zero"]
+    assert not torch.equal(seen["model"].layer_weight.detach(), seen["w0"])       # SGD moved it
+    log = (tmp_path / "run" / "HGR" / "adaptive_0.5_0.5" / "arugements.log").read_text()
+    assert log.count("loss:") == 3
+
+
+def test_vit_l14_coop_true_dimension_om_step_vs_oracle(tmp_path):
+    """BASELINE configs[4] at its TRUE dimensions: ViT-L/14 (24 x 1024-wide layers, 257 tokens, patch 14) + 12 x 768 text
+    tower + 16 learnable context vectors, one OM step at batch 16 - against fp32 autograd through the oracle
+    (oracle/train_ref.py, pinned by the reference's train_batch fixtures; model/clip_tree.py:222-281, model/CoOp.py:58-113).
+    Checked: loss, the global gradient norm, gradient norm + cosine of >= 10 tensors spread over both towers, d loss/d ctx."""
+    import random
+    import types
+    from oracle import train_ref
+    cfg = synth.CLIP_CONFIGS["ViT-L/14"]
+    sd = synth.clip_state_dict(cfg, 0)
+    n = 400
+    edges = synth.make_dag(n, depth=8, seed=5, multi_parent=0.04)
+    (tmp_path / "g.json").write_text(json.dumps(edges))
+    h = build_hierarchy(edges)
+    splits = synth.make_splits(h.nodes, [len(c) == 0 for c in h.p2c], 150, 200, 13)
+    o = types.SimpleNamespace(device=DEV, folder=str(tmp_path / "o"), exp_name="HGR", weights="equal", from_epoch=-1, graph_path=str(tmp_path / "g.json"),
+                              arch="x", fetch=False, load=False, load_path="none", scale=1.0, train_dtype="bf16", num_compare=24, k=1,
+                              sample_strategy="topk", weighting="both", out_ratio=0.25, in_ratio=0.5, n_ctx=16)
+    tokens = synth.make_tokens(n, 11, cfg["vocab_size"], n_ctx=16)
+    model = tree_model(o, splits["all"], splits["rest"], node_tokens=tokens, clip_model=build_model(sd).to(DEV))
+    ctx0 = torch.from_numpy(synth.normal(21, "ctx", 16 * cfg["transformer_width"]).astype(np.float32).reshape(16, -1)) * 0.02
+    model.ctx.data.copy_(ctx0.to(DEV))
+    target = max(model.train_index.tolist(), key=lambda i: (len(model.c2p[i]), -i))
+    b = 16
+    img = synth.images(b, 224, 77)
+    random.seed(3)
+    loss = model.train_batch(img.to(DEV), torch.full((b,), target, dtype=torch.long, device=DEV), "OM", "topk")
+    picks = model._trainer.last_contra
+    plan = model.outer_inner_plan(target)
+    assert len(plan) == len(picks) >= 2
+    weights = [float(model.get_weights("equal", st["M"])[st["m_loop"]] * model.get_weights("equal", st["K"])[st["k_loop"]]) for st in plan]
+    ref_loss, ref_g, _ = train_ref.om_step(sd, img, tokens, picks, weights, ctx=ctx0)
+    assert abs(loss - ref_loss) < 5e-3 * abs(ref_loss), (loss, ref_loss)
+    named = dict(model.clip_model.named_parameters())
+    named["ctx"] = model.ctx
+    keys = ["visual.conv1.weight", "visual.class_embedding", "visual.positional_embedding", "visual.proj", "visual.ln_pre.weight",
+            "visual.transformer.resblocks.0.attn.in_proj_weight", "visual.transformer.resblocks.0.mlp.c_fc.weight",
+            "visual.transformer.resblocks.11.attn.out_proj.weight", "visual.transformer.resblocks.11.ln_2.weight",
+            "visual.transformer.resblocks.23.mlp.c_proj.weight", "visual.transformer.resblocks.23.mlp.c_fc.bias", "visual.ln_post.weight",
+            "transformer.resblocks.0.attn.in_proj_weight", "transformer.resblocks.5.mlp.c_fc.weight", "transformer.resblocks.11.mlp.c_proj.weight",
+            "transformer.resblocks.11.attn.out_proj.bias", "ln_final.weight", "text_projection", "positional_embedding", "logit_scale", "ctx"]
+    report = []
+    for k in keys:
+        g, r = named[k].grad.detach().float().cpu().flatten(), ref_g[k].flatten()
+        rn = float(r.norm())
+        cos = float(torch.dot(g, r) / (g.norm() * r.norm() + 1e-30))
+        report.append((k, float(g.norm()) / max(rn, 1e-30), cos))
+        if k == "logit_scale":                                  # a small remainder of O(1) terms: absolute bound
+            assert abs(float(g) - float(r)) < 5e-3 + 0.05 * abs(float(r)), (float(g), float(r))
+            continue
+        assert abs(float(g.norm()) - rn) < 0.05 * rn + 1e-7, (k, float(g.norm()), rn)
+        assert cos > 0.99, (k, cos)
+    tot = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in named.values() if p.grad is not None)))
+    tot_ref = float(torch.sqrt(sum((v.double() ** 2).sum() for v in ref_g.values())))
+    assert abs(tot - tot_ref) < 0.03 * tot_ref, (tot, tot_ref)
+    print(f"\n[ViT-L/14 + 16 ctx, batch {b}] loss {loss:.5f} vs oracle {ref_loss:.5f}; total grad norm {tot:.4e} vs {tot_ref:.4e}; "
+          + "; ".join(f"{k.split('.')[-3] if k.count('.') > 2 else ''}{k.split('.')[-2] if '.' in k else ''}.{k.split('.')[-1]} n {a:.3f} cos {c:.4f}" for k, a, c in report))

@@ -156,3 +156,44 @@ def test_resample_oracle_matches_pillow_live():
         nw, nh = resample_ref.resized_size(w, h, n)
         ref = np.asarray(Image.fromarray(img).resize((nw, nh), Image.BICUBIC))
         assert np.array_equal(resample_ref.resize_bicubic(img, nw, nh), ref), (h, w, n)
+
+
+@pytest.mark.parametrize("case", ["tinyvit_n90", "tinyrn_n64"])
+def test_train_ref_matches_reference_fixture(case, golden_dir, tmp_path):
+    """oracle/train_ref.om_step (fp32 autograd over the functional towers) against what the reference's own
+    train_batch produced on the same weights / images / sampled negatives: loss, EVERY parameter's gradient norm and
+    the stored full gradients.  This pins the oracle used for the true-dimension ViT-L/14 + CoOp step on the GPU."""
+    import types
+    from hgr_net_amd.clip.model import build_model
+    from hgr_net_amd.model import tree_model
+    from oracle import train_ref
+    meta = json.load(open(golden_dir / f"tree_{case}.json"))
+    z = np.load(golden_dir / f"tree_{case}.npz")
+    gold = np.load(golden_dir / f"train_{case}.npz")
+    cfg, d, t = meta["config"], meta["dag"], meta["train"]
+    if isinstance(cfg["vision_layers"], list):
+        cfg["vision_layers"] = tuple(cfg["vision_layers"])
+    edges = synth.make_dag(meta["n_nodes"], d["depth"], d["seed"], d["multi_parent"])
+    (tmp_path / "g.json").write_text(json.dumps(edges))
+    h = build_hierarchy(edges)
+    splits = synth.make_splits(h.nodes, [len(c) == 0 for c in h.p2c], meta["n_train"], meta["n_test"], meta["split_seed"])
+    sd = synth.clip_state_dict(cfg, 0)
+    o = types.SimpleNamespace(device="cpu", folder=str(tmp_path), exp_name="HGR", weights="equal", from_epoch=-1, graph_path=str(tmp_path / "g.json"),
+                              arch="x", fetch=False, load=False, load_path="none", scale=1.0, **t["opts"])
+    tokens = torch.from_numpy(z["node_tokens"].astype(np.int64))
+    m = tree_model(o, splits["all"], splits["rest"], node_tokens=tokens, clip_model=build_model(sd))      # host logic only
+    plan = m.outer_inner_plan(t["target"])
+    weights = [float(m.get_weights("equal", st["M"])[st["m_loop"]] * m.get_weights("equal", st["K"])[st["k_loop"]]) for st in plan]
+    img = synth.images(t["bsz"], cfg["image_resolution"], t["image_seed"])
+    loss, grads, _ = train_ref.om_step(sd, img, tokens, [tuple(c) for c in t["contra"]], weights)
+    assert abs(loss - t["loss"]) < 1e-4 * abs(t["loss"]), (loss, t["loss"])
+    for k, ref in t["grad_norms"].items():
+        got = float(grads[k].norm()) if k in grads else 0.0
+        assert abs(got - ref) <= 2e-3 * ref + 1e-6, (k, got, ref)
+    n_full = 0
+    for key in gold.files:
+        if key.startswith("grad/"):
+            gref = torch.from_numpy(gold[key])
+            assert float((grads[key[5:]] - gref).abs().max()) <= 2e-3 * float(gref.abs().max()) + 1e-7, key
+            n_full += 1
+    assert n_full >= 10

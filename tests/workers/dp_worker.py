@@ -1,0 +1,98 @@
+"""Child process of tests/test_gpu_multirank.py: one rank of a data-parallel evaluation / OM training step.
+
+    python dp_worker.py <eval|train> <out.pt>          (RANK / WORLD_SIZE / MASTER_* from the environment)
+
+With HGR_TEST_ONE_GPU=1 every rank uses cuda:0 and the gloo backend (RCCL refuses two ranks on one device; the
+driver's real multi-GPU runs use RCCL).  WORLD_SIZE=1 runs the same code with no process group: the 1-rank reference
+the N-rank result is compared with (hard part H7)."""
+import json
+import os
+import random
+import sys
+import tempfile
+import types
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent.parent
+sys.path.insert(0, str(ROOT))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch
+
+from hgr_net_amd import evaluate, synth
+from hgr_net_amd.clip.model import build_model
+from hgr_net_amd.hierarchy import build_hierarchy
+from hgr_net_amd.model import tree_model
+from hgr_net_amd.parallel import batches_of_rank
+
+mode, out_path = sys.argv[1], sys.argv[2]
+rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+one_gpu = os.environ.get("HGR_TEST_ONE_GPU") == "1"
+local = 0 if one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
+torch.cuda.set_device(local)
+dev = f"cuda:{local}"
+group = None
+if world > 1:
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo" if one_gpu else "nccl")
+    group = dist.group.WORLD
+
+cfg = synth.CLIP_CONFIGS["small-vit"]
+sd = synth.clip_state_dict(cfg, 0)
+n = 301                                                   # odd: uneven text shards under world 2
+edges = synth.make_dag(n, depth=8, seed=7, multi_parent=0.05)
+h = build_hierarchy(edges)
+splits = synth.make_splits(h.nodes, [len(c) == 0 for c in h.p2c], 100, 150, 13)
+tokens = synth.make_tokens(n, 11, cfg["vocab_size"])
+tmp = tempfile.mkdtemp(prefix="hgr_dp_")
+gp = os.path.join(tmp, "g.json")
+json.dump(edges, open(gp, "w"))
+opts = types.SimpleNamespace(device=dev, folder=tmp, exp_name="HGR", weights="equal", out_ratio=0.5, in_ratio=0.5, from_epoch=-1,
+                             graph_path=gp, arch="synthetic", fetch=False, load=False, load_path="none", scale=1.0, num_compare=12, k=1,
+                             sample_strategy="topk", weighting="both", train_dtype="bf16")
+model = tree_model(opts, splits["all"], splits["rest"], node_tokens=tokens, clip_model=build_model(sd).to(dev))
+res = cfg["image_resolution"]
+
+if mode == "eval":
+    # main.test's loop (main.py:131-191) over 7 single-class batches dealt round-robin over the ranks
+    model.update_classifier(group=group)
+    ev = evaluate.Evaluator(model)
+    te = model.test_index.tolist()
+    n_batches, bsz = 7, 16
+    for i in batches_of_rank(n_batches, world, rank):
+        img = synth.images(bsz, res, 500 + i).to(dev)
+        target = te[(7 * i + 3) % len(te)]
+        logits = model(img, None, static_output=True)
+        ev.add_batch(logits, target, torch.full((bsz,), target, dtype=torch.long, device=dev), want_outputs=False)
+    counters = ev.counters(group)
+    summary = ev.summary(group)
+    if rank == 0:
+        torch.save({"counters": counters, "summary": summary, "zsl": model.zsl_weights.cpu()}, out_path)
+else:
+    # one OM step on ONE single-class global batch sharded over the ranks with identical sampling seeds (H7)
+    from hgr_net_amd.training import FusedAdamW
+    gb = 8
+    img = synth.images(gb, res, 77)
+    lo, hi = rank * gb // world, (rank + 1) * gb // world
+    target = max(model.train_index.tolist(), key=lambda i: (len(model.c2p[i]), -i))
+    params = [p for nm, p in model.named_parameters() if p.requires_grad and nm != "layer_weight"]
+    names = [nm for nm, p in model.named_parameters() if p.requires_grad and nm != "layer_weight"]
+    opt = FusedAdamW(params, lr=1e-6, max_norm=1.0)
+    opt.zero_grad()
+    random.seed(5)
+    loss = model.train_batch(img[lo:hi].to(dev), torch.full((hi - lo,), target, dtype=torch.long, device=dev), "OM", "topk")
+    loss_t = torch.tensor([loss], dtype=torch.float64, device=dev)
+    if group is not None:
+        import torch.distributed as dist
+        opt.allreduce(group)
+        dist.all_reduce(loss_t)
+        loss_t /= world
+    torch.cuda.synchronize()
+    if rank == 0:
+        grads = {nm: (p.grad.detach() * opt.grad_scale).cpu() for nm, p in zip(names, params)}
+        torch.save({"loss": float(loss_t.item()), "grads": grads, "contra": model._trainer.last_contra}, out_path)
+if group is not None:
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()

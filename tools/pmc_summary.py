@@ -4,43 +4,62 @@ traffic per launch from the FETCH_SIZE / WRITE_SIZE PMC passes (collected in sep
 on gfx950 FETCH_SIZE reports half the bytes of a wide coalesced read stream - MI355X_MICROARCH.md "HBM" - so it is
 doubled; the LayerNorm row calibrates that correction: 4 B read + 2 B written per element).
 
+The summary records `kernel_source_hash` (sha256 over hgr-net_amd/csrc/*): bench.py quotes a summary's traffic only
+when that hash equals the sources of the library it is running, so a stale profile can never be quoted silently.
+
 usage: pmc_summary.py <tag> <stats_csv> <fetch_counter_csv> <write_counter_csv>
 """
-import collections, csv, json, sys
+import collections, csv, hashlib, json, sys
 from pathlib import Path
 
-tag, stats, fetch, write = sys.argv[1:5]
 ROOT = Path(__file__).resolve().parent.parent
 
-def short(n):
-    n = n.replace("void ", "").replace("(anonymous namespace)::", "")
-    return n.split("(")[0]
 
-def counters(path):
-    d = collections.defaultdict(list)
-    for r in csv.DictReader(open(path)):
-        d[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
-    return d
+def kernel_source_hash() -> str:
+    h = hashlib.sha256()
+    for f in sorted((ROOT / "hgr-net_amd" / "csrc").glob("*")):
+        if f.suffix in (".hip", ".h") or f.name == "Makefile":
+            h.update(f.name.encode())
+            h.update(f.read_bytes())
+    return h.hexdigest()[:16]
 
-f, w = counters(fetch), counters(write)
-rows = []
-for r in csv.DictReader(open(stats)):
-    k = short(r["Name"])
-    if not k.startswith(("gemm_nt", "layernorm", "mha_fwd", "im2col", "topk", "level_argmax", "eval_rows", "vit_embed", "l2norm", "text_embed")):
-        continue
-    fv, wv = f.get(k, []), w.get(k, [])
-    fetch_b = 2 * 1024 * sum(fv) / len(fv) if fv else None
-    write_b = 1024 * sum(wv) / len(wv) if wv else None
-    rows.append(dict(kernel=k, calls=int(r["Calls"]), avg_us=round(float(r["AverageNs"]) / 1e3, 1), pct=float(r["Percentage"]),
-                     hbm_read_bytes_per_launch=round(fetch_b) if fetch_b else None,
-                     hbm_write_bytes_per_launch=round(write_b) if write_b else None))
-gem = [r for r in rows if r["kernel"].startswith("gemm_nt") and r["avg_us"] > 60 and r["hbm_read_bytes_per_launch"]]
-tot_calls = sum(r["calls"] for r in gem)
-out = dict(tag=tag, note="FETCH_SIZE doubled (gfx950 correction), WRITE_SIZE as is; KiB -> bytes; averages per launch",
-           kernels=rows,
-           tower_gemm=dict(avg_us=round(sum(r["avg_us"] * r["calls"] for r in gem) / tot_calls, 1),
-                           hbm_bytes_per_launch=round(sum((r["hbm_read_bytes_per_launch"] + r["hbm_write_bytes_per_launch"]) * r["calls"] for r in gem) / tot_calls)))
-json.dump(out, open(ROOT / "profiles" / f"{tag}_pmc_summary.json", "w"), indent=1)
-print(json.dumps(out["tower_gemm"]))
-for r in rows[:10]:
-    print(r)
+
+def main():
+    tag, stats, fetch, write = sys.argv[1:5]
+
+    def short(n):
+        n = n.replace("void ", "").replace("(anonymous namespace)::", "")
+        return n.split("(")[0]
+
+    def counters(path):
+        d = collections.defaultdict(list)
+        for r in csv.DictReader(open(path)):
+            d[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+        return d
+
+    f, w = counters(fetch), counters(write)
+    rows = []
+    for r in csv.DictReader(open(stats)):
+        k = short(r["Name"])
+        if not k.startswith(("gemm_nt", "layernorm", "mha_fwd", "im2col", "topk", "level_argmax", "eval_rows", "vit_embed", "l2norm", "text_embed")):
+            continue
+        fv, wv = f.get(k, []), w.get(k, [])
+        fetch_b = 2 * 1024 * sum(fv) / len(fv) if fv else None
+        write_b = 1024 * sum(wv) / len(wv) if wv else None
+        rows.append(dict(kernel=k, calls=int(r["Calls"]), avg_us=round(float(r["AverageNs"]) / 1e3, 1), pct=float(r["Percentage"]),
+                         hbm_read_bytes_per_launch=round(fetch_b) if fetch_b else None,
+                         hbm_write_bytes_per_launch=round(write_b) if write_b else None))
+    gem = [r for r in rows if r["kernel"].startswith("gemm_nt") and r["avg_us"] > 60 and r["hbm_read_bytes_per_launch"]]
+    tot_calls = sum(r["calls"] for r in gem)
+    out = dict(tag=tag, kernel_source_hash=kernel_source_hash(), note="FETCH_SIZE doubled (gfx950 correction), WRITE_SIZE as is; KiB -> bytes; averages per launch",
+               kernels=rows,
+               tower_gemm=dict(avg_us=round(sum(r["avg_us"] * r["calls"] for r in gem) / tot_calls, 1),
+                               hbm_bytes_per_launch=round(sum((r["hbm_read_bytes_per_launch"] + r["hbm_write_bytes_per_launch"]) * r["calls"] for r in gem) / tot_calls)))
+    json.dump(out, open(ROOT / "profiles" / f"{tag}_pmc_summary.json", "w"), indent=1)
+    print(json.dumps(out["tower_gemm"]))
+    for r in rows[:10]:
+        print(r)
+
+
+if __name__ == "__main__":
+    main()
