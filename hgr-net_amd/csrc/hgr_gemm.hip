@@ -773,6 +773,300 @@ __global__ __launch_bounds__(NT256) void gemm_nt_256(GemmArgs p) {
     }
 }
 
+
+// =================================================================================================
+// gemm_nt_duo: 256 (M) x 128 (N) x 64 tile, 256 threads = 4 waves as 2 (M) x 2 (N); a wave owns 128 x 64, the register
+// tile of gemm_nt_256 (128 accumulators, 4 quadrant phases per K-tile).  TWO workgroups share a CU: 80 KB of LDS and
+// <= 256 registers per wave each, one wave of each workgroup per SIMD.
+//
+// Why: at one workgroup per CU nothing overlaps a tile's prologue (first operand pieces) and epilogue (bias / fp32
+// residual loads, stores): ~14 us of a ~35 us tile at K = 768, and a whole round of 256 tiles stores (and, for the
+// residual epilogue, re-reads) its 33 - 67 MB in one burst.  A wave's stores and its LDS-DMA loads share one in-order
+// vmcnt, so a single persistent workgroup cannot hide them either (finding 3).  Two independent
+// workgroups per CU can: while one is in its epilogue or waits for operands, the other one's waves own the matrix
+// pipes of the same SIMDs.  No ping-pong groups inside a workgroup, so ONE barrier per phase (4 per K-tile).
+//
+// LDS: A0 (m-half-0 rows of both wave rows, 16 KB) and A1 (m-half 1) double-buffered, W0 / W1 (n-half 0 / 1 rows of both
+// wave columns, 8 KB each) single-buffered: 2 x 32 + 16 = 80 KB.  A piece's slot is refilled in the phase after the
+// barrier that follows its last read:
+//     ph1 reads W0(t), A0(t)   issues A1(t+1) x4           waits vmcnt(8)  : W1(t) landed
+//     ph2 reads W1(t)          issues W0(t+1) x2           waits vmcnt(14) : A1(t) landed
+//     ph3 reads A1(t)          issues W1(t+1) x2, A0(t+2) first half x2    (ph4 reads nothing new)
+//     ph4                      issues A0(t+2) second half x2   waits vmcnt(6) : W0(t+1), A0(t+1) landed
+// (xN = global_load_lds_dwordx4 instructions per thread; the counts are "my N youngest may still be in flight").
+// The activations are prefetched 5 - 7 phases ahead, the weights (L2 / MALL resident panels shared by every row panel)
+// 3 phases ahead; if a piece is late the partner workgroup's MFMAs fill the gap.
+// =================================================================================================
+constexpr int NTD = 256;
+constexpr int DUO_A0 = 0, DUO_A1 = 32768, DUO_W0 = 65536, DUO_W1 = 73728, DUO_LDS = 81920;
+
+template <int DT, int EPI, bool OUT32>
+__global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
+    typedef typename T16<DT>::vec8 vec8;
+    typedef typename T16<DT>::elem E;
+    if (p.kc) {                                   // split-K (see gemm_nt_128)
+        const int sp = blockIdx.y;
+        p.A += (int64_t)sp * p.kc * 2; p.W += (int64_t)sp * p.kc * 2;
+        p.C = (char *)p.C + (int64_t)sp * p.csplit * 4;
+        p.K = min(p.kc, p.K - sp * p.kc);
+    }
+    __shared__ __attribute__((aligned(1024))) char smem[DUO_LDS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 15, g = lane >> 4;
+
+    const int nwg = gridDim.x;
+    const int orig = blockIdx.x;
+    const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    constexpr int GROUP = 4;      // 64 tiles in flight per XCD = 4 row panels of 256 x 16 column panels of 128
+    int tm, tn;
+    if (p.m_fastest) {
+        const int per = GROUP * p.tiles_m, grp = wg / per, first = grp * GROUP;
+        const int gs = min(GROUP, p.tiles_n - first), loc = wg - grp * per;
+        tn = first + loc % gs; tm = loc / gs;
+    } else {
+        const int per = GROUP * p.tiles_n, grp = wg / per, first = grp * GROUP;
+        const int gs = min(GROUP, p.tiles_m - first), loc = wg - grp * per;
+        tm = first + loc % gs; tn = loc / gs;
+    }
+    const int m0 = tm * 256, n0 = tn * 128;
+
+    // per-lane source offsets (bytes from A / W; operands are < 4 GB, checked on the host) of the LDS-DMA instructions of
+    // one K-tile: 4 per A piece (32 piece rows each), 2 per W piece.  Piece row pr of A0 = tile row (pr / 64) * 128 + pr % 64,
+    // of W0 = tile row (pr / 32) * 64 + pr % 32; A1 / W1 = the same rows + 64 / + 32.  Source chunk ^= row & 7 (rule 21).
+    unsigned oA0[4], oA1[4], oW0[2], oW1[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int id = (i * 4 + wave) * 64 + lane;
+        const int pr = id >> 3, c = (id & 7) ^ (pr & 7);
+        const int ra = (pr >> 6) * 128 + (pr & 63);
+        oA0[i] = (unsigned)(((int64_t)min(m0 + ra, p.M - 1) * p.lda + c * 8) * 2);
+        oA1[i] = (unsigned)(((int64_t)min(m0 + ra + 64, p.M - 1) * p.lda + c * 8) * 2);
+        if (i < 2) {
+            const int rw = (pr >> 5) * 64 + (pr & 31);
+            oW0[i] = (unsigned)(((int64_t)min(n0 + rw, p.N - 1) * p.ldw + c * 8) * 2);
+            oW1[i] = (unsigned)(((int64_t)min(n0 + rw + 32, p.N - 1) * p.ldw + c * 8) * 2);
+        }
+    }
+    char *const ldsw = smem + wave * 1024;
+    // halves of an A piece: instructions [2h, 2h + 2)
+    auto issueA = [&](const unsigned (&off)[4], int slot_base, int t, int h) {
+        const char *base = p.A + (int64_t)t * 128;
+        char *dst = ldsw + slot_base + (t & 1) * 16384;
+#pragma unroll
+        for (int i = 2 * h; i < 2 * h + 2; ++i)
+            __builtin_amdgcn_global_load_lds((const AS1 void *)(base + off[i]), (AS3 void *)(dst + i * 4096), 16, 0, 0);
+    };
+    auto issueW = [&](const unsigned (&off)[2], int slot_base, int t) {
+        const char *base = p.W + (int64_t)t * 128;
+        char *dst = ldsw + slot_base;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((const AS1 void *)(base + off[i]), (AS3 void *)(dst + i * 4096), 16, 0, 0);
+    };
+
+    f32x4 acc[2][2][4][2];      // [m-half][n-half][m tile][n tile]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[a][b][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / 64;    // >= 2 (host guarantees)
+    // prologue in steady-state order: A0(0), A1(0), W0(0), W1(0), A0(1)
+    issueA(oA0, DUO_A0, 0, 0); issueA(oA0, DUO_A0, 0, 1);
+    issueA(oA1, DUO_A1, 0, 0); issueA(oA1, DUO_A1, 0, 1);
+    issueW(oW0, DUO_W0, 0); issueW(oW1, DUO_W1, 0);
+    issueA(oA0, DUO_A0, 1, 0); issueA(oA0, DUO_A0, 1, 1);
+    HGR_RWAIT(6);               // A0(0), W0(0) landed
+
+    const int offA = (wm * 64 + r) * 128;      // + m tile * 2048, within pieces A0 / A1
+    const int offW = (wn * 32 + r) * 128;      // + n tile * 2048, within pieces W0 / W1
+    const int sw0 = ((0 + g) ^ (r & 7)) * 16, sw1 = ((4 + g) ^ (r & 7)) * 16;
+    vec8 af[4][2], wf0[2][2], wf1[2][2];
+
+    // MODE 0: steady state (t + 2 < nk), 1: second-last K-tile, 2: last K-tile
+    auto ktile = [&](int t, auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        const char *bufA0 = smem + DUO_A0 + (t & 1) * 16384, *bufA1 = smem + DUO_A1 + (t & 1) * 16384;
+        // ---- ph1: Q(0,0) ----
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            wf0[j][0] = *(const vec8 *)(smem + DUO_W0 + offW + j * 2048 + sw0);
+            wf0[j][1] = *(const vec8 *)(smem + DUO_W0 + offW + j * 2048 + sw1);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            af[i][0] = *(const vec8 *)(bufA0 + offA + i * 2048 + sw0);
+            af[i][1] = *(const vec8 *)(bufA0 + offA + i * 2048 + sw1);
+        }
+        if (MODE <= 1) { issueA(oA1, DUO_A1, t + 1, 0); issueA(oA1, DUO_A1, t + 1, 1); }
+        if (MODE <= 1) HGR_RWAIT(8); else HGR_RWAIT(0);                 // W1(t) landed
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[0][0][i][j] = T16<DT>::mfma16(wf0[j][kk], af[i][kk], acc[0][0][i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        // ---- ph2: Q(0,1) ----
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            wf1[j][0] = *(const vec8 *)(smem + DUO_W1 + offW + j * 2048 + sw0);
+            wf1[j][1] = *(const vec8 *)(smem + DUO_W1 + offW + j * 2048 + sw1);
+        }
+        if (MODE <= 1) issueW(oW0, DUO_W0, t + 1);
+        if (MODE <= 1) HGR_RWAIT(14); else HGR_RBAR();                  // A1(t) landed
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[0][1][i][j] = T16<DT>::mfma16(wf1[j][kk], af[i][kk], acc[0][1][i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        // ---- ph3: Q(1,1) ----
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            af[i][0] = *(const vec8 *)(bufA1 + offA + i * 2048 + sw0);
+            af[i][1] = *(const vec8 *)(bufA1 + offA + i * 2048 + sw1);
+        }
+        if (MODE <= 1) issueW(oW1, DUO_W1, t + 1);
+        if (MODE == 0) issueA(oA0, DUO_A0, t + 2, 0);
+        HGR_RBAR();                                                     // ph4 reads nothing new
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[1][1][i][j] = T16<DT>::mfma16(wf1[j][kk], af[i][kk], acc[1][1][i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        // ---- ph4: Q(1,0) ----
+        if (MODE == 0) issueA(oA0, DUO_A0, t + 2, 1);
+        if (MODE == 0) HGR_RWAIT(6); else if (MODE == 1) HGR_RWAIT(2);  // W0(t+1), A0(t+1) landed
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[1][0][i][j] = T16<DT>::mfma16(wf0[j][kk], af[i][kk], acc[1][0][i][j]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    for (int t = 0; t < nk - 2; ++t) ktile(t, std::integral_constant<int, 0>());
+    ktile(nk - 2, std::integral_constant<int, 1>());
+    ktile(nk - 1, std::integral_constant<int, 2>());
+    HGR_MBAR();                 // every wave's LDS reads are done, no DMA in flight: the staging area is free
+
+    // tile (a, b, i, j) of this lane holds C[m][n .. n+3],  m = m0 + wm*128 + a*64 + i*16 + r,  n = n0 + wn*64 + b*32 + j*16 + g*4
+    constexpr bool HAS_BIAS = EPI != HGR_EPI_NONE && EPI != HGR_EPI_ACCUM;
+    constexpr bool HAS_ADD = EPI == HGR_EPI_BIAS_RESIDUAL || EPI == HGR_EPI_ACCUM;
+    const bool full = p.vec_ok && m0 + 256 <= p.M && n0 + 128 <= p.N;
+    if (full && !OUT32 && (p.ldc & 7) == 0 && (EPI <= HGR_EPI_BIAS_QUICKGELU || EPI == HGR_EPI_BIAS_RELU)) {
+        // 16-bit output: the wave's 128 x 64 tile through its private LDS slice (rows of 128 B + 16 B pad), then full
+        // 128-byte lines with 16-byte stores (8 lanes per row, 8 rows per instruction)
+        constexpr int RS = 144;
+        char *my = smem + wave * (128 * RS);
+        f32x4 bq[2][2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                bq[b][j] = HAS_BIAS ? *(const f32x4 *)(p.bias + n0 + wn * 64 + b * 32 + j * 16 + g * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f32x4 v = acc[a][b][i][j] + bq[b][j];
+            if (EPI == HGR_EPI_BIAS_QUICKGELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
+            }
+            if (EPI == HGR_EPI_BIAS_RELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            *(typename T16<DT>::vec4 *)(my + (a * 64 + i * 16 + r) * RS + (b * 32 + j * 16 + g * 4) * 2) = cvt4<DT>(v[0], v[1], v[2], v[3]);
+        }
+        const int ch = lane & 7, rr = lane >> 3;
+        E *dst0 = (E *)p.C + (int64_t)(m0 + wm * 128 + rr) * p.ldc + n0 + wn * 64 + ch * 8;
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            *(u32x4 *)(dst0 + (int64_t)q * 8 * p.ldc) = *(const u32x4 *)(my + (q * 8 + rr) * RS + ch * 16);
+        return;
+    }
+    if (full && OUT32 && (EPI == HGR_EPI_NONE || EPI == HGR_EPI_BIAS || HAS_ADD) && (p.ldc & 3) == 0 && (!HAS_ADD || EPI == HGR_EPI_ACCUM || (p.ldr & 3) == 0)) {
+        // fp32 output (+ fp32 residual / old C): 4 passes of 32 rows through the wave's private LDS slice (rows of 256 B +
+        // 16 B pad); every global access is then 16 bytes per lane over whole 256-byte row segments (2 full lines per row,
+        // 4 rows per instruction) instead of 64-byte fragments of 16 rows.  The pass's 8 addend loads are issued before its
+        // LDS round trip; residual and C may alias: a pass loads before it stores, and passes touch disjoint rows.
+        constexpr int RS = 272;
+        char *my = smem + wave * (32 * RS);
+        f32x4 bq[2][2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                bq[b][j] = HAS_BIAS ? *(const f32x4 *)(p.bias + n0 + wn * 64 + b * 32 + j * 16 + g * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int rq = lane >> 4, cq = lane & 15;           // row-in-group and 16-byte column chunk of this lane on the way out
+        const float *addp = EPI == HGR_EPI_ACCUM ? (const float *)p.C : p.res;
+        const int64_t ldadd = EPI == HGR_EPI_ACCUM ? p.ldc : p.ldr;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int ih = 0; ih < 2; ++ih) {
+            const int row0 = m0 + wm * 128 + a * 64 + ih * 32;
+            f32x4 ad[8];
+            if (HAS_ADD) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) ad[q] = *(const f32x4 *)(addp + (int64_t)(row0 + q * 4 + rq) * ldadd + n0 + wn * 64 + cq * 4);
+            }
+#pragma unroll
+            for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                *(f32x4 *)(my + (i2 * 16 + r) * RS + (b * 32 + j * 16 + g * 4) * 4) = acc[a][b][ih * 2 + i2][j] + bq[b][j];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                f32x4 v = *(const f32x4 *)(my + (q * 4 + rq) * RS + cq * 16);
+                if (HAS_ADD) v += ad[q];
+                *(f32x4 *)((float *)p.C + (int64_t)(row0 + q * 4 + rq) * p.ldc + n0 + wn * 64 + cq * 4) = v;
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 128 + a * 64 + i * 16 + r;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + b * 32 + j * 16 + g * 4;
+            if (n < p.N) store_quad<DT, EPI, OUT32>(p, acc[a][b][i][j], m, n);
+        }
+    }
+}
+
 template <int DT, int EPI>
 void launch_epi(const GemmArgs &a, bool out32, dim3 grid, hipStream_t s, bool big) {
     if constexpr (EPI == HGR_EPI_BIAS || EPI == HGR_EPI_BIAS_RELU || EPI == HGR_EPI_BIAS_ADD16_RELU) {
@@ -803,7 +1097,22 @@ void launch_dt(const GemmArgs &a, int epi, bool out32, dim3 grid, hipStream_t s,
     }
 }
 
-// tile plan override (hgr_gemm_set_tile); HGR_GEMM_TILE=128|256 sets the initial value
+template <int DT>
+void launch_duo(const GemmArgs &a, int epi, bool out32, dim3 grid, hipStream_t s) {
+#define HGR_DUO(E) do { if (out32) hipLaunchKernelGGL((gemm_nt_duo<DT, E, true>), grid, dim3(NTD), 0, s, a); \
+                        else hipLaunchKernelGGL((gemm_nt_duo<DT, E, false>), grid, dim3(NTD), 0, s, a); } while (0)
+    switch (epi) {
+        case HGR_EPI_NONE: HGR_DUO(HGR_EPI_NONE); break;
+        case HGR_EPI_BIAS: HGR_DUO(HGR_EPI_BIAS); break;
+        case HGR_EPI_BIAS_QUICKGELU: HGR_DUO(HGR_EPI_BIAS_QUICKGELU); break;
+        case HGR_EPI_BIAS_RELU: HGR_DUO(HGR_EPI_BIAS_RELU); break;
+        case HGR_EPI_ACCUM: hipLaunchKernelGGL((gemm_nt_duo<DT, HGR_EPI_ACCUM, true>), grid, dim3(NTD), 0, s, a); break;
+        default: hipLaunchKernelGGL((gemm_nt_duo<DT, HGR_EPI_BIAS_RESIDUAL, true>), grid, dim3(NTD), 0, s, a); break;
+    }
+#undef HGR_DUO
+}
+
+// tile plan override (hgr_gemm_set_tile); HGR_GEMM_TILE=128|256|2 sets the initial value
 int g_force_tile = -1;
 int hgr_gemm_force_tile() {
     if (g_force_tile < 0) { const char *e = getenv("HGR_GEMM_TILE"); g_force_tile = e ? atoi(e) : 0; }
@@ -813,7 +1122,7 @@ int hgr_gemm_force_tile() {
 }  // namespace
 
 extern "C" int hgr_gemm_set_tile(int tile) {
-    HGR_REQUIRE(tile == 0 || tile == 128 || tile == 256, "hgr_gemm_set_tile: tile must be 0, 128 or 256, got %d", tile);
+    HGR_REQUIRE(tile == 0 || tile == 128 || tile == 256 || tile == 2, "hgr_gemm_set_tile: tile must be 0, 128, 256 or 2 (256 x 128 tiles, two workgroups per CU), got %d", tile);
     const int prev = hgr_gemm_force_tile();
     g_force_tile = tile;
     return prev;
@@ -900,7 +1209,22 @@ extern "C" int hgr_gemm_nt(const void *A, int64_t lda, const void *W, int64_t ld
         const int64_t ts = (int64_t)((M - m1 + 127) / 128) * ((N + 127) / 128);
         cost_split = (double)rounds * Tb + (double)((ts + 511) / 512) * Ts + 2.0;          // + one kernel boundary
     }
-    if (force == 128 || K < 128) launch(0, M, false);
+    // 256 x 128 tiles, two workgroups per CU (gemm_nt_duo): fp32 residual / 16-bit epilogues of the transformer towers
+    const bool duo_ok = K >= 128 && epilogue != HGR_EPI_BIAS_ADD16_RELU && (out_f32 || (epilogue != HGR_EPI_BIAS_RESIDUAL && epilogue != HGR_EPI_ACCUM)) &&
+                        (int64_t)M * lda * 2 < (1ll << 32) && (int64_t)N * ldw * 2 < (1ll << 32);
+    auto launch_d = [&]() {
+        GemmArgs a;
+        a.A = (const char *)A; a.lda = lda; a.W = (const char *)W; a.ldw = ldw; a.C = C; a.ldc = ldc; a.bias = bias;
+        a.res = (const float *)residual; a.ldr = ldr; a.M = M; a.N = N; a.K = K;
+        a.tiles_m = (M + 255) / 256; a.tiles_n = (N + 127) / 128;
+        a.m_fastest = ((int64_t)N * K > (int64_t)M * K) ? 1 : 0;
+        a.vec_ok = vec ? 1 : 0; a.dbg = dbg; a.kc = 0; a.csplit = 0;
+        dim3 grid((unsigned)(a.tiles_m * a.tiles_n));
+        if (dtype == HGR_BF16) launch_duo<HGR_BF16>(a, epilogue, out_f32 != 0, grid, s);
+        else launch_duo<HGR_F16>(a, epilogue, out_f32 != 0, grid, s);
+    };
+    if (force == 2 && duo_ok) launch_d();
+    else if (force == 128 || K < 128) launch(0, M, false);
     else if (epilogue == HGR_EPI_BIAS_ADD16_RELU && force != 256) launch(0, M, false);   // only the 128 kernel loads the identity / stores by full lines
     else if (force == 256) launch(0, M, true);
     else if (cost_split < cost_big && cost_split < cost_small) { launch(0, m1, true); launch(m1, M - m1, false); }

@@ -56,14 +56,17 @@ def test_om_step_matches_reference(case, golden_dir, tmp_path):
     assert abs(loss - t["loss"]) < 2e-2 * abs(t["loss"]), (loss, t["loss"])
     named = dict(model.clip_model.named_parameters())
     # every parameter received a gradient of the right size (bf16 MFMA inputs: a few % on norms)
-    bad = []
+    bad, worst_norm = [], 0.0
     for k, ref in t["grad_norms"].items():
         got = float(named[k].grad.norm())
+        if k != "logit_scale" and ref > 1e-3:
+            worst_norm = max(worst_norm, abs(got - ref) / ref)
         # logit_scale's gradient is sum_rows (E_softmax[logit] - logit_label): a small remainder of O(1) terms, so
         # with bf16 tower features it carries an absolute, not a relative, error
         if abs(got - ref) > 0.08 * ref + (5e-3 if k == "logit_scale" else 1e-4):
             bad.append((k, got, ref))
     assert not bad, bad[:8]
+    worst_cos = 1.0
     for key in gold.files:
         if not key.startswith("grad/"):
             continue
@@ -73,7 +76,10 @@ def test_om_step_matches_reference(case, golden_dir, tmp_path):
             assert float(ggot.norm()) < 1e-4, key              # softmax is shift invariant); only rounding noise on both sides
             continue
         cos = float(torch.dot(gref, ggot) / (gref.norm() * ggot.norm() + 1e-30))
+        worst_cos = min(worst_cos, cos)
         assert cos > 0.99, (key, cos)
+    print(f"\n[OM step {case}] loss {loss:.5f} vs reference {t['loss']:.5f} ({abs(loss - t['loss']) / abs(t['loss']):.2e}); "
+          f"worst gradient-norm deviation {worst_norm:.2e}; worst cosine {worst_cos:.5f}")
     # clip_grad_norm_(1.0) + AdamW(lr) as fused kernels vs the reference's torch optimiser
     params = [p for n, p in model.named_parameters() if p.requires_grad and n != "layer_weight"]
     opt = FusedAdamW(params, lr=t["lr"], weight_decay=0.0, max_norm=1.0)
@@ -447,7 +453,7 @@ def test_driver_runs_with_the_default_adaptive_weights(golden_dir, tmp_path):
     (tmp_path / "g.json").write_text(json.dumps(edges))
     (tmp_path / "s.json").write_text(json.dumps(splits))
     argv = ["--device", "0", "--folder", str(tmp_path / "run"), "--graph_path", str(tmp_path / "g.json"), "--split_path", str(tmp_path / "s.json"),
-            "--num_compare", "8", "--out_ratio", "0.5", "--epochs", "1", "--synthetic", "3", "--batch_size", "6", "--w_lr", "1e-2",
+            "--num_compare", "8", "--out_ratio", "0.5", "--epochs", "1", "--synthetic", "3", "--batch_size", "6", "--w_lr", "1e4",
             "--test_batch_size", "8", "--lr", "1e-5", "--print_freq", "1", "--model_train", "all"]
     opts = drv.build_parser().parse_args(argv)
     assert opts.weights == "adaptive"
@@ -474,7 +480,9 @@ def test_driver_runs_with_the_default_adaptive_weights(golden_dir, tmp_path):
         os.chdir(cwd)
         tree_model.train_batch = orig
     assert seen["dev"] == "cuda" and seen["entry_grad_zero"]
-    assert not torch.equal(seen["model"].layer_weight.detach(), seen["w0"])       # SGD moved it
+    g = seen["model"].layer_weight.grad
+    assert g is not None and torch.isfinite(g).all() and float(g.abs().sum()) > 0
+    assert not torch.equal(seen["model"].layer_weight.detach(), seen["w0"])       # SGD moved it (w_lr is huge on purpose: d softmax(100 ** w) is tiny)
     log = (tmp_path / "run" / "HGR" / "adaptive_0.5_0.5" / "arugements.log").read_text()
     assert log.count("loss:") == 3
 
@@ -529,10 +537,10 @@ def test_vit_l14_coop_true_dimension_om_step_vs_oracle(tmp_path):
         if k == "logit_scale":                                  # a small remainder of O(1) terms: absolute bound
             assert abs(float(g) - float(r)) < 5e-3 + 0.05 * abs(float(r)), (float(g), float(r))
             continue
-        assert abs(float(g.norm()) - rn) < 0.05 * rn + 1e-7, (k, float(g.norm()), rn)
-        assert cos > 0.99, (k, cos)
+        assert abs(float(g.norm()) - rn) < 0.015 * rn + 1e-7, (k, float(g.norm()), rn)     # measured <= 0.4 %
+        assert cos > 0.998, (k, cos)                                                          # measured >= 0.9993
     tot = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in named.values() if p.grad is not None)))
     tot_ref = float(torch.sqrt(sum((v.double() ** 2).sum() for v in ref_g.values())))
-    assert abs(tot - tot_ref) < 0.03 * tot_ref, (tot, tot_ref)
+    assert abs(tot - tot_ref) < 0.01 * tot_ref, (tot, tot_ref)                               # measured 0.09 %
     print(f"\n[ViT-L/14 + 16 ctx, batch {b}] loss {loss:.5f} vs oracle {ref_loss:.5f}; total grad norm {tot:.4e} vs {tot_ref:.4e}; "
           + "; ".join(f"{k.split('.')[-3] if k.count('.') > 2 else ''}{k.split('.')[-2] if '.' in k else ''}.{k.split('.')[-1]} n {a:.3f} cos {c:.4f}" for k, a, c in report))
