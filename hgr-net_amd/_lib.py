@@ -76,6 +76,14 @@ SIGNATURES = {
     "hgr_bn_fold": [_p, _p, _p, _p, _p, _f, _p, _p, _i, _i, _i, _i, _i, _p],
     "hgr_bn_unfold_grad": [_p, _l, _p, _p, _p, _p, _p, _f, _p, _p, _p, _i, _i, _i, _p],
     "hgr_csr_group_aggregate": [_p, _l, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _p, _p, _l, _i, _f, _i, _p],
+    "hgr_comm_unique_id": [_p],
+    "hgr_comm_init": [_i, _i, _p],
+    "hgr_comm_destroy": [],
+    "hgr_comm_rank": [],
+    "hgr_comm_world": [],
+    "hgr_allreduce": [_p, _p, _l, _i, _i, _p],
+    "hgr_allgather": [_p, _p, _l, _i, _p],
+    "hgr_broadcast": [_p, _l, _i, _i, _p],
     "hgr_adamw": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _p, _f, _f, _p],
 }
 

@@ -1223,7 +1223,12 @@ extern "C" int hgr_gemm_nt(const void *A, int64_t lda, const void *W, int64_t ld
         if (dtype == HGR_BF16) launch_duo<HGR_BF16>(a, epilogue, out_f32 != 0, grid, s);
         else launch_duo<HGR_F16>(a, epilogue, out_f32 != 0, grid, s);
     };
-    if (force == 2 && duo_ok) launch_d();
+    // Plan choice for the shapes gemm_nt_duo covers: measured (tools/gemm_plan_ab.py, same-process A/B, f16, one MI355X; bit-identical
+    // outputs): qkv 97 -> 91 us, out-proj 59 -> 49, c_fc 136 -> 124, c_proj 145 -> 126, patch 124 -> 118, class logits 24.7 -> 20.7,
+    // text qkv 168 -> 154, ViT-L/14 out / proj 411 -> 361 / 1029 -> 999, ViT-L/14 qkv / fc a tie; a launch with fewer tiles than
+    // half the chip's 512 slots (small text batches, ragged test shapes) stays on the 128^2 / cost-model plans.
+    const int64_t tduo = (int64_t)((M + 255) / 256) * ((N + 127) / 128);
+    if (duo_ok && (force == 2 || (force == 0 && tduo >= 256))) launch_d();
     else if (force == 128 || K < 128) launch(0, M, false);
     else if (epilogue == HGR_EPI_BIAS_ADD16_RELU && force != 256) launch(0, M, false);   // only the 128 kernel loads the identity / stores by full lines
     else if (force == 256) launch(0, M, true);

@@ -10,7 +10,9 @@
  * Conventions
  *   - plain pointers and sizes only; every tensor argument is a raw DEVICE pointer, row-major;
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); every call is asynchronous
- *     and stream-ordered, never synchronises, allocates no device memory and keeps no global state;
+ *     and stream-ordered, never synchronises and allocates no device memory.  The only process-wide mutable state is
+ *     (a) the development knob hgr_gemm_set_tile (tile-plan override for A/B runs and tests; default = cost model) and
+ *     (b) the optional RCCL communicator created / destroyed explicitly by hgr_comm_init / hgr_comm_destroy;
  *   - returns 0 on success, a negative HGR_E* code otherwise; hgr_last_error() returns the message of
  *     the last failure on the calling thread.  Arguments are validated on the host before any launch
  *     (shape / alignment assumptions of the kernel), so a bad call fails loudly instead of faulting;
@@ -420,6 +422,33 @@ int hgr_sumsq(const float *x, int64_t n, float *out, void *stream);
  */
 int hgr_adamw(float *p, const float *g, float *m, float *v, int64_t n, float lr, float beta1, float beta2, float eps,
               float wd, int step, const float *sumsq_total, float max_norm, float grad_scale, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Data-parallel collectives over RCCL / xGMI (one process per GPU).  The reference has no distributed code (its only
+ * mention is an unused DDP import, baseline/CLIP/clip_train.py:19); these serve the sharding this build adds:
+ *   evaluation  - every rank text-encodes N/world prompts of update_classifier (model/clip_tree.py:318-325) and the
+ *                 row slices are ALL-GATHERED; the 9 metric counters of main.test (main.py:121-128) are ALL-REDUCED once;
+ *   OM training - one single-class batch is sharded over the ranks, the flat fp32 gradient buffer is ALL-REDUCED (sum)
+ *                 before clip_grad_norm_ + AdamW (main.py:87-91); parameters can be BROADCAST from a root.
+ * Bootstrap: rank 0 calls hgr_comm_unique_id and ships the HGR_COMM_ID_BYTES bytes to every rank by any side channel
+ * (file, TCP store, torch.distributed); every rank then calls hgr_comm_init with its HIP device current.  Calls are
+ * stream-ordered on `stream` and asynchronous like every other entry point.  librccl.so.1 is resolved at run time
+ * (HGR_RCCL_LIB overrides the path), so the library loads without it; the calls then fail with HGR_EUNSUPPORTED.
+ * ------------------------------------------------------------------------------------------------ */
+#define HGR_COMM_ID_BYTES 128
+typedef enum { HGR_COMM_F32 = 0, HGR_COMM_F64 = 1, HGR_COMM_F16 = 2, HGR_COMM_BF16 = 3, HGR_COMM_I32 = 4, HGR_COMM_I64 = 5, HGR_COMM_U8 = 6 } hgr_comm_dtype_t;
+typedef enum { HGR_COMM_SUM = 0, HGR_COMM_MAX = 1 } hgr_comm_op_t;
+
+int hgr_comm_unique_id(void *id_out /* HGR_COMM_ID_BYTES */);
+int hgr_comm_init(int rank, int world, const void *unique_id /* HGR_COMM_ID_BYTES */);
+int hgr_comm_destroy(void);
+int hgr_comm_rank(void);    /* -1 without a communicator */
+int hgr_comm_world(void);   /*  0 without a communicator */
+/* recv[i] = op over ranks of send[i]; in place (send == recv) allowed */
+int hgr_allreduce(const void *send, void *recv, int64_t count, int dtype, int op, void *stream);
+/* recv[r * count_per_rank + i] = rank r's send[i]; in place when send == recv + rank * count_per_rank */
+int hgr_allgather(const void *send, void *recv, int64_t count_per_rank, int dtype, void *stream);
+int hgr_broadcast(void *buf, int64_t count, int dtype, int root, void *stream);
 
 #ifdef __cplusplus
 }

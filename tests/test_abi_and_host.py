@@ -156,7 +156,7 @@ def test_world_size_2_gloo_sharding(tmp_path):
 
 
 def test_tokenizer_matches_reference_ids(golden_dir):
-    """BPE ids captured from the reference's tokenizer (tools: see tests/golden/tokenizer_ids.json).
+    """BPE ids captured from the reference's tokenizer (tools/make_golden_tokenizer.py -> tests/golden/tokenizer_ids.json).
     Needs the user's merges file; skipped where it is absent (it is reference data, not shipped)."""
     from hgr_net_amd.clip import simple_tokenizer as st
     import os
