@@ -76,6 +76,10 @@ SIGNATURES = {
     "hgr_bn_fold": [_p, _p, _p, _p, _p, _f, _p, _p, _i, _i, _i, _i, _i, _p],
     "hgr_bn_unfold_grad": [_p, _l, _p, _p, _p, _p, _p, _f, _p, _p, _p, _i, _i, _i, _p],
     "hgr_csr_group_aggregate": [_p, _l, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _p, _p, _l, _i, _f, _i, _p],
+    "hgr_gemm_nt_res_stats": [_p, _l, _p, _l, _p, _l, _p, _p, _l, _p, _i, _i, _i, _i, _p],
+    "hgr_gemm_nt_ln": [_p, _l, _p, _l, _p, _l, _p, _p, _p, _f, _i, _i, _i, _i, _i, _p],
+    "hgr_vit_embed_ln_stats": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p],
+    "hgr_row_stats16": [_p, _p, _p, _i, _i, _i, _p],
     "hgr_comm_unique_id": [_p],
     "hgr_comm_init": [_i, _i, _p],
     "hgr_comm_destroy": [],

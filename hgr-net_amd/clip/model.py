@@ -13,6 +13,7 @@ Token layout is batch-major ([B*L, W] rows = b*L + t) instead of the reference's
 """
 from __future__ import annotations
 
+import os
 from collections import OrderedDict
 from typing import Dict, Optional, Tuple, Union
 
@@ -136,6 +137,17 @@ class _Block16:
         self.w_out, self.b_out = _w16(blk.attn.out_proj.weight, dt), _f32(blk.attn.out_proj.bias)
         self.w_fc, self.b_fc = _w16(blk.mlp.c_fc.weight, dt), _f32(blk.mlp.c_fc.bias)
         self.w_proj, self.b_proj = _w16(blk.mlp.c_proj.weight, dt), _f32(blk.mlp.c_proj.bias)
+        # LayerNorm folded into its consumer GEMM (hgr_gemm_nt_ln): W' = gamma o W rounded ONCE to the MFMA type,
+        # s_n = sum_k W'_nk over the ROUNDED values (it must cancel exactly what the MFMA summed), c = W beta + b in fp32
+        self.wf_in, self.s_in, self.c_in = self._fold(blk.attn.in_proj_weight, blk.attn.in_proj_bias, blk.ln_1, dt)
+        self.wf_fc, self.s_fc, self.c_fc = self._fold(blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, blk.ln_2, dt)
+        self.eps1, self.eps2 = float(blk.ln_1.eps), float(blk.ln_2.eps)
+
+    @staticmethod
+    def _fold(w, b, ln, dt):
+        w32, g32, be32 = w.detach().float(), ln.weight.detach().float(), ln.bias.detach().float()
+        wf = (w32 * g32[None, :]).to(dt).contiguous()
+        return wf, wf.float().sum(dim=1).contiguous(), (w32 @ be32 + b.detach().float()).contiguous()
 
 
 class _Workspace:
@@ -155,17 +167,40 @@ class _Workspace:
         return t[:n].view(*shape)
 
 
+LN_FUSED = os.environ.get("HGR_LN_FUSED", "1") != "0"     # HGR_LN_FUSED=0: separate LayerNorm launches (the first build's path), for A/B runs
+
+
+def ln_fusable(w: int) -> bool:
+    """The LayerNorm-folded GEMM pair needs the row width to be a multiple of 128 (two 64-column statistic slots per load)."""
+    return LN_FUSED and w % 128 == 0
+
+
 def _run_blocks(x: torch.Tensor, blocks, heads: int, b: int, l: int, causal: bool, dt: torch.dtype, ws: _Workspace, tag: str,
-                taps: Optional[dict] = None, tap_prefix: str = ""):
-    """The residual stack (clip/model.py:185-188 per block) on the fp32 residual stream x [b*l, w]:
-    LN -> QKV GEMM(+bias) -> attention -> out GEMM(+bias, +residual) -> LN -> fc GEMM(+bias, QuickGELU)
-    -> proj GEMM(+bias, +residual).  7 kernel launches per block."""
+                taps: Optional[dict] = None, tap_prefix: str = "", x16: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None):
+    """The residual stack (clip/model.py:185-188 per block) on the fp32 residual stream x [b*l, w].
+
+    With ``x16`` / ``stats`` (16-bit copy + LayerNorm slot statistics of x, from hgr_vit_embed_ln_stats / hgr_row_stats16) the
+    LayerNorms are folded into the GEMMs around them - 5 launches per block, no LayerNorm pass:
+        QKV = LN-folded GEMM(x16) -> attention -> x += out GEMM (+ x16, stats) -> u = LN-folded GEMM(x16, QuickGELU)
+        -> x += proj GEMM (+ x16, stats)
+    otherwise LN -> QKV GEMM(+bias) -> attention -> out GEMM(+bias, +residual) -> LN -> fc GEMM(+bias, QuickGELU)
+    -> proj GEMM(+bias, +residual): 7 launches per block."""
     m, w = x.shape
     dev = x.device
-    h16 = ws.get(tag + ".h16", (m, w), dt, dev)
     qkv = ws.get(tag + ".qkv", (m, 3 * w), dt, dev)
     att = ws.get(tag + ".att", (m, w), dt, dev)
     u16 = ws.get(tag + ".u16", (m, 4 * w), dt, dev)
+    if x16 is not None:
+        for i, k in enumerate(blocks):
+            ops.gemm_nt_ln(x16, k.wf_in, qkv, k.s_in, k.c_in, stats, k.eps1, tag="qkv")
+            ops.mha(qkv, att, b, l, heads, causal)
+            ops.gemm_nt_res_stats(att, k.w_out, x, k.b_out, x16, stats, tag="out")
+            ops.gemm_nt_ln(x16, k.wf_fc, u16, k.s_fc, k.c_fc, stats, k.eps2, quickgelu=True, tag="fc")
+            ops.gemm_nt_res_stats(u16, k.w_proj, x, k.b_proj, x16, stats, tag="proj")
+            if taps is not None:
+                taps[f"{tap_prefix}.resblocks.{i}"] = x.view(b, l, w).clone()
+        return x
+    h16 = ws.get(tag + ".h16", (m, w), dt, dev)
     for i, k in enumerate(blocks):
         ops.layernorm(x, k.ln1[0], k.ln1[1], h16)
         ops.gemm_nt(h16, k.w_in, qkv, bias=k.b_in, epilogue=EPI_BIAS)
@@ -415,10 +450,16 @@ class CLIP(nn.Module):
         pe = ws.get("v.pe", (b * gg, w), torch.float32, dev)
         ops.gemm_nt(patches, p["conv_w_nhwc"] if u8 else p["conv_w"], pe)
         x = ws.get("v.x", (b * l, w), torch.float32, dev)
-        ops.vit_embed_ln(pe, p["cls"], p["pos"], p["ln_pre"][0], p["ln_pre"][1], x, b, gg)
+        x16 = stats = None
+        if ln_fusable(w):
+            x16 = ws.get("v.x16", (b * l, w), dt, dev)
+            stats = ws.get("v.stats", (b * l, w // 64, 2), torch.float32, dev)
+            ops.vit_embed_ln_stats(pe, p["cls"], p["pos"], p["ln_pre"][0], p["ln_pre"][1], x, x16, stats, b, gg)
+        else:
+            ops.vit_embed_ln(pe, p["cls"], p["pos"], p["ln_pre"][0], p["ln_pre"][1], x, b, gg)
         if taps is not None:
             taps["visual.ln_pre"] = x.view(b, l, w).clone()
-        _run_blocks(x, p["vblocks"], w // 64, b, l, False, dt, ws, "v", taps, "visual.transformer")
+        _run_blocks(x, p["vblocks"], w // 64, b, l, False, dt, ws, "v", taps, "visual.transformer", x16, stats)
         cls16 = ws.get("v.cls16", (b, w), dt, dev)
         ops.layernorm(x, p["ln_post"][0], p["ln_post"][1], cls16, rows=b, row_mul=l)
         out = torch.empty((b, v.output_dim), dtype=torch.float32, device=dev)
@@ -449,7 +490,12 @@ class CLIP(nn.Module):
             ops.text_embed(text[s:e], p["tok"], p["tpos"], x, l)
             if ctx is not None:
                 ops.ctx_splice(x, ctx.detach().float().contiguous(), p["tpos"], c, l)
-            _run_blocks(x, p["tblocks"], w // 64, c, l, True, dt, ws, "t")
+            x16 = stats = None
+            if ln_fusable(w):
+                x16 = ws.get("t.x16", (c * l, w), dt, dev)
+                stats = ws.get("t.stats", (c * l, w // 64, 2), torch.float32, dev)
+                ops.row_stats16(x, x16, stats)
+            _run_blocks(x, p["tblocks"], w // 64, c, l, True, dt, ws, "t", x16=x16, stats=stats)
             f16 = ws.get("t.f16", (c, w), dt, dev)
             ops.layernorm(x, p["ln_final"][0], p["ln_final"][1], f16, rows=c, row_mul=l, row_idx=eot[s:e])
             ops.gemm_nt(f16, p["tproj_t"], out[s:e])

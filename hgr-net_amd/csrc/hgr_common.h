@@ -65,6 +65,16 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// sum over the 16 lanes of a DPP row (lanes with equal lane >> 4), result in every lane of the row; fixed order.
+// Must be executed by all lanes of the wave's rows it concerns (no divergence inside a row).
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+    return v;
+}
+
 // ---- host-side error plumbing -------------------------------------------------------------------
 int hgr_set_error(int code, const char *fmt, ...);
 

@@ -49,6 +49,14 @@ struct GemmArgs {
     // split-K (gemm_nt_128 only): blockIdx.y = split s works on K columns [s * kc, min(K, (s + 1) * kc)) and writes its own
     // fp32 partial C + s * csplit elements; 0 = off
     int kc; int64_t csplit;
+    // LayerNorm folded into the GEMMs around it (gemm_nt_duo only, LN template parameter):
+    //   producer (LN = 1, x += A W^T + b): also writes the new residual as 16-bit x16 and, per row and 64-column slot, the
+    //            partial (sum, sum of squares) of the new values -> ln_stats [M][ln_slots][2]
+    //   consumer (LN = 2, y = LN(x) W^T + b): A is the un-normalised 16-bit x, W the gamma-folded weight,
+    //            y = rstd_m (acc - mean_m ln_s[n]) + ln_c[n] with row statistics from ln_stats (K = row width)
+    float *ln_stats; int ln_slots; float ln_eps;
+    void *ln_x16; int64_t ln_ldx16;
+    const float *ln_s, *ln_c;
 };
 
 // 16 zero bytes every out-of-bounds conv tap (and the K padding) is loaded from
@@ -800,7 +808,7 @@ __global__ __launch_bounds__(NT256) void gemm_nt_256(GemmArgs p) {
 constexpr int NTD = 256;
 constexpr int DUO_A0 = 0, DUO_A1 = 32768, DUO_W0 = 65536, DUO_W1 = 73728, DUO_LDS = 81920;
 
-template <int DT, int EPI, bool OUT32>
+template <int DT, int EPI, bool OUT32, int LN = 0>
 __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
     typedef typename T16<DT>::vec8 vec8;
     typedef typename T16<DT>::elem E;
@@ -879,6 +887,17 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[a][b][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // LN consumer: thread t finalises the statistics of tile row t (the producer's per-slot partial sums) BEFORE any LDS-DMA
+    // is in flight (a waited ordinary load drains the DMA queue), and carries (mean, rstd) in two registers to the epilogue
+    float ln_mean = 0.f, ln_rstd = 0.f;
+    if (LN == 2) {
+        const f32x4 *sp = (const f32x4 *)(p.ln_stats + (int64_t)min(m0 + tid, p.M - 1) * p.ln_slots * 2);
+        float s1 = 0.f, s2 = 0.f;
+        for (int i = 0; i < p.ln_slots / 2; ++i) { const f32x4 t = sp[i]; s1 += t[0] + t[2]; s2 += t[1] + t[3]; }
+        const float inv = 1.0f / (float)p.K;
+        ln_mean = s1 * inv;
+        ln_rstd = rsqrtf(fmaxf(s2 * inv - ln_mean * ln_mean, 0.f) + p.ln_eps);
+    }
     const int nk = p.K / 64;    // >= 2 (host guarantees)
     // prologue in steady-state order: A0(0), A1(0), W0(0), W1(0), A0(1)
     issueA(oA0, DUO_A0, 0, 0); issueA(oA0, DUO_A0, 0, 1);
@@ -977,21 +996,35 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
         // 128-byte lines with 16-byte stores (8 lanes per row, 8 rows per instruction)
         constexpr int RS = 144;
         char *my = smem + wave * (128 * RS);
-        f32x4 bq[2][2];
+        f32x4 bq[2][2], lsq[2][2];
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-                bq[b][j] = HAS_BIAS ? *(const f32x4 *)(p.bias + n0 + wn * 64 + b * 32 + j * 16 + g * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + wn * 64 + b * 32 + j * 16 + g * 4;
+                if (LN == 2) { bq[b][j] = *(const f32x4 *)(p.ln_c + n); lsq[b][j] = *(const f32x4 *)(p.ln_s + n); }
+                else bq[b][j] = HAS_BIAS ? *(const f32x4 *)(p.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        float2 *lnrow = (float2 *)(smem + 4 * 128 * RS);      // 256 x (mean, rstd) behind the four staging slices
+        if (LN == 2) {
+            lnrow[tid] = make_float2(ln_mean, ln_rstd);
+            __syncthreads();
+        }
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) {
+        float2 mr = make_float2(0.f, 1.f);
+        if (LN == 2) mr = lnrow[wm * 128 + a * 64 + i * 16 + r];
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            f32x4 v = acc[a][b][i][j] + bq[b][j];
+            f32x4 v;
+            if (LN == 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(mr.y, acc[a][b][i][j][e] - mr.x * lsq[b][j][e], bq[b][j][e]);
+            } else v = acc[a][b][i][j] + bq[b][j];
             if (EPI == HGR_EPI_BIAS_QUICKGELU) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
@@ -1001,6 +1034,7 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
                 for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
             }
             *(typename T16<DT>::vec4 *)(my + (a * 64 + i * 16 + r) * RS + (b * 32 + j * 16 + g * 4) * 2) = cvt4<DT>(v[0], v[1], v[2], v[3]);
+        }
         }
         const int ch = lane & 7, rr = lane >> 3;
         E *dst0 = (E *)p.C + (int64_t)(m0 + wm * 128 + rr) * p.ldc + n0 + wn * 64 + ch * 8;
@@ -1046,7 +1080,80 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
             for (int q = 0; q < 8; ++q) {
                 f32x4 v = *(const f32x4 *)(my + (q * 4 + rq) * RS + cq * 16);
                 if (HAS_ADD) v += ad[q];
-                *(f32x4 *)((float *)p.C + (int64_t)(row0 + q * 4 + rq) * p.ldc + n0 + wn * 64 + cq * 4) = v;
+                const int64_t row = row0 + q * 4 + rq;
+                *(f32x4 *)((float *)p.C + row * p.ldc + n0 + wn * 64 + cq * 4) = v;
+                if (LN == 1) {
+                    // the new residual once more in 16 bit (the next GEMM's A operand: 16 lanes = one 128-byte line per row)
+                    // and this wave's 64-column share of the row's LayerNorm statistics
+                    *(typename T16<DT>::vec4 *)((E *)p.ln_x16 + row * p.ln_ldx16 + n0 + wn * 64 + cq * 4) = cvt4<DT>(v[0], v[1], v[2], v[3]);
+                    const float s1 = row16_sum((v[0] + v[1]) + (v[2] + v[3]));
+                    const float s2 = row16_sum((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]));
+                    if (cq == 0) *(float2 *)(p.ln_stats + (row * p.ln_slots + (n0 >> 6) + wn) * 2) = make_float2(s1, s2);
+                }
+            }
+        }
+        return;
+    }
+    if (LN == 2) {
+        // edge tile of an LN consumer (rows beyond M; N is a multiple of 128 by the host's contract): same arithmetic, guarded rows
+        float2 *lnrow = (float2 *)smem;
+        lnrow[tid] = make_float2(ln_mean, ln_rstd);
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wm * 128 + a * 64 + i * 16 + r;
+            const float2 mr = lnrow[wm * 128 + a * 64 + i * 16 + r];
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + wn * 64 + b * 32 + j * 16 + g * 4;
+                const f32x4 sq = *(const f32x4 *)(p.ln_s + n), cq4 = *(const f32x4 *)(p.ln_c + n);
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = fmaf(mr.y, acc[a][b][i][j][e] - mr.x * sq[e], cq4[e]);
+                    if (EPI == HGR_EPI_BIAS_QUICKGELU) v[e] = quick_gelu(v[e]);
+                }
+                store_quad<DT, HGR_EPI_NONE, OUT32>(p, v, m, n);
+            }
+        }
+        return;
+    }
+    if (LN == 1) {
+        // edge tile of an LN producer: the same pass structure with guarded rows (stores of a partial last row panel)
+        constexpr int RS = 272;
+        char *my = smem + wave * (32 * RS);
+        const int rq = lane >> 4, cq = lane & 15;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int ih = 0; ih < 2; ++ih) {
+            const int row0 = m0 + wm * 128 + a * 64 + ih * 32;
+#pragma unroll
+            for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                *(f32x4 *)(my + (i2 * 16 + r) * RS + (b * 32 + j * 16 + g * 4) * 4) =
+                    acc[a][b][ih * 2 + i2][j] + *(const f32x4 *)(p.bias + n0 + wn * 64 + b * 32 + j * 16 + g * 4);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int64_t row = row0 + q * 4 + rq;
+                f32x4 v = *(const f32x4 *)(my + (q * 4 + rq) * RS + cq * 16);
+                const bool ok = row < p.M;
+                if (ok) v += *(const f32x4 *)(p.res + row * p.ldr + n0 + wn * 64 + cq * 4);
+                const float s1 = row16_sum((v[0] + v[1]) + (v[2] + v[3]));
+                const float s2 = row16_sum((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]));
+                if (ok) {
+                    *(f32x4 *)((float *)p.C + row * p.ldc + n0 + wn * 64 + cq * 4) = v;
+                    *(typename T16<DT>::vec4 *)((E *)p.ln_x16 + row * p.ln_ldx16 + n0 + wn * 64 + cq * 4) = cvt4<DT>(v[0], v[1], v[2], v[3]);
+                    if (cq == 0) *(float2 *)(p.ln_stats + (row * p.ln_slots + (n0 >> 6) + wn) * 2) = make_float2(s1, s2);
+                }
             }
         }
         return;
@@ -1341,5 +1448,66 @@ extern "C" int hgr_gemm_nt_splitk(const void *A, int64_t lda, const void *W, int
     if (dtype == HGR_BF16) hipLaunchKernelGGL((gemm_nt_128<HGR_BF16, HGR_EPI_NONE, true, false>), grid, dim3(NT), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((gemm_nt_128<HGR_F16, HGR_EPI_NONE, true, false>), grid, dim3(NT), 0, (hipStream_t)stream, a);
     HGR_CHECK_LAUNCH("hgr_gemm_nt_splitk");
+    return HGR_OK;
+}
+
+// ---- LayerNorm folded into the GEMMs around it --------------------------------------------------------------------------
+namespace {
+int ln_common_checks(const char *who, const void *A, int64_t lda, const void *W, int64_t ldw, int M, int N, int K, int dtype) {
+    HGR_REQUIRE(A && W, "%s: null operand", who);
+    HGR_REQUIRE(M >= 1 && N >= 128 && N % 128 == 0 && K >= 128 && K % 64 == 0, "%s: bad shape M=%d N=%d K=%d (N %% 128 == 0, K %% 64 == 0, K >= 128)", who, M, N, K);
+    HGR_REQUIRE(lda >= K && ldw >= K && lda % 8 == 0 && ldw % 8 == 0 && hgr_aligned(A, 16) && hgr_aligned(W, 16), "%s: operands must be 16-byte aligned with leading dimensions %% 8 == 0", who);
+    HGR_REQUIRE((int64_t)M * lda * 2 < (1ll << 32) && (int64_t)N * ldw * 2 < (1ll << 32), "%s: operands beyond 4 GB", who);
+    HGR_REQUIRE(dtype == HGR_BF16 || dtype == HGR_F16, "%s: bad dtype %d", who, dtype);
+    return HGR_OK;
+}
+void ln_args(GemmArgs &a, const void *A, int64_t lda, const void *W, int64_t ldw, void *C, int64_t ldc, int M, int N, int K) {
+    a.A = (const char *)A; a.lda = lda; a.W = (const char *)W; a.ldw = ldw; a.C = C; a.ldc = ldc; a.bias = nullptr; a.res = nullptr; a.ldr = 0;
+    a.M = M; a.N = N; a.K = K; a.tiles_m = (M + 255) / 256; a.tiles_n = N / 128;
+    a.m_fastest = ((int64_t)N * K > (int64_t)M * K) ? 1 : 0; a.vec_ok = 1; a.dbg = 0; a.kc = 0; a.csplit = 0;
+    a.cH = a.cW = a.cC = a.cStride = a.cHo = a.cWo = 0; a.cMagic = 0;
+    a.ln_stats = nullptr; a.ln_slots = 0; a.ln_eps = 0.f; a.ln_x16 = nullptr; a.ln_ldx16 = 0; a.ln_s = a.ln_c = nullptr;
+}
+}  // namespace
+
+extern "C" int hgr_gemm_nt_res_stats(const void *A, int64_t lda, const void *W, int64_t ldw, float *X, int64_t ldx, const float *bias,
+                                     void *x16, int64_t ldx16, float *stats, int M, int N, int K, int dtype, void *stream) {
+    if (int rc = ln_common_checks("hgr_gemm_nt_res_stats", A, lda, W, ldw, M, N, K, dtype)) return rc;
+    HGR_REQUIRE(X && bias && x16 && stats, "hgr_gemm_nt_res_stats: null X / bias / x16 / stats");
+    HGR_REQUIRE(ldx >= N && ldx % 4 == 0 && hgr_aligned(X, 16) && hgr_aligned(bias, 16), "hgr_gemm_nt_res_stats: X / bias must be 16-byte aligned, ldx %% 4 == 0");
+    HGR_REQUIRE(ldx16 >= N && ldx16 % 4 == 0 && hgr_aligned(x16, 8) && hgr_aligned(stats, 8), "hgr_gemm_nt_res_stats: x16 must be 8-byte aligned with ldx16 %% 4 == 0");
+    GemmArgs a;
+    ln_args(a, A, lda, W, ldw, X, ldx, M, N, K);
+    a.bias = bias; a.res = X; a.ldr = ldx;
+    a.ln_stats = stats; a.ln_slots = N / 64; a.ln_x16 = x16; a.ln_ldx16 = ldx16;
+    dim3 grid((unsigned)(a.tiles_m * a.tiles_n));
+    if (dtype == HGR_BF16) hipLaunchKernelGGL((gemm_nt_duo<HGR_BF16, HGR_EPI_BIAS_RESIDUAL, true, 1>), grid, dim3(NTD), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((gemm_nt_duo<HGR_F16, HGR_EPI_BIAS_RESIDUAL, true, 1>), grid, dim3(NTD), 0, (hipStream_t)stream, a);
+    HGR_CHECK_LAUNCH("hgr_gemm_nt_res_stats");
+    return HGR_OK;
+}
+
+extern "C" int hgr_gemm_nt_ln(const void *X16, int64_t ldx, const void *Wfold, int64_t ldw, void *C, int64_t ldc,
+                              const float *ln_s, const float *ln_c, const float *stats, float eps,
+                              int M, int N, int K, int dtype, int act, void *stream) {
+    if (int rc = ln_common_checks("hgr_gemm_nt_ln", X16, ldx, Wfold, ldw, M, N, K, dtype)) return rc;
+    HGR_REQUIRE(C && ln_s && ln_c && stats, "hgr_gemm_nt_ln: null C / ln_s / ln_c / stats");
+    HGR_REQUIRE(K % 128 == 0, "hgr_gemm_nt_ln: the row width K=%d must be a multiple of 128 (two 64-column statistic slots per 16-byte load)", K);
+    HGR_REQUIRE(ldc >= N && ldc % 8 == 0 && hgr_aligned(C, 16), "hgr_gemm_nt_ln: C must be 16-byte aligned with ldc %% 8 == 0");
+    HGR_REQUIRE(hgr_aligned(ln_s, 16) && hgr_aligned(ln_c, 16) && hgr_aligned(stats, 16), "hgr_gemm_nt_ln: ln_s / ln_c / stats must be 16-byte aligned");
+    HGR_REQUIRE(act == 0 || act == 1, "hgr_gemm_nt_ln: act must be 0 (none) or 1 (QuickGELU), got %d", act);
+    GemmArgs a;
+    ln_args(a, X16, ldx, Wfold, ldw, C, ldc, M, N, K);
+    a.ln_stats = const_cast<float *>(stats); a.ln_slots = K / 64; a.ln_eps = eps; a.ln_s = ln_s; a.ln_c = ln_c;
+    dim3 grid((unsigned)(a.tiles_m * a.tiles_n));
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == HGR_BF16) {
+        if (act) hipLaunchKernelGGL((gemm_nt_duo<HGR_BF16, HGR_EPI_BIAS_QUICKGELU, false, 2>), grid, dim3(NTD), 0, s, a);
+        else hipLaunchKernelGGL((gemm_nt_duo<HGR_BF16, HGR_EPI_BIAS, false, 2>), grid, dim3(NTD), 0, s, a);
+    } else {
+        if (act) hipLaunchKernelGGL((gemm_nt_duo<HGR_F16, HGR_EPI_BIAS_QUICKGELU, false, 2>), grid, dim3(NTD), 0, s, a);
+        else hipLaunchKernelGGL((gemm_nt_duo<HGR_F16, HGR_EPI_BIAS, false, 2>), grid, dim3(NTD), 0, s, a);
+    }
+    HGR_CHECK_LAUNCH("hgr_gemm_nt_ln");
     return HGR_OK;
 }

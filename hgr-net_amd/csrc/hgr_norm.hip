@@ -58,11 +58,11 @@ __global__ __launch_bounds__(256) void layernorm_rows(const float *__restrict__ 
 }
 
 // x[b*L + t] = LN((t == 0 ? cls : patches[b*G + t-1]) + pos[t])
-template <int NV>
+template <int NV, int DT = HGR_F16, bool STATS = false>
 __global__ __launch_bounds__(256) void vit_embed_ln(const float *__restrict__ patches, const float *__restrict__ cls,
                                                     const float *__restrict__ pos, const float *__restrict__ gamma,
                                                     const float *__restrict__ beta, float *__restrict__ x,
-                                                    int B, int G, int W, float eps) {
+                                                    int B, int G, int W, float eps, void *__restrict__ x16 = nullptr, float *__restrict__ stats = nullptr) {
     const int lane = threadIdx.x & 63;
     const int L = G + 1;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -103,6 +103,36 @@ __global__ __launch_bounds__(256) void vit_embed_ln(const float *__restrict__ pa
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * ga[e] + be[e];
             out[c] = o;
+            if (STATS) {
+                // the first block's LayerNorm is folded into its QKV GEMM (hgr_gemm_nt_ln): 16-bit copy of the row + the
+                // (sum, sum of squares) of every 64-column slot = one DPP row of 16 lanes per slot (W % 64 == 0)
+                ((typename T16<DT>::vec4 *)((typename T16<DT>::elem *)x16 + (int64_t)row * W))[c] = cvt4<DT>(o[0], o[1], o[2], o[3]);
+                const float s1 = row16_sum((o[0] + o[1]) + (o[2] + o[3]));
+                const float s2 = row16_sum((o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]));
+                if ((lane & 15) == 0) *(float2 *)(stats + ((int64_t)row * (W >> 6) + (c >> 4)) * 2) = make_float2(s1, s2);
+            }
+        }
+    }
+}
+
+// x fp32 [rows, W] -> 16-bit copy + per-slot LayerNorm statistics (the form hgr_gemm_nt_res_stats emits), for the input of
+// the first residual block of a tower
+template <int DT>
+__global__ __launch_bounds__(256) void row_stats16(const float *__restrict__ x, void *__restrict__ x16, float *__restrict__ stats, int rows, int W) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const f32x4 *xr = (const f32x4 *)(x + (int64_t)row * W);
+    const int nv = W >> 2;
+    for (int c0 = 0; c0 < nv; c0 += 64) {
+        const int c = c0 + lane;
+        const bool ok = c < nv;                      // whole DPP rows are in or out: W % 64 == 0
+        const f32x4 v = ok ? xr[c] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float s1 = row16_sum((v[0] + v[1]) + (v[2] + v[3]));
+        const float s2 = row16_sum((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]));
+        if (ok) {
+            ((typename T16<DT>::vec4 *)((typename T16<DT>::elem *)x16 + (int64_t)row * W))[c] = cvt4<DT>(v[0], v[1], v[2], v[3]);
+            if ((lane & 15) == 0) *(float2 *)(stats + ((int64_t)row * (W >> 6) + (c >> 4)) * 2) = make_float2(s1, s2);
         }
     }
 }
@@ -190,5 +220,37 @@ extern "C" int hgr_l2norm_rows(const float *x, void *y16, float *y32, int rows, 
     if (nvl <= 1) HGR_L2(1); else if (nvl <= 2) HGR_L2(2); else if (nvl <= 4) HGR_L2(4); else if (nvl <= 8) HGR_L2(8); else HGR_L2(16);
 #undef HGR_L2
     HGR_CHECK_LAUNCH("hgr_l2norm_rows");
+    return HGR_OK;
+}
+
+
+extern "C" int hgr_vit_embed_ln_stats(const float *patches, const float *class_embedding, const float *positional_embedding,
+                                      const float *gamma, const float *beta, float *x, void *x16, float *stats,
+                                      int B, int G, int W, float eps, int dtype, void *stream) {
+    HGR_REQUIRE(patches && class_embedding && positional_embedding && gamma && beta && x && x16 && stats, "hgr_vit_embed_ln_stats: null operand");
+    HGR_REQUIRE(B >= 1 && G >= 1 && W >= 64 && W % 64 == 0 && W <= 4 * 64 * MAXV, "hgr_vit_embed_ln_stats: B=%d G=%d W=%d unsupported (W %% 64 == 0)", B, G, W);
+    HGR_REQUIRE(hgr_aligned(patches, 16) && hgr_aligned(class_embedding, 16) && hgr_aligned(positional_embedding, 16) &&
+                hgr_aligned(gamma, 16) && hgr_aligned(beta, 16) && hgr_aligned(x, 16) && hgr_aligned(x16, 8) && hgr_aligned(stats, 8),
+                "hgr_vit_embed_ln_stats: misaligned operand");
+    HGR_REQUIRE(dtype == HGR_BF16 || dtype == HGR_F16, "hgr_vit_embed_ln_stats: bad dtype %d", dtype);
+    const int rows = B * (G + 1);
+#define HGR_VE(NVV) do { \
+        if (dtype == HGR_BF16) hipLaunchKernelGGL((vit_embed_ln<NVV, HGR_BF16, true>), dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, patches, class_embedding, positional_embedding, gamma, beta, x, B, G, W, eps, x16, stats); \
+        else hipLaunchKernelGGL((vit_embed_ln<NVV, HGR_F16, true>), dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, patches, class_embedding, positional_embedding, gamma, beta, x, B, G, W, eps, x16, stats); } while (0)
+    const int nvl = (W / 4 + 63) / 64;
+    if (nvl <= 1) HGR_VE(1); else if (nvl <= 2) HGR_VE(2); else if (nvl <= 4) HGR_VE(4); else if (nvl <= 8) HGR_VE(8); else HGR_VE(16);
+#undef HGR_VE
+    HGR_CHECK_LAUNCH("hgr_vit_embed_ln_stats");
+    return HGR_OK;
+}
+
+extern "C" int hgr_row_stats16(const float *x, void *x16, float *stats, int rows, int W, int dtype, void *stream) {
+    HGR_REQUIRE(x && x16 && stats, "hgr_row_stats16: null operand");
+    HGR_REQUIRE(rows >= 1 && W >= 64 && W % 64 == 0, "hgr_row_stats16: rows=%d W=%d unsupported (W %% 64 == 0)", rows, W);
+    HGR_REQUIRE(hgr_aligned(x, 16) && hgr_aligned(x16, 8) && hgr_aligned(stats, 8), "hgr_row_stats16: misaligned operand");
+    HGR_REQUIRE(dtype == HGR_BF16 || dtype == HGR_F16, "hgr_row_stats16: bad dtype %d", dtype);
+    if (dtype == HGR_BF16) hipLaunchKernelGGL((row_stats16<HGR_BF16>), dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, x16, stats, rows, W);
+    else hipLaunchKernelGGL((row_stats16<HGR_F16>), dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, x16, stats, rows, W);
+    HGR_CHECK_LAUNCH("hgr_row_stats16");
     return HGR_OK;
 }

@@ -69,6 +69,61 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias: Optional[
     return out
 
 
+def _prof_begin():
+    if PROFILE is None:
+        return None
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    return ev0, ev1
+
+
+def _prof_end(ev, flops, byts, tag):
+    if ev is not None:
+        ev[1].record()
+        PROFILE.append(("gemm_nt", ev[0], ev[1], float(flops), float(byts), tag))
+
+
+def gemm_nt_res_stats(a: torch.Tensor, w: torch.Tensor, x: torch.Tensor, bias: torch.Tensor, x16: torch.Tensor, stats: torch.Tensor,
+                      tag: str = "") -> torch.Tensor:
+    """x += a @ w^T + bias (fp32, in place) and, for the LayerNorm that follows, x16 = 16-bit copy of the new x and
+    stats[m, slot] = (sum, sum of squares) of every 64-column slot of the new row (hgr_gemm_nt_res_stats)."""
+    m, k = a.shape
+    n = w.shape[0]
+    assert a.dtype == w.dtype == x16.dtype and x.dtype == torch.float32 and x.shape == (m, n) and x16.shape == (m, n)
+    assert stats.dtype == torch.float32 and stats.numel() >= m * (n // 64) * 2 and a.stride(1) == w.stride(1) == x.stride(1) == x16.stride(1) == 1
+    ev = _prof_begin()
+    _lib.call("hgr_gemm_nt_res_stats", _dev(a), a.stride(0), _dev(w), w.stride(0), _dev(x), x.stride(0), _dev(bias), _dev(x16), x16.stride(0),
+              _dev(stats), m, n, k, DT_OF[a.dtype], _stream())
+    _prof_end(ev, 2.0 * m * n * k, 2 * m * k + 2 * n * k + 8 * m * n + 2 * m * n, tag)
+    return x
+
+
+def gemm_nt_ln(x16: torch.Tensor, wfold: torch.Tensor, out: torch.Tensor, ln_s: torch.Tensor, ln_c: torch.Tensor, stats: torch.Tensor,
+               eps: float = 1e-5, quickgelu: bool = False, tag: str = "") -> torch.Tensor:
+    """out (16-bit) = act(LayerNorm(x) @ W^T + b) from the un-normalised 16-bit rows x16, the gamma-folded weight and the
+    row statistics of the producer (hgr_gemm_nt_ln; see include/hgr.h)."""
+    m, k = x16.shape
+    n = wfold.shape[0]
+    assert x16.dtype == wfold.dtype == out.dtype and out.shape[0] == m and out.shape[1] >= n and ln_s.numel() == n and ln_c.numel() == n
+    assert x16.stride(1) == wfold.stride(1) == out.stride(1) == 1 and stats.dtype == torch.float32 and stats.numel() >= m * (k // 64) * 2
+    ev = _prof_begin()
+    _lib.call("hgr_gemm_nt_ln", _dev(x16), x16.stride(0), _dev(wfold), wfold.stride(0), _dev(out), out.stride(0), _dev(ln_s), _dev(ln_c),
+              _dev(stats), float(eps), m, n, k, DT_OF[x16.dtype], 1 if quickgelu else 0, _stream())
+    _prof_end(ev, 2.0 * m * n * k, 2 * m * k + 2 * n * k + 2 * m * n, tag)
+    return out
+
+
+def vit_embed_ln_stats(patches, cls, pos, gamma, beta, x, x16, stats, b, g, eps=1e-5):
+    _lib.call("hgr_vit_embed_ln_stats", _dev(patches), _dev(cls), _dev(pos), _dev(gamma), _dev(beta), _dev(x), _dev(x16), _dev(stats),
+              b, g, x.shape[1], eps, DT_OF[x16.dtype], _stream())
+    return x
+
+
+def row_stats16(x: torch.Tensor, x16: torch.Tensor, stats: torch.Tensor) -> None:
+    assert x.dtype == torch.float32 and x.is_contiguous() and x16.is_contiguous() and x16.shape == x.shape and stats.numel() >= x.shape[0] * (x.shape[1] // 64) * 2
+    _lib.call("hgr_row_stats16", _dev(x), _dev(x16), _dev(stats), x.shape[0], x.shape[1], DT_OF[x16.dtype], _stream())
+
+
 def gemm_set_tile(tile: int) -> int:
     """Pin hgr_gemm_nt's tile plan (0 = cost model, 128, 256); returns the previous setting."""
     lib = _lib.load()

@@ -424,6 +424,32 @@ int hgr_adamw(float *p, const float *g, float *m, float *v, int64_t n, float lr,
               float wd, int step, const float *sumsq_total, float max_norm, float grad_scale, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * LayerNorm folded into the GEMMs around it.  A residual block of the reference is
+ *     x = x + attn(ln_1(x));  x = x + c_proj(QuickGELU(c_fc(ln_2(x))))          (clip/model.py:185-188, LayerNorm :153-159)
+ * i.e. every LayerNorm sits between a GEMM that PRODUCES its input row (out_proj / c_proj + residual add) and a GEMM that
+ * CONSUMES its output (in_proj / c_fc).  With
+ *     LN(x) W^T + b = rstd * ( x (gamma o W)^T - mean * s ) + c,    s_n = sum_k gamma_k W_nk,   c_n = sum_k beta_k W_nk + b_n
+ * the producer emits the new residual once more in 16 bit plus per-row partial (sum, sum of squares) per 64-column slot,
+ * and the consumer runs on the un-normalised 16-bit rows with the gamma-folded weight: the separate LayerNorm pass (118 MB
+ * of traffic per call at ViT-B/32 batch 512) disappears.  Error study: tools/studies/ln_fusion_study.py.
+ *   stats  fp32 [M][N/64][2]  (N = row width);  x16 16-bit [M, ldx16];  requirements: row width % 128 == 0.
+ * ------------------------------------------------------------------------------------------------ */
+/* X += A W^T + bias (fp32, in place: the residual add of clip/model.py:186-187), x16 = (16-bit) X, stats = slot partials of X */
+int hgr_gemm_nt_res_stats(const void *A, int64_t lda, const void *W, int64_t ldw, float *X, int64_t ldx, const float *bias,
+                          void *x16, int64_t ldx16, float *stats, int M, int N, int K, int dtype, void *stream);
+/* C (16-bit) = act( rstd_m (X16 Wfold^T - mean_m ln_s) + ln_c ), act: 0 none (ln_1 -> in_proj), 1 QuickGELU (ln_2 -> c_fc -> gelu);
+ * K = row width, mean / rstd from `stats` ([M][K/64][2], as written by the producers), eps of the LayerNorm */
+int hgr_gemm_nt_ln(const void *X16, int64_t ldx, const void *Wfold, int64_t ldw, void *C, int64_t ldc,
+                   const float *ln_s, const float *ln_c, const float *stats, float eps,
+                   int M, int N, int K, int dtype, int act, void *stream);
+/* hgr_vit_embed_ln that also emits the 16-bit copy and slot statistics of its output rows (input of the first block) */
+int hgr_vit_embed_ln_stats(const float *patches, const float *class_embedding, const float *positional_embedding,
+                           const float *gamma, const float *beta, float *x, void *x16, float *stats,
+                           int B, int G, int W, float eps, int dtype, void *stream);
+/* x fp32 [rows, W] -> x16 + slot statistics (text tower: embedding rows feed the first block) */
+int hgr_row_stats16(const float *x, void *x16, float *stats, int rows, int W, int dtype, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Data-parallel collectives over RCCL / xGMI (one process per GPU).  The reference has no distributed code (its only
  * mention is an unused DDP import, baseline/CLIP/clip_train.py:19); these serve the sharding this build adds:
  *   evaluation  - every rank text-encodes N/world prompts of update_classifier (model/clip_tree.py:318-325) and the

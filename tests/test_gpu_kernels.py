@@ -62,7 +62,7 @@ def test_gemm_epilogues(dt):
 
 
 @pytest.mark.parametrize("dt", DTS)
-@pytest.mark.parametrize("tile", [0, 128, 256])
+@pytest.mark.parametrize("tile", [0, 128, 256, 2])
 @pytest.mark.parametrize("m,n,k", [(4400, 4200, 256), (8192, 4224, 512), (5120, 3072, 320)])
 def test_gemm_many_tiles_exact(dt, tile, m, n, k):
     """More 256x256 tiles than CUs (several rounds of workgroups, edge tiles in both dimensions) under every tile
@@ -523,3 +523,90 @@ def test_eval_counters_vs_host_recount(seed):
         want[6] += (match[:-1] & match[1:]).sum() / (L - 1) if L > 1 else float(match[0])
         want[8] += 1
     assert np.allclose(acc.cpu().numpy(), 2 * want, rtol=0, atol=1e-9)
+
+
+# ---- LayerNorm folded into the GEMMs around it (hgr_gemm_nt_res_stats / hgr_gemm_nt_ln) ------------------------------------
+def _slot_stats(x):
+    m, n = x.shape
+    xs = x.double().view(m, n // 64, 64)
+    return torch.stack([xs.sum(-1), (xs * xs).sum(-1)], dim=-1).float()
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("m,n,k", [(512, 256, 128), (1000, 768, 768), (25600, 768, 768), (257, 128, 3072), (3, 1024, 192)])
+def test_gemm_nt_res_stats(dt, m, n, k):
+    """Producer of the folded LayerNorm: x += a w^T + b must equal hgr_gemm_nt's residual epilogue BIT FOR BIT (same K
+    order), x16 must be the rounded new x, the slot statistics the (sum, sum of squares) of every 64-column slot of the
+    new rows (fp32 sums of <= 64 terms + a fixed-order DPP reduction: compared with fp64 at 1e-5 relative); ragged M."""
+    a, w = _rand((m, k), 11).to(dt).to(DEV), _rand((n, k), 12, 0.1).to(dt).to(DEV)
+    bias, x0 = _rand((n,), 13).to(DEV), _rand((m, n), 14, 2.0).to(DEV)
+    want = x0.clone()
+    ops.gemm_nt(a, w, want, bias=bias, residual=want, epilogue=EPI_BIAS_RESIDUAL)
+    x = x0.clone()
+    x16 = torch.full((m, n), 7.0, dtype=dt, device=DEV)
+    stats = torch.full((m, n // 64, 2), -1.0, dtype=torch.float32, device=DEV)
+    ops.gemm_nt_res_stats(a, w, x, bias, x16, stats)
+    assert torch.equal(x, want)
+    assert torch.equal(x16, want.to(dt))
+    ref = _slot_stats(want.cpu())
+    got = stats.cpu()
+    assert torch.allclose(got[..., 0], ref[..., 0], rtol=1e-5, atol=1e-4)
+    assert torch.allclose(got[..., 1], ref[..., 1], rtol=1e-5, atol=1e-4)
+    again = torch.empty_like(stats)
+    x2 = x0.clone()
+    ops.gemm_nt_res_stats(a, w, x2, bias, torch.empty_like(x16), again)
+    assert torch.equal(again, stats) and torch.equal(x2, x)          # bit-deterministic
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("gelu", [False, True])
+@pytest.mark.parametrize("m,n,k", [(512, 384, 128), (1000, 2304, 768), (25600, 3072, 768), (300, 128, 1024)])
+def test_gemm_nt_ln(dt, gelu, m, n, k):
+    """Consumer of the folded LayerNorm against fp32 LayerNorm -> Linear (clip/model.py:153-159 feeding :171 / :177-180),
+    rows with a non-zero mean and unequal scales; tolerance = the 16-bit rounding of the operands, as for the unfused path,
+    and the two paths are compared with each other too."""
+    x = (_rand((m, k), 21, 1.5) + 0.3 * _rand((m, 1), 22) + 0.2)
+    x = x * (0.5 + torch.rand(m, 1, generator=torch.Generator().manual_seed(3)))
+    w, b = _rand((n, k), 23, 0.05), _rand((n,), 24)
+    gamma, beta = 1.0 + 0.2 * _rand((k,), 25), 0.1 * _rand((k,), 26)
+    ref = torch.nn.functional.layer_norm(x, (k,), gamma, beta, 1e-5) @ w.t() + b
+    if gelu:
+        ref = clip_ref.quick_gelu(ref)
+    xd = x.to(DEV)
+    x16 = torch.empty(m, k, dtype=dt, device=DEV)
+    stats = torch.empty(m, k // 64, 2, dtype=torch.float32, device=DEV)
+    ops.row_stats16(xd, x16, stats)
+    assert torch.equal(x16, xd.to(dt))
+    st = _slot_stats(x)
+    assert torch.allclose(stats.cpu(), st, rtol=1e-5, atol=1e-4)
+    wf = (w * gamma[None, :]).to(dt)
+    s = wf.float().sum(1).to(DEV)
+    c = (w @ beta + b).to(DEV)
+    out = torch.full((m, n), 7.0, dtype=dt, device=DEV)
+    ops.gemm_nt_ln(x16, wf.to(DEV), out, s, c, stats, 1e-5, quickgelu=gelu)
+    tol = dict(rtol=2e-2, atol=3e-2) if dt == torch.bfloat16 else dict(rtol=3e-3, atol=4e-3)
+    assert torch.allclose(out.float().cpu(), ref, **tol), float((out.float().cpu() - ref).abs().max())
+    # the unfused path on the same data: LayerNorm kernel -> GEMM with bias (+ QuickGELU)
+    h16 = torch.empty(m, k, dtype=dt, device=DEV)
+    ops.layernorm(xd, gamma.to(DEV), beta.to(DEV), h16)
+    out2 = torch.empty(m, n, dtype=dt, device=DEV)
+    ops.gemm_nt(h16, w.to(dt).to(DEV), out2, bias=b.to(DEV), epilogue=EPI_BIAS_QUICKGELU if gelu else EPI_BIAS)
+    e_fused = float((out.float().cpu() - ref).abs().max())
+    e_plain = float((out2.float().cpu() - ref).abs().max())
+    assert e_fused < 2.0 * e_plain + 1e-3, (e_fused, e_plain)          # folding does not cost accuracy
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_vit_embed_ln_stats_equals_unfused(dt):
+    b, g, w = 5, 49, 768
+    pe = _rand((b * g, w), 31).to(DEV)
+    cls, pos = _rand((w,), 32).to(DEV), _rand((g + 1, w), 33).to(DEV)
+    gamma, beta = (1.0 + 0.1 * _rand((w,), 34)).to(DEV), (0.1 * _rand((w,), 35)).to(DEV)
+    x1 = torch.empty(b * (g + 1), w, device=DEV)
+    ops.vit_embed_ln(pe, cls, pos, gamma, beta, x1, b, g)
+    x2 = torch.empty_like(x1)
+    x16 = torch.empty(b * (g + 1), w, dtype=dt, device=DEV)
+    stats = torch.empty(b * (g + 1), w // 64, 2, device=DEV)
+    ops.vit_embed_ln_stats(pe, cls, pos, gamma, beta, x2, x16, stats, b, g)
+    assert torch.equal(x1, x2) and torch.equal(x16, x1.to(dt))
+    assert torch.allclose(stats.cpu(), _slot_stats(x1.cpu()), rtol=1e-5, atol=1e-4)
