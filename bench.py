@@ -126,6 +126,93 @@ def cpu_baseline(sd, zsl_cpu, arch="ViT-B/32"):
     return out
 
 
+def tower_forward_flops(cfg, n_img: int, n_txt: int, l_txt: int) -> float:
+    """Algorithmic forward FLOPs (2 x MAC, attention included) of `n_img` images and `n_txt` prompts of `l_txt` tokens:
+    per token and layer 24 W^2 (qkv, out, fc, proj) + 4 L W (q k^T and p v), plus patch embedding and the projections
+    (ModifiedResNet towers: the survey's measured per-image figure)."""
+    wt, d = cfg["transformer_width"], cfg["embed_dim"]
+    txt = n_txt * (l_txt * cfg["transformer_layers"] * (24.0 * wt * wt + 4.0 * l_txt * wt) + 2.0 * wt * d)
+    if cfg["vision_patch_size"]:
+        w, ps = cfg["vision_width"], cfg["vision_patch_size"]
+        g = cfg["image_resolution"] // ps
+        L = g * g + 1
+        img = n_img * (L * cfg["vision_layers"] * (24.0 * w * w + 4.0 * L * w) + 2.0 * g * g * 3 * ps * ps * w + 2.0 * w * d)
+    else:
+        img = n_img * {"RN50": 12.22e9, "RN101": 19.6e9}.get("RN50" if cfg["vision_layers"] == (3, 4, 6, 3) else "RN101", 12.22e9)
+    return img + txt
+
+
+def train_mode(a, model, cfg, h, rank, world, group, ranks_seen, dev, real_stdout):
+    """`--mode train`: one step = one OM training step of the reference's loop (main.py:79-94 around
+    model/clip_tree.py:222-281): zero_grad, train_batch('OM', 'topk') on ONE single-class batch sharded over the ranks
+    (SURVEY H7), gradient all-reduce, clip_grad_norm_(1.0) + AdamW as fused kernels.  BASELINE configs[4] =
+    `--arch ViT-L/14 --n-ctx 16 --train-dtype bf16`.  Reports images/sec and the achieved rate over 3 x the forward FLOPs
+    the step executes (each distinct prompt of the K x M inner steps is encoded once: identical arithmetic, fewer passes)."""
+    import random
+    from hgr_net_amd import synth
+    from hgr_net_amd.training import FusedAdamW
+    params = [p for n, p in model.named_parameters() if p.requires_grad and n != "layer_weight"]
+    opt = FusedAdamW(params, lr=3e-7, weight_decay=0.0, max_norm=1.0)
+    img = synth.images(a.batch * world, cfg["image_resolution"], 1234)[rank * a.batch: (rank + 1) * a.batch].to(dev)
+    target = max(model.train_index.tolist(), key=lambda i: (len(model.c2p[i]), -i))     # a deepest class: the longest OM schedule
+    tg = torch.full((a.batch,), target, dtype=torch.long, device=dev)
+    random.seed(0)                                                                     # identical negatives on every rank
+
+    def step():
+        opt.zero_grad()
+        loss = model.train_batch(img, tg, "OM", "topk")
+        if group is not None:
+            opt.allreduce(group)
+        opt.step()
+        return loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if group is not None:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    loss0 = None
+    for _ in range(a.warmup):
+        loss0 = step()
+    fence()
+    torch.cuda.reset_peak_memory_stats()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    picks = model._trainer.last_contra
+    uniq = len({i for ids, _ in picks for i in ids})
+    l_txt = int(model.node_tokens[:, :].argmax(dim=-1).max().item()) + 1
+    fl = 3.0 * tower_forward_flops(cfg, a.batch, uniq, l_txt)
+    ms = elapsed / a.steps * 1e3
+    if rank == 0:
+        line = {"metric": "images/sec, OM training step (model/clip_tree.py:222-281 + clip/AdamW, main.py:79-94)",
+                "value": round(a.batch * world * a.steps / elapsed, 1), "unit": "images/sec", "n_gpus": world, "ranks_seen": ranks_seen,
+                "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": a.train_dtype, "data": "synthetic",
+                "config": {"workload": f"{a.arch} OM training step, {a.n_ctx} CoOp context vectors, N={a.nodes} nodes, depth-{len(model.c2p[target])} class: "
+                                       f"{len(picks)} inner steps x <= 257 prompts ({uniq} distinct, {l_txt} tokens), batch {a.batch}/GPU",
+                           "global_batch": a.batch * world, "parallelism": f"dp{world}", "weights": "random-init (hash-seeded)"},
+                "roofline": {"kernel": "whole step (forward + backward GEMMs of both towers)", "bound": "mfma", "achieved": round(fl / (ms * 1e-3) / 1e12, 1),
+                             "peak": PEAK_TFLOPS_BF16, "unit": "TFLOP/s", "frac": round(fl / (ms * 1e-3) / 1e12 / PEAK_TFLOPS_BF16, 4), "traffic": None,
+                             "flops_per_step": fl, "note": "3 x forward FLOPs of the executed passes (per rank)"},
+                "cpu_baseline": None, "loss_first": loss0, "loss_last": loss,
+                "peak_memory_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
+    if group is not None:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
 def main():
     global np, torch                                  # imported after the launcher decision (the parent never loads torch)
     ap = argparse.ArgumentParser()
@@ -195,14 +282,19 @@ def main():
     h = build_hierarchy(edges)
     n_test = int(round(a.nodes * 13442 / 20842))                 # seen/unseen proportion of BASELINE configs[2]
     splits = synth.make_splits(h.nodes, [len(c) == 0 for c in h.p2c], a.nodes - n_test, n_test, 13)
-    tokens = synth.make_tokens(a.nodes, 11, cfg["vocab_size"])
+    tokens = synth.make_tokens(a.nodes, 11, cfg["vocab_size"], n_ctx=a.n_ctx if a.mode == "train" else 0)
     tmp = tempfile.mkdtemp(prefix="hgr_bench_")
     gp = os.path.join(tmp, "graph.json")
     json.dump(edges, open(gp, "w"))
     opts = types.SimpleNamespace(device=dev, folder=tmp, exp_name="HGR", weights="equal", out_ratio=0.25, in_ratio=0.5,
-                                 from_epoch=-1, graph_path=gp, arch=a.arch, fetch=False, load=False, load_path="none", scale=1.0)
+                                 from_epoch=-1, graph_path=gp, arch=a.arch, fetch=False, load=False, load_path="none", scale=1.0,
+                                 num_compare=256, k=1, sample_strategy="topk", weighting="both", train_dtype=a.train_dtype,
+                                 n_ctx=a.n_ctx if a.mode == "train" else 0)
     clip_model = build_model(sd, image_dtype=a.image_dtype, text_dtype=a.text_dtype).to(dev)
     model = tree_model(opts, splits["all"], splits["rest"], node_tokens=tokens, clip_model=clip_model)
+    if a.mode == "train":
+        train_mode(a, model, cfg, h, rank, world, group, ranks_seen, dev, real_stdout)
+        return
     # synthetic single-class batches (every batch is one group), resident in HBM
     base = synth.images(a.batch, cfg["image_resolution"], 1234 + rank).to(dev)
     batches = [base, base.flip(0).contiguous()]

@@ -57,6 +57,7 @@ struct GemmArgs {
     float *ln_stats; int ln_slots; float ln_eps;
     void *ln_x16; int64_t ln_ldx16;
     const float *ln_s, *ln_c;
+    int group;       // gemm_nt_duo: row (or column) panels per raster group (HGR_GEMM_GROUP, default 4)
 };
 
 // 16 zero bytes every out-of-bounds conv tap (and the K padding) is loaded from
@@ -808,6 +809,12 @@ __global__ __launch_bounds__(NT256) void gemm_nt_256(GemmArgs p) {
 constexpr int NTD = 256;
 constexpr int DUO_A0 = 0, DUO_A1 = 32768, DUO_W0 = 65536, DUO_W1 = 73728, DUO_LDS = 81920;
 
+// 16-byte store that does not keep the line in the XCD's L2 (sc1: write-through, line dropped): a tile's output is never
+// re-read by this launch, and 64 tiles in flight per XCD write as many bytes as the L2 holds (experiment: HGR_GEMM_DBG=8)
+__device__ __forceinline__ void store16_sc1(void *ptr, u32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
+}
+
 template <int DT, int EPI, bool OUT32, int LN = 0>
 __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
     typedef typename T16<DT>::vec8 vec8;
@@ -830,7 +837,7 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
     const int orig = blockIdx.x;
     const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
     const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-    constexpr int GROUP = 4;      // 64 tiles in flight per XCD = 4 row panels of 256 x 16 column panels of 128
+    const int GROUP = p.group;    // default 4: 64 tiles in flight per XCD = 4 row panels of 256 x 16 column panels of 128
     int tm, tn;
     if (p.m_fastest) {
         const int per = GROUP * p.tiles_m, grp = wg / per, first = grp * GROUP;
@@ -887,17 +894,17 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[a][b][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // LN consumer: thread t finalises the statistics of tile row t (the producer's per-slot partial sums) BEFORE any LDS-DMA
-    // is in flight (a waited ordinary load drains the DMA queue), and carries (mean, rstd) in two registers to the epilogue
-    float ln_mean = 0.f, ln_rstd = 0.f;
-    if (LN == 2) {
+    // LN consumer: thread t finalises the statistics of tile row t from the producer's per-slot partial sums.  Called in the
+    // epilogue, where its loads travel together with the bias / ln_s / ln_c loads (one exposed round trip per tile, covered
+    // by the partner workgroup); at kernel entry it would delay the first LDS-DMA by a memory round trip.
+    auto ln_row_stats = [&]() {
         const f32x4 *sp = (const f32x4 *)(p.ln_stats + (int64_t)min(m0 + tid, p.M - 1) * p.ln_slots * 2);
         float s1 = 0.f, s2 = 0.f;
         for (int i = 0; i < p.ln_slots / 2; ++i) { const f32x4 t = sp[i]; s1 += t[0] + t[2]; s2 += t[1] + t[3]; }
         const float inv = 1.0f / (float)p.K;
-        ln_mean = s1 * inv;
-        ln_rstd = rsqrtf(fmaxf(s2 * inv - ln_mean * ln_mean, 0.f) + p.ln_eps);
-    }
+        const float mean = s1 * inv;
+        return make_float2(mean, rsqrtf(fmaxf(s2 * inv - mean * mean, 0.f) + p.ln_eps));
+    };
     const int nk = p.K / 64;    // >= 2 (host guarantees)
     // prologue in steady-state order: A0(0), A1(0), W0(0), W1(0), A0(1)
     issueA(oA0, DUO_A0, 0, 0); issueA(oA0, DUO_A0, 0, 1);
@@ -1007,7 +1014,7 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
             }
         float2 *lnrow = (float2 *)(smem + 4 * 128 * RS);      // 256 x (mean, rstd) behind the four staging slices
         if (LN == 2) {
-            lnrow[tid] = make_float2(ln_mean, ln_rstd);
+            lnrow[tid] = ln_row_stats();
             __syncthreads();
         }
 #pragma unroll
@@ -1038,6 +1045,11 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
         }
         const int ch = lane & 7, rr = lane >> 3;
         E *dst0 = (E *)p.C + (int64_t)(m0 + wm * 128 + rr) * p.ldc + n0 + wn * 64 + ch * 8;
+        if (p.dbg & 8) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) store16_sc1(dst0 + (int64_t)q * 8 * p.ldc, *(const u32x4 *)(my + (q * 8 + rr) * RS + ch * 16));
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < 16; ++q)
             *(u32x4 *)(dst0 + (int64_t)q * 8 * p.ldc) = *(const u32x4 *)(my + (q * 8 + rr) * RS + ch * 16);
@@ -1076,19 +1088,44 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
                 *(f32x4 *)(my + (i2 * 16 + r) * RS + (b * 32 + j * 16 + g * 4) * 4) = acc[a][b][ih * 2 + i2][j] + bq[b][j];
+            f32x4 vq[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                f32x4 v = *(const f32x4 *)(my + (q * 4 + rq) * RS + cq * 16);
-                if (HAS_ADD) v += ad[q];
-                const int64_t row = row0 + q * 4 + rq;
-                *(f32x4 *)((float *)p.C + row * p.ldc + n0 + wn * 64 + cq * 4) = v;
-                if (LN == 1) {
-                    // the new residual once more in 16 bit (the next GEMM's A operand: 16 lanes = one 128-byte line per row)
-                    // and this wave's 64-column share of the row's LayerNorm statistics
-                    *(typename T16<DT>::vec4 *)((E *)p.ln_x16 + row * p.ln_ldx16 + n0 + wn * 64 + cq * 4) = cvt4<DT>(v[0], v[1], v[2], v[3]);
-                    const float s1 = row16_sum((v[0] + v[1]) + (v[2] + v[3]));
-                    const float s2 = row16_sum((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]));
-                    if (cq == 0) *(float2 *)(p.ln_stats + (row * p.ln_slots + (n0 >> 6) + wn) * 2) = make_float2(s1, s2);
+                vq[q] = *(const f32x4 *)(my + (q * 4 + rq) * RS + cq * 16);
+                if (HAS_ADD) vq[q] += ad[q];
+            }
+            if (p.dbg & 8) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    store16_sc1((float *)p.C + (int64_t)(row0 + q * 4 + rq) * p.ldc + n0 + wn * 64 + cq * 4, __builtin_bit_cast(u32x4, vq[q]));
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    *(f32x4 *)((float *)p.C + (int64_t)(row0 + q * 4 + rq) * p.ldc + n0 + wn * 64 + cq * 4) = vq[q];
+            }
+            if (LN == 1) {
+                // the new residual once more in 16 bit (the next GEMM's A operand: 16 lanes = one 128-byte line per row) and
+                // this wave's 64-column share of the rows' LayerNorm statistics.  The 16 reduction chains of the pass (8 row
+                // groups x {sum, sum of squares}) advance stage by stage, so the DPP latencies overlap.
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    *(typename T16<DT>::vec4 *)((E *)p.ln_x16 + (int64_t)(row0 + q * 4 + rq) * p.ln_ldx16 + n0 + wn * 64 + cq * 4) =
+                        cvt4<DT>(vq[q][0], vq[q][1], vq[q][2], vq[q][3]);
+                float s1[8], s2[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    s1[q] = (vq[q][0] + vq[q][1]) + (vq[q][2] + vq[q][3]);
+                    s2[q] = (vq[q][0] * vq[q][0] + vq[q][1] * vq[q][1]) + (vq[q][2] * vq[q][2] + vq[q][3] * vq[q][3]);
+                }
+#define HGR_DPP_STAGE(CTRL) _Pragma("unroll") for (int q = 0; q < 8; ++q) { \
+                    s1[q] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1[q]), CTRL, 0xF, 0xF, true)); \
+                    s2[q] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s2[q]), CTRL, 0xF, 0xF, true)); }
+                HGR_DPP_STAGE(0xB1) HGR_DPP_STAGE(0x4E) HGR_DPP_STAGE(0x141) HGR_DPP_STAGE(0x140)
+#undef HGR_DPP_STAGE
+                if (cq == 0) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        *(float2 *)(p.ln_stats + ((int64_t)(row0 + q * 4 + rq) * p.ln_slots + (n0 >> 6) + wn) * 2) = make_float2(s1[q], s2[q]);
                 }
             }
         }
@@ -1097,7 +1134,7 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
     if (LN == 2) {
         // edge tile of an LN consumer (rows beyond M; N is a multiple of 128 by the host's contract): same arithmetic, guarded rows
         float2 *lnrow = (float2 *)smem;
-        lnrow[tid] = make_float2(ln_mean, ln_rstd);
+        lnrow[tid] = ln_row_stats();
         __syncthreads();
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -1219,6 +1256,18 @@ void launch_duo(const GemmArgs &a, int epi, bool out32, dim3 grid, hipStream_t s
 #undef HGR_DUO
 }
 
+// development knobs of gemm_nt_duo, read once: HGR_GEMM_GROUP (raster group, default 4), HGR_GEMM_DBG (bit 8: sc1 output stores)
+int duo_group() {
+    static int g = -1;
+    if (g < 0) { const char *e = getenv("HGR_GEMM_GROUP"); g = e ? atoi(e) : 4; if (g < 1) g = 4; }
+    return g;
+}
+int duo_dbg() {
+    static int d = -1;
+    if (d < 0) { const char *e = getenv("HGR_GEMM_DBG"); d = e ? atoi(e) : 0; }
+    return d;
+}
+
 // tile plan override (hgr_gemm_set_tile); HGR_GEMM_TILE=128|256|2 sets the initial value
 int g_force_tile = -1;
 int hgr_gemm_force_tile() {
@@ -1325,7 +1374,7 @@ extern "C" int hgr_gemm_nt(const void *A, int64_t lda, const void *W, int64_t ld
         a.res = (const float *)residual; a.ldr = ldr; a.M = M; a.N = N; a.K = K;
         a.tiles_m = (M + 255) / 256; a.tiles_n = (N + 127) / 128;
         a.m_fastest = ((int64_t)N * K > (int64_t)M * K) ? 1 : 0;
-        a.vec_ok = vec ? 1 : 0; a.dbg = dbg; a.kc = 0; a.csplit = 0;
+        a.vec_ok = vec ? 1 : 0; a.dbg = dbg; a.kc = 0; a.csplit = 0; a.group = duo_group();
         dim3 grid((unsigned)(a.tiles_m * a.tiles_n));
         if (dtype == HGR_BF16) launch_duo<HGR_BF16>(a, epilogue, out_f32 != 0, grid, s);
         else launch_duo<HGR_F16>(a, epilogue, out_f32 != 0, grid, s);
@@ -1464,7 +1513,7 @@ int ln_common_checks(const char *who, const void *A, int64_t lda, const void *W,
 void ln_args(GemmArgs &a, const void *A, int64_t lda, const void *W, int64_t ldw, void *C, int64_t ldc, int M, int N, int K) {
     a.A = (const char *)A; a.lda = lda; a.W = (const char *)W; a.ldw = ldw; a.C = C; a.ldc = ldc; a.bias = nullptr; a.res = nullptr; a.ldr = 0;
     a.M = M; a.N = N; a.K = K; a.tiles_m = (M + 255) / 256; a.tiles_n = N / 128;
-    a.m_fastest = ((int64_t)N * K > (int64_t)M * K) ? 1 : 0; a.vec_ok = 1; a.dbg = 0; a.kc = 0; a.csplit = 0;
+    a.m_fastest = ((int64_t)N * K > (int64_t)M * K) ? 1 : 0; a.vec_ok = 1; a.dbg = duo_dbg(); a.kc = 0; a.csplit = 0; a.group = duo_group();
     a.cH = a.cW = a.cC = a.cStride = a.cHo = a.cWo = 0; a.cMagic = 0;
     a.ln_stats = nullptr; a.ln_slots = 0; a.ln_eps = 0.f; a.ln_x16 = nullptr; a.ln_ldx16 = 0; a.ln_s = a.ln_c = nullptr;
 }
