@@ -1043,16 +1043,20 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
             *(typename T16<DT>::vec4 *)(my + (a * 64 + i * 16 + r) * RS + (b * 32 + j * 16 + g * 4) * 2) = cvt4<DT>(v[0], v[1], v[2], v[3]);
         }
         }
+        // addresses = wave-uniform 64-bit base + 32-bit per-lane byte offset (one VALU add per store; a 64-bit row * ldc product
+        // per access costs ~6 VALU instructions, and this epilogue competes with the partner workgroup for issue slots)
         const int ch = lane & 7, rr = lane >> 3;
-        E *dst0 = (E *)p.C + (int64_t)(m0 + wm * 128 + rr) * p.ldc + n0 + wn * 64 + ch * 8;
+        char *cw = (char *)p.C + ((int64_t)(m0 + wm * 128) * p.ldc + n0 + wn * 64) * 2;
+        const unsigned ldcB = (unsigned)p.ldc * 2u;
+        const unsigned cl = (unsigned)rr * ldcB + ch * 16;
         if (p.dbg & 8) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) store16_sc1(dst0 + (int64_t)q * 8 * p.ldc, *(const u32x4 *)(my + (q * 8 + rr) * RS + ch * 16));
+            for (int q = 0; q < 16; ++q) store16_sc1(cw + (cl + q * 8 * ldcB), *(const u32x4 *)(my + (q * 8 + rr) * RS + ch * 16));
             return;
         }
 #pragma unroll
         for (int q = 0; q < 16; ++q)
-            *(u32x4 *)(dst0 + (int64_t)q * 8 * p.ldc) = *(const u32x4 *)(my + (q * 8 + rr) * RS + ch * 16);
+            *(u32x4 *)(cw + (cl + q * 8 * ldcB)) = *(const u32x4 *)(my + (q * 8 + rr) * RS + ch * 16);
         return;
     }
     if (full && OUT32 && (EPI == HGR_EPI_NONE || EPI == HGR_EPI_BIAS || HAS_ADD) && (p.ldc & 3) == 0 && (!HAS_ADD || EPI == HGR_EPI_ACCUM || (p.ldr & 3) == 0)) {
@@ -1069,17 +1073,26 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
             for (int j = 0; j < 2; ++j)
                 bq[b][j] = HAS_BIAS ? *(const f32x4 *)(p.bias + n0 + wn * 64 + b * 32 + j * 16 + g * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
         const int rq = lane >> 4, cq = lane & 15;           // row-in-group and 16-byte column chunk of this lane on the way out
+        // every global address below = wave-uniform 64-bit base + 32-bit per-lane byte offset (see the 16-bit epilogue)
         const float *addp = EPI == HGR_EPI_ACCUM ? (const float *)p.C : p.res;
         const int64_t ldadd = EPI == HGR_EPI_ACCUM ? p.ldc : p.ldr;
+        const int64_t wrow = m0 + wm * 128, wcol = n0 + wn * 64;
+        char *cw = (char *)p.C + (wrow * p.ldc + wcol) * 4;
+        const char *aw = (const char *)addp + (wrow * ldadd + wcol) * 4;
+        char *xw = LN == 1 ? (char *)p.ln_x16 + (wrow * p.ln_ldx16 + wcol) * 2 : nullptr;
+        char *sw = LN == 1 ? (char *)(p.ln_stats + (wrow * p.ln_slots + (n0 >> 6) + wn) * 2) : nullptr;
+        const unsigned ldcB = (unsigned)p.ldc * 4u, ldaB = (unsigned)ldadd * 4u, ldxB = LN == 1 ? (unsigned)p.ln_ldx16 * 2u : 0u;
+        const unsigned ldsB = LN == 1 ? (unsigned)p.ln_slots * 8u : 0u;
+        const unsigned cl = rq * ldcB + cq * 16, al = rq * ldaB + cq * 16, xl = rq * ldxB + cq * 8, sl = rq * ldsB;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int ih = 0; ih < 2; ++ih) {
-            const int row0 = m0 + wm * 128 + a * 64 + ih * 32;
+            const int rl = a * 64 + ih * 32;                 // first row of the pass inside the wave's 128 rows
             f32x4 ad[8];
             if (HAS_ADD) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) ad[q] = *(const f32x4 *)(addp + (int64_t)(row0 + q * 4 + rq) * ldadd + n0 + wn * 64 + cq * 4);
+                for (int q = 0; q < 8; ++q) ad[q] = *(const f32x4 *)(aw + (al + (rl + q * 4) * ldaB));
             }
 #pragma unroll
             for (int i2 = 0; i2 < 2; ++i2)
@@ -1096,12 +1109,10 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
             }
             if (p.dbg & 8) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    store16_sc1((float *)p.C + (int64_t)(row0 + q * 4 + rq) * p.ldc + n0 + wn * 64 + cq * 4, __builtin_bit_cast(u32x4, vq[q]));
+                for (int q = 0; q < 8; ++q) store16_sc1(cw + (cl + (rl + q * 4) * ldcB), __builtin_bit_cast(u32x4, vq[q]));
             } else {
 #pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    *(f32x4 *)((float *)p.C + (int64_t)(row0 + q * 4 + rq) * p.ldc + n0 + wn * 64 + cq * 4) = vq[q];
+                for (int q = 0; q < 8; ++q) *(f32x4 *)(cw + (cl + (rl + q * 4) * ldcB)) = vq[q];
             }
             if (LN == 1) {
                 // the new residual once more in 16 bit (the next GEMM's A operand: 16 lanes = one 128-byte line per row) and
@@ -1109,8 +1120,7 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
                 // groups x {sum, sum of squares}) advance stage by stage, so the DPP latencies overlap.
 #pragma unroll
                 for (int q = 0; q < 8; ++q)
-                    *(typename T16<DT>::vec4 *)((E *)p.ln_x16 + (int64_t)(row0 + q * 4 + rq) * p.ln_ldx16 + n0 + wn * 64 + cq * 4) =
-                        cvt4<DT>(vq[q][0], vq[q][1], vq[q][2], vq[q][3]);
+                    *(typename T16<DT>::vec4 *)(xw + (xl + (rl + q * 4) * ldxB)) = cvt4<DT>(vq[q][0], vq[q][1], vq[q][2], vq[q][3]);
                 float s1[8], s2[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
@@ -1124,8 +1134,7 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
 #undef HGR_DPP_STAGE
                 if (cq == 0) {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q)
-                        *(float2 *)(p.ln_stats + ((int64_t)(row0 + q * 4 + rq) * p.ln_slots + (n0 >> 6) + wn) * 2) = make_float2(s1[q], s2[q]);
+                    for (int q = 0; q < 8; ++q) *(float2 *)(sw + (sl + (rl + q * 4) * ldsB)) = make_float2(s1[q], s2[q]);
                 }
             }
         }
@@ -1367,7 +1376,7 @@ extern "C" int hgr_gemm_nt(const void *A, int64_t lda, const void *W, int64_t ld
     }
     // 256 x 128 tiles, two workgroups per CU (gemm_nt_duo): fp32 residual / 16-bit epilogues of the transformer towers
     const bool duo_ok = K >= 128 && epilogue != HGR_EPI_BIAS_ADD16_RELU && (out_f32 || (epilogue != HGR_EPI_BIAS_RESIDUAL && epilogue != HGR_EPI_ACCUM)) &&
-                        (int64_t)M * lda * 2 < (1ll << 32) && (int64_t)N * ldw * 2 < (1ll << 32);
+                        (int64_t)M * lda * 2 < (1ll << 32) && (int64_t)N * ldw * 2 < (1ll << 32) && ldc < (1 << 20) && ldr < (1 << 20);
     auto launch_d = [&]() {
         GemmArgs a;
         a.A = (const char *)A; a.lda = lda; a.W = (const char *)W; a.ldw = ldw; a.C = C; a.ldc = ldc; a.bias = bias;
@@ -1506,7 +1515,7 @@ int ln_common_checks(const char *who, const void *A, int64_t lda, const void *W,
     HGR_REQUIRE(A && W, "%s: null operand", who);
     HGR_REQUIRE(M >= 1 && N >= 128 && N % 128 == 0 && K >= 128 && K % 64 == 0, "%s: bad shape M=%d N=%d K=%d (N %% 128 == 0, K %% 64 == 0, K >= 128)", who, M, N, K);
     HGR_REQUIRE(lda >= K && ldw >= K && lda % 8 == 0 && ldw % 8 == 0 && hgr_aligned(A, 16) && hgr_aligned(W, 16), "%s: operands must be 16-byte aligned with leading dimensions %% 8 == 0", who);
-    HGR_REQUIRE((int64_t)M * lda * 2 < (1ll << 32) && (int64_t)N * ldw * 2 < (1ll << 32), "%s: operands beyond 4 GB", who);
+    HGR_REQUIRE((int64_t)M * lda * 2 < (1ll << 32) && (int64_t)N * ldw * 2 < (1ll << 32) && N < (1 << 20), "%s: operands beyond 4 GB / N >= 2^20", who);
     HGR_REQUIRE(dtype == HGR_BF16 || dtype == HGR_F16, "%s: bad dtype %d", who, dtype);
     return HGR_OK;
 }
@@ -1525,6 +1534,7 @@ extern "C" int hgr_gemm_nt_res_stats(const void *A, int64_t lda, const void *W, 
     HGR_REQUIRE(X && bias && x16 && stats, "hgr_gemm_nt_res_stats: null X / bias / x16 / stats");
     HGR_REQUIRE(ldx >= N && ldx % 4 == 0 && hgr_aligned(X, 16) && hgr_aligned(bias, 16), "hgr_gemm_nt_res_stats: X / bias must be 16-byte aligned, ldx %% 4 == 0");
     HGR_REQUIRE(ldx16 >= N && ldx16 % 4 == 0 && hgr_aligned(x16, 8) && hgr_aligned(stats, 8), "hgr_gemm_nt_res_stats: x16 must be 8-byte aligned with ldx16 %% 4 == 0");
+    HGR_REQUIRE(ldx < (1 << 20) && ldx16 < (1 << 20), "hgr_gemm_nt_res_stats: leading dimensions must be below 2^20");
     GemmArgs a;
     ln_args(a, A, lda, W, ldw, X, ldx, M, N, K);
     a.bias = bias; a.res = X; a.ldr = ldx;
@@ -1542,7 +1552,7 @@ extern "C" int hgr_gemm_nt_ln(const void *X16, int64_t ldx, const void *Wfold, i
     if (int rc = ln_common_checks("hgr_gemm_nt_ln", X16, ldx, Wfold, ldw, M, N, K, dtype)) return rc;
     HGR_REQUIRE(C && ln_s && ln_c && stats, "hgr_gemm_nt_ln: null C / ln_s / ln_c / stats");
     HGR_REQUIRE(K % 128 == 0, "hgr_gemm_nt_ln: the row width K=%d must be a multiple of 128 (two 64-column statistic slots per 16-byte load)", K);
-    HGR_REQUIRE(ldc >= N && ldc % 8 == 0 && hgr_aligned(C, 16), "hgr_gemm_nt_ln: C must be 16-byte aligned with ldc %% 8 == 0");
+    HGR_REQUIRE(ldc >= N && ldc % 8 == 0 && ldc < (1 << 20) && hgr_aligned(C, 16), "hgr_gemm_nt_ln: C must be 16-byte aligned with ldc %% 8 == 0, ldc < 2^20");
     HGR_REQUIRE(hgr_aligned(ln_s, 16) && hgr_aligned(ln_c, 16) && hgr_aligned(stats, 16), "hgr_gemm_nt_ln: ln_s / ln_c / stats must be 16-byte aligned");
     HGR_REQUIRE(act == 0 || act == 1, "hgr_gemm_nt_ln: act must be 0 (none) or 1 (QuickGELU), got %d", act);
     GemmArgs a;
