@@ -900,7 +900,25 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
     auto ln_row_stats = [&]() {
         const f32x4 *sp = (const f32x4 *)(p.ln_stats + (int64_t)min(m0 + tid, p.M - 1) * p.ln_slots * 2);
         float s1 = 0.f, s2 = 0.f;
-        for (int i = 0; i < p.ln_slots / 2; ++i) { const f32x4 t = sp[i]; s1 += t[0] + t[2]; s2 += t[1] + t[3]; }
+        // the usual row widths get all their loads issued back to back (a load inside a run-time loop is waited for on the spot:
+        // six dependent L2 round trips for width 768)
+        auto fixed = [&](auto nq_tag) {
+            constexpr int NQ = decltype(nq_tag)::value;
+            f32x4 t[NQ];
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) t[i] = sp[i];
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) { s1 += t[i][0] + t[i][2]; s2 += t[i][1] + t[i][3]; }
+        };
+        switch (p.ln_slots) {
+            case 4: fixed(std::integral_constant<int, 2>()); break;      // width 256
+            case 8: fixed(std::integral_constant<int, 4>()); break;      // 512
+            case 10: fixed(std::integral_constant<int, 5>()); break;     // 640
+            case 12: fixed(std::integral_constant<int, 6>()); break;     // 768
+            case 16: fixed(std::integral_constant<int, 8>()); break;     // 1024
+            default:
+                for (int i = 0; i < p.ln_slots / 2; ++i) { const f32x4 t = sp[i]; s1 += t[0] + t[2]; s2 += t[1] + t[3]; }
+        }
         const float inv = 1.0f / (float)p.K;
         const float mean = s1 * inv;
         return make_float2(mean, rsqrtf(fmaxf(s2 * inv - mean * mean, 0.f) + p.ln_eps));
@@ -993,6 +1011,9 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
     ktile(nk - 2, std::integral_constant<int, 1>());
     ktile(nk - 1, std::integral_constant<int, 2>());
     HGR_MBAR();                 // every wave's LDS reads are done, no DMA in flight: the staging area is free
+    // the epilogue is VALU / LDS work next to the partner workgroup's MFMA clusters (priority 1): run it above them, or its
+    // instructions only get the issue slots the matrix stream leaves over (HGR_GEMM_DBG bit 16 = off, for A/B runs)
+    if (!(p.dbg & 16)) __builtin_amdgcn_s_setprio(3);
 
     // tile (a, b, i, j) of this lane holds C[m][n .. n+3],  m = m0 + wm*128 + a*64 + i*16 + r,  n = n0 + wn*64 + b*32 + j*16 + g*4
     constexpr bool HAS_BIAS = EPI != HGR_EPI_NONE && EPI != HGR_EPI_ACCUM;
