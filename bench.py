@@ -160,8 +160,14 @@ def train_mode(a, model, cfg, h, rank, world, group, ranks_seen, dev, real_stdou
 
     def step():
         opt.zero_grad()
+        tr = getattr(model, "_trainer", None)
+        if group is not None and tr is not None and tr.grad_ready_hook is None:
+            # overlapped: text-tower / head buckets are all-reduced while the image tower back-propagates
+            opt.set_late_params(model.clip_model.visual.parameters())
+            tr.grad_ready_hook = lambda part: opt.allreduce_part(part, group)
+        overlapped = group is not None and tr is not None
         loss = model.train_batch(img, tg, "OM", "topk")
-        if group is not None:
+        if group is not None and not overlapped:               # first step only: the trainer is built inside train_batch
             opt.allreduce(group)
         opt.step()
         return loss

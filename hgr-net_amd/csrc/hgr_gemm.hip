@@ -1139,9 +1139,12 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
                 // the new residual once more in 16 bit (the next GEMM's A operand: 16 lanes = one 128-byte line per row) and
                 // this wave's 64-column share of the rows' LayerNorm statistics.  The 16 reduction chains of the pass (8 row
                 // groups x {sum, sum of squares}) advance stage by stage, so the DPP latencies overlap.
+                if (!(p.dbg & 64)) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q)
                     *(typename T16<DT>::vec4 *)(xw + (xl + (rl + q * 4) * ldxB)) = cvt4<DT>(vq[q][0], vq[q][1], vq[q][2], vq[q][3]);
+                }
+                if (p.dbg & 32) continue;
                 float s1[8], s2[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {

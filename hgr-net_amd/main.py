@@ -108,9 +108,15 @@ def train(opts, epoch, model, train_loader, num_batches, optimizer, optimizer2, 
             optimizer.zero_grad()
             if optimizer2 is not None:
                 optimizer2.zero_grad()                    # layer_weight.grad follows the same rule as the CLIP gradients
+        if group is not None and getattr(model, "_trainer", None) is not None and model._trainer.grad_ready_hook is None:
+            # bucketed RCCL all-reduce on the flat gradient buffer, overlapped: the text-tower / head buckets go out while
+            # the image tower is still in its backward (the last thing train_batch does, clip_tree.py:280)
+            optimizer.set_late_params(model.clip_model.visual.parameters())
+            model._trainer.grad_ready_hook = lambda part: optimizer.allreduce_part(part, group)
+        overlapped = group is not None and getattr(model, "_trainer", None) is not None
         loss = model.train_batch(imgs, targets, opts.training_method, opts.sample_strategy)
-        if group is not None:
-            optimizer.allreduce(group)                    # bucketed RCCL all-reduce on the flat gradient buffer
+        if group is not None and not overlapped:          # first step: the trainer did not exist before train_batch built it
+            optimizer.allreduce(group)
             if optimizer2 is not None and model.layer_weight.grad is not None:
                 import torch.distributed as dist          # <= 13 floats: keep the ranks' layer weights identical
                 dist.all_reduce(model.layer_weight.grad, op=dist.ReduceOp.SUM, group=group)

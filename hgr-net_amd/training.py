@@ -311,6 +311,9 @@ class OMTrainer:
         # test hook: force the negative-class lists of the inner steps (list of (ids, label_pos)), else sample
         self.contra_override: Optional[Callable[[int], tuple]] = None
         self.last_contra: list = []
+        # data-parallel hook: called with "early" once every gradient except the image tower's is final (right before the
+        # image tower's backward, model/clip_tree.py:280) and with "late" at the end of the step
+        self.grad_ready_hook: Optional[Callable[[str], None]] = None
 
     def _head(self, img_n, dimg_n, tfeat, label_pos: int, weight, loss_acc, ce_out=None):
         """logits = img_n tn^T * exp(logit_scale); CE (all rows share the label); gradients of the three inputs."""
@@ -405,9 +408,13 @@ class OMTrainer:
                         w_out = tree.get_weights("equal" if wmode == "in" else "adaptive", st["K"])
                         ws.append(w_in[st["m_loop"]] * w_out[st["k_loop"]])
                 (torch.stack(ws) * ces.view(-1)).sum().backward()
+        if self.grad_ready_hook is not None:
+            self.grad_ready_hook("early")
         dfeat = torch.empty_like(feat)
         ops.l2norm_bwd(feat, dimg_n, dfeat)
         e.image_bwd(dfeat, isave)
+        if self.grad_ready_hook is not None:
+            self.grad_ready_hook("late")
         return float(loss_acc.item())
 
 
@@ -457,6 +464,45 @@ class FusedAdamW:
                     g.zero_()
                 p.grad = g
             off += (n + 63) // 64 * 64
+
+    def set_late_params(self, late_params) -> None:
+        """Mark the parameters whose gradients become final LAST in a step (the image tower: the reference's single
+        image-tower backward is the last thing train_batch does, model/clip_tree.py:280).  Everything else - text tower,
+        projections, logit_scale, CoOp context - is final before that backward starts, so its buckets can be all-reduced
+        while the image tower is still back-propagating (`allreduce_part`)."""
+        late = {id(p) for p in late_params}
+        early, lateb = [], []
+        off = 0
+        for p in self.params:
+            n = (p.numel() + 63) // 64 * 64
+            dst = lateb if id(p) in late else early
+            if dst and dst[-1][1] == off:
+                dst[-1][1] = off + n
+            else:
+                dst.append([off, off + n])
+            off += n
+        self._ranges = {"early": [tuple(r) for r in early], "late": [tuple(r) for r in lateb]}
+        self._works = []
+
+    def allreduce_part(self, part: str, group=None, bucket_bytes: int = 64 << 20) -> None:
+        """Overlapped gradient all-reduce: `part` = "early" right after the text tower's backward (asynchronous: the
+        collectives run on the communicator's stream beside the image tower's backward kernels), then "late" after the
+        image tower's backward, which also waits for everything.  Same result as `allreduce` (sum, 1/world folded into the
+        next step's grad_scale); bucketed views of the flat buffer, no packing."""
+        import torch.distributed as dist
+        if not hasattr(self, "_ranges"):
+            raise HgrError("FusedAdamW.allreduce_part: call set_late_params(image-tower parameters) first")
+        if part == "early":
+            self._relink()
+        step = max(1, bucket_bytes // 4)
+        for lo, hi in self._ranges[part]:
+            for b in range(lo, hi, step):
+                self._works.append(dist.all_reduce(self.gflat[b: min(hi, b + step)], op=dist.ReduceOp.SUM, group=group, async_op=True))
+        if part == "late":
+            for w in self._works:
+                w.wait()
+            self._works = []
+            self.grad_scale = 1.0 / dist.get_world_size(group)
 
     def allreduce(self, group=None, bucket_bytes: int = 64 << 20):
         """Sum the flat gradient buffer over the ranks, bucket by bucket (RCCL all-reduce on views, no packing);

@@ -138,6 +138,19 @@ parallel.allreduce_grads(ps, bucket_bytes=4096)
 for i, p in enumerate(ps):
     contrib = [0.0 if (i == 1 and r == 0) else float((r + 1) * (i + 1)) for r in range(world)]
     assert torch.allclose(p.grad, torch.full_like(p.data, sum(contrib) / world)), i
+# overlapped all-reduce of FusedAdamW (early = everything but the image tower, late = the image tower): same sums as allreduce()
+from hgr_net_amd.training import FusedAdamW
+qs = [torch.nn.Parameter(torch.zeros(s)) for s in ((70,), (3, 5), (129,), (64,), (10, 10))]
+opt = FusedAdamW(qs, lr=1e-3)
+for i, q in enumerate(qs):
+    q.grad.fill_(float((rank + 1) * (i + 1)))
+opt.set_late_params([qs[1], qs[2]])
+assert sum(h - l for l, h in opt._ranges["early"] + opt._ranges["late"]) == opt.gflat.numel()
+opt.allreduce_part("early", bucket_bytes=256)
+opt.allreduce_part("late", bucket_bytes=256)
+for i, q in enumerate(qs):
+    assert torch.equal(q.grad, torch.full_like(q.data, float(sum(r + 1 for r in range(world)) * (i + 1)))), i
+assert opt.grad_scale == 1.0 / world
 dist.barrier()
 if rank == 0: print("OK")
 dist.destroy_process_group()

@@ -80,12 +80,18 @@ else:
     names = [nm for nm, p in model.named_parameters() if p.requires_grad and nm != "layer_weight"]
     opt = FusedAdamW(params, lr=1e-6, max_norm=1.0)
     opt.zero_grad()
+    if group is not None:
+        # the product path of hgr_net_amd.main from the second step on: text-tower / head buckets are all-reduced (async) right
+        # before the image tower's backward, the image tower's buckets after it
+        from hgr_net_amd.training import OMTrainer
+        model._trainer = OMTrainer(model, opts.train_dtype)
+        opt.set_late_params(model.clip_model.visual.parameters())
+        model._trainer.grad_ready_hook = lambda part: opt.allreduce_part(part, group)
     random.seed(5)
     loss = model.train_batch(img[lo:hi].to(dev), torch.full((hi - lo,), target, dtype=torch.long, device=dev), "OM", "topk")
     loss_t = torch.tensor([loss], dtype=torch.float64, device=dev)
     if group is not None:
         import torch.distributed as dist
-        opt.allreduce(group)
         dist.all_reduce(loss_t)
         loss_t /= world
     torch.cuda.synchronize()
