@@ -1139,27 +1139,12 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
                 // the new residual once more in 16 bit (the next GEMM's A operand: 16 lanes = one 128-byte line per row) and
                 // this wave's 64-column share of the rows' LayerNorm statistics.  The 16 reduction chains of the pass (8 row
                 // groups x {sum, sum of squares}) advance stage by stage, so the DPP latencies overlap.
-                if (p.dbg & 128) {                       // A/B: the plain form, 8 bytes per lane
+                // (a 16-byte form - lane pairs exchanging a packed quad through DPP - was measured and is slower: 146 -> 155 us on
+                //  c_proj; the cost of this copy is its 39 MB of additional writes, not store issue: HGR_GEMM_DBG=64 skips it)
+                if (!(p.dbg & 64)) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q)
                         *(typename T16<DT>::vec4 *)(xw + (xl + (rl + q * 4) * ldxB)) = cvt4<DT>(vq[q][0], vq[q][1], vq[q][2], vq[q][3]);
-                } else if (!(p.dbg & 64)) {
-                    // 16-byte stores (the epilogue is store-ISSUE bound: 8-byte stores cost as much as 16-byte ones): lanes
-                    // (2c, 2c+1) exchange one packed quad through DPP, so the even lane holds 8 consecutive columns of row
-                    // group q and the odd lane 8 consecutive columns of row group q + 1
-                    const bool odd = cq & 1;
-#pragma unroll
-                    for (int q = 0; q < 8; q += 2) {
-                        const u32x2 qa = __builtin_bit_cast(u32x2, cvt4<DT>(vq[q][0], vq[q][1], vq[q][2], vq[q][3]));
-                        const u32x2 qb = __builtin_bit_cast(u32x2, cvt4<DT>(vq[q + 1][0], vq[q + 1][1], vq[q + 1][2], vq[q + 1][3]));
-                        const u32x2 keep = odd ? qb : qa, give = odd ? qa : qb;
-                        u32x2 recv;
-                        recv[0] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)give[0], 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]
-                        recv[1] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)give[1], 0xB1, 0xF, 0xF, true);
-                        const u32x4 o = odd ? (u32x4){recv[0], recv[1], keep[0], keep[1]} : (u32x4){keep[0], keep[1], recv[0], recv[1]};
-                        // even lane: row group q, columns 4 cq ..; odd lane: row group q + 1, columns 4 (cq - 1) ..
-                        *(u32x4 *)(xw + (xl - (odd ? 8u : 0u) + (rl + (q + (odd ? 1 : 0)) * 4) * ldxB)) = o;
-                    }
                 }
                 if (p.dbg & 32) continue;
                 float s1[8], s2[8];
@@ -1574,7 +1559,7 @@ extern "C" int hgr_gemm_nt_res_stats(const void *A, int64_t lda, const void *W, 
     if (int rc = ln_common_checks("hgr_gemm_nt_res_stats", A, lda, W, ldw, M, N, K, dtype)) return rc;
     HGR_REQUIRE(X && bias && x16 && stats, "hgr_gemm_nt_res_stats: null X / bias / x16 / stats");
     HGR_REQUIRE(ldx >= N && ldx % 4 == 0 && hgr_aligned(X, 16) && hgr_aligned(bias, 16), "hgr_gemm_nt_res_stats: X / bias must be 16-byte aligned, ldx %% 4 == 0");
-    HGR_REQUIRE(ldx16 >= N && ldx16 % 8 == 0 && hgr_aligned(x16, 16) && hgr_aligned(stats, 8), "hgr_gemm_nt_res_stats: x16 must be 16-byte aligned with ldx16 %% 8 == 0");
+    HGR_REQUIRE(ldx16 >= N && ldx16 % 4 == 0 && hgr_aligned(x16, 8) && hgr_aligned(stats, 8), "hgr_gemm_nt_res_stats: x16 must be 8-byte aligned with ldx16 %% 4 == 0");
     HGR_REQUIRE(ldx < (1 << 20) && ldx16 < (1 << 20), "hgr_gemm_nt_res_stats: leading dimensions must be below 2^20");
     GemmArgs a;
     ln_args(a, A, lda, W, ldw, X, ldx, M, N, K);

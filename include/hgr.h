@@ -432,7 +432,7 @@ int hgr_adamw(float *p, const float *g, float *m, float *v, int64_t n, float lr,
  * the producer emits the new residual once more in 16 bit plus per-row partial (sum, sum of squares) per 64-column slot,
  * and the consumer runs on the un-normalised 16-bit rows with the gamma-folded weight: the separate LayerNorm pass (118 MB
  * of traffic per call at ViT-B/32 batch 512) disappears.  Error study: tools/studies/ln_fusion_study.py.
- *   stats  fp32 [M][N/64][2]  (N = row width);  x16 16-bit [M, ldx16], 16-byte aligned, ldx16 % 8 == 0;  requirements: row width % 128 == 0.
+ *   stats  fp32 [M][N/64][2]  (N = row width);  x16 16-bit [M, ldx16];  requirements: row width % 128 == 0.
  * ------------------------------------------------------------------------------------------------ */
 /* X += A W^T + bias (fp32, in place: the residual add of clip/model.py:186-187), x16 = (16-bit) X, stats = slot partials of X */
 int hgr_gemm_nt_res_stats(const void *A, int64_t lda, const void *W, int64_t ldw, float *X, int64_t ldx, const float *bias,
