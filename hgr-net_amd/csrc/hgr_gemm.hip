@@ -1080,6 +1080,55 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
             *(u32x4 *)(cw + (cl + q * 8 * ldcB)) = *(const u32x4 *)(my + (q * 8 + rr) * RS + ch * 16);
         return;
     }
+    if (full && !OUT32 && EPI == HGR_EPI_BIAS_ADD16_RELU && (p.ldc & 7) == 0 && (p.ldr & 7) == 0) {
+        // relu(acc + bias + 16-bit identity) -> 16 bit (bn3(conv3) ; out += identity ; relu, clip/model.py:46-52): the sum is
+        // formed in fp32 and rounded once.  4 passes of 32 rows through the wave's LDS slice (fp32 rows of 256 B + 16 B pad);
+        // on the way out a lane owns 8 consecutive columns of a row, so the identity is LOADED and the result STORED as
+        // 16 bytes per lane over whole 128-byte lines (8 lanes per row, 8 rows per instruction).
+        constexpr int RS = 272;
+        char *my = smem + wave * (32 * RS);
+        f32x4 bq[2][2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bq[b][j] = *(const f32x4 *)(p.bias + n0 + wn * 64 + b * 32 + j * 16 + g * 4);
+        const int r8 = lane >> 3, c8 = lane & 7;
+        const int64_t wrow = m0 + wm * 128, wcol = n0 + wn * 64;
+        char *cw = (char *)p.C + (wrow * p.ldc + wcol) * 2;
+        const char *iw = (const char *)p.res + (wrow * p.ldr + wcol) * 2;
+        const unsigned ldcB = (unsigned)p.ldc * 2u, ldiB = (unsigned)p.ldr * 2u;
+        const unsigned cl = r8 * ldcB + c8 * 16, il = r8 * ldiB + c8 * 16;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int ih = 0; ih < 2; ++ih) {
+            const int rl = a * 64 + ih * 32;
+            u32x4 idn[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) idn[q] = *(const u32x4 *)(iw + (il + (rl + q * 8) * ldiB));
+#pragma unroll
+            for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                *(f32x4 *)(my + (i2 * 16 + r) * RS + (b * 32 + j * 16 + g * 4) * 4) = acc[a][b][ih * 2 + i2][j] + bq[b][j];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 lo = *(const f32x4 *)(my + (q * 8 + r8) * RS + c8 * 32);
+                const f32x4 hi = *(const f32x4 *)(my + (q * 8 + r8) * RS + c8 * 32 + 16);
+                const typename T16<DT>::vec8 iv = __builtin_bit_cast(typename T16<DT>::vec8, idn[q]);
+                typename T16<DT>::vec8 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = (E)fmaxf(lo[e] + (float)iv[e], 0.f);
+                    o[e + 4] = (E)fmaxf(hi[e] + (float)iv[e + 4], 0.f);
+                }
+                *(u32x4 *)(cw + (cl + (rl + q * 8) * ldcB)) = __builtin_bit_cast(u32x4, o);
+            }
+        }
+        return;
+    }
     if (full && OUT32 && (EPI == HGR_EPI_NONE || EPI == HGR_EPI_BIAS || HAS_ADD) && (p.ldc & 3) == 0 && (!HAS_ADD || EPI == HGR_EPI_ACCUM || (p.ldr & 3) == 0)) {
         // fp32 output (+ fp32 residual / old C): 4 passes of 32 rows through the wave's private LDS slice (rows of 256 B +
         // 16 B pad); every global access is then 16 bytes per lane over whole 256-byte row segments (2 full lines per row,
@@ -1285,6 +1334,7 @@ void launch_duo(const GemmArgs &a, int epi, bool out32, dim3 grid, hipStream_t s
         case HGR_EPI_BIAS: HGR_DUO(HGR_EPI_BIAS); break;
         case HGR_EPI_BIAS_QUICKGELU: HGR_DUO(HGR_EPI_BIAS_QUICKGELU); break;
         case HGR_EPI_BIAS_RELU: HGR_DUO(HGR_EPI_BIAS_RELU); break;
+        case HGR_EPI_BIAS_ADD16_RELU: hipLaunchKernelGGL((gemm_nt_duo<DT, HGR_EPI_BIAS_ADD16_RELU, false>), grid, dim3(NTD), 0, s, a); break;
         case HGR_EPI_ACCUM: hipLaunchKernelGGL((gemm_nt_duo<DT, HGR_EPI_ACCUM, true>), grid, dim3(NTD), 0, s, a); break;
         default: hipLaunchKernelGGL((gemm_nt_duo<DT, HGR_EPI_BIAS_RESIDUAL, true>), grid, dim3(NTD), 0, s, a); break;
     }
@@ -1401,7 +1451,7 @@ extern "C" int hgr_gemm_nt(const void *A, int64_t lda, const void *W, int64_t ld
         cost_split = (double)rounds * Tb + (double)((ts + 511) / 512) * Ts + 2.0;          // + one kernel boundary
     }
     // 256 x 128 tiles, two workgroups per CU (gemm_nt_duo): fp32 residual / 16-bit epilogues of the transformer towers
-    const bool duo_ok = K >= 128 && epilogue != HGR_EPI_BIAS_ADD16_RELU && (out_f32 || (epilogue != HGR_EPI_BIAS_RESIDUAL && epilogue != HGR_EPI_ACCUM)) &&
+    const bool duo_ok = K >= 128 && (out_f32 || (epilogue != HGR_EPI_BIAS_RESIDUAL && epilogue != HGR_EPI_ACCUM)) &&
                         (int64_t)M * lda * 2 < (1ll << 32) && (int64_t)N * ldw * 2 < (1ll << 32) && ldc < (1 << 20) && ldr < (1 << 20);
     auto launch_d = [&]() {
         GemmArgs a;

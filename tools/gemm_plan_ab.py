@@ -17,14 +17,19 @@ import torch
 from hgr_net_amd import ops
 from hgr_net_amd._lib import EPI_BIAS, EPI_BIAS_QUICKGELU, EPI_BIAS_RESIDUAL, EPI_NONE
 
-plans = [int(x) for x in sys.argv[1:]] or [0, 256, 128, 2]
+plans = [int(x) for x in sys.argv[1:] if not x.startswith("--")] or [0, 256, 128, 2]
 SHAPES = [("qkv", 25600, 2304, 768, EPI_BIAS, False), ("out", 25600, 768, 768, EPI_BIAS_RESIDUAL, True),
           ("fc", 25600, 3072, 768, EPI_BIAS_QUICKGELU, False), ("proj", 25600, 768, 3072, EPI_BIAS_RESIDUAL, True),
           ("patch", 25088, 768, 3072, EPI_NONE, True), ("logits", 512, 21841, 512, EPI_NONE, True),
           ("L14qkv", 131584, 3072, 1024, EPI_BIAS, False), ("L14out", 131584, 1024, 1024, EPI_BIAS_RESIDUAL, True),
           ("L14fc", 131584, 4096, 1024, EPI_BIAS_QUICKGELU, False), ("L14proj", 131584, 1024, 4096, EPI_BIAS_RESIDUAL, True),
           ("txtqkv", 8192 * 11, 1536, 512, EPI_BIAS, False), ("ragged", 1000, 777 + 3, 192, EPI_BIAS, False),
-          ("sq4096", 4096, 4096, 4096, EPI_NONE, False)]
+          ("sq4096", 4096, 4096, 4096, EPI_NONE, False),
+          # ModifiedResNet 1x1 convolutions at batch 512 (5 = bias + 16-bit identity + ReLU, 4 = bias + ReLU)
+          ("rn28_c3", 401408, 512, 128, 5, False), ("rn14_c3", 100352, 1024, 256, 5, False), ("rn7_c3", 25088, 2048, 512, 5, False),
+          ("rn56_c1", 1605632, 64, 256, 4, False), ("rn28_c1", 401408, 128, 512, 4, False), ("rn14_c1", 100352, 256, 1024, 4, False)]
+if "--rn" in sys.argv:
+    SHAPES = [x for x in SHAPES if x[0].startswith("rn")]
 
 
 def timeit(fn, iters=20):
@@ -43,7 +48,7 @@ for name, m, n, k, epi, o32 in SHAPES:
     w = ((torch.rand(n, k, device="cuda") * 2 - 1) * 0.05).half()
     bias = torch.rand(n, device="cuda") if epi != EPI_NONE else None
     ld = (n + 63) // 64 * 64
-    res = torch.rand(m, ld, device="cuda") if epi == EPI_BIAS_RESIDUAL else None
+    res = torch.rand(m, ld, device="cuda") if epi == EPI_BIAS_RESIDUAL else (torch.rand(m, ld, device="cuda").half() if epi == 5 else None)
     outs = {}
     for pl in plans:                                  # correctness: separate residual, fresh output
         ops.gemm_set_tile(pl)
@@ -62,12 +67,14 @@ for name, m, n, k, epi, o32 in SHAPES:
     if epi == EPI_BIAS_QUICKGELU:
         exact = exact * torch.sigmoid(1.702 * exact)
     if res is not None:
-        exact = exact + res[rows, :n]
+        exact = exact + res[rows, :n].float()
+    if epi in (4, 5):
+        exact = torch.relu(exact)
     err = {pl: float((outs[pl][rows, :n].float() - exact).abs().max()) for pl in plans}
 
     def make(pl):
         out = torch.zeros(m, ld, dtype=torch.float32 if o32 else torch.float16, device="cuda")
-        r = out if epi == EPI_BIAS_RESIDUAL else None      # in place, as the towers call it
+        r = out if epi == EPI_BIAS_RESIDUAL else res       # fp32 residual in place, as the towers call it; 16-bit identity as is
 
         def f():
             ops.gemm_set_tile(pl)
