@@ -1469,7 +1469,10 @@ extern "C" int hgr_gemm_nt(const void *A, int64_t lda, const void *W, int64_t ld
     // text qkv 168 -> 154, ViT-L/14 out / proj 411 -> 361 / 1029 -> 999, ViT-L/14 qkv / fc a tie; a launch with fewer tiles than
     // half the chip's 512 slots (small text batches, ragged test shapes) stays on the 128^2 / cost-model plans.
     const int64_t tduo = (int64_t)((M + 255) / 256) * ((N + 127) / 128);
-    if (duo_ok && (force == 2 || (force == 0 && tduo >= 256))) launch_d();
+    // ... and an output much narrower than its 128-column tiles (the 64-channel ResNet stage: half of every tile would be padding;
+    // measured 252 vs 194 us on the 256 x 64 arrangement of the small kernel) stays where it was
+    const bool duo_fits = (N + 127) / 128 * 128 - N <= N / 8;
+    if (duo_ok && (force == 2 || (force == 0 && tduo >= 256 && duo_fits))) launch_d();
     else if (force == 128 || K < 128) launch(0, M, false);
     else if (epilogue == HGR_EPI_BIAS_ADD16_RELU && force != 256) launch(0, M, false);   // only the 128 kernel loads the identity / stores by full lines
     else if (force == 256) launch(0, M, true);
