@@ -80,6 +80,8 @@ SIGNATURES = {
     "hgr_gemm_nt_ln": [_p, _l, _p, _l, _p, _l, _p, _p, _p, _f, _i, _i, _i, _i, _i, _p],
     "hgr_vit_embed_ln_stats": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p],
     "hgr_row_stats16": [_p, _p, _p, _i, _i, _i, _p],
+    "hgr_logits_eval_workspace_bytes": [_i, _i],
+    "hgr_logits_eval": [_p, _p, _i, _i, _i, _p, _p, _p, _i, _p, _p, _i, _p, _i, _i, _p, _p, _p, _p, _i, _p],
     "hgr_comm_unique_id": [_p],
     "hgr_comm_init": [_i, _i, _p],
     "hgr_comm_destroy": [],
@@ -113,7 +115,7 @@ def load() -> C.CDLL:
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)            # AttributeError if the .so does not export a declared symbol
         fn.argtypes = argtypes
-        fn.restype = _l if name.endswith("_scratch_floats") else _i
+        fn.restype = _l if name.endswith(("_scratch_floats", "_workspace_bytes")) else _i
     if lib.hgr_abi_version() != 1:
         raise HgrError(f"libhgr.so ABI {lib.hgr_abi_version()} != 1")
     _lib = lib

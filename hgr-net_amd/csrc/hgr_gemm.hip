@@ -58,6 +58,10 @@ struct GemmArgs {
     void *ln_x16; int64_t ln_ldx16;
     const float *ln_s, *ln_c;
     int group;       // gemm_nt_duo: row (or column) panels per raster group (HGR_GEMM_GROUP, default 4)
+    // fused evaluation (LN = 3, hgr_logits_eval): W = level-sorted, level-aligned class matrix, so every 64-column slice (one
+    // wave's share of a tile) lies inside ONE hierarchy level.  Nothing of C is written; per (row, slice) the epilogue emits
+    // the best train column as an orderable key and the largest value over the test columns.
+    unsigned long long *ev_key; float *ev_tmax; const int *ev_tpos, *ev_epos; int ev_slices;
 };
 
 // 16 zero bytes every out-of-bounds conv tap (and the K padding) is loaded from
@@ -1016,6 +1020,55 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
     if (!(p.dbg & 16)) __builtin_amdgcn_s_setprio(3);
 
     // tile (a, b, i, j) of this lane holds C[m][n .. n+3],  m = m0 + wm*128 + a*64 + i*16 + r,  n = n0 + wn*64 + b*32 + j*16 + g*4
+    if (LN == 3) {
+        // Evaluation consumers in place of the C store (main.py:136-176 consuming model/clip_tree.py:331).  This wave's 128 rows x
+        // 64 columns are slice s = n0 / 64 + wn of every row; a lane holds, per row, 16 of the 64 columns (4 quads), the other
+        // 48 sit in the lanes r + 16, r + 32, r + 48.  key = (orderable(value) << 32) | (0x7fffffff - train position): unsigned
+        // max = "larger value, then smaller position" (the tie rule of logits[:, train_index].topk); 0 = no train column.
+        const int sl = (n0 >> 6) + wn;
+        int tp[2][2][4], ep[2][2][4];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + b * 32 + j * 16 + g * 4;
+            const int4 t4 = *(const int4 *)(p.ev_tpos + n), e4 = *(const int4 *)(p.ev_epos + n);
+            tp[b][j][0] = t4.x; tp[b][j][1] = t4.y; tp[b][j][2] = t4.z; tp[b][j][3] = t4.w;
+            ep[b][j][0] = e4.x; ep[b][j][1] = e4.y; ep[b][j][2] = e4.z; ep[b][j][3] = e4.w;
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned long long key = 0ull;
+            float tm = -INFINITY;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = acc[a][b][i][j][e] + 0.0f;                 // -0 -> +0, as the row sweep of hgr_eval_rows does
+                const unsigned u = __float_as_uint(v);
+                const unsigned long long k2 = ((unsigned long long)(u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u)) << 32) | (unsigned)(0x7fffffff - tp[b][j][e]);
+                if (tp[b][j][e] >= 0 && k2 > key) key = k2;
+                if (ep[b][j][e] >= 0) tm = fmaxf(tm, v);
+            }
+#pragma unroll
+            for (int o = 16; o <= 32; o <<= 1) {
+                const unsigned hi = __shfl_xor((unsigned)(key >> 32), o), lo = __shfl_xor((unsigned)key, o);
+                const unsigned long long x = ((unsigned long long)hi << 32) | lo;
+                key = x > key ? x : key;
+                tm = fmaxf(tm, __shfl_xor(tm, o));
+            }
+            const int m = m0 + wm * 128 + a * 64 + i * 16 + r;
+            if (g == 0 && m < p.M) {
+                p.ev_key[(int64_t)m * p.ev_slices + sl] = key;
+                p.ev_tmax[(int64_t)m * p.ev_slices + sl] = tm;
+            }
+        }
+        return;
+    }
     constexpr bool HAS_BIAS = EPI != HGR_EPI_NONE && EPI != HGR_EPI_ACCUM;
     constexpr bool HAS_ADD = EPI == HGR_EPI_BIAS_RESIDUAL || EPI == HGR_EPI_ACCUM;
     const bool full = p.vec_ok && m0 + 256 <= p.M && n0 + 128 <= p.N;
@@ -1648,4 +1701,41 @@ extern "C" int hgr_gemm_nt_ln(const void *X16, int64_t ldx, const void *Wfold, i
     }
     HGR_CHECK_LAUNCH("hgr_gemm_nt_ln");
     return HGR_OK;
+}
+
+// ---- logits GEMM with the evaluation consumers in its epilogue ------------------------------------------------------------
+int hgr_logits_eval_rows_launch(const void *feat, const void *zslp, int D, int S, const unsigned long long *keys, const float *tmax,
+                                const unsigned char *slice_level, int n_levels, const int32_t *filler_pos, const int32_t *train_cols, int n_train,
+                                const int32_t *epos, const int32_t *test_cols, int n_test, int k, int32_t *out_level, int32_t *out_top1,
+                                int32_t *out_topk, int rows, int dtype, void *stream);      // hgr_select.hip
+
+extern "C" int64_t hgr_logits_eval_workspace_bytes(int rows, int n_perm) {
+    if (rows < 1 || n_perm < 128 || n_perm % 128) return -1;
+    return (int64_t)rows * (n_perm / 64) * 12;           // 8-byte key + 4-byte test maximum per (row, slice)
+}
+
+extern "C" int hgr_logits_eval(const void *feat16, const void *zsl_perm16, int rows, int D, int n_perm,
+                               const int32_t *tpos_perm, const int32_t *epos_perm, const unsigned char *slice_level,
+                               int n_levels, const int32_t *filler_pos, const int32_t *train_cols, int n_train,
+                               const int32_t *test_cols, int n_test, int k,
+                               int32_t *out_level, int32_t *out_top1, int32_t *out_topk, void *workspace, int dtype, void *stream) {
+    HGR_REQUIRE(feat16 && zsl_perm16 && tpos_perm && epos_perm && slice_level && filler_pos && train_cols && out_level && workspace, "hgr_logits_eval: null operand");
+    HGR_REQUIRE(rows >= 1 && D >= 128 && D % 128 == 0 && D <= 1024, "hgr_logits_eval: rows=%d D=%d unsupported (D %% 128 == 0, D <= 1024)", rows, D);
+    HGR_REQUIRE(n_perm >= 128 && n_perm % 128 == 0 && n_perm / 64 <= 1024, "hgr_logits_eval: n_perm=%d must be a multiple of 128 and <= 65536 (level-aligned, padded columns)", n_perm);
+    HGR_REQUIRE(n_levels >= 1 && n_levels <= 32 && n_train >= 1, "hgr_logits_eval: bad sizes (n_levels <= 32)");
+    HGR_REQUIRE(k == 0 || (out_topk && test_cols && k >= 1 && k <= 32 && n_test >= k), "hgr_logits_eval: bad top-k arguments");
+    HGR_REQUIRE(hgr_aligned(feat16, 16) && hgr_aligned(zsl_perm16, 16) && hgr_aligned(tpos_perm, 16) && hgr_aligned(epos_perm, 16) && hgr_aligned(workspace, 16), "hgr_logits_eval: operands must be 16-byte aligned");
+    HGR_REQUIRE(dtype == HGR_BF16 || dtype == HGR_F16, "hgr_logits_eval: bad dtype %d", dtype);
+    const int S = n_perm / 64;
+    GemmArgs a;
+    ln_args(a, feat16, D, zsl_perm16, D, nullptr, 0, rows, n_perm, D);
+    a.ev_key = (unsigned long long *)workspace;
+    a.ev_tmax = (float *)((char *)workspace + (size_t)rows * S * 8);
+    a.ev_tpos = tpos_perm; a.ev_epos = epos_perm; a.ev_slices = S;
+    dim3 grid((unsigned)(a.tiles_m * a.tiles_n));
+    if (dtype == HGR_BF16) hipLaunchKernelGGL((gemm_nt_duo<HGR_BF16, HGR_EPI_NONE, true, 3>), grid, dim3(NTD), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((gemm_nt_duo<HGR_F16, HGR_EPI_NONE, true, 3>), grid, dim3(NTD), 0, (hipStream_t)stream, a);
+    HGR_CHECK_LAUNCH("hgr_logits_eval (tile stage)");
+    return hgr_logits_eval_rows_launch(feat16, zsl_perm16, D, S, a.ev_key, a.ev_tmax, slice_level, n_levels, filler_pos, train_cols, n_train,
+                                       epos_perm, test_cols, n_test, k, out_level, out_top1, out_topk, rows, dtype, stream);
 }

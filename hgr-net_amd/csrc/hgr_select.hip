@@ -514,6 +514,164 @@ __global__ __launch_bounds__(EL_NT) void eval_rows_lds(const float *__restrict__
     }
 }
 
+
+// ---- second stage of hgr_logits_eval (first stage: gemm_nt_duo<.., LN = 3> in hgr_gemm.hip) ------------------------------------
+// One workgroup per image row.  Input: per 64-column slice of the level-sorted class matrix the best train key and the largest
+// test value of this row.  (1) level arg-max = max of the keys of the level's slices, with the reference's -1 filler rule;
+// unmasked top-1 = best of the level bests; (2) threshold t = k-th largest slice maximum over the test columns (k distinct
+// elements >= t exist; fewer than k non-empty slices: t = -inf); (3) ONLY the slices whose maximum reaches t can hold one of the
+// k best: their 64 logits are recomputed on the matrix cores with the first stage's operand roles and K order (bit-identical
+// values), elements >= t are ranked by (value, test position).  The [B, N] logits never exist in memory.
+constexpr int LE_NT = 256, LE_MAXS = 1024, LE_CAP = 2048;
+
+template <int DT>
+__global__ __launch_bounds__(LE_NT) void logits_eval_rows(const void *__restrict__ feat, const void *__restrict__ zslp, int D, int S,
+                                                        const unsigned long long *__restrict__ keys, const float *__restrict__ tmax,
+                                                        const unsigned char *__restrict__ slice_level, int n_levels, const int32_t *__restrict__ filler_pos,
+                                                        const int32_t *__restrict__ train_cols, int n_train, const int32_t *__restrict__ epos,
+                                                        const int32_t *__restrict__ test_cols, int n_test, int k,
+                                                        int32_t *__restrict__ out_level, int32_t *__restrict__ out_top1, int32_t *__restrict__ out_topk) {
+    typedef typename T16<DT>::vec8 vec8;
+    typedef typename T16<DT>::elem E;
+    __shared__ unsigned long long s_lkey[32];
+    __shared__ float s_tm[LE_MAXS];
+    __shared__ int s_cand[LE_MAXS];
+    __shared__ float s_cv[LE_CAP];
+    __shared__ int s_cp[LE_CAP];
+    __shared__ float s_t;
+    __shared__ int s_ncand, s_cnt, s_nonempty;
+    __shared__ float s_bv[4];
+    __shared__ int s_bp[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row = blockIdx.x;
+    if (tid < 32) s_lkey[tid] = 0ull;
+    if (tid == 0) { s_ncand = 0; s_cnt = 0; s_nonempty = 0; s_t = -INFINITY; }
+    __syncthreads();
+    for (int s = tid; s < S; s += LE_NT) {
+        const unsigned long long key = keys[(int64_t)row * S + s];
+        const int lv = slice_level[s];
+        if (key && lv < 32) atomicMax(&s_lkey[lv], key);
+        const float t = tmax[(int64_t)row * S + s];
+        s_tm[s] = t;
+        if (t > -INFINITY) atomicAdd(&s_nonempty, 1);
+    }
+    __syncthreads();
+    if (wave == 0) {                                        // lane l < n_levels finishes level l (hgr_eval_rows' rule, main.py:162-176)
+        const int l = lane;
+        Best b = {-INFINITY, 0x7fffffff};
+        if (l < n_levels) {
+            const unsigned long long m = l < 32 ? s_lkey[l] : 0ull;
+            if (m) {
+                const unsigned u = (unsigned)(m >> 32);
+                b.v = __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+                b.p = 0x7fffffff - (int)(unsigned)m;
+            }
+            const int fo = filler_pos[l];
+            const bool has_c = b.p < n_train, has_f = fo >= 0;
+            int win;
+            if (has_c && (!has_f || b.v > -1.0f || (b.v == -1.0f && b.p < fo))) win = b.p;
+            else win = has_f ? fo : b.p;
+            out_level[(int64_t)row * n_levels + l] = train_cols[win];
+        }
+        const Best top = wave_best(b);
+        if (lane == 0 && out_top1) out_top1[row] = top.p < n_train ? train_cols[top.p] : -1;
+    }
+    if (k <= 0) return;
+    // threshold: the k-th best slice maximum, ties between slices ordered by the slice index (any fixed order gives the same VALUE)
+    if (s_nonempty >= k) {
+        for (int s = tid; s < S; s += LE_NT) {
+            const float mv = s_tm[s];
+            if (!(mv > -INFINITY)) continue;
+            int rank = 0;
+            for (int j = 0; j < S; ++j) { const float o = s_tm[j]; rank += (o > mv || (o == mv && j < s)) ? 1 : 0; }
+            if (rank == k - 1) s_t = mv;
+        }
+    }
+    __syncthreads();
+    const float t = s_t;
+    for (int s = tid; s < S; s += LE_NT)
+        if (s_tm[s] > -INFINITY && s_tm[s] >= t) s_cand[atomicAdd(&s_ncand, 1)] = s;
+    __syncthreads();
+    const int ncand = s_ncand;
+    // the row's feature as MFMA B-operand fragments (every one of the 16 "rows" m of the fragment is this image): lane (r, g) holds
+    // x[32 kk + 8 g .. + 7] for k-step kk; D <= 1024 -> at most 32 k-steps
+    const int r16 = lane & 15, g = lane >> 4;
+    const int ks = D >> 5;
+    const E *fr = (const E *)feat + (int64_t)row * D;
+    // visitor(value, test position) over every test element of the candidate slices, each wave on slices wave, wave + 4, ...
+    auto scan = [&](auto visit) {
+        for (int ci = wave; ci < ncand; ci += 4) {
+            const int sl = s_cand[ci];
+#pragma unroll 1
+            for (int nt = 0; nt < 4; ++nt) {
+                const E *wr = (const E *)zslp + ((int64_t)sl * 64 + nt * 16 + r16) * D + g * 8;
+                f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int kk = 0; kk < ks; kk += 4) {                 // D % 128 == 0: 4 k-steps per trip, loads first
+                    vec8 wf[4], xf[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { wf[u] = *(const vec8 *)(wr + (kk + u) * 32); xf[u] = *(const vec8 *)(fr + (kk + u) * 32 + g * 8); }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc = T16<DT>::mfma16(wf[u], xf[u], acc);
+                }
+                // lane (r16, g) holds columns 4 g .. 4 g + 3 of this 16-column group (identical for every r16): lane r16 < 4 takes e = r16
+                float v = r16 == 0 ? acc[0] : r16 == 1 ? acc[1] : r16 == 2 ? acc[2] : acc[3];
+                v += 0.0f;
+                if (r16 < 4) {
+                    const int te = epos[sl * 64 + nt * 16 + g * 4 + r16];
+                    if (te >= 0) visit(v, te);
+                }
+            }
+        }
+    };
+    scan([&](float v, int te) {
+        if (v >= t) {
+            const int slot = atomicAdd(&s_cnt, 1);
+            if (slot < LE_CAP) { s_cv[slot] = v; s_cp[slot] = te; }
+        }
+    });
+    __syncthreads();
+    const int cnt = s_cnt;
+    if (cnt <= LE_CAP) {
+        for (int c = tid; c < cnt; c += LE_NT) {
+            const float v = s_cv[c]; const int p = s_cp[c];
+            int rk = 0;
+            for (int j = 0; j < cnt; ++j) rk += better(s_cv[j], s_cp[j], v, p) ? 1 : 0;
+            if (rk < k) out_topk[(int64_t)row * k + rk] = test_cols[p];
+        }
+        return;
+    }
+    // heavily duplicated data (more than LE_CAP elements tie at the threshold): k rounds of arg-max over the candidate slices, an
+    // element is "removed" by requiring it to be worse than the previous winner in (value, position) order
+    Best last = {INFINITY, -1};
+    for (int j = 0; j < k; ++j) {
+        Best b = {-INFINITY, 0x7fffffff};
+        scan([&](float v, int te) { if (better(last.v, last.p, v, te) && better(v, te, b.v, b.p)) { b.v = v; b.p = te; } });
+        b = wave_best(b);
+        __syncthreads();
+        if (lane == 0) { s_bv[wave] = b.v; s_bp[wave] = b.p; }
+        __syncthreads();
+        Best w = {s_bv[0], s_bp[0]};
+        for (int i = 1; i < 4; ++i) if (better(s_bv[i], s_bp[i], w.v, w.p)) { w.v = s_bv[i]; w.p = s_bp[i]; }
+        if (tid == 0) out_topk[(int64_t)row * k + j] = w.p < n_test ? test_cols[w.p] : -1;
+        last = w;
+    }
+}
+
+}  // namespace
+
+int hgr_logits_eval_rows_launch(const void *feat, const void *zslp, int D, int S, const unsigned long long *keys, const float *tmax,
+                                const unsigned char *slice_level, int n_levels, const int32_t *filler_pos, const int32_t *train_cols, int n_train,
+                                const int32_t *epos, const int32_t *test_cols, int n_test, int k, int32_t *out_level, int32_t *out_top1,
+                                int32_t *out_topk, int rows, int dtype, void *stream) {
+    if (dtype == HGR_BF16) hipLaunchKernelGGL((logits_eval_rows<HGR_BF16>), dim3(rows), dim3(LE_NT), 0, (hipStream_t)stream, feat, zslp, D, S, keys, tmax, slice_level,
+                                              n_levels, filler_pos, train_cols, n_train, epos, test_cols, n_test, k, out_level, out_top1, out_topk);
+    else hipLaunchKernelGGL((logits_eval_rows<HGR_F16>), dim3(rows), dim3(LE_NT), 0, (hipStream_t)stream, feat, zslp, D, S, keys, tmax, slice_level,
+                            n_levels, filler_pos, train_cols, n_train, epos, test_cols, n_test, k, out_level, out_top1, out_topk);
+    HGR_CHECK_LAUNCH("hgr_logits_eval (row stage)");
+    return HGR_OK;
+}
+
+namespace {
 }  // namespace
 
 extern "C" int hgr_topk_rows(const float *logits, int64_t ld, const int32_t *cols, int n_cols, int k,

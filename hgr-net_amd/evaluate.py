@@ -11,6 +11,7 @@ Outputs (counter values and the printed string) are identical to the reference's
 from __future__ import annotations
 
 import copy
+import os
 from typing import Dict, Iterable, Optional
 
 import torch
@@ -30,6 +31,7 @@ class Evaluator:
         self.n_levels = model.max_depth + 1
         self.index = ops.EvalIndex(model.depth32, model.train_index32, model.test_index32, self.n_levels)   # dense per-column maps, built once
         self._parents_cache: Dict[int, tuple] = {}
+        self._plan = None        # level-sorted class matrix of the fused logits + evaluation kernel, built on first use
 
     def _parents(self, target: int):
         c = self._parents_cache.get(target)
@@ -60,6 +62,28 @@ class Evaluator:
         if not want_outputs:
             return None
         return pred, lv[:, levels64]                                                 # dict_path [B, L]
+
+    def fused_ok(self) -> bool:
+        """hgr_logits_eval needs an embedding width that is a multiple of 128 (<= 1024) and <= 32 levels."""
+        d = self.model._zsl16.shape[1] if self.model._zsl16 is not None else 0
+        return d % 128 == 0 and 128 <= d <= 1024 and self.n_levels <= 32 and self.index.n_test >= max(TOPK)
+
+    @torch.no_grad()
+    def add_images(self, imgs: torch.Tensor, target: int, targets: Optional[torch.Tensor] = None, want_outputs: bool = False):
+        """One iteration of main.py:131-191 WITHOUT materialising the logits: image tower -> L2 norm -> hgr_logits_eval (the
+        class-logits GEMM with top-20 / top-1 / per-level arg-max in its epilogue) -> hgr_eval_counters.  Same counters, bit for
+        bit, as add_batch(model(imgs), ...); use add_batch when the caller needs the logits themselves."""
+        if self._plan is None:
+            self._plan = ops.LogitsEvalPlan(self.index)
+        lv, p1, pred = self.model.forward_eval(imgs, self._plan, max(TOPK))
+        parents, levels64, levels32, L = self._parents(target)
+        tg = None
+        if targets is not None:
+            tg = (targets if targets.dtype == torch.int64 else targets.to(torch.int64)).contiguous()
+        ops.eval_counters(pred, tg, int(target), p1.view(-1), lv, parents, levels32, self.acc)
+        if not want_outputs:
+            return None
+        return pred, lv[:, levels64]
 
     def counters(self, group=None) -> Dict[str, float]:
         """Read the counters (one D2H copy); with a process group, all-reduce(sum) them first."""
@@ -107,9 +131,13 @@ def test(opts, model, device, splits=None, loader: Optional[Iterable] = None, gr
         print("number of batches:{}".format(loader.batch_sampler.num_batch))
     print("Running.", flush=True)
     ev = Evaluator(model)
+    fused = ev.fused_ok() and os.environ.get("HGR_EVAL_FUSED", "1") != "0"
     for data in loader:
         imgs, targets = data["img"].to(device, non_blocking=True)[0], data["label"].to(device, non_blocking=True)[0]
         target = int(data["label"][0][0])           # host copy of the label: no device sync in the loop
+        if fused:                                   # the loop never looks at the logits: GEMM + evaluation in one pass, nothing [B, N] written
+            ev.add_images(imgs, target, targets)
+            continue
         logits = model(imgs, targets, static_output=True)     # consumed by add_batch before the next forward
         ev.add_batch(logits, target, targets, want_outputs=False)
     print("End of testing.")

@@ -145,7 +145,20 @@ class tree_model(nn.Module):
             return self._forward_graphed(inputs, static_output)
         return self._forward_eager(inputs)
 
-    def _forward_graphed(self, inputs, static_output: bool = False):
+    @torch.no_grad()
+    def forward_eval(self, inputs, plan, k: int):
+        """Evaluation-only forward: (level arg-max [B, L], top-1 [B, 1], top-k [B, k]) int32 node ids of main.py:136-176 from
+        the image batch, with the class-logits GEMM and its consumers fused (ops.logits_eval): the [B, N] logits of
+        clip_tree.py:331 are never written.  `forward()` keeps returning the logits for callers that want them.
+        Outputs are static buffers of a replayed HIP graph: consume them before the next call."""
+        if self._zsl16 is None:
+            raise HgrError("call update_classifier() before forward_eval()")
+        plan.bind(self._zsl16)
+        if self.use_graph and inputs.is_cuda:
+            return self._forward_graphed(inputs, True, ("eval", plan, k))
+        return self._forward_eager(inputs, ("eval", plan, k))
+
+    def _forward_graphed(self, inputs, static_output: bool = False, mode=None):
         """The ~100 launches of one forward replayed as a HIP graph: no host launch cost and no inter-kernel gaps
         (+6 % on the ViT-B/32 step).  Same kernels, same bits.  A graph is bound to the buffers it was captured on, so
         graphs live for one generation = (input shape, dtype, classifier, prepared weights): anything else clears them
@@ -154,14 +167,15 @@ class tree_model(nn.Module):
         input is copied into one static buffer instead.  The logits are returned as a fresh tensor unless the caller passes
         ``static_output=True`` (it consumes them before the next forward: the evaluation loop does)."""
         def generation():
-            return (tuple(inputs.shape), inputs.dtype, self._zsl16.data_ptr(), self.clip_model._ws.epoch, self.clip_model._fingerprint())
+            return (tuple(inputs.shape), inputs.dtype, self._zsl16.data_ptr(), self.clip_model._ws.epoch, self.clip_model._fingerprint(),
+                    None if mode is None else (mode[0], id(mode[1]), mode[1].zsl.data_ptr(), mode[2]))
 
         if generation() != self._graph_gen:
             # warm-up BEFORE the key is fixed: it builds the prepared weights and may (re)allocate workspace buffers, both of
             # which move the key; graphs captured afterwards then see a stable generation.  A direct encode_image call with
             # a larger batch between two forwards re-allocates the workspace -> epoch moves -> stale graphs are dropped here.
             self._graphs.clear()
-            self._forward_eager(inputs)
+            self._forward_eager(inputs, mode)
             self._graph_gen, self._graph_misses, self._graph_static = generation(), 0, None
         ent = self._graphs.get(inputs.data_ptr())
         if ent is None:
@@ -170,32 +184,34 @@ class tree_model(nn.Module):
                 if self._graph_static is None:
                     buf = torch.empty_like(inputs)
                     buf.copy_(inputs)
-                    self._graph_static = (buf,) + self._capture(buf)
+                    self._graph_static = (buf,) + self._capture(buf, mode)
                 buf, g, out = self._graph_static
                 buf.copy_(inputs)
                 g.replay()
-                return out if static_output else out.clone()
+                return out if (static_output or mode is not None) else out.clone()
             if len(self._graphs) >= 4:
                 self._graphs.pop(next(iter(self._graphs)))
-            ent = self._graphs[inputs.data_ptr()] = self._capture(inputs)
+            ent = self._graphs[inputs.data_ptr()] = self._capture(inputs, mode)
         else:
             self._graph_misses = 0
         ent[0].replay()
-        return ent[1] if static_output else ent[1].clone()
+        return ent[1] if (static_output or mode is not None) else ent[1].clone()
 
-    def _capture(self, inputs):
-        self._forward_eager(inputs)                             # warm-up: workspace buffers and prepared weights exist
+    def _capture(self, inputs, mode=None):
+        self._forward_eager(inputs, mode)                       # warm-up: workspace buffers and prepared weights exist
         torch.cuda.current_stream().synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            out = self._forward_eager(inputs)
+            out = self._forward_eager(inputs, mode)
         return g, out
 
-    def _forward_eager(self, inputs):
+    def _forward_eager(self, inputs, mode=None):
         feats = self.clip_model.encode_image(inputs)
         b, n = feats.shape[0], self._zsl16.shape[0]
         f16 = torch.empty(feats.shape, dtype=self._zsl16.dtype, device=feats.device)
         ops.l2norm_rows(feats, y16=f16)
+        if mode is not None:                                    # ("eval", plan, k): logits GEMM + evaluation fused, no logits written
+            return ops.logits_eval(f16, mode[1], mode[2])
         ld = (n + 63) // 64 * 64                   # 16-byte aligned rows for the vector stores
         logits = torch.empty((b, ld), dtype=torch.float32, device=feats.device)
         ops.gemm_nt(f16, self._zsl16, logits, n=n, tag="logits")

@@ -301,6 +301,78 @@ def eval_rows(logits: torch.Tensor, index: EvalIndex, k: int):
     return lvl, top1, topk
 
 
+class LogitsEvalPlan:
+    """Level-sorted view of the class matrix for hgr_logits_eval (include/hgr.h): the column permutation (levels contiguous, each
+    padded to a multiple of 64 columns, total to a multiple of 128), the per-column train / test positions in permuted order and
+    the level of every 64-column slice.  Built once per model from an EvalIndex; `bind(zsl16)` gathers the permuted 16-bit class
+    matrix (once per update_classifier)."""
+
+    def __init__(self, index: EvalIndex):
+        import numpy as np
+        lvl = index.lvl8.cpu().numpy().astype(np.int64)
+        tpos = index.train_pos.cpu().numpy()
+        epos = index.test_pos.cpu().numpy() if index.test_pos is not None else np.full(len(lvl), -1, dtype=np.int32)
+        cols, slice_level = [], []
+        for l in range(int(lvl.max()) + 1):
+            c = np.nonzero(lvl == l)[0]
+            if c.size == 0:
+                continue
+            pad = (-c.size) % 64
+            cols.append(np.concatenate([c, np.full(pad, -1, dtype=np.int64)]))
+            slice_level += [min(l, 255)] * ((c.size + pad) // 64)
+        perm = np.concatenate(cols)
+        if (perm.size // 64) % 2:                                    # whole 128-column tiles
+            perm = np.concatenate([perm, np.full(64, -1, dtype=np.int64)])
+            slice_level.append(255)
+        dev = index.lvl8.device
+        valid = perm >= 0
+        safe = np.where(valid, perm, 0)
+        self.index = index
+        self.n_perm = int(perm.size)
+        self.perm = torch.from_numpy(safe).to(dev)
+        self.valid = torch.from_numpy(valid).to(dev)
+        self.tpos = torch.from_numpy(np.where(valid, tpos[safe], -1).astype(np.int32)).to(dev)
+        self.epos = torch.from_numpy(np.where(valid, epos[safe], -1).astype(np.int32)).to(dev)
+        self.slice_level = torch.from_numpy(np.asarray(slice_level, dtype=np.uint8)).to(dev)
+        self.zsl = None
+        self._src = None
+        self._ws = None
+
+    def bind(self, zsl16: torch.Tensor) -> "LogitsEvalPlan":
+        key = (zsl16.data_ptr(), zsl16._version, tuple(zsl16.shape))
+        if self._src != key:
+            z = zsl16[self.perm]
+            z[~self.valid] = 0
+            self.zsl, self._src = z.contiguous(), key
+        return self
+
+    def workspace(self, rows: int, dev) -> torch.Tensor:
+        need = int(_lib.load().hgr_logits_eval_workspace_bytes(rows, self.n_perm))
+        if self._ws is None or self._ws.numel() < need or self._ws.device != torch.device(dev):
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        return self._ws
+
+
+def logits_eval(feat16: torch.Tensor, plan: LogitsEvalPlan, k: int):
+    """(level arg-max [rows, n_levels], top-1 [rows, 1], top-k [rows, k]) int32 node ids straight from the L2-normalised 16-bit
+    image features: the logits GEMM with the evaluation in its epilogue (hgr_logits_eval) - no [rows, N] logits in memory."""
+    ix = plan.index
+    assert plan.zsl is not None, "LogitsEvalPlan.bind(zsl16) first"
+    assert feat16.is_contiguous() and feat16.dtype == plan.zsl.dtype and feat16.shape[1] == plan.zsl.shape[1]
+    rows, d = feat16.shape
+    dev = feat16.device
+    lvl = torch.empty((rows, ix.n_levels), dtype=torch.int32, device=dev)
+    top1 = torch.empty((rows, 1), dtype=torch.int32, device=dev)
+    topk = torch.empty((rows, max(k, 1)), dtype=torch.int32, device=dev)
+    prof = PROFILE
+    ev = _prof_begin()
+    _lib.call("hgr_logits_eval", _dev(feat16), _dev(plan.zsl), rows, d, plan.n_perm, _dev(plan.tpos), _dev(plan.epos), _dev(plan.slice_level),
+              ix.n_levels, _dev(ix.filler), _dev(ix.train_cols), ix.n_train, _dev(ix.test_cols), ix.n_test, k,
+              _dev(lvl), _dev(top1), _dev(topk), _dev(plan.workspace(rows, dev)), DT_OF[feat16.dtype], _stream())
+    _prof_end(ev, 2.0 * rows * ix.n_nodes * d, 2 * rows * d + 2 * ix.n_nodes * d, "logits_eval")
+    return lvl, top1, topk
+
+
 def eval_counters(pred: torch.Tensor, targets: Optional[torch.Tensor], target: int, top1: torch.Tensor, lv: torch.Tensor,
                   parents: torch.Tensor, levels: torch.Tensor, acc: torch.Tensor) -> None:
     """Advance the nine float64 evaluation counters with one batch (main.py:139-191) from eval_rows' outputs."""

@@ -450,6 +450,28 @@ int hgr_vit_embed_ln_stats(const float *patches, const float *class_embedding, c
 int hgr_row_stats16(const float *x, void *x16, float *stats, int rows, int W, int dtype, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * hgr_logits_eval: the class-logits GEMM of tree_model.forward (model/clip_tree.py:331) with the evaluation consumers of main.test
+ * (main.py:136-176: top-20 over the test columns, top-1 over the train columns, arg-max per depth level) in its epilogue, so the
+ * [rows, N] logits are never written or re-read.  Same outputs, bit for bit, as hgr_gemm_nt (fp32 logits) followed by
+ * hgr_eval_rows.  The caller prepares, once per classifier, a LEVEL-SORTED class matrix: columns ordered by depth level, every
+ * level padded with zero rows to a multiple of 64 columns (and the total to a multiple of 128), so that each 64-column slice lies
+ * inside one level:
+ *   zsl_perm16 16-bit [n_perm, D] (D = row stride);  tpos_perm / epos_perm int32 [n_perm]: position of the column in
+ *   train_index / test_index or -1 (padding: both -1);  slice_level uint8 [n_perm / 64]: the level of each slice (255 = padding);
+ *   filler_pos / train_cols / test_cols exactly as for hgr_eval_rows;  feat16: L2-normalised image features, 16-bit [rows, D].
+ * Stage 1 (gemm_nt_duo tiles): per (row, slice) the best train column as an orderable key and the largest test value -> workspace.
+ * Stage 2 (one workgroup per row): level arg-max / top-1 from the keys; top-k threshold = k-th largest slice maximum; the few slices
+ * that reach it are recomputed on the matrix cores (same operand roles and K order: identical bits) and their elements ranked.
+ * workspace: hgr_logits_eval_workspace_bytes(rows, n_perm) bytes, 16-byte aligned.  D % 128 == 0, D <= 1024, n_levels <= 32.
+ * ------------------------------------------------------------------------------------------------ */
+int64_t hgr_logits_eval_workspace_bytes(int rows, int n_perm);
+int hgr_logits_eval(const void *feat16, const void *zsl_perm16, int rows, int D, int n_perm,
+                    const int32_t *tpos_perm, const int32_t *epos_perm, const unsigned char *slice_level,
+                    int n_levels, const int32_t *filler_pos, const int32_t *train_cols, int n_train,
+                    const int32_t *test_cols, int n_test, int k,
+                    int32_t *out_level, int32_t *out_top1, int32_t *out_topk, void *workspace, int dtype, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Data-parallel collectives over RCCL / xGMI (one process per GPU).  The reference has no distributed code (its only
  * mention is an unused DDP import, baseline/CLIP/clip_train.py:19); these serve the sharding this build adds:
  *   evaluation  - every rank text-encodes N/world prompts of update_classifier (model/clip_tree.py:318-325) and the

@@ -610,3 +610,51 @@ def test_vit_embed_ln_stats_equals_unfused(dt):
     ops.vit_embed_ln_stats(pe, cls, pos, gamma, beta, x2, x16, stats, b, g)
     assert torch.equal(x1, x2) and torch.equal(x16, x1.to(dt))
     assert torch.allclose(stats.cpu(), _slot_stats(x1.cpu()), rtol=1e-5, atol=1e-4)
+
+
+# ---- logits GEMM with the evaluation in its epilogue (hgr_logits_eval) --------------------------------------------------------
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("case", ["n21841", "ragged_rows", "empty_level", "ties", "all_equal", "clustered_test", "d1024"])
+def test_logits_eval_bit_exact_vs_gemm_plus_eval_rows(dt, case):
+    """hgr_logits_eval (no logits in memory: tile stage -> per-slice keys / maxima, row stage -> level arg-max, top-1, recomputed
+    candidates -> top-20) must give EXACTLY the ids of hgr_gemm_nt (fp32 logits) + hgr_eval_rows on the same operands
+    (main.py:136-176 on model/clip_tree.py:331): the full-size class matrix, ragged row counts, an empty level, exact ties
+    (duplicated class rows), all-equal logits (the k-round fallback), a tiny clustered test set, D = 1024."""
+    rows, n, d, levels, k = 64, 3000, 256, 9, 20
+    if case == "n21841":
+        rows, n, d, levels = 512, 21841, 512, 12
+    if case == "ragged_rows":
+        rows, n = 37, 1111
+    if case == "d1024":
+        rows, n, d = 300, 5000, 1024
+    f = _rand((rows, d), 81)
+    f = f / f.norm(dim=1, keepdim=True)
+    z = _rand((n, d), 82)
+    z = z / z.norm(dim=1, keepdim=True)
+    if case == "ties":
+        z[5::7] = z[3]                                        # many identical class rows: exact ties across levels and subsets
+        z[100:140] = z[99]
+    if case == "all_equal":
+        z[:] = z[0]
+    depth = synth.randint(3, "depth", n, 0, levels).astype(np.int32)
+    depth[:3] = 0
+    if case == "empty_level":
+        depth[depth == 4] = 3
+    perm = np.argsort(synth.uniform(4, "perm", n), kind="stable").astype(np.int32)
+    train = perm[: n - n // 3].copy()
+    test = perm[n - n // 2:].copy()                           # unsorted: tie order follows the subset positions
+    if case == "clustered_test":
+        test = np.arange(40, 64, dtype=np.int32)[::-1].copy()
+    f16, z16 = f.to(dt).to(DEV), z.to(dt).to(DEV)
+    index = ops.EvalIndex(torch.from_numpy(depth).to(DEV), torch.from_numpy(train).to(DEV), torch.from_numpy(test).to(DEV), levels)
+    ld = (n + 63) // 64 * 64
+    lg = torch.empty(rows, ld, dtype=torch.float32, device=DEV)
+    ops.gemm_nt(f16, z16, lg, n=n)
+    want = ops.eval_rows(lg[:, :n], index, k)
+    plan = ops.LogitsEvalPlan(index).bind(z16)
+    assert plan.n_perm % 128 == 0 and int(plan.valid.sum()) == n
+    got = ops.logits_eval(f16, plan, k)
+    for w, g_, name in zip(want, got, ("level arg-max", "top-1", "top-k")):
+        assert torch.equal(w, g_), (case, name, int((w != g_).sum()))
+    again = ops.logits_eval(f16, plan, k)
+    assert all(torch.equal(a, b) for a, b in zip(got, again))           # run-to-run identical

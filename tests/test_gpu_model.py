@@ -379,3 +379,33 @@ def test_graphs_survive_a_workspace_reallocation(golden_dir, tmp_path):
     del junk
     assert torch.equal(a, b)
     assert torch.equal(model(img, None), a)
+
+
+def test_fused_evaluation_equals_logits_then_eval(golden_dir, tmp_path):
+    """Evaluator.add_images (image tower -> hgr_logits_eval, graph replay on) advances the nine counters of main.test exactly like
+    add_batch(model(imgs)) (main.py:131-191), on the reference fixture's model; and evaluate.test, which takes the fused route,
+    prints the metric string the reference printed (HGR logits differ from the fixture's fp32 logits by < 1e-3, so the string is
+    compared with the unfused route's, which the other tests tie to the reference)."""
+    meta, z, cfg, edges = _tree_case("smallvit_n300", golden_dir)
+    sd = synth.clip_state_dict(cfg, 0)
+    from hgr_net_amd.hierarchy import build_hierarchy
+    h = build_hierarchy(edges)
+    splits = synth.make_splits(h.nodes, [len(c) == 0 for c in h.p2c], meta["n_train"], meta["n_test"], meta["split_seed"])
+    model = tree_model(_opts(tmp_path, edges), splits["all"], splits["rest"],
+                       node_tokens=torch.from_numpy(z["node_tokens"].astype(np.int64)), clip_model=build_model(sd).to(DEV))
+    model.update_classifier()
+    ev_a, ev_b = evaluate.Evaluator(model), evaluate.Evaluator(model)
+    assert ev_b.fused_ok()
+    for i in range(meta["batches"]):
+        img = synth.images(meta["bsz"], cfg["image_resolution"], meta["image_seed0"] + i).to(DEV)
+        pa = ev_a.add_batch(model(img, None), meta["targets"][i])
+        pb = ev_b.add_images(img, meta["targets"][i], want_outputs=True)
+        assert torch.equal(pa[0], pb[0]) and torch.equal(pa[1], pb[1])
+    assert ev_a.counters() == ev_b.counters() and ev_a.summary() == ev_b.summary()
+
+    def loader():
+        for i in range(meta["batches"]):
+            yield {"img": synth.images(meta["bsz"], cfg["image_resolution"], meta["image_seed0"] + i)[None],
+                   "label": torch.full((1, meta["bsz"]), meta["targets"][i], dtype=torch.long)}
+    out = evaluate.test(model.opts, model, DEV, None, loader=loader(), log=False)
+    assert out == ev_a.summary()
