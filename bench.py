@@ -232,6 +232,7 @@ def main():
     ap.add_argument("--text-dtype", default="f16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", dest="pcie", action="store_false", help="skip the PCIe-inclusive (host uint8 input) measurement")
+    ap.add_argument("--unfused-eval", action="store_true", help="materialise the logits and run hgr_eval_rows on them (the first build's path)")
     ap.add_argument("--mode", default="eval", choices=["eval", "train"], help="eval: the BASELINE metric (zero-shot step); "
                     "train: one OM training step per step (configs[4] shape with --arch ViT-L/14 --n-ctx 16)")
     ap.add_argument("--n-ctx", type=int, default=0, help="train mode: CoOp learnable context vectors")
@@ -314,8 +315,14 @@ def main():
     log(f"[bench] update_classifier (text tower, {a.nodes} prompts, one-off, untimed): {time.time() - t0:.2f}s")
 
     ev = evaluate.Evaluator(model)
+    # the evaluation loop never looks at the logits themselves: the class-logits GEMM runs with the top-20 / top-1 / per-level
+    # arg-max consumers in its epilogue (hgr_logits_eval), nothing [B, N] is written (--unfused-eval: logits + hgr_eval_rows)
+    fused_eval = ev.fused_ok() and not a.unfused_eval
 
     def step(i):
+        if fused_eval:
+            ev.add_images(batches[i & 1], targets[i])
+            return
         logits = model(batches[i & 1], None, static_output=True)      # consumed by add_batch before the next forward
         ev.add_batch(logits, targets[i], want_outputs=False)
 
@@ -380,12 +387,14 @@ def main():
                     "traffic": traffic, "traffic_unit": traffic_src,
                     "algorithmic_bytes_per_launch": round(sum(b for _, _, b in tower) / len(tower)),
                     "launches": len(tower), "avg_launch_us": round(tsum / len(tower) * 1e6, 1)}
-        lg = [(s_.elapsed_time(e_) * 1e-3, fl, by) for (name, s_, e_, fl, by, tag) in recs if tag == "logits"]     # tagged by tree_model, not guessed from sizes
+        lg = [(s_.elapsed_time(e_) * 1e-3, fl, by) for (name, s_, e_, fl, by, tag) in recs if tag in ("logits", "logits_eval")]     # tagged, not guessed from sizes
         if lg and roof:
             tl = sum(t for t, _, _ in lg) / len(lg)
             roof["logits_gemm"] = {"us": round(tl * 1e6, 1), "tflops": round(lg[0][1] / tl / 1e12, 1),
                                    "frac_mfma": round(lg[0][1] / tl / 1e12 / PEAK_TFLOPS_BF16, 4),
-                                   "gbps": round(lg[0][2] / tl / 1e9, 1), "frac_hbm": round(lg[0][2] / tl / 8e12, 4)}
+                                   "gbps": round(lg[0][2] / tl / 1e9, 1), "frac_hbm": round(lg[0][2] / tl / 8e12, 4),
+                                   "what": ("hgr_logits_eval: logits GEMM + top-20 / top-1 / level arg-max in its epilogue, both stages, no logits written "
+                                            "(target of north_star: >= 0.40 of the MFMA peak)") if fused_eval else "hgr_gemm_nt writing fp32 logits (hgr_eval_rows runs behind it)"}
 
     # PCIe-inclusive rate (never `value`): the same step fed from pinned HOST memory with uint8 NHWC crops (what a
     # JPEG decoder hands over), H2D on a copy stream double-buffered against compute, normalisation fused into the
@@ -411,8 +420,11 @@ def main():
         def ustep(i):
             prefetch(i + 1)
             torch.cuda.current_stream().wait_event(ready[i & 1])
-            logits = model(dbuf[i & 1], None, static_output=True)
-            ev.add_batch(logits, targets[i % len(targets)], want_outputs=False)
+            if fused_eval:
+                ev.add_images(dbuf[i & 1], targets[i % len(targets)])
+            else:
+                logits = model(dbuf[i & 1], None, static_output=True)
+                ev.add_batch(logits, targets[i % len(targets)], want_outputs=False)
             free[i & 1].record()
 
         prefetch(0)
@@ -456,7 +468,7 @@ def main():
                 "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": a.image_dtype, "data": "synthetic",
                 "config": {"workload": f"{a.arch} zero-shot eval step: encode_image + L2 + [{a.batch}x{cfg['embed_dim']}]x[{cfg['embed_dim']}x{a.nodes}] logits "
-                                       f"+ top-20/top-1/level-argmax metrics (main.py:131-191), N={a.nodes} nodes, batch {a.batch}/GPU",
+                                       f"+ top-20/top-1/level-argmax metrics (main.py:131-191; {'fused into the logits GEMM' if fused_eval else 'hgr_eval_rows on materialised logits'}), N={a.nodes} nodes, batch {a.batch}/GPU",
                            "global_batch": a.batch * world, "parallelism": f"dp{world}", "text_dtype": a.text_dtype,
                            "weights": "random-init (hash-seeded), no checkpoint offline"},
                 "roofline": roof, "cpu_baseline": cpu, "parity": parity, "pcie_inclusive": pcie, "metrics_string": summary.strip()}

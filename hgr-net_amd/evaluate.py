@@ -117,7 +117,6 @@ def test(opts, model, device, splits=None, loader: Optional[Iterable] = None, gr
     if loader is None:                                   # main.py:111-114
         print("Loading datasets", flush=True)
         from .dataset import DataManager_test
-        import os
         data = DataManager_test(opts=opts, split=opts.data_split_test, node_set=model.nodes, candidates=splits[opts.data_test],
                                 resolution=model.resolution)
         # ViT towers take the uint8 crops directly (normalisation fused into the patch kernel): a quarter of the bytes
