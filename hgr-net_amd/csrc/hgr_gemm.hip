@@ -1041,30 +1041,34 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             unsigned long long key = 0ull;
-            float tm = -INFINITY;
+            f32x4 gm;                                   // largest test value of each of the slice's four 16-column groups (b, j)
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j) {
+                float tm = -INFINITY;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float v = acc[a][b][i][j][e] + 0.0f;                 // -0 -> +0, as the row sweep of hgr_eval_rows does
-                const unsigned u = __float_as_uint(v);
-                const unsigned long long k2 = ((unsigned long long)(u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u)) << 32) | (unsigned)(0x7fffffff - tp[b][j][e]);
-                if (tp[b][j][e] >= 0 && k2 > key) key = k2;
-                if (ep[b][j][e] >= 0) tm = fmaxf(tm, v);
+                for (int e = 0; e < 4; ++e) {
+                    const float v = acc[a][b][i][j][e] + 0.0f;             // -0 -> +0, as the row sweep of hgr_eval_rows does
+                    const unsigned u = __float_as_uint(v);
+                    const unsigned long long k2 = ((unsigned long long)(u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u)) << 32) | (unsigned)(0x7fffffff - tp[b][j][e]);
+                    if (tp[b][j][e] >= 0 && k2 > key) key = k2;
+                    if (ep[b][j][e] >= 0) tm = fmaxf(tm, v);
+                }
+                gm[b * 2 + j] = tm;
             }
 #pragma unroll
             for (int o = 16; o <= 32; o <<= 1) {
                 const unsigned hi = __shfl_xor((unsigned)(key >> 32), o), lo = __shfl_xor((unsigned)key, o);
                 const unsigned long long x = ((unsigned long long)hi << 32) | lo;
                 key = x > key ? x : key;
-                tm = fmaxf(tm, __shfl_xor(tm, o));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) gm[q] = fmaxf(gm[q], __shfl_xor(gm[q], o));
             }
             const int m = m0 + wm * 128 + a * 64 + i * 16 + r;
             if (g == 0 && m < p.M) {
                 p.ev_key[(int64_t)m * p.ev_slices + sl] = key;
-                p.ev_tmax[(int64_t)m * p.ev_slices + sl] = tm;
+                *(f32x4 *)(p.ev_tmax + ((int64_t)m * p.ev_slices + sl) * 4) = gm;
             }
         }
         return;
@@ -1711,7 +1715,7 @@ int hgr_logits_eval_rows_launch(const void *feat, const void *zslp, int D, int S
 
 extern "C" int64_t hgr_logits_eval_workspace_bytes(int rows, int n_perm) {
     if (rows < 1 || n_perm < 128 || n_perm % 128) return -1;
-    return (int64_t)rows * (n_perm / 64) * 12;           // 8-byte key + 4-byte test maximum per (row, slice)
+    return (int64_t)rows * (n_perm / 64) * 24;           // per (row, slice): 8-byte train key + four 4-byte test maxima (16-column groups)
 }
 
 extern "C" int hgr_logits_eval(const void *feat16, const void *zsl_perm16, int rows, int D, int n_perm,

@@ -516,17 +516,18 @@ __global__ __launch_bounds__(EL_NT) void eval_rows_lds(const float *__restrict__
 
 
 // ---- second stage of hgr_logits_eval (first stage: gemm_nt_duo<.., LN = 3> in hgr_gemm.hip) ------------------------------------
-// One workgroup per image row.  Input: per 64-column slice of the level-sorted class matrix the best train key and the largest
-// test value of this row.  (1) level arg-max = max of the keys of the level's slices, with the reference's -1 filler rule;
-// unmasked top-1 = best of the level bests; (2) threshold t = k-th largest slice maximum over the test columns (k distinct
-// elements >= t exist; fewer than k non-empty slices: t = -inf); (3) ONLY the slices whose maximum reaches t can hold one of the
-// k best: their 64 logits are recomputed on the matrix cores with the first stage's operand roles and K order (bit-identical
-// values), elements >= t are ranked by (value, test position).  The [B, N] logits never exist in memory.
+// One workgroup per image row.  Input: per 64-column slice of the level-sorted class matrix the best train key of this row and the
+// largest test value of each of the slice's four 16-column groups.  (1) level arg-max = max of the keys of the level's slices,
+// with the reference's -1 filler rule; unmasked top-1 = best of the level bests; (2) threshold t = k-th largest SLICE maximum over
+// the test columns (k distinct elements >= t exist; fewer than k non-empty slices: t = -inf); (3) only a 16-column group whose
+// maximum reaches t can hold one of the k best (typically k .. k + 5 groups of ~1 400): its 16 logits are recomputed on the matrix
+// cores with the first stage's operand roles and K order (bit-identical values), elements >= t are ranked by (value, test
+// position).  The [B, N] logits never exist in memory.
 constexpr int LE_NT = 256, LE_MAXS = 1024, LE_CAP = 2048;
 
 template <int DT>
 __global__ __launch_bounds__(LE_NT) void logits_eval_rows(const void *__restrict__ feat, const void *__restrict__ zslp, int D, int S,
-                                                        const unsigned long long *__restrict__ keys, const float *__restrict__ tmax,
+                                                        const unsigned long long *__restrict__ keys, const float *__restrict__ gmax,
                                                         const unsigned char *__restrict__ slice_level, int n_levels, const int32_t *__restrict__ filler_pos,
                                                         const int32_t *__restrict__ train_cols, int n_train, const int32_t *__restrict__ epos,
                                                         const int32_t *__restrict__ test_cols, int n_test, int k,
@@ -534,8 +535,10 @@ __global__ __launch_bounds__(LE_NT) void logits_eval_rows(const void *__restrict
     typedef typename T16<DT>::vec8 vec8;
     typedef typename T16<DT>::elem E;
     __shared__ unsigned long long s_lkey[32];
+    __shared__ __attribute__((aligned(16))) float s_gm[LE_MAXS * 4];
     __shared__ float s_tm[LE_MAXS];
-    __shared__ int s_cand[LE_MAXS];
+    __shared__ short s_cand[LE_MAXS * 4];
+    __shared__ __attribute__((aligned(16))) E s_feat[1024];
     __shared__ float s_cv[LE_CAP];
     __shared__ int s_cp[LE_CAP];
     __shared__ float s_t;
@@ -546,12 +549,15 @@ __global__ __launch_bounds__(LE_NT) void logits_eval_rows(const void *__restrict
     const int row = blockIdx.x;
     if (tid < 32) s_lkey[tid] = 0ull;
     if (tid == 0) { s_ncand = 0; s_cnt = 0; s_nonempty = 0; s_t = -INFINITY; }
+    for (int c = tid; c < (D >> 3); c += LE_NT) ((u32x4 *)s_feat)[c] = ((const u32x4 *)((const E *)feat + (int64_t)row * D))[c];
     __syncthreads();
     for (int s = tid; s < S; s += LE_NT) {
         const unsigned long long key = keys[(int64_t)row * S + s];
         const int lv = slice_level[s];
         if (key && lv < 32) atomicMax(&s_lkey[lv], key);
-        const float t = tmax[(int64_t)row * S + s];
+        const f32x4 g4 = *(const f32x4 *)(gmax + ((int64_t)row * S + s) * 4);
+        *(f32x4 *)(s_gm + s * 4) = g4;
+        const float t = fmaxf(fmaxf(g4[0], g4[1]), fmaxf(g4[2], g4[3]));
         s_tm[s] = t;
         if (t > -INFINITY) atomicAdd(&s_nonempty, 1);
     }
@@ -589,36 +595,42 @@ __global__ __launch_bounds__(LE_NT) void logits_eval_rows(const void *__restrict
     }
     __syncthreads();
     const float t = s_t;
-    for (int s = tid; s < S; s += LE_NT)
-        if (s_tm[s] > -INFINITY && s_tm[s] >= t) s_cand[atomicAdd(&s_ncand, 1)] = s;
+    for (int q = tid; q < S * 4; q += LE_NT)
+        if (s_gm[q] > -INFINITY && s_gm[q] >= t) s_cand[atomicAdd(&s_ncand, 1)] = (short)q;
     __syncthreads();
     const int ncand = s_ncand;
-    // the row's feature as MFMA B-operand fragments (every one of the 16 "rows" m of the fragment is this image): lane (r, g) holds
-    // x[32 kk + 8 g .. + 7] for k-step kk; D <= 1024 -> at most 32 k-steps
+    // visitor(value, test position) over every test element of the candidate groups; a wave takes TWO groups per trip (two
+    // independent accumulators, 16 class-row fragments in flight).  Fragments: A operand = 16 class rows x 32 k (lane (r16, g): row
+    // r16, k = 32 kk + 8 g ..), B operand = the image's feature for every one of its 16 "rows" m (from LDS, same address for all r16).
     const int r16 = lane & 15, g = lane >> 4;
     const int ks = D >> 5;
-    const E *fr = (const E *)feat + (int64_t)row * D;
-    // visitor(value, test position) over every test element of the candidate slices, each wave on slices wave, wave + 4, ...
     auto scan = [&](auto visit) {
-        for (int ci = wave; ci < ncand; ci += 4) {
-            const int sl = s_cand[ci];
-#pragma unroll 1
-            for (int nt = 0; nt < 4; ++nt) {
-                const E *wr = (const E *)zslp + ((int64_t)sl * 64 + nt * 16 + r16) * D + g * 8;
-                f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-                for (int kk = 0; kk < ks; kk += 4) {                 // D % 128 == 0: 4 k-steps per trip, loads first
-                    vec8 wf[4], xf[4];
+        for (int ci = wave * 2; ci < ncand; ci += 8) {
+            const int q0 = s_cand[ci], q1 = s_cand[min(ci + 1, ncand - 1)];
+            const E *w0 = (const E *)zslp + ((int64_t)q0 * 16 + r16) * D + g * 8;
+            const E *w1 = (const E *)zslp + ((int64_t)q1 * 16 + r16) * D + g * 8;
+            f32x4 a0 = (f32x4){0.f, 0.f, 0.f, 0.f}, a1 = a0;
+            for (int kk = 0; kk < ks; kk += 4) {                     // D % 128 == 0: 4 k-steps per trip, all 8 loads first
+                vec8 f0[4], f1[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) { wf[u] = *(const vec8 *)(wr + (kk + u) * 32); xf[u] = *(const vec8 *)(fr + (kk + u) * 32 + g * 8); }
+                for (int u = 0; u < 4; ++u) { f0[u] = *(const vec8 *)(w0 + (kk + u) * 32); f1[u] = *(const vec8 *)(w1 + (kk + u) * 32); }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) acc = T16<DT>::mfma16(wf[u], xf[u], acc);
+                for (int u = 0; u < 4; ++u) {
+                    const vec8 xf = *(const vec8 *)(s_feat + (kk + u) * 32 + g * 8);
+                    a0 = T16<DT>::mfma16(f0[u], xf, a0);
+                    a1 = T16<DT>::mfma16(f1[u], xf, a1);
                 }
-                // lane (r16, g) holds columns 4 g .. 4 g + 3 of this 16-column group (identical for every r16): lane r16 < 4 takes e = r16
-                float v = r16 == 0 ? acc[0] : r16 == 1 ? acc[1] : r16 == 2 ? acc[2] : acc[3];
-                v += 0.0f;
-                if (r16 < 4) {
-                    const int te = epos[sl * 64 + nt * 16 + g * 4 + r16];
-                    if (te >= 0) visit(v, te);
+            }
+            // lane (r16, g) holds columns 4 g .. 4 g + 3 of the group (identical for every r16): lanes r16 < 4 take element r16
+            float v0 = r16 == 0 ? a0[0] : r16 == 1 ? a0[1] : r16 == 2 ? a0[2] : a0[3];
+            float v1 = r16 == 0 ? a1[0] : r16 == 1 ? a1[1] : r16 == 2 ? a1[2] : a1[3];
+            v0 += 0.0f; v1 += 0.0f;
+            if (r16 < 4) {
+                const int te0 = epos[q0 * 16 + g * 4 + r16];
+                if (te0 >= 0) visit(v0, te0);
+                if (ci + 1 < ncand) {
+                    const int te1 = epos[q1 * 16 + g * 4 + r16];
+                    if (te1 >= 0) visit(v1, te1);
                 }
             }
         }
@@ -640,7 +652,7 @@ __global__ __launch_bounds__(LE_NT) void logits_eval_rows(const void *__restrict
         }
         return;
     }
-    // heavily duplicated data (more than LE_CAP elements tie at the threshold): k rounds of arg-max over the candidate slices, an
+    // heavily duplicated data (more than LE_CAP elements tie at the threshold): k rounds of arg-max over the candidate groups, an
     // element is "removed" by requiring it to be worse than the previous winner in (value, position) order
     Best last = {INFINITY, -1};
     for (int j = 0; j < k; ++j) {
