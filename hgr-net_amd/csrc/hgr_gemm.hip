@@ -1709,7 +1709,7 @@ extern "C" int hgr_gemm_nt_ln(const void *X16, int64_t ldx, const void *Wfold, i
 
 // ---- logits GEMM with the evaluation consumers in its epilogue ------------------------------------------------------------
 int hgr_logits_eval_rows_launch(const void *feat, const void *zslp, int D, int S, const unsigned long long *keys, const float *tmax,
-                                const unsigned char *slice_level, int n_levels, const int32_t *filler_pos, const int32_t *train_cols, int n_train,
+                                const int32_t *level_first, int n_levels, const int32_t *filler_pos, const int32_t *train_cols, int n_train,
                                 const int32_t *epos, const int32_t *test_cols, int n_test, int k, int32_t *out_level, int32_t *out_top1,
                                 int32_t *out_topk, int rows, int dtype, void *stream);      // hgr_select.hip
 
@@ -1719,11 +1719,11 @@ extern "C" int64_t hgr_logits_eval_workspace_bytes(int rows, int n_perm) {
 }
 
 extern "C" int hgr_logits_eval(const void *feat16, const void *zsl_perm16, int rows, int D, int n_perm,
-                               const int32_t *tpos_perm, const int32_t *epos_perm, const unsigned char *slice_level,
+                               const int32_t *tpos_perm, const int32_t *epos_perm, const int32_t *level_first,
                                int n_levels, const int32_t *filler_pos, const int32_t *train_cols, int n_train,
                                const int32_t *test_cols, int n_test, int k,
                                int32_t *out_level, int32_t *out_top1, int32_t *out_topk, void *workspace, int dtype, void *stream) {
-    HGR_REQUIRE(feat16 && zsl_perm16 && tpos_perm && epos_perm && slice_level && filler_pos && train_cols && out_level && workspace, "hgr_logits_eval: null operand");
+    HGR_REQUIRE(feat16 && zsl_perm16 && tpos_perm && epos_perm && level_first && filler_pos && train_cols && out_level && workspace, "hgr_logits_eval: null operand");
     HGR_REQUIRE(rows >= 1 && D >= 128 && D % 128 == 0 && D <= 1024, "hgr_logits_eval: rows=%d D=%d unsupported (D %% 128 == 0, D <= 1024)", rows, D);
     HGR_REQUIRE(n_perm >= 128 && n_perm % 128 == 0 && n_perm / 64 <= 1024, "hgr_logits_eval: n_perm=%d must be a multiple of 128 and <= 65536 (level-aligned, padded columns)", n_perm);
     HGR_REQUIRE(n_levels >= 1 && n_levels <= 32 && n_train >= 1, "hgr_logits_eval: bad sizes (n_levels <= 32)");
@@ -1740,6 +1740,6 @@ extern "C" int hgr_logits_eval(const void *feat16, const void *zsl_perm16, int r
     if (dtype == HGR_BF16) hipLaunchKernelGGL((gemm_nt_duo<HGR_BF16, HGR_EPI_NONE, true, 3>), grid, dim3(NTD), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((gemm_nt_duo<HGR_F16, HGR_EPI_NONE, true, 3>), grid, dim3(NTD), 0, (hipStream_t)stream, a);
     HGR_CHECK_LAUNCH("hgr_logits_eval (tile stage)");
-    return hgr_logits_eval_rows_launch(feat16, zsl_perm16, D, S, a.ev_key, a.ev_tmax, slice_level, n_levels, filler_pos, train_cols, n_train,
+    return hgr_logits_eval_rows_launch(feat16, zsl_perm16, D, S, a.ev_key, a.ev_tmax, level_first, n_levels, filler_pos, train_cols, n_train,
                                        epos_perm, test_cols, n_test, k, out_level, out_top1, out_topk, rows, dtype, stream);
 }

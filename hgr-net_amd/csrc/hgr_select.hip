@@ -523,12 +523,12 @@ __global__ __launch_bounds__(EL_NT) void eval_rows_lds(const float *__restrict__
 // maximum reaches t can hold one of the k best (typically k .. k + 5 groups of ~1 400): its 16 logits are recomputed on the matrix
 // cores with the first stage's operand roles and K order (bit-identical values), elements >= t are ranked by (value, test
 // position).  The [B, N] logits never exist in memory.
-constexpr int LE_NT = 256, LE_MAXS = 1024, LE_CAP = 2048;
+constexpr int LE_NT = 512, LE_NW = LE_NT / 64, LE_MAXS = 1024, LE_CAP = 2048;
 
 template <int DT>
 __global__ __launch_bounds__(LE_NT) void logits_eval_rows(const void *__restrict__ feat, const void *__restrict__ zslp, int D, int S,
                                                         const unsigned long long *__restrict__ keys, const float *__restrict__ gmax,
-                                                        const unsigned char *__restrict__ slice_level, int n_levels, const int32_t *__restrict__ filler_pos,
+                                                        const int32_t *__restrict__ level_first, int n_levels, const int32_t *__restrict__ filler_pos,
                                                         const int32_t *__restrict__ train_cols, int n_train, const int32_t *__restrict__ epos,
                                                         const int32_t *__restrict__ test_cols, int n_test, int k,
                                                         int32_t *__restrict__ out_level, int32_t *__restrict__ out_top1, int32_t *__restrict__ out_topk) {
@@ -543,8 +543,8 @@ __global__ __launch_bounds__(LE_NT) void logits_eval_rows(const void *__restrict
     __shared__ int s_cp[LE_CAP];
     __shared__ float s_t;
     __shared__ int s_ncand, s_cnt, s_nonempty;
-    __shared__ float s_bv[4];
-    __shared__ int s_bp[4];
+    __shared__ float s_bv[LE_NW];
+    __shared__ int s_bp[LE_NW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row = blockIdx.x;
     if (tid < 32) s_lkey[tid] = 0ull;
@@ -552,14 +552,24 @@ __global__ __launch_bounds__(LE_NT) void logits_eval_rows(const void *__restrict
     for (int c = tid; c < (D >> 3); c += LE_NT) ((u32x4 *)s_feat)[c] = ((const u32x4 *)((const E *)feat + (int64_t)row * D))[c];
     __syncthreads();
     for (int s = tid; s < S; s += LE_NT) {
-        const unsigned long long key = keys[(int64_t)row * S + s];
-        const int lv = slice_level[s];
-        if (key && lv < 32) atomicMax(&s_lkey[lv], key);
         const f32x4 g4 = *(const f32x4 *)(gmax + ((int64_t)row * S + s) * 4);
         *(f32x4 *)(s_gm + s * 4) = g4;
         const float t = fmaxf(fmaxf(g4[0], g4[1]), fmaxf(g4[2], g4[3]));
         s_tm[s] = t;
         if (t > -INFINITY) atomicAdd(&s_nonempty, 1);
+    }
+    // level bests: the slices of level l are the contiguous range [level_first[l], level_first[l + 1]); wave w reduces levels
+    // w, w + 8, ... (same-address LDS atomics would serialise: ~30 per level)
+    for (int l = wave; l < n_levels; l += LE_NW) {
+        unsigned long long m = 0ull;
+        for (int s = level_first[l] + lane; s < level_first[l + 1]; s += 64) { const unsigned long long x = keys[(int64_t)row * S + s]; m = x > m ? x : m; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned hi = __shfl_xor((unsigned)(m >> 32), o), lo = __shfl_xor((unsigned)m, o);
+            const unsigned long long x = ((unsigned long long)hi << 32) | lo;
+            m = x > m ? x : m;
+        }
+        if (lane == 0) s_lkey[l] = m;
     }
     __syncthreads();
     if (wave == 0) {                                        // lane l < n_levels finishes level l (hgr_eval_rows' rule, main.py:162-176)
@@ -605,20 +615,25 @@ __global__ __launch_bounds__(LE_NT) void logits_eval_rows(const void *__restrict
     const int r16 = lane & 15, g = lane >> 4;
     const int ks = D >> 5;
     auto scan = [&](auto visit) {
-        for (int ci = wave * 2; ci < ncand; ci += 8) {
+        for (int ci = wave * 2; ci < ncand; ci += 2 * LE_NW) {
             const int q0 = s_cand[ci], q1 = s_cand[min(ci + 1, ncand - 1)];
             const E *w0 = (const E *)zslp + ((int64_t)q0 * 16 + r16) * D + g * 8;
             const E *w1 = (const E *)zslp + ((int64_t)q1 * 16 + r16) * D + g * 8;
             f32x4 a0 = (f32x4){0.f, 0.f, 0.f, 0.f}, a1 = a0;
-            for (int kk = 0; kk < ks; kk += 4) {                     // D % 128 == 0: 4 k-steps per trip, all 8 loads first
-                vec8 f0[4], f1[4];
+            for (int kk = 0; kk < ks; kk += 8) {                     // 8 k-steps per trip (D % 256 == 0 fast path), all 16 loads first
+                vec8 f0[8], f1[8];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { f0[u] = *(const vec8 *)(w0 + (kk + u) * 32); f1[u] = *(const vec8 *)(w1 + (kk + u) * 32); }
+                for (int u = 0; u < 8; ++u) {
+                    const int kq = min(kk + u, ks - 1);               // D = 128 / 384 / 640: the tail repeats a step and skips its MFMA
+                    f0[u] = *(const vec8 *)(w0 + kq * 32); f1[u] = *(const vec8 *)(w1 + kq * 32);
+                }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const vec8 xf = *(const vec8 *)(s_feat + (kk + u) * 32 + g * 8);
-                    a0 = T16<DT>::mfma16(f0[u], xf, a0);
-                    a1 = T16<DT>::mfma16(f1[u], xf, a1);
+                for (int u = 0; u < 8; ++u) {
+                    if (kk + u < ks) {
+                        const vec8 xf = *(const vec8 *)(s_feat + (kk + u) * 32 + g * 8);
+                        a0 = T16<DT>::mfma16(f0[u], xf, a0);
+                        a1 = T16<DT>::mfma16(f1[u], xf, a1);
+                    }
                 }
             }
             // lane (r16, g) holds columns 4 g .. 4 g + 3 of the group (identical for every r16): lanes r16 < 4 take element r16
@@ -663,7 +678,7 @@ __global__ __launch_bounds__(LE_NT) void logits_eval_rows(const void *__restrict
         if (lane == 0) { s_bv[wave] = b.v; s_bp[wave] = b.p; }
         __syncthreads();
         Best w = {s_bv[0], s_bp[0]};
-        for (int i = 1; i < 4; ++i) if (better(s_bv[i], s_bp[i], w.v, w.p)) { w.v = s_bv[i]; w.p = s_bp[i]; }
+        for (int i = 1; i < LE_NW; ++i) if (better(s_bv[i], s_bp[i], w.v, w.p)) { w.v = s_bv[i]; w.p = s_bp[i]; }
         if (tid == 0) out_topk[(int64_t)row * k + j] = w.p < n_test ? test_cols[w.p] : -1;
         last = w;
     }
@@ -672,12 +687,12 @@ __global__ __launch_bounds__(LE_NT) void logits_eval_rows(const void *__restrict
 }  // namespace
 
 int hgr_logits_eval_rows_launch(const void *feat, const void *zslp, int D, int S, const unsigned long long *keys, const float *tmax,
-                                const unsigned char *slice_level, int n_levels, const int32_t *filler_pos, const int32_t *train_cols, int n_train,
+                                const int32_t *level_first, int n_levels, const int32_t *filler_pos, const int32_t *train_cols, int n_train,
                                 const int32_t *epos, const int32_t *test_cols, int n_test, int k, int32_t *out_level, int32_t *out_top1,
                                 int32_t *out_topk, int rows, int dtype, void *stream) {
-    if (dtype == HGR_BF16) hipLaunchKernelGGL((logits_eval_rows<HGR_BF16>), dim3(rows), dim3(LE_NT), 0, (hipStream_t)stream, feat, zslp, D, S, keys, tmax, slice_level,
+    if (dtype == HGR_BF16) hipLaunchKernelGGL((logits_eval_rows<HGR_BF16>), dim3(rows), dim3(LE_NT), 0, (hipStream_t)stream, feat, zslp, D, S, keys, tmax, level_first,
                                               n_levels, filler_pos, train_cols, n_train, epos, test_cols, n_test, k, out_level, out_top1, out_topk);
-    else hipLaunchKernelGGL((logits_eval_rows<HGR_F16>), dim3(rows), dim3(LE_NT), 0, (hipStream_t)stream, feat, zslp, D, S, keys, tmax, slice_level,
+    else hipLaunchKernelGGL((logits_eval_rows<HGR_F16>), dim3(rows), dim3(LE_NT), 0, (hipStream_t)stream, feat, zslp, D, S, keys, tmax, level_first,
                             n_levels, filler_pos, train_cols, n_train, epos, test_cols, n_test, k, out_level, out_top1, out_topk);
     HGR_CHECK_LAUNCH("hgr_logits_eval (row stage)");
     return HGR_OK;

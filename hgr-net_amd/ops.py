@@ -312,18 +312,16 @@ class LogitsEvalPlan:
         lvl = index.lvl8.cpu().numpy().astype(np.int64)
         tpos = index.train_pos.cpu().numpy()
         epos = index.test_pos.cpu().numpy() if index.test_pos is not None else np.full(len(lvl), -1, dtype=np.int32)
-        cols, slice_level = [], []
-        for l in range(int(lvl.max()) + 1):
+        cols, level_first = [], [0]
+        for l in range(index.n_levels):
             c = np.nonzero(lvl == l)[0]
-            if c.size == 0:
-                continue
             pad = (-c.size) % 64
             cols.append(np.concatenate([c, np.full(pad, -1, dtype=np.int64)]))
-            slice_level += [min(l, 255)] * ((c.size + pad) // 64)
+            level_first.append(level_first[-1] + (c.size + pad) // 64)
+        assert int((lvl >= index.n_levels).sum()) == 0, "a node lies deeper than n_levels"
         perm = np.concatenate(cols)
-        if (perm.size // 64) % 2:                                    # whole 128-column tiles
+        if (perm.size // 64) % 2:                                    # whole 128-column tiles; the last slice belongs to no level
             perm = np.concatenate([perm, np.full(64, -1, dtype=np.int64)])
-            slice_level.append(255)
         dev = index.lvl8.device
         valid = perm >= 0
         safe = np.where(valid, perm, 0)
@@ -333,7 +331,7 @@ class LogitsEvalPlan:
         self.valid = torch.from_numpy(valid).to(dev)
         self.tpos = torch.from_numpy(np.where(valid, tpos[safe], -1).astype(np.int32)).to(dev)
         self.epos = torch.from_numpy(np.where(valid, epos[safe], -1).astype(np.int32)).to(dev)
-        self.slice_level = torch.from_numpy(np.asarray(slice_level, dtype=np.uint8)).to(dev)
+        self.level_first = torch.from_numpy(np.asarray(level_first, dtype=np.int32)).to(dev)
         self.zsl = None
         self._src = None
         self._ws = None
@@ -366,7 +364,7 @@ def logits_eval(feat16: torch.Tensor, plan: LogitsEvalPlan, k: int):
     topk = torch.empty((rows, max(k, 1)), dtype=torch.int32, device=dev)
     prof = PROFILE
     ev = _prof_begin()
-    _lib.call("hgr_logits_eval", _dev(feat16), _dev(plan.zsl), rows, d, plan.n_perm, _dev(plan.tpos), _dev(plan.epos), _dev(plan.slice_level),
+    _lib.call("hgr_logits_eval", _dev(feat16), _dev(plan.zsl), rows, d, plan.n_perm, _dev(plan.tpos), _dev(plan.epos), _dev(plan.level_first),
               ix.n_levels, _dev(ix.filler), _dev(ix.train_cols), ix.n_train, _dev(ix.test_cols), ix.n_test, k,
               _dev(lvl), _dev(top1), _dev(topk), _dev(plan.workspace(rows, dev)), DT_OF[feat16.dtype], _stream())
     _prof_end(ev, 2.0 * rows * ix.n_nodes * d, 2 * rows * d + 2 * ix.n_nodes * d, "logits_eval")

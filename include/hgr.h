@@ -457,7 +457,8 @@ int hgr_row_stats16(const float *x, void *x16, float *stats, int rows, int W, in
  * level padded with zero rows to a multiple of 64 columns (and the total to a multiple of 128), so that each 64-column slice lies
  * inside one level:
  *   zsl_perm16 16-bit [n_perm, D] (D = row stride);  tpos_perm / epos_perm int32 [n_perm]: position of the column in
- *   train_index / test_index or -1 (padding: both -1);  slice_level uint8 [n_perm / 64]: the level of each slice (255 = padding);
+ *   train_index / test_index or -1 (padding: both -1);  level_first int32 [n_levels + 1]: level l owns the 64-column slices
+ *   [level_first[l], level_first[l + 1]) (an empty level: an empty range; trailing padding slices belong to no level);
  *   filler_pos / train_cols / test_cols exactly as for hgr_eval_rows;  feat16: L2-normalised image features, 16-bit [rows, D].
  * Stage 1 (gemm_nt_duo tiles): per (row, slice) the best train column as an orderable key and the largest test value -> workspace.
  * Stage 2 (one workgroup per row): level arg-max / top-1 from the keys; top-k threshold = k-th largest slice maximum; the few slices
@@ -466,7 +467,7 @@ int hgr_row_stats16(const float *x, void *x16, float *stats, int rows, int W, in
  * ------------------------------------------------------------------------------------------------ */
 int64_t hgr_logits_eval_workspace_bytes(int rows, int n_perm);
 int hgr_logits_eval(const void *feat16, const void *zsl_perm16, int rows, int D, int n_perm,
-                    const int32_t *tpos_perm, const int32_t *epos_perm, const unsigned char *slice_level,
+                    const int32_t *tpos_perm, const int32_t *epos_perm, const int32_t *level_first,
                     int n_levels, const int32_t *filler_pos, const int32_t *train_cols, int n_train,
                     const int32_t *test_cols, int n_test, int k,
                     int32_t *out_level, int32_t *out_top1, int32_t *out_topk, void *workspace, int dtype, void *stream);
