@@ -551,12 +551,18 @@ __global__ __launch_bounds__(LE_NT) void logits_eval_rows(const void *__restrict
     if (tid == 0) { s_ncand = 0; s_cnt = 0; s_nonempty = 0; s_t = -INFINITY; }
     for (int c = tid; c < (D >> 3); c += LE_NT) ((u32x4 *)s_feat)[c] = ((const u32x4 *)((const E *)feat + (int64_t)row * D))[c];
     __syncthreads();
-    for (int s = tid; s < S; s += LE_NT) {
-        const f32x4 g4 = *(const f32x4 *)(gmax + ((int64_t)row * S + s) * 4);
-        *(f32x4 *)(s_gm + s * 4) = g4;
-        const float t = fmaxf(fmaxf(g4[0], g4[1]), fmaxf(g4[2], g4[3]));
-        s_tm[s] = t;
-        if (t > -INFINITY) atomicAdd(&s_nonempty, 1);
+    {
+        int mine = 0;                                       // non-empty slices seen by this thread (one LDS atomic per WAVE: same-address
+        for (int s = tid; s < S; s += LE_NT) {              // LDS atomics serialise, 355 of them cost more than the rest of the kernel)
+            const f32x4 g4 = *(const f32x4 *)(gmax + ((int64_t)row * S + s) * 4);
+            *(f32x4 *)(s_gm + s * 4) = g4;
+            const float t = fmaxf(fmaxf(g4[0], g4[1]), fmaxf(g4[2], g4[3]));
+            s_tm[s] = t;
+            mine += t > -INFINITY ? 1 : 0;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+        if (lane == 0 && mine) atomicAdd(&s_nonempty, mine);
     }
     // level bests: the slices of level l are the contiguous range [level_first[l], level_first[l + 1]); wave w reduces levels
     // w, w + 8, ... (same-address LDS atomics would serialise: ~30 per level)
