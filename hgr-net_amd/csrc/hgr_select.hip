@@ -531,7 +531,7 @@ __global__ __launch_bounds__(LE_NT) void logits_eval_rows(const void *__restrict
                                                         const int32_t *__restrict__ level_first, int n_levels, const int32_t *__restrict__ filler_pos,
                                                         const int32_t *__restrict__ train_cols, int n_train, const int32_t *__restrict__ epos,
                                                         const int32_t *__restrict__ test_cols, int n_test, int k,
-                                                        int32_t *__restrict__ out_level, int32_t *__restrict__ out_top1, int32_t *__restrict__ out_topk) {
+                                                        int32_t *__restrict__ out_level, int32_t *__restrict__ out_top1, int32_t *__restrict__ out_topk, int dbg) {
     typedef typename T16<DT>::vec8 vec8;
     typedef typename T16<DT>::elem E;
     __shared__ unsigned long long s_lkey[32];
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(LE_NT) void logits_eval_rows(const void *__restrict
         const Best top = wave_best(b);
         if (lane == 0 && out_top1) out_top1[row] = top.p < n_train ? train_cols[top.p] : -1;
     }
-    if (k <= 0) return;
+    if (k <= 0 || dbg == 1) return;
     // threshold: the k-th best slice maximum, ties between slices ordered by the slice index (any fixed order gives the same VALUE)
     if (s_nonempty >= k) {
         for (int s = tid; s < S; s += LE_NT) {
@@ -610,11 +610,13 @@ __global__ __launch_bounds__(LE_NT) void logits_eval_rows(const void *__restrict
         }
     }
     __syncthreads();
+    if (dbg == 2) return;
     const float t = s_t;
     for (int q = tid; q < S * 4; q += LE_NT)
         if (s_gm[q] > -INFINITY && s_gm[q] >= t) s_cand[atomicAdd(&s_ncand, 1)] = (short)q;
     __syncthreads();
     const int ncand = s_ncand;
+    if (dbg == 3) return;
     // visitor(value, test position) over every test element of the candidate groups; a wave takes TWO groups per trip (two
     // independent accumulators, 16 class-row fragments in flight).  Fragments: A operand = 16 class rows x 32 k (lane (r16, g): row
     // r16, k = 32 kk + 8 g ..), B operand = the image's feature for every one of its 16 "rows" m (from LDS, same address for all r16).
@@ -663,6 +665,7 @@ __global__ __launch_bounds__(LE_NT) void logits_eval_rows(const void *__restrict
         }
     });
     __syncthreads();
+    if (dbg == 4) return;
     const int cnt = s_cnt;
     if (cnt <= LE_CAP) {
         for (int c = tid; c < cnt; c += LE_NT) {
@@ -696,10 +699,12 @@ int hgr_logits_eval_rows_launch(const void *feat, const void *zslp, int D, int S
                                 const int32_t *level_first, int n_levels, const int32_t *filler_pos, const int32_t *train_cols, int n_train,
                                 const int32_t *epos, const int32_t *test_cols, int n_test, int k, int32_t *out_level, int32_t *out_top1,
                                 int32_t *out_topk, int rows, int dtype, void *stream) {
+    static int dbg = -1;                              // HGR_LE_DBG = 1..4: leave the row stage after level / threshold / candidate list / scan (timing experiments only)
+    if (dbg < 0) { const char *e = getenv("HGR_LE_DBG"); dbg = e ? atoi(e) : 0; }
     if (dtype == HGR_BF16) hipLaunchKernelGGL((logits_eval_rows<HGR_BF16>), dim3(rows), dim3(LE_NT), 0, (hipStream_t)stream, feat, zslp, D, S, keys, tmax, level_first,
-                                              n_levels, filler_pos, train_cols, n_train, epos, test_cols, n_test, k, out_level, out_top1, out_topk);
+                                              n_levels, filler_pos, train_cols, n_train, epos, test_cols, n_test, k, out_level, out_top1, out_topk, dbg);
     else hipLaunchKernelGGL((logits_eval_rows<HGR_F16>), dim3(rows), dim3(LE_NT), 0, (hipStream_t)stream, feat, zslp, D, S, keys, tmax, level_first,
-                            n_levels, filler_pos, train_cols, n_train, epos, test_cols, n_test, k, out_level, out_top1, out_topk);
+                            n_levels, filler_pos, train_cols, n_train, epos, test_cols, n_test, k, out_level, out_top1, out_topk, dbg);
     HGR_CHECK_LAUNCH("hgr_logits_eval (row stage)");
     return HGR_OK;
 }
