@@ -61,7 +61,7 @@ struct GemmArgs {
     // fused evaluation (LN = 3, hgr_logits_eval): W = level-sorted, level-aligned class matrix, so every 64-column slice (one
     // wave's share of a tile) lies inside ONE hierarchy level.  Nothing of C is written; per (row, slice) the epilogue emits
     // the best train column as an orderable key and the largest value over the test columns.
-    unsigned long long *ev_key; float *ev_tmax; const int *ev_tpos, *ev_epos; int ev_slices;
+    unsigned long long *ev_key; float *ev_tmax, *ev_m2; int *ev_p1; const int *ev_tpos, *ev_epos; int ev_slices;
 };
 
 // 16 zero bytes every out-of-bounds conv tap (and the K padding) is loaded from
@@ -1041,21 +1041,28 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             unsigned long long key = 0ull;
-            f32x4 gm;                                   // largest test value of each of the slice's four 16-column groups (b, j)
+            // per 16-column group (b, j) of the slice: largest test value, the test position of one element attaining it, and
+            // the second largest value (multiplicity counted: m2 == m1 when the maximum is attained twice)
+            f32x4 m1, m2;
+            int p1[4];
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                float tm = -INFINITY;
+                float x[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float v = acc[a][b][i][j][e] + 0.0f;             // -0 -> +0, as the row sweep of hgr_eval_rows does
                     const unsigned u = __float_as_uint(v);
                     const unsigned long long k2 = ((unsigned long long)(u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u)) << 32) | (unsigned)(0x7fffffff - tp[b][j][e]);
                     if (tp[b][j][e] >= 0 && k2 > key) key = k2;
-                    if (ep[b][j][e] >= 0) tm = fmaxf(tm, v);
+                    x[e] = ep[b][j][e] >= 0 ? v : -INFINITY;
                 }
-                gm[b * 2 + j] = tm;
+                const float hi01 = fmaxf(x[0], x[1]), lo01 = fminf(x[0], x[1]), hi23 = fmaxf(x[2], x[3]), lo23 = fminf(x[2], x[3]);
+                const float top = fmaxf(hi01, hi23);
+                m1[b * 2 + j] = top;
+                m2[b * 2 + j] = fmaxf(fminf(hi01, hi23), fmaxf(lo01, lo23));
+                p1[b * 2 + j] = x[0] == top ? ep[b][j][0] : x[1] == top ? ep[b][j][1] : x[2] == top ? ep[b][j][2] : ep[b][j][3];
             }
 #pragma unroll
             for (int o = 16; o <= 32; o <<= 1) {
@@ -1063,12 +1070,21 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
                 const unsigned long long x = ((unsigned long long)hi << 32) | lo;
                 key = x > key ? x : key;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) gm[q] = fmaxf(gm[q], __shfl_xor(gm[q], o));
+                for (int q = 0; q < 4; ++q) {
+                    const float o1 = __shfl_xor(m1[q], o), o2 = __shfl_xor(m2[q], o);
+                    const int op = __shfl_xor(p1[q], o);
+                    m2[q] = fmaxf(fminf(m1[q], o1), fmaxf(m2[q], o2));
+                    p1[q] = o1 > m1[q] ? op : p1[q];
+                    m1[q] = fmaxf(m1[q], o1);
+                }
             }
             const int m = m0 + wm * 128 + a * 64 + i * 16 + r;
             if (g == 0 && m < p.M) {
-                p.ev_key[(int64_t)m * p.ev_slices + sl] = key;
-                *(f32x4 *)(p.ev_tmax + ((int64_t)m * p.ev_slices + sl) * 4) = gm;
+                const int64_t at = (int64_t)m * p.ev_slices + sl;
+                p.ev_key[at] = key;
+                *(f32x4 *)(p.ev_tmax + at * 4) = m1;
+                *(int4 *)(p.ev_p1 + at * 4) = make_int4(p1[0], p1[1], p1[2], p1[3]);
+                *(f32x4 *)(p.ev_m2 + at * 4) = m2;
             }
         }
         return;
@@ -1709,13 +1725,13 @@ extern "C" int hgr_gemm_nt_ln(const void *X16, int64_t ldx, const void *Wfold, i
 
 // ---- logits GEMM with the evaluation consumers in its epilogue ------------------------------------------------------------
 int hgr_logits_eval_rows_launch(const void *feat, const void *zslp, int D, int S, const unsigned long long *keys, const float *tmax,
-                                const int32_t *level_first, int n_levels, const int32_t *filler_pos, const int32_t *train_cols, int n_train,
+                                const int *gp1, const float *gm2, const int32_t *level_first, int n_levels, const int32_t *filler_pos, const int32_t *train_cols, int n_train,
                                 const int32_t *epos, const int32_t *test_cols, int n_test, int k, int32_t *out_level, int32_t *out_top1,
                                 int32_t *out_topk, int rows, int dtype, void *stream);      // hgr_select.hip
 
 extern "C" int64_t hgr_logits_eval_workspace_bytes(int rows, int n_perm) {
     if (rows < 1 || n_perm < 128 || n_perm % 128) return -1;
-    return (int64_t)rows * (n_perm / 64) * 24;           // per (row, slice): 8-byte train key + four 4-byte test maxima (16-column groups)
+    return (int64_t)rows * (n_perm / 64) * 56;           // per (row, slice): 8-byte train key + per 16-column group (max, position, second) = 4 x 12 bytes
 }
 
 extern "C" int hgr_logits_eval(const void *feat16, const void *zsl_perm16, int rows, int D, int n_perm,
@@ -1735,11 +1751,13 @@ extern "C" int hgr_logits_eval(const void *feat16, const void *zsl_perm16, int r
     ln_args(a, feat16, D, zsl_perm16, D, nullptr, 0, rows, n_perm, D);
     a.ev_key = (unsigned long long *)workspace;
     a.ev_tmax = (float *)((char *)workspace + (size_t)rows * S * 8);
+    a.ev_p1 = (int *)((char *)workspace + (size_t)rows * S * 24);
+    a.ev_m2 = (float *)((char *)workspace + (size_t)rows * S * 40);
     a.ev_tpos = tpos_perm; a.ev_epos = epos_perm; a.ev_slices = S;
     dim3 grid((unsigned)(a.tiles_m * a.tiles_n));
     if (dtype == HGR_BF16) hipLaunchKernelGGL((gemm_nt_duo<HGR_BF16, HGR_EPI_NONE, true, 3>), grid, dim3(NTD), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((gemm_nt_duo<HGR_F16, HGR_EPI_NONE, true, 3>), grid, dim3(NTD), 0, (hipStream_t)stream, a);
     HGR_CHECK_LAUNCH("hgr_logits_eval (tile stage)");
-    return hgr_logits_eval_rows_launch(feat16, zsl_perm16, D, S, a.ev_key, a.ev_tmax, level_first, n_levels, filler_pos, train_cols, n_train,
+    return hgr_logits_eval_rows_launch(feat16, zsl_perm16, D, S, a.ev_key, a.ev_tmax, a.ev_p1, a.ev_m2, level_first, n_levels, filler_pos, train_cols, n_train,
                                        epos_perm, test_cols, n_test, k, out_level, out_top1, out_topk, rows, dtype, stream);
 }

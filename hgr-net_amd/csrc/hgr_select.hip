@@ -528,6 +528,7 @@ constexpr int LE_NT = 512, LE_NW = LE_NT / 64, LE_MAXS = 1024, LE_CAP = 2048;
 template <int DT>
 __global__ __launch_bounds__(LE_NT) void logits_eval_rows(const void *__restrict__ feat, const void *__restrict__ zslp, int D, int S,
                                                         const unsigned long long *__restrict__ keys, const float *__restrict__ gmax,
+                                                        const int *__restrict__ gp1, const float *__restrict__ gm2,
                                                         const int32_t *__restrict__ level_first, int n_levels, const int32_t *__restrict__ filler_pos,
                                                         const int32_t *__restrict__ train_cols, int n_train, const int32_t *__restrict__ epos,
                                                         const int32_t *__restrict__ test_cols, int n_test, int k,
@@ -599,23 +600,44 @@ __global__ __launch_bounds__(LE_NT) void logits_eval_rows(const void *__restrict
         if (lane == 0 && out_top1) out_top1[row] = top.p < n_train ? train_cols[top.p] : -1;
     }
     if (k <= 0 || dbg == 1) return;
-    // threshold: the k-th best slice maximum, ties between slices ordered by the slice index (any fixed order gives the same VALUE)
-    if (s_nonempty >= k) {
-        for (int s = tid; s < S; s += LE_NT) {
-            const float mv = s_tm[s];
-            if (!(mv > -INFINITY)) continue;
-            int rank = 0;
-            for (int j = 0; j < S; ++j) { const float o = s_tm[j]; rank += (o > mv || (o == mv && j < s)) ? 1 : 0; }
-            if (rank == k - 1) s_t = mv;
+    // threshold: the k-th largest slice maximum, found by wave 0 alone: the <= 1024 maxima as orderable keys in registers, a
+    // 32-step search for the largest x with #(key >= x) >= k (ballot + popcount: no LDS traffic, no barrier inside)
+    if (wave == 0 && s_nonempty >= k) {
+        unsigned kv[LE_MAXS / 64];
+#pragma unroll
+        for (int i = 0; i < LE_MAXS / 64; ++i) {
+            const int s = i * 64 + lane;
+            const unsigned u = __float_as_uint(s < S ? s_tm[s] : -INFINITY);
+            kv[i] = u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
         }
+        unsigned x = 0;
+        for (int bit = 31; bit >= 0; --bit) {
+            const unsigned c = x | (1u << bit);
+            int cntc = 0;
+#pragma unroll
+            for (int i = 0; i < LE_MAXS / 64; ++i) cntc += __popcll(__ballot(kv[i] >= c));
+            if (cntc >= k) x = c;
+        }
+        if (lane == 0) s_t = __uint_as_float(x ^ ((x >> 31) ? 0x80000000u : 0xFFFFFFFFu));
     }
     __syncthreads();
     if (dbg == 2) return;
     const float t = s_t;
-    for (int q = tid; q < S * 4; q += LE_NT)
-        if (s_gm[q] > -INFINITY && s_gm[q] >= t) s_cand[atomicAdd(&s_ncand, 1)] = (short)q;
+    // a group whose maximum reaches t holds a candidate: its (value, position) are already known from the tile stage; only when its
+    // SECOND largest value reaches t too (two of the best k in one 16-column group, or a tie at the maximum) the group is recomputed
+    for (int q = tid; q < S * 4; q += LE_NT) {
+        const float m1 = s_gm[q];
+        if (m1 > -INFINITY && m1 >= t) {
+            const int64_t at = (int64_t)row * S * 4 + q;
+            if (gm2[at] >= t) s_cand[atomicAdd(&s_ncand, 1)] = (short)q;
+            else {
+                const int slot = atomicAdd(&s_cnt, 1);
+                if (slot < LE_CAP) { s_cv[slot] = m1; s_cp[slot] = gp1[at]; }
+            }
+        }
+    }
     __syncthreads();
-    const int ncand = s_ncand;
+    int ncand = s_ncand;
     if (dbg == 3) return;
     // visitor(value, test position) over every test element of the candidate groups; a wave takes TWO groups per trip (two
     // independent accumulators, 16 class-row fragments in flight).  Fragments: A operand = 16 class rows x 32 k (lane (r16, g): row
@@ -676,8 +698,16 @@ __global__ __launch_bounds__(LE_NT) void logits_eval_rows(const void *__restrict
         }
         return;
     }
-    // heavily duplicated data (more than LE_CAP elements tie at the threshold): k rounds of arg-max over the candidate groups, an
-    // element is "removed" by requiring it to be worse than the previous winner in (value, position) order
+    // heavily duplicated data (more than LE_CAP elements tie at the threshold): every group that reaches t becomes a recompute
+    // candidate, then k rounds of arg-max over them; an element is "removed" by requiring it to be worse than the previous winner
+    // in (value, position) order
+    __syncthreads();
+    if (tid == 0) s_ncand = 0;
+    __syncthreads();
+    for (int q = tid; q < S * 4; q += LE_NT)
+        if (s_gm[q] > -INFINITY && s_gm[q] >= t) s_cand[atomicAdd(&s_ncand, 1)] = (short)q;
+    __syncthreads();
+    ncand = s_ncand;
     Best last = {INFINITY, -1};
     for (int j = 0; j < k; ++j) {
         Best b = {-INFINITY, 0x7fffffff};
@@ -696,14 +726,14 @@ __global__ __launch_bounds__(LE_NT) void logits_eval_rows(const void *__restrict
 }  // namespace
 
 int hgr_logits_eval_rows_launch(const void *feat, const void *zslp, int D, int S, const unsigned long long *keys, const float *tmax,
-                                const int32_t *level_first, int n_levels, const int32_t *filler_pos, const int32_t *train_cols, int n_train,
+                                const int *gp1, const float *gm2, const int32_t *level_first, int n_levels, const int32_t *filler_pos, const int32_t *train_cols, int n_train,
                                 const int32_t *epos, const int32_t *test_cols, int n_test, int k, int32_t *out_level, int32_t *out_top1,
                                 int32_t *out_topk, int rows, int dtype, void *stream) {
     static int dbg = -1;                              // HGR_LE_DBG = 1..4: leave the row stage after level / threshold / candidate list / scan (timing experiments only)
     if (dbg < 0) { const char *e = getenv("HGR_LE_DBG"); dbg = e ? atoi(e) : 0; }
-    if (dtype == HGR_BF16) hipLaunchKernelGGL((logits_eval_rows<HGR_BF16>), dim3(rows), dim3(LE_NT), 0, (hipStream_t)stream, feat, zslp, D, S, keys, tmax, level_first,
+    if (dtype == HGR_BF16) hipLaunchKernelGGL((logits_eval_rows<HGR_BF16>), dim3(rows), dim3(LE_NT), 0, (hipStream_t)stream, feat, zslp, D, S, keys, tmax, gp1, gm2, level_first,
                                               n_levels, filler_pos, train_cols, n_train, epos, test_cols, n_test, k, out_level, out_top1, out_topk, dbg);
-    else hipLaunchKernelGGL((logits_eval_rows<HGR_F16>), dim3(rows), dim3(LE_NT), 0, (hipStream_t)stream, feat, zslp, D, S, keys, tmax, level_first,
+    else hipLaunchKernelGGL((logits_eval_rows<HGR_F16>), dim3(rows), dim3(LE_NT), 0, (hipStream_t)stream, feat, zslp, D, S, keys, tmax, gp1, gm2, level_first,
                             n_levels, filler_pos, train_cols, n_train, epos, test_cols, n_test, k, out_level, out_top1, out_topk, dbg);
     HGR_CHECK_LAUNCH("hgr_logits_eval (row stage)");
     return HGR_OK;
