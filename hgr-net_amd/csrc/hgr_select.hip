@@ -536,6 +536,7 @@ __global__ __launch_bounds__(LE_NT) void logits_eval_rows(const void *__restrict
     typedef typename T16<DT>::vec8 vec8;
     typedef typename T16<DT>::elem E;
     __shared__ unsigned long long s_lkey[32];
+    __shared__ unsigned long long s_keys[LE_MAXS];
     __shared__ __attribute__((aligned(16))) float s_gm[LE_MAXS * 4];
     __shared__ float s_tm[LE_MAXS];
     __shared__ short s_cand[LE_MAXS * 4];
@@ -556,6 +557,7 @@ __global__ __launch_bounds__(LE_NT) void logits_eval_rows(const void *__restrict
         int mine = 0;                                       // non-empty slices seen by this thread (one LDS atomic per WAVE: same-address
         for (int s = tid; s < S; s += LE_NT) {              // LDS atomics serialise, 355 of them cost more than the rest of the kernel)
             const f32x4 g4 = *(const f32x4 *)(gmax + ((int64_t)row * S + s) * 4);
+            s_keys[s] = keys[(int64_t)row * S + s];
             *(f32x4 *)(s_gm + s * 4) = g4;
             const float t = fmaxf(fmaxf(g4[0], g4[1]), fmaxf(g4[2], g4[3]));
             s_tm[s] = t;
@@ -565,11 +567,12 @@ __global__ __launch_bounds__(LE_NT) void logits_eval_rows(const void *__restrict
         for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
         if (lane == 0 && mine) atomicAdd(&s_nonempty, mine);
     }
+    __syncthreads();
     // level bests: the slices of level l are the contiguous range [level_first[l], level_first[l + 1]); wave w reduces levels
-    // w, w + 8, ... (same-address LDS atomics would serialise: ~30 per level)
+    // w, w + 8, ... from the staged keys (same-address LDS atomics would serialise: ~30 per level)
     for (int l = wave; l < n_levels; l += LE_NW) {
         unsigned long long m = 0ull;
-        for (int s = level_first[l] + lane; s < level_first[l + 1]; s += 64) { const unsigned long long x = keys[(int64_t)row * S + s]; m = x > m ? x : m; }
+        for (int s = level_first[l] + lane; s < level_first[l + 1]; s += 64) { const unsigned long long x = s_keys[s]; m = x > m ? x : m; }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const unsigned hi = __shfl_xor((unsigned)(m >> 32), o), lo = __shfl_xor((unsigned)m, o);
@@ -604,6 +607,7 @@ __global__ __launch_bounds__(LE_NT) void logits_eval_rows(const void *__restrict
     // 32-step search for the largest x with #(key >= x) >= k (ballot + popcount: no LDS traffic, no barrier inside)
     if (wave == 0 && s_nonempty >= k) {
         unsigned kv[LE_MAXS / 64];
+        const int nreg = (S + 63) >> 6;                     // registers that hold real slices (6 at N = 21 841): wave-uniform
 #pragma unroll
         for (int i = 0; i < LE_MAXS / 64; ++i) {
             const int s = i * 64 + lane;
@@ -615,7 +619,8 @@ __global__ __launch_bounds__(LE_NT) void logits_eval_rows(const void *__restrict
             const unsigned c = x | (1u << bit);
             int cntc = 0;
 #pragma unroll
-            for (int i = 0; i < LE_MAXS / 64; ++i) cntc += __popcll(__ballot(kv[i] >= c));
+            for (int i = 0; i < LE_MAXS / 64; ++i)
+                if (i < nreg) cntc += __popcll(__ballot(kv[i] >= c));
             if (cntc >= k) x = c;
         }
         if (lane == 0) s_t = __uint_as_float(x ^ ((x >> 31) ? 0x80000000u : 0xFFFFFFFFu));
