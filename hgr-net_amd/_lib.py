@@ -76,10 +76,11 @@ SIGNATURES = {
     "hgr_bn_fold": [_p, _p, _p, _p, _p, _f, _p, _p, _i, _i, _i, _i, _i, _p],
     "hgr_bn_unfold_grad": [_p, _l, _p, _p, _p, _p, _p, _f, _p, _p, _p, _i, _i, _i, _p],
     "hgr_csr_group_aggregate": [_p, _l, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _p, _p, _l, _i, _f, _i, _p],
-    "hgr_gemm_nt_res_stats": [_p, _l, _p, _l, _p, _l, _p, _p, _l, _p, _i, _i, _i, _i, _p],
+    "hgr_gemm_nt_res_stats": [_p, _l, _p, _l, _p, _p, _l, _p, _p, _i, _i, _i, _i, _p],
     "hgr_gemm_nt_ln": [_p, _l, _p, _l, _p, _l, _p, _p, _p, _f, _i, _i, _i, _i, _i, _p],
     "hgr_vit_embed_ln_stats": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p],
-    "hgr_row_stats16": [_p, _p, _p, _i, _i, _i, _p],
+    "hgr_row_stats16": [_p, _p, _p, _p, _i, _i, _i, _p],
+    "hgr_pair_rows_f32": [_p, _p, _p, _i, _i, _l, _p, _i, _p],
     "hgr_logits_eval_workspace_bytes": [_i, _i],
     "hgr_logits_eval": [_p, _p, _i, _i, _i, _p, _p, _p, _i, _p, _p, _i, _p, _i, _i, _p, _p, _p, _p, _i, _p],
     "hgr_comm_unique_id": [_p],

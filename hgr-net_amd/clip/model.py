@@ -175,31 +175,33 @@ def ln_fusable(w: int) -> bool:
     return LN_FUSED and w % 128 == 0
 
 
-def _run_blocks(x: torch.Tensor, blocks, heads: int, b: int, l: int, causal: bool, dt: torch.dtype, ws: _Workspace, tag: str,
-                taps: Optional[dict] = None, tap_prefix: str = "", x16: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None):
-    """The residual stack (clip/model.py:185-188 per block) on the fp32 residual stream x [b*l, w].
+def _run_blocks(x: Optional[torch.Tensor], blocks, heads: int, b: int, l: int, causal: bool, dt: torch.dtype, ws: _Workspace, tag: str,
+                taps: Optional[dict] = None, tap_prefix: str = "", pair=None, stats: Optional[torch.Tensor] = None):
+    """The residual stack (clip/model.py:185-188 per block).
 
-    With ``x16`` / ``stats`` (16-bit copy + LayerNorm slot statistics of x, from hgr_vit_embed_ln_stats / hgr_row_stats16) the
-    LayerNorms are folded into the GEMMs around them - 5 launches per block, no LayerNorm pass:
-        QKV = LN-folded GEMM(x16) -> attention -> x += out GEMM (+ x16, stats) -> u = LN-folded GEMM(x16, QuickGELU)
-        -> x += proj GEMM (+ x16, stats)
-    otherwise LN -> QKV GEMM(+bias) -> attention -> out GEMM(+bias, +residual) -> LN -> fc GEMM(+bias, QuickGELU)
-    -> proj GEMM(+bias, +residual): 7 launches per block."""
-    m, w = x.shape
-    dev = x.device
+    Fused form (``pair`` = (xh, xl): the residual stream as a 16-bit pair, x = xh + xl, with its LayerNorm slot statistics in
+    ``stats`` - from hgr_vit_embed_ln_stats / hgr_row_stats16): the LayerNorms are folded into the GEMMs around them, 5 launches
+    per block and no LayerNorm pass:
+        QKV = LN-folded GEMM(xh) -> attention -> (xh, xl) += out GEMM (+ stats) -> u = LN-folded GEMM(xh, QuickGELU)
+        -> (xh, xl) += proj GEMM (+ stats)
+    Otherwise, on the fp32 stream x [b*l, w]: LN -> QKV GEMM(+bias) -> attention -> out GEMM(+bias, +residual) -> LN -> fc
+    GEMM(+bias, QuickGELU) -> proj GEMM(+bias, +residual): 7 launches per block."""
+    m, w = (pair[0] if pair is not None else x).shape
+    dev = (pair[0] if pair is not None else x).device
     qkv = ws.get(tag + ".qkv", (m, 3 * w), dt, dev)
     att = ws.get(tag + ".att", (m, w), dt, dev)
     u16 = ws.get(tag + ".u16", (m, 4 * w), dt, dev)
-    if x16 is not None:
+    if pair is not None:
+        xh, xl = pair
         for i, k in enumerate(blocks):
-            ops.gemm_nt_ln(x16, k.wf_in, qkv, k.s_in, k.c_in, stats, k.eps1, tag="qkv")
+            ops.gemm_nt_ln(xh, k.wf_in, qkv, k.s_in, k.c_in, stats, k.eps1, tag="qkv")
             ops.mha(qkv, att, b, l, heads, causal)
-            ops.gemm_nt_res_stats(att, k.w_out, x, k.b_out, x16, stats, tag="out")
-            ops.gemm_nt_ln(x16, k.wf_fc, u16, k.s_fc, k.c_fc, stats, k.eps2, quickgelu=True, tag="fc")
-            ops.gemm_nt_res_stats(u16, k.w_proj, x, k.b_proj, x16, stats, tag="proj")
+            ops.gemm_nt_res_stats(att, k.w_out, xh, xl, k.b_out, stats, tag="out")
+            ops.gemm_nt_ln(xh, k.wf_fc, u16, k.s_fc, k.c_fc, stats, k.eps2, quickgelu=True, tag="fc")
+            ops.gemm_nt_res_stats(u16, k.w_proj, xh, xl, k.b_proj, stats, tag="proj")
             if taps is not None:
-                taps[f"{tap_prefix}.resblocks.{i}"] = x.view(b, l, w).clone()
-        return x
+                taps[f"{tap_prefix}.resblocks.{i}"] = (xh.float() + xl.float()).view(b, l, w)
+        return None
     h16 = ws.get(tag + ".h16", (m, w), dt, dev)
     for i, k in enumerate(blocks):
         ops.layernorm(x, k.ln1[0], k.ln1[1], h16)
@@ -449,19 +451,25 @@ class CLIP(nn.Module):
             ops.im2col_patches(image, patches, ps)
         pe = ws.get("v.pe", (b * gg, w), torch.float32, dev)
         ops.gemm_nt(patches, p["conv_w_nhwc"] if u8 else p["conv_w"], pe)
-        x = ws.get("v.x", (b * l, w), torch.float32, dev)
-        x16 = stats = None
-        if ln_fusable(w):
-            x16 = ws.get("v.x16", (b * l, w), dt, dev)
-            stats = ws.get("v.stats", (b * l, w // 64, 2), torch.float32, dev)
-            ops.vit_embed_ln_stats(pe, p["cls"], p["pos"], p["ln_pre"][0], p["ln_pre"][1], x, x16, stats, b, gg)
-        else:
-            ops.vit_embed_ln(pe, p["cls"], p["pos"], p["ln_pre"][0], p["ln_pre"][1], x, b, gg)
-        if taps is not None:
-            taps["visual.ln_pre"] = x.view(b, l, w).clone()
-        _run_blocks(x, p["vblocks"], w // 64, b, l, False, dt, ws, "v", taps, "visual.transformer", x16, stats)
         cls16 = ws.get("v.cls16", (b, w), dt, dev)
-        ops.layernorm(x, p["ln_post"][0], p["ln_post"][1], cls16, rows=b, row_mul=l)
+        if ln_fusable(w):
+            xh = ws.get("v.xh", (b * l, w), dt, dev)
+            xl = ws.get("v.xl", (b * l, w), torch.float16, dev)
+            stats = ws.get("v.stats", (b * l, w // 64, 2), torch.float32, dev)
+            ops.vit_embed_ln_stats(pe, p["cls"], p["pos"], p["ln_pre"][0], p["ln_pre"][1], xh, xl, stats, b, gg)
+            if taps is not None:
+                taps["visual.ln_pre"] = (xh.float() + xl.float()).view(b, l, w)
+            _run_blocks(None, p["vblocks"], w // 64, b, l, False, dt, ws, "v", taps, "visual.transformer", (xh, xl), stats)
+            cls32 = ws.get("v.cls32", (b, w), torch.float32, dev)
+            ops.pair_rows_f32(xh, xl, cls32, row_mul=l)                          # the class tokens back in fp32 for ln_post
+            ops.layernorm(cls32, p["ln_post"][0], p["ln_post"][1], cls16, rows=b)
+        else:
+            x = ws.get("v.x", (b * l, w), torch.float32, dev)
+            ops.vit_embed_ln(pe, p["cls"], p["pos"], p["ln_pre"][0], p["ln_pre"][1], x, b, gg)
+            if taps is not None:
+                taps["visual.ln_pre"] = x.view(b, l, w).clone()
+            _run_blocks(x, p["vblocks"], w // 64, b, l, False, dt, ws, "v", taps, "visual.transformer")
+            ops.layernorm(x, p["ln_post"][0], p["ln_post"][1], cls16, rows=b, row_mul=l)
         out = torch.empty((b, v.output_dim), dtype=torch.float32, device=dev)
         ops.gemm_nt(cls16, p["proj_t"], out)
         return out
@@ -490,14 +498,19 @@ class CLIP(nn.Module):
             ops.text_embed(text[s:e], p["tok"], p["tpos"], x, l)
             if ctx is not None:
                 ops.ctx_splice(x, ctx.detach().float().contiguous(), p["tpos"], c, l)
-            x16 = stats = None
-            if ln_fusable(w):
-                x16 = ws.get("t.x16", (c * l, w), dt, dev)
-                stats = ws.get("t.stats", (c * l, w // 64, 2), torch.float32, dev)
-                ops.row_stats16(x, x16, stats)
-            _run_blocks(x, p["tblocks"], w // 64, c, l, True, dt, ws, "t", x16=x16, stats=stats)
             f16 = ws.get("t.f16", (c, w), dt, dev)
-            ops.layernorm(x, p["ln_final"][0], p["ln_final"][1], f16, rows=c, row_mul=l, row_idx=eot[s:e])
+            if ln_fusable(w):
+                xh = ws.get("t.xh", (c * l, w), dt, dev)
+                xl = ws.get("t.xl", (c * l, w), torch.float16, dev)
+                stats = ws.get("t.stats", (c * l, w // 64, 2), torch.float32, dev)
+                ops.row_stats16(x, xh, xl, stats)
+                _run_blocks(None, p["tblocks"], w // 64, c, l, True, dt, ws, "t", pair=(xh, xl), stats=stats)
+                e32 = ws.get("t.e32", (c, w), torch.float32, dev)
+                ops.pair_rows_f32(xh, xl, e32, row_mul=l, row_idx=eot[s:e])       # the EOT rows back in fp32 for ln_final
+                ops.layernorm(e32, p["ln_final"][0], p["ln_final"][1], f16, rows=c)
+            else:
+                _run_blocks(x, p["tblocks"], w // 64, c, l, True, dt, ws, "t")
+                ops.layernorm(x, p["ln_final"][0], p["ln_final"][1], f16, rows=c, row_mul=l, row_idx=eot[s:e])
             ops.gemm_nt(f16, p["tproj_t"], out[s:e])
         return out
 

@@ -50,12 +50,13 @@ struct GemmArgs {
     // fp32 partial C + s * csplit elements; 0 = off
     int kc; int64_t csplit;
     // LayerNorm folded into the GEMMs around it (gemm_nt_duo only, LN template parameter):
-    //   producer (LN = 1, x += A W^T + b): also writes the new residual as 16-bit x16 and, per row and 64-column slot, the
-    //            partial (sum, sum of squares) of the new values -> ln_stats [M][ln_slots][2]
+    //   producer (LN = 1, x += A W^T + b): the residual stream is kept as a 16-bit pair (hi, lo) with x = hi + lo - 4 bytes per
+    //            element like fp32, and hi IS the next GEMM's A operand; per row and 64-column slot it also emits the partial
+    //            (sum, sum of squares) of the new values -> ln_stats [M][ln_slots][2]
     //   consumer (LN = 2, y = LN(x) W^T + b): A is the un-normalised 16-bit x, W the gamma-folded weight,
     //            y = rstd_m (acc - mean_m ln_s[n]) + ln_c[n] with row statistics from ln_stats (K = row width)
     float *ln_stats; int ln_slots; float ln_eps;
-    void *ln_x16; int64_t ln_ldx16;
+    void *ln_xh, *ln_xl; int64_t ln_ldx;      // producer: the residual stream as a 16-bit PAIR, x = hi + lo (hi in the MFMA type, lo f16)
     const float *ln_s, *ln_c;
     int group;       // gemm_nt_duo: row (or column) panels per raster group (HGR_GEMM_GROUP, default 4)
     // fused evaluation (LN = 3, hgr_logits_eval): W = level-sorted, level-aligned class matrix, so every 64-column slice (one
@@ -1202,7 +1203,8 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
         }
         return;
     }
-    if (full && OUT32 && (EPI == HGR_EPI_NONE || EPI == HGR_EPI_BIAS || HAS_ADD) && (p.ldc & 3) == 0 && (!HAS_ADD || EPI == HGR_EPI_ACCUM || (p.ldr & 3) == 0)) {
+    if (full && OUT32 && (EPI == HGR_EPI_NONE || EPI == HGR_EPI_BIAS || HAS_ADD) &&
+        (LN == 1 || ((p.ldc & 3) == 0 && (!HAS_ADD || EPI == HGR_EPI_ACCUM || (p.ldr & 3) == 0)))) {
         // fp32 output (+ fp32 residual / old C): 4 passes of 32 rows through the wave's private LDS slice (rows of 256 B +
         // 16 B pad); every global access is then 16 bytes per lane over whole 256-byte row segments (2 full lines per row,
         // 4 rows per instruction) instead of 64-byte fragments of 16 rows.  The pass's 8 addend loads are issued before its
@@ -1217,16 +1219,79 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
                 bq[b][j] = HAS_BIAS ? *(const f32x4 *)(p.bias + n0 + wn * 64 + b * 32 + j * 16 + g * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
         const int rq = lane >> 4, cq = lane & 15;           // row-in-group and 16-byte column chunk of this lane on the way out
         // every global address below = wave-uniform 64-bit base + 32-bit per-lane byte offset (see the 16-bit epilogue)
+        const int64_t wrow = m0 + wm * 128, wcol = n0 + wn * 64;
+        if (LN == 1) {
+            // Producer of a folded LayerNorm.  The residual stream lives in memory as a 16-bit pair: x = hi + lo, hi = x rounded to
+            // the MFMA type (= the A operand of the next GEMM, no second copy of the stream), lo = f16(x - hi): |x - hi - lo| <=
+            // 2^-11 |x - hi| (2^-22 |x| with f16 hi, 2^-19 |x| with bf16 hi), far below the 16-bit rounding of every GEMM input.
+            // Same bytes as an fp32 read-modify-write.  Plus this wave's 64-column share of the rows' LayerNorm statistics; the
+            // 16 reduction chains of a pass (8 row groups x {sum, sum of squares}) advance stage by stage (DPP latencies overlap).
+            typedef typename T16<DT>::vec4 hvec4;
+            char *hw = (char *)p.ln_xh + (wrow * p.ln_ldx + wcol) * 2;
+            char *lw = (char *)p.ln_xl + (wrow * p.ln_ldx + wcol) * 2;
+            char *sw = (char *)(p.ln_stats + (wrow * p.ln_slots + (n0 >> 6) + wn) * 2);
+            const unsigned ldxB = (unsigned)p.ln_ldx * 2u, ldsB = (unsigned)p.ln_slots * 8u;
+            const unsigned xl = rq * ldxB + cq * 8, sl = rq * ldsB;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int ih = 0; ih < 2; ++ih) {
+                const int rl = a * 64 + ih * 32;
+                hvec4 oh[8];
+                f16x4 ol[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    oh[q] = *(const hvec4 *)(hw + (xl + (rl + q * 4) * ldxB));
+                    ol[q] = *(const f16x4 *)(lw + (xl + (rl + q * 4) * ldxB));
+                }
+#pragma unroll
+                for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    *(f32x4 *)(my + (i2 * 16 + r) * RS + (b * 32 + j * 16 + g * 4) * 4) = acc[a][b][ih * 2 + i2][j] + bq[b][j];
+                f32x4 vq[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    vq[q] = *(const f32x4 *)(my + (q * 4 + rq) * RS + cq * 16);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) vq[q][e] += (float)oh[q][e] + (float)ol[q][e];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const hvec4 nh = cvt4<DT>(vq[q][0], vq[q][1], vq[q][2], vq[q][3]);
+                    f16x4 nl;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) nl[e] = (_Float16)(vq[q][e] - (float)nh[e]);
+                    *(hvec4 *)(hw + (xl + (rl + q * 4) * ldxB)) = nh;
+                    *(f16x4 *)(lw + (xl + (rl + q * 4) * ldxB)) = nl;
+                }
+                if (p.dbg & 32) continue;
+                float s1[8], s2[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    s1[q] = (vq[q][0] + vq[q][1]) + (vq[q][2] + vq[q][3]);
+                    s2[q] = (vq[q][0] * vq[q][0] + vq[q][1] * vq[q][1]) + (vq[q][2] * vq[q][2] + vq[q][3] * vq[q][3]);
+                }
+#define HGR_DPP_STAGE(CTRL) _Pragma("unroll") for (int q = 0; q < 8; ++q) { \
+                    s1[q] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1[q]), CTRL, 0xF, 0xF, true)); \
+                    s2[q] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s2[q]), CTRL, 0xF, 0xF, true)); }
+                HGR_DPP_STAGE(0xB1) HGR_DPP_STAGE(0x4E) HGR_DPP_STAGE(0x141) HGR_DPP_STAGE(0x140)
+#undef HGR_DPP_STAGE
+                if (cq == 0) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) *(float2 *)(sw + (sl + (rl + q * 4) * ldsB)) = make_float2(s1[q], s2[q]);
+                }
+            }
+            return;
+        }
         const float *addp = EPI == HGR_EPI_ACCUM ? (const float *)p.C : p.res;
         const int64_t ldadd = EPI == HGR_EPI_ACCUM ? p.ldc : p.ldr;
-        const int64_t wrow = m0 + wm * 128, wcol = n0 + wn * 64;
         char *cw = (char *)p.C + (wrow * p.ldc + wcol) * 4;
         const char *aw = (const char *)addp + (wrow * ldadd + wcol) * 4;
-        char *xw = LN == 1 ? (char *)p.ln_x16 + (wrow * p.ln_ldx16 + wcol) * 2 : nullptr;
-        char *sw = LN == 1 ? (char *)(p.ln_stats + (wrow * p.ln_slots + (n0 >> 6) + wn) * 2) : nullptr;
-        const unsigned ldcB = (unsigned)p.ldc * 4u, ldaB = (unsigned)ldadd * 4u, ldxB = LN == 1 ? (unsigned)p.ln_ldx16 * 2u : 0u;
-        const unsigned ldsB = LN == 1 ? (unsigned)p.ln_slots * 8u : 0u;
-        const unsigned cl = rq * ldcB + cq * 16, al = rq * ldaB + cq * 16, xl = rq * ldxB + cq * 8, sl = rq * ldsB;
+        const unsigned ldcB = (unsigned)p.ldc * 4u, ldaB = (unsigned)ldadd * 4u;
+        const unsigned cl = rq * ldcB + cq * 16, al = rq * ldaB + cq * 16;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -1256,34 +1321,6 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
             } else {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) *(f32x4 *)(cw + (cl + (rl + q * 4) * ldcB)) = vq[q];
-            }
-            if (LN == 1) {
-                // the new residual once more in 16 bit (the next GEMM's A operand: 16 lanes = one 128-byte line per row) and
-                // this wave's 64-column share of the rows' LayerNorm statistics.  The 16 reduction chains of the pass (8 row
-                // groups x {sum, sum of squares}) advance stage by stage, so the DPP latencies overlap.
-                // (a 16-byte form - lane pairs exchanging a packed quad through DPP - was measured and is slower: 146 -> 155 us on
-                //  c_proj; the cost of this copy is its 39 MB of additional writes, not store issue: HGR_GEMM_DBG=64 skips it)
-                if (!(p.dbg & 64)) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q)
-                        *(typename T16<DT>::vec4 *)(xw + (xl + (rl + q * 4) * ldxB)) = cvt4<DT>(vq[q][0], vq[q][1], vq[q][2], vq[q][3]);
-                }
-                if (p.dbg & 32) continue;
-                float s1[8], s2[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    s1[q] = (vq[q][0] + vq[q][1]) + (vq[q][2] + vq[q][3]);
-                    s2[q] = (vq[q][0] * vq[q][0] + vq[q][1] * vq[q][1]) + (vq[q][2] * vq[q][2] + vq[q][3] * vq[q][3]);
-                }
-#define HGR_DPP_STAGE(CTRL) _Pragma("unroll") for (int q = 0; q < 8; ++q) { \
-                    s1[q] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1[q]), CTRL, 0xF, 0xF, true)); \
-                    s2[q] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s2[q]), CTRL, 0xF, 0xF, true)); }
-                HGR_DPP_STAGE(0xB1) HGR_DPP_STAGE(0x4E) HGR_DPP_STAGE(0x141) HGR_DPP_STAGE(0x140)
-#undef HGR_DPP_STAGE
-                if (cq == 0) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) *(float2 *)(sw + (sl + (rl + q * 4) * ldsB)) = make_float2(s1[q], s2[q]);
-                }
             }
         }
         return;
@@ -1318,7 +1355,8 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
         return;
     }
     if (LN == 1) {
-        // edge tile of an LN producer: the same pass structure with guarded rows (stores of a partial last row panel)
+        // edge tile of an LN producer: the same pass structure with guarded rows (a partial last row panel)
+        typedef typename T16<DT>::vec4 hvec4;
         constexpr int RS = 272;
         char *my = smem + wave * (32 * RS);
         const int rq = lane >> 4, cq = lane & 15;
@@ -1340,12 +1378,22 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
                 const int64_t row = row0 + q * 4 + rq;
                 f32x4 v = *(const f32x4 *)(my + (q * 4 + rq) * RS + cq * 16);
                 const bool ok = row < p.M;
-                if (ok) v += *(const f32x4 *)(p.res + row * p.ldr + n0 + wn * 64 + cq * 4);
+                const int64_t at = row * p.ln_ldx + n0 + wn * 64 + cq * 4;
+                if (ok) {
+                    const hvec4 oh = *(const hvec4 *)((const E *)p.ln_xh + at);
+                    const f16x4 ol = *(const f16x4 *)((const _Float16 *)p.ln_xl + at);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += (float)oh[e] + (float)ol[e];
+                }
                 const float s1 = row16_sum((v[0] + v[1]) + (v[2] + v[3]));
                 const float s2 = row16_sum((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]));
                 if (ok) {
-                    *(f32x4 *)((float *)p.C + row * p.ldc + n0 + wn * 64 + cq * 4) = v;
-                    *(typename T16<DT>::vec4 *)((E *)p.ln_x16 + row * p.ln_ldx16 + n0 + wn * 64 + cq * 4) = cvt4<DT>(v[0], v[1], v[2], v[3]);
+                    const hvec4 nh = cvt4<DT>(v[0], v[1], v[2], v[3]);
+                    f16x4 nl;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) nl[e] = (_Float16)(v[e] - (float)nh[e]);
+                    *(hvec4 *)((E *)p.ln_xh + at) = nh;
+                    *(f16x4 *)((_Float16 *)p.ln_xl + at) = nl;
                     if (cq == 0) *(float2 *)(p.ln_stats + (row * p.ln_slots + (n0 >> 6) + wn) * 2) = make_float2(s1, s2);
                 }
             }
@@ -1676,21 +1724,20 @@ void ln_args(GemmArgs &a, const void *A, int64_t lda, const void *W, int64_t ldw
     a.M = M; a.N = N; a.K = K; a.tiles_m = (M + 255) / 256; a.tiles_n = N / 128;
     a.m_fastest = ((int64_t)N * K > (int64_t)M * K) ? 1 : 0; a.vec_ok = 1; a.dbg = duo_dbg(); a.kc = 0; a.csplit = 0; a.group = duo_group();
     a.cH = a.cW = a.cC = a.cStride = a.cHo = a.cWo = 0; a.cMagic = 0;
-    a.ln_stats = nullptr; a.ln_slots = 0; a.ln_eps = 0.f; a.ln_x16 = nullptr; a.ln_ldx16 = 0; a.ln_s = a.ln_c = nullptr;
+    a.ln_stats = nullptr; a.ln_slots = 0; a.ln_eps = 0.f; a.ln_xh = a.ln_xl = nullptr; a.ln_ldx = 0; a.ln_s = a.ln_c = nullptr;
 }
 }  // namespace
 
-extern "C" int hgr_gemm_nt_res_stats(const void *A, int64_t lda, const void *W, int64_t ldw, float *X, int64_t ldx, const float *bias,
-                                     void *x16, int64_t ldx16, float *stats, int M, int N, int K, int dtype, void *stream) {
+extern "C" int hgr_gemm_nt_res_stats(const void *A, int64_t lda, const void *W, int64_t ldw, void *xh, void *xl, int64_t ldx,
+                                     const float *bias, float *stats, int M, int N, int K, int dtype, void *stream) {
     if (int rc = ln_common_checks("hgr_gemm_nt_res_stats", A, lda, W, ldw, M, N, K, dtype)) return rc;
-    HGR_REQUIRE(X && bias && x16 && stats, "hgr_gemm_nt_res_stats: null X / bias / x16 / stats");
-    HGR_REQUIRE(ldx >= N && ldx % 4 == 0 && hgr_aligned(X, 16) && hgr_aligned(bias, 16), "hgr_gemm_nt_res_stats: X / bias must be 16-byte aligned, ldx %% 4 == 0");
-    HGR_REQUIRE(ldx16 >= N && ldx16 % 4 == 0 && hgr_aligned(x16, 8) && hgr_aligned(stats, 8), "hgr_gemm_nt_res_stats: x16 must be 8-byte aligned with ldx16 %% 4 == 0");
-    HGR_REQUIRE(ldx < (1 << 20) && ldx16 < (1 << 20), "hgr_gemm_nt_res_stats: leading dimensions must be below 2^20");
+    HGR_REQUIRE(xh && xl && bias && stats, "hgr_gemm_nt_res_stats: null xh / xl / bias / stats");
+    HGR_REQUIRE(ldx >= N && ldx % 4 == 0 && ldx < (1 << 20) && hgr_aligned(xh, 8) && hgr_aligned(xl, 8), "hgr_gemm_nt_res_stats: xh / xl must be 8-byte aligned, ldx %% 4 == 0, ldx < 2^20");
+    HGR_REQUIRE(hgr_aligned(bias, 16) && hgr_aligned(stats, 8), "hgr_gemm_nt_res_stats: bias must be 16-byte, stats 8-byte aligned");
     GemmArgs a;
-    ln_args(a, A, lda, W, ldw, X, ldx, M, N, K);
-    a.bias = bias; a.res = X; a.ldr = ldx;
-    a.ln_stats = stats; a.ln_slots = N / 64; a.ln_x16 = x16; a.ln_ldx16 = ldx16;
+    ln_args(a, A, lda, W, ldw, nullptr, 0, M, N, K);
+    a.bias = bias;
+    a.ln_stats = stats; a.ln_slots = N / 64; a.ln_xh = xh; a.ln_xl = xl; a.ln_ldx = ldx;
     dim3 grid((unsigned)(a.tiles_m * a.tiles_n));
     if (dtype == HGR_BF16) hipLaunchKernelGGL((gemm_nt_duo<HGR_BF16, HGR_EPI_BIAS_RESIDUAL, true, 1>), grid, dim3(NTD), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((gemm_nt_duo<HGR_F16, HGR_EPI_BIAS_RESIDUAL, true, 1>), grid, dim3(NTD), 0, (hipStream_t)stream, a);

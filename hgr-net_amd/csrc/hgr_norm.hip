@@ -62,7 +62,8 @@ template <int NV, int DT = HGR_F16, bool STATS = false>
 __global__ __launch_bounds__(256) void vit_embed_ln(const float *__restrict__ patches, const float *__restrict__ cls,
                                                     const float *__restrict__ pos, const float *__restrict__ gamma,
                                                     const float *__restrict__ beta, float *__restrict__ x,
-                                                    int B, int G, int W, float eps, void *__restrict__ x16 = nullptr, float *__restrict__ stats = nullptr) {
+                                                    int B, int G, int W, float eps, void *__restrict__ xh = nullptr, void *__restrict__ xl = nullptr,
+                                                    float *__restrict__ stats = nullptr) {
     const int lane = threadIdx.x & 63;
     const int L = G + 1;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256) void vit_embed_ln(const float *__restrict__ pa
     }
     const float rstd = rsqrtf(wave_sum(q) / (float)W + eps);
     const f32x4 *gv = (const f32x4 *)gamma, *bv = (const f32x4 *)beta;
-    f32x4 *out = (f32x4 *)(x + (int64_t)row * W);
+    f32x4 *out = STATS ? nullptr : (f32x4 *)(x + (int64_t)row * W);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = i * 64 + lane;
@@ -102,11 +103,17 @@ __global__ __launch_bounds__(256) void vit_embed_ln(const float *__restrict__ pa
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * ga[e] + be[e];
-            out[c] = o;
+            if (!STATS) out[c] = o;
             if (STATS) {
-                // the first block's LayerNorm is folded into its QKV GEMM (hgr_gemm_nt_ln): 16-bit copy of the row + the
-                // (sum, sum of squares) of every 64-column slot = one DPP row of 16 lanes per slot (W % 64 == 0)
-                ((typename T16<DT>::vec4 *)((typename T16<DT>::elem *)x16 + (int64_t)row * W))[c] = cvt4<DT>(o[0], o[1], o[2], o[3]);
+                // the first block's LayerNorm is folded into its QKV GEMM (hgr_gemm_nt_ln): the row leaves as the 16-bit pair
+                // (hi, lo), x = hi + lo, the form the residual stream keeps between the GEMMs, + the (sum, sum of squares)
+                // of every 64-column slot = one DPP row of 16 lanes per slot (W % 64 == 0)
+                const typename T16<DT>::vec4 nh = cvt4<DT>(o[0], o[1], o[2], o[3]);
+                f16x4 nl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) nl[e] = (_Float16)(o[e] - (float)nh[e]);
+                ((typename T16<DT>::vec4 *)((typename T16<DT>::elem *)xh + (int64_t)row * W))[c] = nh;
+                ((f16x4 *)((_Float16 *)xl + (int64_t)row * W))[c] = nl;
                 const float s1 = row16_sum((o[0] + o[1]) + (o[2] + o[3]));
                 const float s2 = row16_sum((o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]));
                 if ((lane & 15) == 0) *(float2 *)(stats + ((int64_t)row * (W >> 6) + (c >> 4)) * 2) = make_float2(s1, s2);
@@ -115,10 +122,10 @@ __global__ __launch_bounds__(256) void vit_embed_ln(const float *__restrict__ pa
     }
 }
 
-// x fp32 [rows, W] -> 16-bit copy + per-slot LayerNorm statistics (the form hgr_gemm_nt_res_stats emits), for the input of
-// the first residual block of a tower
+// x fp32 [rows, W] -> the 16-bit pair (hi, lo) + per-slot LayerNorm statistics (the form hgr_gemm_nt_res_stats keeps), for the
+// input of the first residual block of a tower
 template <int DT>
-__global__ __launch_bounds__(256) void row_stats16(const float *__restrict__ x, void *__restrict__ x16, float *__restrict__ stats, int rows, int W) {
+__global__ __launch_bounds__(256) void row_stats16(const float *__restrict__ x, void *__restrict__ xh, void *__restrict__ xl, float *__restrict__ stats, int rows, int W) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -131,9 +138,30 @@ __global__ __launch_bounds__(256) void row_stats16(const float *__restrict__ x, 
         const float s1 = row16_sum((v[0] + v[1]) + (v[2] + v[3]));
         const float s2 = row16_sum((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]));
         if (ok) {
-            ((typename T16<DT>::vec4 *)((typename T16<DT>::elem *)x16 + (int64_t)row * W))[c] = cvt4<DT>(v[0], v[1], v[2], v[3]);
+            const typename T16<DT>::vec4 nh = cvt4<DT>(v[0], v[1], v[2], v[3]);
+            f16x4 nl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) nl[e] = (_Float16)(v[e] - (float)nh[e]);
+            ((typename T16<DT>::vec4 *)((typename T16<DT>::elem *)xh + (int64_t)row * W))[c] = nh;
+            ((f16x4 *)((_Float16 *)xl + (int64_t)row * W))[c] = nl;
             if ((lane & 15) == 0) *(float2 *)(stats + ((int64_t)row * (W >> 6) + (c >> 4)) * 2) = make_float2(s1, s2);
         }
+    }
+}
+
+// out[i] (fp32, compact rows) = hi[src] + lo[src], src = i * row_mul + (row_idx ? row_idx[i] : 0): selected rows of the pair back
+// in fp32 (ln_post on the class tokens, ln_final on the EOT rows, taps)
+template <int DT>
+__global__ __launch_bounds__(256) void pair_rows_f32(const void *__restrict__ xh, const void *__restrict__ xl, float *__restrict__ out, int rows, int W,
+                                                     int64_t row_mul, const int32_t *__restrict__ row_idx) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int64_t src = (int64_t)row * row_mul + (row_idx ? row_idx[row] : 0);
+    for (int c = lane; c < (W >> 2); c += 64) {
+        const typename T16<DT>::vec4 h = ((const typename T16<DT>::vec4 *)((const typename T16<DT>::elem *)xh + src * W))[c];
+        const f16x4 l = ((const f16x4 *)((const _Float16 *)xl + src * W))[c];
+        ((f32x4 *)(out + (int64_t)row * W))[c] = (f32x4){(float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2], (float)h[3] + (float)l[3]};
     }
 }
 
@@ -225,18 +253,19 @@ extern "C" int hgr_l2norm_rows(const float *x, void *y16, float *y32, int rows, 
 
 
 extern "C" int hgr_vit_embed_ln_stats(const float *patches, const float *class_embedding, const float *positional_embedding,
-                                      const float *gamma, const float *beta, float *x, void *x16, float *stats,
+                                      const float *gamma, const float *beta, void *xh, void *xl, float *stats,
                                       int B, int G, int W, float eps, int dtype, void *stream) {
-    HGR_REQUIRE(patches && class_embedding && positional_embedding && gamma && beta && x && x16 && stats, "hgr_vit_embed_ln_stats: null operand");
+    HGR_REQUIRE(patches && class_embedding && positional_embedding && gamma && beta && xh && xl && stats, "hgr_vit_embed_ln_stats: null operand");
     HGR_REQUIRE(B >= 1 && G >= 1 && W >= 64 && W % 64 == 0 && W <= 4 * 64 * MAXV, "hgr_vit_embed_ln_stats: B=%d G=%d W=%d unsupported (W %% 64 == 0)", B, G, W);
     HGR_REQUIRE(hgr_aligned(patches, 16) && hgr_aligned(class_embedding, 16) && hgr_aligned(positional_embedding, 16) &&
-                hgr_aligned(gamma, 16) && hgr_aligned(beta, 16) && hgr_aligned(x, 16) && hgr_aligned(x16, 8) && hgr_aligned(stats, 8),
+                hgr_aligned(gamma, 16) && hgr_aligned(beta, 16) && hgr_aligned(xh, 8) && hgr_aligned(xl, 8) && hgr_aligned(stats, 8),
                 "hgr_vit_embed_ln_stats: misaligned operand");
     HGR_REQUIRE(dtype == HGR_BF16 || dtype == HGR_F16, "hgr_vit_embed_ln_stats: bad dtype %d", dtype);
     const int rows = B * (G + 1);
+    float *nox = nullptr;
 #define HGR_VE(NVV) do { \
-        if (dtype == HGR_BF16) hipLaunchKernelGGL((vit_embed_ln<NVV, HGR_BF16, true>), dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, patches, class_embedding, positional_embedding, gamma, beta, x, B, G, W, eps, x16, stats); \
-        else hipLaunchKernelGGL((vit_embed_ln<NVV, HGR_F16, true>), dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, patches, class_embedding, positional_embedding, gamma, beta, x, B, G, W, eps, x16, stats); } while (0)
+        if (dtype == HGR_BF16) hipLaunchKernelGGL((vit_embed_ln<NVV, HGR_BF16, true>), dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, patches, class_embedding, positional_embedding, gamma, beta, nox, B, G, W, eps, xh, xl, stats); \
+        else hipLaunchKernelGGL((vit_embed_ln<NVV, HGR_F16, true>), dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, patches, class_embedding, positional_embedding, gamma, beta, nox, B, G, W, eps, xh, xl, stats); } while (0)
     const int nvl = (W / 4 + 63) / 64;
     if (nvl <= 1) HGR_VE(1); else if (nvl <= 2) HGR_VE(2); else if (nvl <= 4) HGR_VE(4); else if (nvl <= 8) HGR_VE(8); else HGR_VE(16);
 #undef HGR_VE
@@ -244,13 +273,24 @@ extern "C" int hgr_vit_embed_ln_stats(const float *patches, const float *class_e
     return HGR_OK;
 }
 
-extern "C" int hgr_row_stats16(const float *x, void *x16, float *stats, int rows, int W, int dtype, void *stream) {
-    HGR_REQUIRE(x && x16 && stats, "hgr_row_stats16: null operand");
+extern "C" int hgr_row_stats16(const float *x, void *xh, void *xl, float *stats, int rows, int W, int dtype, void *stream) {
+    HGR_REQUIRE(x && xh && xl && stats, "hgr_row_stats16: null operand");
     HGR_REQUIRE(rows >= 1 && W >= 64 && W % 64 == 0, "hgr_row_stats16: rows=%d W=%d unsupported (W %% 64 == 0)", rows, W);
-    HGR_REQUIRE(hgr_aligned(x, 16) && hgr_aligned(x16, 8) && hgr_aligned(stats, 8), "hgr_row_stats16: misaligned operand");
+    HGR_REQUIRE(hgr_aligned(x, 16) && hgr_aligned(xh, 8) && hgr_aligned(xl, 8) && hgr_aligned(stats, 8), "hgr_row_stats16: misaligned operand");
     HGR_REQUIRE(dtype == HGR_BF16 || dtype == HGR_F16, "hgr_row_stats16: bad dtype %d", dtype);
-    if (dtype == HGR_BF16) hipLaunchKernelGGL((row_stats16<HGR_BF16>), dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, x16, stats, rows, W);
-    else hipLaunchKernelGGL((row_stats16<HGR_F16>), dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, x16, stats, rows, W);
+    if (dtype == HGR_BF16) hipLaunchKernelGGL((row_stats16<HGR_BF16>), dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, xh, xl, stats, rows, W);
+    else hipLaunchKernelGGL((row_stats16<HGR_F16>), dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, xh, xl, stats, rows, W);
     HGR_CHECK_LAUNCH("hgr_row_stats16");
+    return HGR_OK;
+}
+
+extern "C" int hgr_pair_rows_f32(const void *xh, const void *xl, float *out, int rows, int W, int64_t row_mul, const int32_t *row_idx, int dtype, void *stream) {
+    HGR_REQUIRE(xh && xl && out, "hgr_pair_rows_f32: null operand");
+    HGR_REQUIRE(rows >= 1 && W >= 4 && W % 4 == 0 && row_mul >= 1, "hgr_pair_rows_f32: rows=%d W=%d row_mul=%lld unsupported", rows, W, (long long)row_mul);
+    HGR_REQUIRE(hgr_aligned(xh, 8) && hgr_aligned(xl, 8) && hgr_aligned(out, 16), "hgr_pair_rows_f32: misaligned operand");
+    HGR_REQUIRE(dtype == HGR_BF16 || dtype == HGR_F16, "hgr_pair_rows_f32: bad dtype %d", dtype);
+    if (dtype == HGR_BF16) hipLaunchKernelGGL((pair_rows_f32<HGR_BF16>), dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, xh, xl, out, rows, W, row_mul, row_idx);
+    else hipLaunchKernelGGL((pair_rows_f32<HGR_F16>), dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, xh, xl, out, rows, W, row_mul, row_idx);
+    HGR_CHECK_LAUNCH("hgr_pair_rows_f32");
     return HGR_OK;
 }

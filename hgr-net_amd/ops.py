@@ -83,19 +83,19 @@ def _prof_end(ev, flops, byts, tag):
         PROFILE.append(("gemm_nt", ev[0], ev[1], float(flops), float(byts), tag))
 
 
-def gemm_nt_res_stats(a: torch.Tensor, w: torch.Tensor, x: torch.Tensor, bias: torch.Tensor, x16: torch.Tensor, stats: torch.Tensor,
-                      tag: str = "") -> torch.Tensor:
-    """x += a @ w^T + bias (fp32, in place) and, for the LayerNorm that follows, x16 = 16-bit copy of the new x and
-    stats[m, slot] = (sum, sum of squares) of every 64-column slot of the new row (hgr_gemm_nt_res_stats)."""
+def gemm_nt_res_stats(a: torch.Tensor, w: torch.Tensor, xh: torch.Tensor, xl: torch.Tensor, bias: torch.Tensor, stats: torch.Tensor,
+                      tag: str = "") -> None:
+    """(xh, xl) += a @ w^T + bias on the residual stream kept as a 16-bit pair (x = xh + xl, xh in the MFMA type = the next GEMM's
+    A operand, xl f16) and, for the LayerNorm that follows, stats[m, slot] = (sum, sum of squares) of every 64-column slot of the
+    new row (hgr_gemm_nt_res_stats)."""
     m, k = a.shape
     n = w.shape[0]
-    assert a.dtype == w.dtype == x16.dtype and x.dtype == torch.float32 and x.shape == (m, n) and x16.shape == (m, n)
-    assert stats.dtype == torch.float32 and stats.numel() >= m * (n // 64) * 2 and a.stride(1) == w.stride(1) == x.stride(1) == x16.stride(1) == 1
+    assert a.dtype == w.dtype == xh.dtype and xl.dtype == torch.float16 and xh.shape == xl.shape == (m, n) and xh.stride() == xl.stride()
+    assert stats.dtype == torch.float32 and stats.numel() >= m * (n // 64) * 2 and a.stride(1) == w.stride(1) == xh.stride(1) == 1
     ev = _prof_begin()
-    _lib.call("hgr_gemm_nt_res_stats", _dev(a), a.stride(0), _dev(w), w.stride(0), _dev(x), x.stride(0), _dev(bias), _dev(x16), x16.stride(0),
+    _lib.call("hgr_gemm_nt_res_stats", _dev(a), a.stride(0), _dev(w), w.stride(0), _dev(xh), _dev(xl), xh.stride(0), _dev(bias),
               _dev(stats), m, n, k, DT_OF[a.dtype], _stream())
-    _prof_end(ev, 2.0 * m * n * k, 2 * m * k + 2 * n * k + 8 * m * n + 2 * m * n, tag)
-    return x
+    _prof_end(ev, 2.0 * m * n * k, 2 * m * k + 2 * n * k + 8 * m * n, tag)
 
 
 def gemm_nt_ln(x16: torch.Tensor, wfold: torch.Tensor, out: torch.Tensor, ln_s: torch.Tensor, ln_c: torch.Tensor, stats: torch.Tensor,
@@ -113,15 +113,22 @@ def gemm_nt_ln(x16: torch.Tensor, wfold: torch.Tensor, out: torch.Tensor, ln_s: 
     return out
 
 
-def vit_embed_ln_stats(patches, cls, pos, gamma, beta, x, x16, stats, b, g, eps=1e-5):
-    _lib.call("hgr_vit_embed_ln_stats", _dev(patches), _dev(cls), _dev(pos), _dev(gamma), _dev(beta), _dev(x), _dev(x16), _dev(stats),
-              b, g, x.shape[1], eps, DT_OF[x16.dtype], _stream())
-    return x
+def vit_embed_ln_stats(patches, cls, pos, gamma, beta, xh, xl, stats, b, g, eps=1e-5):
+    _lib.call("hgr_vit_embed_ln_stats", _dev(patches), _dev(cls), _dev(pos), _dev(gamma), _dev(beta), _dev(xh), _dev(xl), _dev(stats),
+              b, g, xh.shape[1], eps, DT_OF[xh.dtype], _stream())
 
 
-def row_stats16(x: torch.Tensor, x16: torch.Tensor, stats: torch.Tensor) -> None:
-    assert x.dtype == torch.float32 and x.is_contiguous() and x16.is_contiguous() and x16.shape == x.shape and stats.numel() >= x.shape[0] * (x.shape[1] // 64) * 2
-    _lib.call("hgr_row_stats16", _dev(x), _dev(x16), _dev(stats), x.shape[0], x.shape[1], DT_OF[x16.dtype], _stream())
+def row_stats16(x: torch.Tensor, xh: torch.Tensor, xl: torch.Tensor, stats: torch.Tensor) -> None:
+    assert x.dtype == torch.float32 and x.is_contiguous() and xh.is_contiguous() and xl.is_contiguous() and xh.shape == xl.shape == x.shape
+    assert xl.dtype == torch.float16 and stats.numel() >= x.shape[0] * (x.shape[1] // 64) * 2
+    _lib.call("hgr_row_stats16", _dev(x), _dev(xh), _dev(xl), _dev(stats), x.shape[0], x.shape[1], DT_OF[xh.dtype], _stream())
+
+
+def pair_rows_f32(xh: torch.Tensor, xl: torch.Tensor, out: torch.Tensor, row_mul: int = 1, row_idx: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[i] = xh[src] + xl[src] (fp32), src = i * row_mul + row_idx[i]: selected rows of the 16-bit pair back in fp32."""
+    assert xh.is_contiguous() and xl.is_contiguous() and out.is_contiguous() and out.dtype == torch.float32 and out.shape[1] == xh.shape[1]
+    _lib.call("hgr_pair_rows_f32", _dev(xh), _dev(xl), _dev(out), out.shape[0], out.shape[1], row_mul, _dev(row_idx), DT_OF[xh.dtype], _stream())
+    return out
 
 
 def gemm_set_tile(tile: int) -> int:

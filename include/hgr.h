@@ -429,25 +429,30 @@ int hgr_adamw(float *p, const float *g, float *m, float *v, int64_t n, float lr,
  * i.e. every LayerNorm sits between a GEMM that PRODUCES its input row (out_proj / c_proj + residual add) and a GEMM that
  * CONSUMES its output (in_proj / c_fc).  With
  *     LN(x) W^T + b = rstd * ( x (gamma o W)^T - mean * s ) + c,    s_n = sum_k gamma_k W_nk,   c_n = sum_k beta_k W_nk + b_n
- * the producer emits the new residual once more in 16 bit plus per-row partial (sum, sum of squares) per 64-column slot,
- * and the consumer runs on the un-normalised 16-bit rows with the gamma-folded weight: the separate LayerNorm pass (118 MB
- * of traffic per call at ViT-B/32 batch 512) disappears.  Error study: tools/studies/ln_fusion_study.py.
- *   stats  fp32 [M][N/64][2]  (N = row width);  x16 16-bit [M, ldx16];  requirements: row width % 128 == 0.
+ * the consumer runs on the un-normalised 16-bit rows with the gamma-folded weight and the producer supplies per-row partial
+ * (sum, sum of squares) per 64-column slot: the separate LayerNorm pass (118 MB of traffic per call at ViT-B/32 batch 512)
+ * disappears.  Between the GEMMs the residual stream is kept as a 16-bit PAIR (xh, xl): x = xh + xl, xh = x rounded to the MFMA
+ * type - it IS the consumer's A operand - and xl = f16(x - xh); 4 bytes per element like fp32, |x - xh - xl| <= 2^-22 |x| (f16)
+ * / 2^-19 |x| (bf16).  Error study: tools/studies/ln_fusion_study.py.
+ *   stats  fp32 [M][N/64][2]  (N = row width);  xh, xl 16-bit [M, ldx];  requirements: row width % 128 == 0.
  * ------------------------------------------------------------------------------------------------ */
-/* X += A W^T + bias (fp32, in place: the residual add of clip/model.py:186-187), x16 = (16-bit) X, stats = slot partials of X */
-int hgr_gemm_nt_res_stats(const void *A, int64_t lda, const void *W, int64_t ldw, float *X, int64_t ldx, const float *bias,
-                          void *x16, int64_t ldx16, float *stats, int M, int N, int K, int dtype, void *stream);
-/* C (16-bit) = act( rstd_m (X16 Wfold^T - mean_m ln_s) + ln_c ), act: 0 none (ln_1 -> in_proj), 1 QuickGELU (ln_2 -> c_fc -> gelu);
+/* (xh, xl) += A W^T + bias  (the residual add of clip/model.py:186-187 on the pair, in place), stats = slot partials of the new rows */
+int hgr_gemm_nt_res_stats(const void *A, int64_t lda, const void *W, int64_t ldw, void *xh, void *xl, int64_t ldx,
+                          const float *bias, float *stats, int M, int N, int K, int dtype, void *stream);
+/* C (16-bit) = act( rstd_m (XH Wfold^T - mean_m ln_s) + ln_c ), act: 0 none (ln_1 -> in_proj), 1 QuickGELU (ln_2 -> c_fc -> gelu);
  * K = row width, mean / rstd from `stats` ([M][K/64][2], as written by the producers), eps of the LayerNorm */
-int hgr_gemm_nt_ln(const void *X16, int64_t ldx, const void *Wfold, int64_t ldw, void *C, int64_t ldc,
+int hgr_gemm_nt_ln(const void *XH, int64_t ldx, const void *Wfold, int64_t ldw, void *C, int64_t ldc,
                    const float *ln_s, const float *ln_c, const float *stats, float eps,
                    int M, int N, int K, int dtype, int act, void *stream);
-/* hgr_vit_embed_ln that also emits the 16-bit copy and slot statistics of its output rows (input of the first block) */
+/* hgr_vit_embed_ln whose output rows leave as the pair + slot statistics (input of the first block) */
 int hgr_vit_embed_ln_stats(const float *patches, const float *class_embedding, const float *positional_embedding,
-                           const float *gamma, const float *beta, float *x, void *x16, float *stats,
+                           const float *gamma, const float *beta, void *xh, void *xl, float *stats,
                            int B, int G, int W, float eps, int dtype, void *stream);
-/* x fp32 [rows, W] -> x16 + slot statistics (text tower: embedding rows feed the first block) */
-int hgr_row_stats16(const float *x, void *x16, float *stats, int rows, int W, int dtype, void *stream);
+/* x fp32 [rows, W] -> pair + slot statistics (text tower: embedding rows feed the first block) */
+int hgr_row_stats16(const float *x, void *xh, void *xl, float *stats, int rows, int W, int dtype, void *stream);
+/* out fp32 [rows, W] (compact) = xh[src] + xl[src], src = i * row_mul + (row_idx ? row_idx[i] : 0): selected rows of the pair back in
+ * fp32 (ln_post on the class tokens clip/model.py:233, ln_final on the EOT rows :349-350) */
+int hgr_pair_rows_f32(const void *xh, const void *xl, float *out, int rows, int W, int64_t row_mul, const int32_t *row_idx, int dtype, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * hgr_logits_eval: the class-logits GEMM of tree_model.forward (model/clip_tree.py:331) with the evaluation consumers of main.test

@@ -38,12 +38,13 @@ int main() {
     EXPECT_OK(hgr_gemm_set_tile(2)); EXPECT_OK(hgr_gemm_set_tile(0));
     EXPECT_FAIL(hgr_gemm_nt_splitk(h16, 64, h16, 64, f32, 64, 4, 4, 64, 32, HGR_F16, nullptr));
     EXPECT_FAIL(hgr_gemm_tn_splitk(nullptr, 64, h16, 64, f32, 64, 128, 64, 64, 64, HGR_F16, nullptr));
-    EXPECT_FAIL(hgr_gemm_nt_res_stats(h16, 128, h16, 128, f32, 100, f32, h16, 128, f32, 4, 100, 128, HGR_F16, nullptr));         // N % 128
-    EXPECT_FAIL(hgr_gemm_nt_res_stats(h16, 128, h16, 128, f32, 128, nullptr, h16, 128, f32, 4, 128, 128, HGR_F16, nullptr));     // bias
+    EXPECT_FAIL(hgr_gemm_nt_res_stats(h16, 128, h16, 128, h16, h16, 100, f32, f32, 4, 100, 128, HGR_F16, nullptr));              // N % 128
+    EXPECT_FAIL(hgr_gemm_nt_res_stats(h16, 128, h16, 128, h16, h16, 128, nullptr, f32, 4, 128, 128, HGR_F16, nullptr));          // bias
+    EXPECT_FAIL(hgr_pair_rows_f32(h16, nullptr, f32, 4, 64, 1, nullptr, HGR_F16, nullptr));
     EXPECT_FAIL(hgr_gemm_nt_ln(h16, 192, h16, 192, h16, 128, f32, f32, f32, 1e-5f, 4, 128, 192, HGR_F16, 0, nullptr));           // K % 128
     EXPECT_FAIL(hgr_gemm_nt_ln(h16, 128, h16, 128, h16, 128, f32, f32, f32, 1e-5f, 4, 128, 128, HGR_F16, 5, nullptr));           // act
-    EXPECT_FAIL(hgr_row_stats16(f32, h16, f32, 4, 100, HGR_F16, nullptr));
-    EXPECT_FAIL(hgr_vit_embed_ln_stats(f32, f32, f32, f32, f32, f32, nullptr, f32, 1, 4, 64, 1e-5f, HGR_F16, nullptr));
+    EXPECT_FAIL(hgr_row_stats16(f32, h16, h16, f32, 4, 100, HGR_F16, nullptr));
+    EXPECT_FAIL(hgr_vit_embed_ln_stats(f32, f32, f32, f32, f32, h16, nullptr, f32, 1, 4, 64, 1e-5f, HGR_F16, nullptr));
     EXPECT_FAIL(hgr_logits_eval(h16, h16, 4, 100, 128, i32, i32, i32, 4, i32, i32, 8, i32, 32, 20, i32, i32, i32, f32, HGR_F16, nullptr));       // D % 128
     EXPECT_FAIL(hgr_logits_eval(h16, h16, 4, 128, 192, i32, i32, i32, 4, i32, i32, 8, i32, 32, 20, i32, i32, i32, f32, HGR_F16, nullptr));       // n_perm % 128
     EXPECT_FAIL(hgr_logits_eval(h16, h16, 4, 128, 256, i32, i32, i32, 4, i32, i32, 8, i32, 8, 20, i32, i32, i32, f32, HGR_F16, nullptr));        // n_test < k

@@ -532,30 +532,47 @@ def _slot_stats(x):
     return torch.stack([xs.sum(-1), (xs * xs).sum(-1)], dim=-1).float()
 
 
+def _pair(x, dt):
+    xh = x.to(dt)
+    return xh, (x - xh.float()).to(torch.float16)
+
+
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("m,n,k", [(512, 256, 128), (1000, 768, 768), (25600, 768, 768), (257, 128, 3072), (3, 1024, 192)])
 def test_gemm_nt_res_stats(dt, m, n, k):
-    """Producer of the folded LayerNorm: x += a w^T + b must equal hgr_gemm_nt's residual epilogue BIT FOR BIT (same K
-    order), x16 must be the rounded new x, the slot statistics the (sum, sum of squares) of every 64-column slot of the
-    new rows (fp32 sums of <= 64 terms + a fixed-order DPP reduction: compared with fp64 at 1e-5 relative); ragged M."""
+    """Producer of the folded LayerNorm on the residual stream kept as a 16-bit pair: (xh, xl) += a w^T + b.  The fp32 value it
+    forms (old pair + the product, same K order as hgr_gemm_nt's residual epilogue) must come back from the new pair to
+    2^-21 |x| (f16 hi: 11 + 11 bits) / 2^-18 |x| (bf16 hi: 8 + 11 bits); xh must be that value rounded to the MFMA type; the
+    slot statistics = (sum, sum of squares) of every 64-column slot of the new rows (fp32 sums + a fixed-order DPP reduction:
+    1e-5 relative to fp64); ragged M; bit-deterministic."""
     a, w = _rand((m, k), 11).to(dt).to(DEV), _rand((n, k), 12, 0.1).to(dt).to(DEV)
     bias, x0 = _rand((n,), 13).to(DEV), _rand((m, n), 14, 2.0).to(DEV)
-    want = x0.clone()
+    xh0, xl0 = _pair(x0, dt)
+    want = (xh0.float() + xl0.float()).contiguous()                  # what the kernel reads back as the old residual
     ops.gemm_nt(a, w, want, bias=bias, residual=want, epilogue=EPI_BIAS_RESIDUAL)
-    x = x0.clone()
-    x16 = torch.full((m, n), 7.0, dtype=dt, device=DEV)
+    xh, xl = xh0.clone(), xl0.clone()
     stats = torch.full((m, n // 64, 2), -1.0, dtype=torch.float32, device=DEV)
-    ops.gemm_nt_res_stats(a, w, x, bias, x16, stats)
-    assert torch.equal(x, want)
-    assert torch.equal(x16, want.to(dt))
+    ops.gemm_nt_res_stats(a, w, xh, xl, bias, stats)
+    assert torch.equal(xh, want.to(dt))
+    back = xh.float() + xl.float()
+    rel = 2.0 ** -21 if dt == torch.float16 else 2.0 ** -18
+    assert float(((back - want).abs() - rel * want.abs()).max()) <= 1e-7
     ref = _slot_stats(want.cpu())
     got = stats.cpu()
     assert torch.allclose(got[..., 0], ref[..., 0], rtol=1e-5, atol=1e-4)
     assert torch.allclose(got[..., 1], ref[..., 1], rtol=1e-5, atol=1e-4)
     again = torch.empty_like(stats)
-    x2 = x0.clone()
-    ops.gemm_nt_res_stats(a, w, x2, bias, torch.empty_like(x16), again)
-    assert torch.equal(again, stats) and torch.equal(x2, x)          # bit-deterministic
+    xh2, xl2 = xh0.clone(), xl0.clone()
+    ops.gemm_nt_res_stats(a, w, xh2, xl2, bias, again)
+    assert torch.equal(again, stats) and torch.equal(xh2, xh) and torch.equal(xl2, xl)          # bit-deterministic
+    # selected rows of the pair back in fp32 (ln_post / ln_final read them this way)
+    rows = min(m, 5)
+    idx = torch.arange(rows, dtype=torch.int32, device=DEV) % 2
+    sel = torch.empty(rows, n, device=DEV)
+    mul = max(1, m // rows)
+    ops.pair_rows_f32(xh, xl, sel, row_mul=mul, row_idx=idx if mul > 1 else None)
+    src = torch.arange(rows, device=DEV) * mul + (idx.long() if mul > 1 else 0)
+    assert torch.equal(sel, back[src])
 
 
 @pytest.mark.parametrize("dt", DTS)
@@ -574,9 +591,10 @@ def test_gemm_nt_ln(dt, gelu, m, n, k):
         ref = clip_ref.quick_gelu(ref)
     xd = x.to(DEV)
     x16 = torch.empty(m, k, dtype=dt, device=DEV)
+    xlo = torch.empty(m, k, dtype=torch.float16, device=DEV)
     stats = torch.empty(m, k // 64, 2, dtype=torch.float32, device=DEV)
-    ops.row_stats16(xd, x16, stats)
-    assert torch.equal(x16, xd.to(dt))
+    ops.row_stats16(xd, x16, xlo, stats)
+    assert torch.equal(x16, xd.to(dt)) and torch.equal(xlo, (xd - x16.float()).to(torch.float16))
     st = _slot_stats(x)
     assert torch.allclose(stats.cpu(), st, rtol=1e-5, atol=1e-4)
     wf = (w * gamma[None, :]).to(dt)
@@ -604,11 +622,11 @@ def test_vit_embed_ln_stats_equals_unfused(dt):
     gamma, beta = (1.0 + 0.1 * _rand((w,), 34)).to(DEV), (0.1 * _rand((w,), 35)).to(DEV)
     x1 = torch.empty(b * (g + 1), w, device=DEV)
     ops.vit_embed_ln(pe, cls, pos, gamma, beta, x1, b, g)
-    x2 = torch.empty_like(x1)
-    x16 = torch.empty(b * (g + 1), w, dtype=dt, device=DEV)
+    xh = torch.empty(b * (g + 1), w, dtype=dt, device=DEV)
+    xl = torch.empty(b * (g + 1), w, dtype=torch.float16, device=DEV)
     stats = torch.empty(b * (g + 1), w // 64, 2, device=DEV)
-    ops.vit_embed_ln_stats(pe, cls, pos, gamma, beta, x2, x16, stats, b, g)
-    assert torch.equal(x1, x2) and torch.equal(x16, x1.to(dt))
+    ops.vit_embed_ln_stats(pe, cls, pos, gamma, beta, xh, xl, stats, b, g)
+    assert torch.equal(xh, x1.to(dt)) and torch.equal(xl, (x1 - xh.float()).to(torch.float16))
     assert torch.allclose(stats.cpu(), _slot_stats(x1.cpu()), rtol=1e-5, atol=1e-4)
 
 

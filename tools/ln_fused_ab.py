@@ -39,6 +39,7 @@ def ab(name, fns, reps=7):
 torch.manual_seed(0)
 x = torch.randn(m, w, device="cuda")
 x16 = torch.empty(m, w, dtype=dt, device="cuda")
+xlo = torch.empty(m, w, dtype=torch.float16, device="cuda")
 stats = torch.empty(m, w // 64, 2, device="cuda")
 h16 = torch.empty(m, w, dtype=dt, device="cuda")
 gamma, beta = torch.rand(w, device="cuda") + 0.5, torch.randn(w, device="cuda") * 0.1
@@ -49,7 +50,7 @@ for name, k_in, n_out, gelu in (("qkv", w, 3 * w, False), ("fc", w, 4 * w, True)
     s, c = wf.float().sum(1).contiguous(), (wt @ beta + b).contiguous()
     w16 = wt.to(dt)
     out = torch.empty(m, n_out, dtype=dt, device="cuda")
-    ops.row_stats16(x, x16, stats)
+    ops.row_stats16(x, x16, xlo, stats)
     ab(name, {"ln_kernel": lambda: ops.layernorm(x, gamma, beta, h16),
               "gemm_bias": lambda: ops.gemm_nt(h16, w16, out, bias=b, epilogue=EPI_BIAS_QUICKGELU if gelu else EPI_BIAS),
               "gemm_ln_folded": lambda: ops.gemm_nt_ln(x16, wf, out, s, c, stats, 1e-5, quickgelu=gelu)})
@@ -59,4 +60,4 @@ for name, k_in in (("out", w), ("proj", 4 * w)):
     b = torch.randn(w, device="cuda")
     xr = torch.randn(m, w, device="cuda")
     ab(name, {"gemm_residual": lambda: ops.gemm_nt(a, wt, xr, bias=b, residual=xr, epilogue=EPI_BIAS_RESIDUAL),
-              "gemm_res_stats": lambda: ops.gemm_nt_res_stats(a, wt, xr, b, x16, stats)})
+              "gemm_res_stats_pair": lambda: ops.gemm_nt_res_stats(a, wt, x16, xlo, b, stats)})
