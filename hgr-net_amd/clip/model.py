@@ -167,6 +167,9 @@ class _Workspace:
         return t[:n].view(*shape)
 
 
+# ViT image batches of at least IMG_STREAMS_MIN_ROWS patch rows run as HGR_IMG_STREAMS independent slices on as many streams
+IMG_STREAMS = max(1, int(os.environ.get("HGR_IMG_STREAMS", "1")))
+IMG_STREAMS_MIN_ROWS = 8192
 LN_FUSED = os.environ.get("HGR_LN_FUSED", "1") != "0"     # HGR_LN_FUSED=0: separate LayerNorm launches (the first build's path), for A/B runs
 
 
@@ -441,38 +444,69 @@ class CLIP(nn.Module):
             raise ValueError(f"expected {v.input_resolution}x{v.input_resolution} input, got {r}")
         if not isinstance(v, VisionTransformer):
             return _rn_forward(v, p["rn"], image, dt, ws)
+        out = torch.empty((b, v.output_dim), dtype=torch.float32, device=dev)
+        ns = IMG_STREAMS if (taps is None and b >= 2 * IMG_STREAMS and b * (r // v.patch_size) ** 2 >= IMG_STREAMS_MIN_ROWS) else 1
+        if ns == 1:
+            self._vit_forward(image, p, out, "v", taps, u8)
+            return out
+        # The batch in ``ns`` independent slices on ``ns`` streams: the residual stack is a strict chain of launches, and a
+        # launch whose tile count is not a multiple of the chip's workgroup slots ends in a partly empty round (N = 768 at
+        # batch 512: 600 tiles on 512 slots).  With a second, independent chain in flight the other slice's workgroups take the
+        # slots a launch's tail leaves idle.  Same kernels on the same rows: the bits do not depend on the split.
+        main = torch.cuda.current_stream()
+        side = self._side_streams(ns - 1, dev)
+        cut = [b * i // ns for i in range(ns + 1)]
+        for i in range(ns):
+            st = main if i == 0 else side[i - 1]
+            if i:
+                st.wait_stream(main)
+            with torch.cuda.stream(st):
+                self._vit_forward(image[cut[i]:cut[i + 1]], p, out[cut[i]:cut[i + 1]], f"v{i}" if i else "v", None, u8)
+        for st in side:
+            main.wait_stream(st)
+        return out
+
+    def _side_streams(self, n: int, dev):
+        have = self.__dict__.setdefault("_streams", [])
+        while len(have) < n:
+            have.append(torch.cuda.Stream(device=dev))
+        return have[:n]
+
+    def _vit_forward(self, image: torch.Tensor, p: dict, out: torch.Tensor, tag: str, taps: Optional[dict], u8: bool) -> None:
+        """VisionTransformer.forward (clip/model.py:219-236) of one slice of the batch on the current stream, features into ``out``."""
+        v = self.visual
+        dt, ws, dev = self.image_dtype, self._ws, image.device
+        b, r = image.shape[0], v.input_resolution
         ps = v.patch_size
         g = r // ps
         gg, l, w = g * g, g * g + 1, v.conv1.weight.shape[0]
-        patches = ws.get("v.patches", (b * gg, p["kp"]), dt, dev)
+        patches = ws.get(tag + ".patches", (b * gg, p["kp"]), dt, dev)
         if u8:
             ops.im2col_patches_u8(image, patches, ps)
         else:
             ops.im2col_patches(image, patches, ps)
-        pe = ws.get("v.pe", (b * gg, w), torch.float32, dev)
+        pe = ws.get(tag + ".pe", (b * gg, w), torch.float32, dev)
         ops.gemm_nt(patches, p["conv_w_nhwc"] if u8 else p["conv_w"], pe)
-        cls16 = ws.get("v.cls16", (b, w), dt, dev)
+        cls16 = ws.get(tag + ".cls16", (b, w), dt, dev)
         if ln_fusable(w):
-            xh = ws.get("v.xh", (b * l, w), dt, dev)
-            xl = ws.get("v.xl", (b * l, w), torch.float16, dev)
-            stats = ws.get("v.stats", (b * l, w // 64, 2), torch.float32, dev)
+            xh = ws.get(tag + ".xh", (b * l, w), dt, dev)
+            xl = ws.get(tag + ".xl", (b * l, w), torch.float16, dev)
+            stats = ws.get(tag + ".stats", (b * l, w // 64, 2), torch.float32, dev)
             ops.vit_embed_ln_stats(pe, p["cls"], p["pos"], p["ln_pre"][0], p["ln_pre"][1], xh, xl, stats, b, gg)
             if taps is not None:
                 taps["visual.ln_pre"] = (xh.float() + xl.float()).view(b, l, w)
-            _run_blocks(None, p["vblocks"], w // 64, b, l, False, dt, ws, "v", taps, "visual.transformer", (xh, xl), stats)
-            cls32 = ws.get("v.cls32", (b, w), torch.float32, dev)
+            _run_blocks(None, p["vblocks"], w // 64, b, l, False, dt, ws, tag, taps, "visual.transformer", (xh, xl), stats)
+            cls32 = ws.get(tag + ".cls32", (b, w), torch.float32, dev)
             ops.pair_rows_f32(xh, xl, cls32, row_mul=l)                          # the class tokens back in fp32 for ln_post
             ops.layernorm(cls32, p["ln_post"][0], p["ln_post"][1], cls16, rows=b)
         else:
-            x = ws.get("v.x", (b * l, w), torch.float32, dev)
+            x = ws.get(tag + ".x", (b * l, w), torch.float32, dev)
             ops.vit_embed_ln(pe, p["cls"], p["pos"], p["ln_pre"][0], p["ln_pre"][1], x, b, gg)
             if taps is not None:
                 taps["visual.ln_pre"] = x.view(b, l, w).clone()
-            _run_blocks(x, p["vblocks"], w // 64, b, l, False, dt, ws, "v", taps, "visual.transformer")
+            _run_blocks(x, p["vblocks"], w // 64, b, l, False, dt, ws, tag, taps, "visual.transformer")
             ops.layernorm(x, p["ln_post"][0], p["ln_post"][1], cls16, rows=b, row_mul=l)
-        out = torch.empty((b, v.output_dim), dtype=torch.float32, device=dev)
         ops.gemm_nt(cls16, p["proj_t"], out)
-        return out
 
     @torch.no_grad()
     def encode_text(self, text: torch.Tensor, trim: bool = True, ctx: Optional[torch.Tensor] = None) -> torch.Tensor:

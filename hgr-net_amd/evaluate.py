@@ -10,7 +10,6 @@ Outputs (counter values and the printed string) are identical to the reference's
 """
 from __future__ import annotations
 
-import copy
 import os
 from typing import Dict, Iterable, Optional
 
@@ -30,20 +29,33 @@ class Evaluator:
         self.acc = torch.zeros(len(COUNTERS), dtype=torch.float64, device=dev)
         self.n_levels = model.max_depth + 1
         self.index = ops.EvalIndex(model.depth32, model.train_index32, model.test_index32, self.n_levels)   # dense per-column maps, built once
-        self._parents_cache: Dict[int, tuple] = {}
+        self._anc = None         # ancestor paths of every node as a device CSR (see _ancestor_tables)
         self._plan = None        # level-sorted class matrix of the fused logits + evaluation kernel, built on first use
 
-    def _parents(self, target: int):
-        c = self._parents_cache.get(target)
-        if c is None:
+    def _ancestor_tables(self):
+        """Every node's path (its ancestors + itself, main.py:163) and the depth of each node on it (main.py:164) as ONE
+        device-resident CSR, uploaded once: a new batch's target then costs two tensor views, not three pageable H2D
+        copies - those are stream-ordered behind the forward just launched, so each one stalled the host until the step
+        had finished and exposed the next step's launch latency (0.3 ms of a 6.3 ms step at ViT-B/32, batch 512)."""
+        if self._anc is None:
             m = self.model
-            parents = copy.copy(m.c2p[target]) + [target]
-            levels = [len(m.c2p[p]) for p in parents]           # main.py:164
+            keys = list(m.c2p.keys()) if isinstance(m.c2p, dict) else list(range(len(m.c2p)))
+            ptr, nodes, levels, off = {}, [], [], 0
+            for t in keys:
+                path = list(m.c2p[t]) + [t]
+                ptr[t] = (off, len(path))
+                nodes.extend(path)
+                levels.extend(len(m.c2p[q]) for q in path)
+                off += len(path)
             dev = m.train_index.device
-            c = (torch.tensor(parents, dtype=torch.int32, device=dev), torch.tensor(levels, dtype=torch.int64, device=dev),
-                 torch.tensor(levels, dtype=torch.int32, device=dev), len(parents))
-            self._parents_cache[target] = c
-        return c
+            lv = torch.tensor(levels, dtype=torch.int64)
+            self._anc = (ptr, torch.tensor(nodes, dtype=torch.int32).to(dev), lv.to(dev), lv.to(torch.int32).to(dev))
+        return self._anc
+
+    def _parents(self, target: int):
+        ptr, nodes, lv64, lv32 = self._ancestor_tables()
+        o, n = ptr[target]
+        return nodes[o:o + n], lv64[o:o + n], lv32[o:o + n], n
 
     @torch.no_grad()
     def add_batch(self, logits: torch.Tensor, target: int, targets: Optional[torch.Tensor] = None, want_outputs: bool = True):
