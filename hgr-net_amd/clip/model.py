@@ -486,7 +486,7 @@ class CLIP(nn.Module):
         else:
             ops.im2col_patches(image, patches, ps)
         pe = ws.get(tag + ".pe", (b * gg, w), torch.float32, dev)
-        ops.gemm_nt(patches, p["conv_w_nhwc"] if u8 else p["conv_w"], pe)
+        ops.gemm_nt(patches, p["conv_w_nhwc"] if u8 else p["conv_w"], pe, tag="patch")
         cls16 = ws.get(tag + ".cls16", (b, w), dt, dev)
         if ln_fusable(w):
             xh = ws.get(tag + ".xh", (b * l, w), dt, dev)

@@ -307,10 +307,12 @@ struct Tile { float (*t)[65]; };
 //             dV_j += P^T dO_i,  dK_j += dS^T Q_i,  dQ_i += dS K_j.   dQ of ALL query blocks lives in registers (5 x 16 per
 //             lane), so nothing is recomputed a second time and there are no atomics.
 // P and dS are rounded to the 16-bit type before the second products (as the forward's P is); Q, K, V, dO are 16-bit in
-// memory anyway.  An MFMA operand is 8 consecutive k for one row, so a transposed product needs the transposed tile: Q, dO
-// (per query block) and K (per key block) are staged both ways, P^T / dS / dS^T are written from the accumulator layout
-// (4 consecutive rows per lane -> one 8-byte store in the transposed image).  LDS rows are padded to 72 elements: the
-// 16-byte operand reads of 32 consecutive rows are bank-conflict free.
+// memory anyway.  An MFMA operand is 8 consecutive k for one row.  P^T / dS / dS^T are written from the accumulator layout
+// (4 consecutive rows per lane -> one 8-byte store in the transposed image); the transposed views of the STAGED tiles
+// (dO^T for dV, Q^T for dK, K^T for dQ) are never materialised: those B operands come out of the row-major tile through
+// gfx950's transposing LDS read (ds_read_b64_tr_b16, mm16_bt below).  7 tiles + the row statistics = 67 KB of LDS, so TWO
+// workgroups share a CU and one's barriers / global loads overlap the other's matrix work.  LDS rows are padded to 72
+// elements: the 16-byte operand reads of 32 consecutive rows are bank-conflict free.
 template <int DT>
 __device__ __forceinline__ void mm16(f32x16 &acc, const typename T16<DT>::elem (*A)[72], int arow, const typename T16<DT>::elem (*B)[72], int brow, int lane) {
     typedef typename T16<DT>::vec8 vec8;
@@ -320,15 +322,41 @@ __device__ __forceinline__ void mm16(f32x16 &acc, const typename T16<DT>::elem (
         acc = T16<DT>::mfma32(*(const vec8 *)&A[arow + r][kk * 16 + kh * 8], *(const vec8 *)&B[brow + r][kk * 16 + kh * 8], acc);
 }
 
+typedef __attribute__((ext_vector_type(4))) short tr_s16x4;
+typedef __attribute__((ext_vector_type(8))) short tr_s16x8;
+__device__ __forceinline__ tr_s16x4 tr_read64(const void *p) { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((AS3 tr_s16x4 *)p); }
+
+// acc[m][n] += sum_k A[arow + m][k] * Bt[k][bcol + n], k = 0..63: the B operand "8 consecutive k of column n" is read from
+// the row-major tile Bt with two transposing reads.  A 16-lane group (n = bcol + 16 * ((lane >> 4) & 1) + lane % 16, k half
+// kh = lane >> 5) reads a 4-row x 16-column block: lane 4 q + pp of the group supplies the address of (row k0 + q, columns
+// 4 pp .. 4 pp + 3) and receives the 4 rows of column lane % 16.  EXEC must be all ones (callers branch block-uniformly).
+template <int DT>
+__device__ __forceinline__ void mm16_bt(f32x16 &acc, const typename T16<DT>::elem (*A)[72], int arow, const typename T16<DT>::elem (*Bt)[72], int bcol, int lane) {
+    typedef typename T16<DT>::vec8 vec8;
+    const int r = lane & 31, kh = lane >> 5, l16 = lane & 15;
+    const int q = l16 >> 2, c = bcol + ((lane >> 4) & 1) * 16 + (l16 & 3) * 4;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const int k0 = kk * 16 + kh * 8;
+        const tr_s16x4 b0 = tr_read64(&Bt[k0 + q][c]), b1 = tr_read64(&Bt[k0 + 4 + q][c]);
+        const vec8 bf = __builtin_bit_cast(vec8, (tr_s16x8)__builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+        acc = T16<DT>::mfma32(*(const vec8 *)&A[arow + r][kk * 16 + kh * 8], bf, acc);
+    }
+}
+
 template <int DT, bool CAUSAL>
-__global__ __launch_bounds__(256) void mha_bwd_tiled(const typename T16<DT>::elem *__restrict__ qkv, const typename T16<DT>::elem *__restrict__ outp,
-                                                     const typename T16<DT>::elem *__restrict__ dout, typename T16<DT>::elem *__restrict__ dqkv, int L, int H) {
+__global__ __launch_bounds__(256, 2) void mha_bwd_tiled(const typename T16<DT>::elem *__restrict__ qkv, const typename T16<DT>::elem *__restrict__ outp,
+                                                        const typename T16<DT>::elem *__restrict__ dout, typename T16<DT>::elem *__restrict__ dqkv, int L, int H) {
     typedef typename T16<DT>::elem E;
     typedef typename T16<DT>::vec8 vec8;
     typedef typename T16<DT>::vec4 vec4;
-    __shared__ __attribute__((aligned(16))) E sQ[64][72], sQt[64][72], sK[64][72], sKt[64][72], sV[64][72], sO[64][72], sOt[64][72],
-        sDS[64][72], sDSt[64][72], sPt[64][72];
-    __shared__ float sS[64][65];
+    typedef E (*TileP)[72];
+    constexpr int TB = 64 * 72 * 2;                               // one 16-bit tile
+    __shared__ __attribute__((aligned(16))) char smem[7 * TB];
+    const TileP sQ = (TileP)smem, sK = (TileP)(smem + TB), sV = (TileP)(smem + 2 * TB), sO = (TileP)(smem + 3 * TB),
+                sDS = (TileP)(smem + 4 * TB), sDSt = (TileP)(smem + 5 * TB), sPt = (TileP)(smem + 6 * TB);
+    float (*const sS)[65] = (float (*)[65])(smem + 4 * TB);      // sweep 0 only: fp32 scores over the (then unused) dS / dS^T tiles
+    static_assert(64 * 65 * 4 <= 2 * TB, "score block must fit the two tiles it aliases");
     __shared__ float rM[320], rLinv[320], rD[320];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
     const int r32 = lane & 31, hh = lane >> 5;
@@ -341,8 +369,8 @@ __global__ __launch_bounds__(256) void mha_bwd_tiled(const typename T16<DT>::ele
     E *dqb = dqkv + (int64_t)b * L * ld + h * 64;
     const int nb = (L + 63) / 64;
 
-    // 64 x 64 block of 16-bit rows -> LDS row-major (and transposed if dt != nullptr); rows past L are zero
-    auto load = [&](E (*dst)[72], E (*dt)[72], const E *src, int64_t stride, int r0) {
+    // 64 x 64 block of 16-bit rows -> LDS row-major; rows past L are zero
+    auto load = [&](TileP dst, const E *src, int64_t stride, int r0) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int id = tid + 256 * j;                  // 512 chunks of 8 elements
@@ -353,9 +381,25 @@ __global__ __launch_bounds__(256) void mha_bwd_tiled(const typename T16<DT>::ele
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = (E)0.f;
             *(vec8 *)&dst[r][c] = v;
-            if (dt)
+        }
+    };
+    // the same in two halves, so that the NEXT block's rows travel while the current one is worked on
+    auto fetch = [&](vec8 (&v)[2], const E *src, int64_t stride, int r0) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) dt[c + e][r] = v[e];
+        for (int j = 0; j < 2; ++j) {
+            const int id = tid + 256 * j;
+            const int r = id >> 3, c = (id & 7) * 8;
+            v[j] = *(const vec8 *)(src + (int64_t)min(r0 + r, L - 1) * stride + c);       // unconditional load (row clamped), zeroed below
+            if (r0 + r >= L)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[j][e] = (E)0.f;
+        }
+    };
+    auto put = [&](TileP dst, const vec8 (&v)[2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int id = tid + 256 * j;
+            *(vec8 *)&dst[id >> 3][(id & 7) * 8] = v[j];
         }
     };
     auto write_rows = [&](E *dstg, int64_t stride, int r0, const f32x16 &acc) {      // 16-bit global rows from an accumulator quadrant
@@ -371,9 +415,9 @@ __global__ __launch_bounds__(256) void mha_bwd_tiled(const typename T16<DT>::ele
     // ---- sweep 0: row statistics ---------------------------------------------------------------------------------------------------------
     for (int qi = 0; qi < nb; ++qi) {
         __syncthreads();
-        load(sQ, nullptr, base, ld, qi * 64);
-        load(sO, nullptr, dob, W, qi * 64);
-        load(sV, nullptr, ob, W, qi * 64);                     // forward output O of this query block (in sV for the moment)
+        load(sQ, base, ld, qi * 64);
+        load(sO, dob, W, qi * 64);
+        load(sV, ob, W, qi * 64);                              // forward output O of this query block (in sV for the moment)
         __syncthreads();
         {   // D = rowsum(dO * O): 4 threads per row
             const int row = tid >> 2, part = tid & 3;
@@ -382,10 +426,13 @@ __global__ __launch_bounds__(256) void mha_bwd_tiled(const typename T16<DT>::ele
             acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2);
             if (part == 0) { rD[qi * 64 + row] = acc; rM[qi * 64 + row] = -INFINITY; rLinv[qi * 64 + row] = 0.f; }
         }
+        vec8 pk[2];
+        fetch(pk, base + W, ld, 0);
         for (int kj = 0; kj < nb; ++kj) {
             if (CAUSAL && kj > qi) break;
             __syncthreads();
-            load(sK, nullptr, base + W, ld, kj * 64);
+            put(sK, pk);
+            fetch(pk, base + W, ld, min(kj + 1, nb - 1) * 64);      // the next key block (a harmless re-read after the last one)
             __syncthreads();
             f32x16 acc = {0.f};
             mm16<DT>(acc, sQ, wr * 32, sK, wc * 32, lane);
@@ -417,17 +464,25 @@ __global__ __launch_bounds__(256) void mha_bwd_tiled(const typename T16<DT>::ele
     f32x16 dq[5];
 #pragma unroll
     for (int i = 0; i < 5; ++i) dq[i] = (f32x16){0.f};
+    vec8 pq[2], po[2];                                           // Q / dO rows of the next (key block, query block) pair, in flight
+    fetch(pq, base, ld, 0);
+    fetch(po, dob, W, 0);
     for (int kj = 0; kj < nb; ++kj) {
         __syncthreads();
-        load(sK, sKt, base + W, ld, kj * 64);
-        load(sV, nullptr, base + 2 * W, ld, kj * 64);
+        load(sK, base + W, ld, kj * 64);
+        load(sV, base + 2 * W, ld, kj * 64);
         f32x16 dk = {0.f}, dv = {0.f};
 #pragma unroll
         for (int qi = 0; qi < 5; ++qi) {
             if (qi >= nb || (CAUSAL && qi < kj)) continue;       // block-uniform
             __syncthreads();
-            load(sQ, sQt, base, ld, qi * 64);
-            load(sO, sOt, dob, W, qi * 64);
+            put(sQ, pq);
+            put(sO, po);
+            {
+                const int nxt = qi + 1 < nb ? qi + 1 : (CAUSAL ? min(kj + 1, nb - 1) : 0);     // the pair after this one starts there
+                fetch(pq, base, ld, nxt * 64);
+                fetch(po, dob, W, nxt * 64);
+            }
             __syncthreads();
             f32x16 sacc = {0.f}, dp = {0.f};
             mm16<DT>(sacc, sQ, wr * 32, sK, wc * 32, lane);       // S = Q K^T
@@ -451,9 +506,9 @@ __global__ __launch_bounds__(256) void mha_bwd_tiled(const typename T16<DT>::ele
                 *(vec4 *)&sDSt[cc][rr0] = d4;
             }
             __syncthreads();
-            mm16<DT>(dv, sPt, wr * 32, sOt, wc * 32, lane);       // dV += P^T dO      (rows = keys, columns = d)
-            mm16<DT>(dk, sDSt, wr * 32, sQt, wc * 32, lane);      // dK += dS^T Q
-            mm16<DT>(dq[qi], sDS, wr * 32, sKt, wc * 32, lane);   // dQ_i += dS K
+            mm16_bt<DT>(dv, sPt, wr * 32, sO, wc * 32, lane);     // dV += P^T dO      (rows = keys, columns = d; k = queries)
+            mm16_bt<DT>(dk, sDSt, wr * 32, sQ, wc * 32, lane);    // dK += dS^T Q
+            mm16_bt<DT>(dq[qi], sDS, wr * 32, sK, wc * 32, lane); // dQ_i += dS K      (k = keys)
         }
         write_rows(dqb + W, ld, kj * 64, dk);
         write_rows(dqb + 2 * W, ld, kj * 64, dv);
