@@ -1232,18 +1232,27 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
             char *sw = (char *)(p.ln_stats + (wrow * p.ln_slots + (n0 >> 6) + wn) * 2);
             const unsigned ldxB = (unsigned)p.ln_ldx * 2u, ldsB = (unsigned)p.ln_slots * 8u;
             const unsigned xl = rq * ldxB + cq * 8, sl = rq * ldsB;
+            // the old pair of pass P + 1 is requested before pass P stores (passes touch disjoint rows; the compiler cannot hoist
+            // the loads itself, the pointers alias): one exposed memory round trip per tile instead of four
+            hvec4 ohb[2][8];
+            f16x4 olb[2][8];
+            auto pair_load = [&](int buf, int rl) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    ohb[buf][q] = *(const hvec4 *)(hw + (xl + (rl + q * 4) * ldxB));
+                    olb[buf][q] = *(const f16x4 *)(lw + (xl + (rl + q * 4) * ldxB));
+                }
+            };
+            pair_load(0, 0);
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int ih = 0; ih < 2; ++ih) {
                 const int rl = a * 64 + ih * 32;
-                hvec4 oh[8];
-                f16x4 ol[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    oh[q] = *(const hvec4 *)(hw + (xl + (rl + q * 4) * ldxB));
-                    ol[q] = *(const f16x4 *)(lw + (xl + (rl + q * 4) * ldxB));
-                }
+                const int pb = ih;                               // pass a * 2 + ih uses buffer ih
+                hvec4 (&oh)[8] = ohb[pb];
+                f16x4 (&ol)[8] = olb[pb];
+                if (a * 2 + ih > 0 && (p.dbg & 64)) pair_load(pb, rl);        // HGR_GEMM_DBG bit 64: every pass loads for itself (A/B runs)
 #pragma unroll
                 for (int i2 = 0; i2 < 2; ++i2)
 #pragma unroll
@@ -1251,6 +1260,7 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     *(f32x4 *)(my + (i2 * 16 + r) * RS + (b * 32 + j * 16 + g * 4) * 4) = acc[a][b][ih * 2 + i2][j] + bq[b][j];
+                if (a * 2 + ih < 3 && !(p.dbg & 64)) pair_load(pb ^ 1, rl + 32);
                 f32x4 vq[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
