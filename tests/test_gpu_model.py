@@ -100,7 +100,9 @@ def test_tree_model_forward_and_metrics_vs_reference(case, idt, golden_dir, tmp_
                        node_tokens=torch.from_numpy(z["node_tokens"].astype(np.int64)), clip_model=clip_model)
     assert model.nodes == meta["nodes"] and model.c2p == meta["c2p"]
     model.update_classifier()
-    assert np.abs(model.zsl_weights.cpu().numpy() - z["zsl_weights"]).max() < 2e-3     # unit rows, f16 text tower
+    zerr = float(np.abs(model.zsl_weights.cpu().numpy() - z["zsl_weights"]).max())
+    print(f"[measured] {case} zsl_weights max |HIP - reference| = {zerr:.2e}")
+    assert zerr < 1e-3, zerr     # unit rows, f16 text tower: the same bar as the logits
     ev = evaluate.Evaluator(model)
     for i in range(meta["batches"]):
         img = synth.images(meta["bsz"], cfg["image_resolution"], meta["image_seed0"] + i)
@@ -209,7 +211,9 @@ def test_config0_rn50_n1000_batch32_vs_cpu_oracle(tmp_path):
     img = synth.images(32, 224, 1234)
     lg = model(img.to(DEV), None).cpu().numpy()
     zsl = tree_ref.update_classifier(sd, tokens, trim=True)
-    assert np.abs(model.zsl_weights.float().cpu().numpy() - zsl.numpy()).max() < 2e-3
+    zerr = float(np.abs(model.zsl_weights.float().cpu().numpy() - zsl.numpy()).max())
+    print(f"[measured] ViT-B/32 N=1000 zsl_weights max |HIP - oracle| = {zerr:.2e}")
+    assert zerr < 1e-3, zerr
     ref = tree_ref.forward(sd, img, zsl).numpy()
     err = float(np.abs(lg - ref).max())
     assert err < 1e-3, err
