@@ -67,6 +67,7 @@ SIGNATURES = {
     "hgr_conv3x3_nhwc_plain": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "hgr_gemm_nt_splitk": [_p, _l, _p, _l, _p, _l, _i, _i, _i, _i, _i, _p],
     "hgr_gemm_tn_splitk": [_p, _l, _p, _l, _p, _l, _i, _i, _i, _i, _i, _p],
+    "hgr_gemm_tn_tile": [_i, _i],
     "hgr_conv3x3_wgrad_splitk": [_p, _l, _p, _p, _l, _i, _i, _i, _i, _i, _i, _i, _p],
     "hgr_relu_bwd16": [_p, _p, _p, _l, _i, _p],
     "hgr_add16": [_p, _p, _p, _l, _i, _p],

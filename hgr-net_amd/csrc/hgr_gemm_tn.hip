@@ -20,6 +20,7 @@
 // LDS stages (64 KB), blockIdx.y = reduction slice.  EXEC is all ones at every transposing read (no divergent code
 // around them), as the ISA requires.
 #include "hgr_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -170,6 +171,131 @@ __global__ __launch_bounds__(256) void gemm_tn_128(TnArgs p) {
     }
 }
 
+
+// gemm_tn_256: the same product on 256 (a) x 256 (b) x 64 (m) stages, 8 waves as 2 (a) x 4 (b), a wave owns 128 x 64 =
+// 8 x 4 tiles (128 accumulators).  Why: a 128 x 128 stage holds 2.1 MFLOP of matrix work, ~0.45 us even with two
+// workgroups sharing the CU - less than one L2 / Infinity-Cache round trip, so every stage waited for its successor's
+// operands.  A 256 x 256 stage is 8.4 MFLOP per 64 KB staged: twice the time for the next stage to land and half the
+// L2 -> LDS bytes per FLOP.  The operand tile is stored as two [64][128] halves (all the addressing of gemm_tn_128 carries
+// over); 2 stages x 4 halves = 128 KB, one workgroup per CU (2 waves per SIMD).  Linear / 1x1 operands only.
+template <int DT>
+__global__ __launch_bounds__(512) void gemm_tn_256(TnArgs p) {
+    typedef typename T16<DT>::vec8 vec8;
+    constexpr int TILE = 64 * 256;                      // one [64][128] half
+    __shared__ __attribute__((aligned(1024))) char smem[8 * TILE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wa = wave >> 2, wb = wave & 3;
+    const int r = lane & 15, g = lane >> 4;
+    const int ta = blockIdx.x / p.tiles_b, tb = blockIdx.x - ta * p.tiles_b;
+    const int a0 = ta * 256, b0 = tb * 256;
+    const int ms = blockIdx.y * p.kc, me = min(p.M, ms + p.kc);
+    const int nk = (me - ms + 63) >> 6;
+
+    // LDS-DMA pieces: a stage = 4 halves (P0, P1, Q0, Q1) x 16 pieces of 1 KB; this wave issues pieces i * 8 + wave, i = 0..7
+    // (i < 4: P, half i >> 1; i >= 4: Q, half (i - 4) >> 1; piece ((i & 1) * 8 + wave) of the half)
+    int prow[8];
+    int64_t poff[8];
+    bool pok[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int piece = (i & 1) * 8 + wave, half = (i & 3) >> 1;
+        const int row = piece * 4 + (lane >> 4), slot = lane & 15;
+        const int ch = slot ^ swz(row);
+        prow[i] = row;
+        const int col = (i < 4 ? a0 : b0) + half * 128 + ch * 8;
+        pok[i] = col < (i < 4 ? p.Na : p.Nb);
+        poff[i] = (int64_t)col * 2;
+    }
+    auto stage = [&](int buf, int kt) {
+        char *sb = smem + buf * (4 * TILE);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = ms + kt * 64 + prow[i];
+            const bool in = m < me && pok[i];
+            const char *src = i < 4 ? p.P + (int64_t)m * p.ldp * 2 : p.Q + (int64_t)m * p.ldq * 2;
+            const char *sp = in ? src + poff[i] : (const char *)tn_zero_page;
+            __builtin_amdgcn_global_load_lds((const AS1 void *)sp, (AS3 void *)(sb + (i >> 1) * TILE + ((i & 1) * 8 + wave) * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int l16 = lane & 15, q = l16 >> 2, pp = l16 & 3;
+    int rdoff[2][2], rdx[2];
+#pragma unroll
+    for (int sec = 0; sec < 2; ++sec) {
+        rdx[sec] = (q << 2) | ((2 * g + sec) & 3);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) rdoff[kk][sec] = (kk * 32 + 8 * g + 4 * sec + q) * 256 + 8 * (pp & 1);
+    }
+    const int chP = pp >> 1, chQ = (wb & 1) * 8 + (pp >> 1);          // + 2 * fragment index
+
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const char *sP = smem + cur * (4 * TILE) + wa * TILE, *sQ = smem + cur * (4 * TILE) + (2 + (wb >> 1)) * TILE;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            vec8 pf[8], qf[4];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const s16x4 p0 = tr_read(sP + rdoff[kk][0] + 16 * ((chP + 2 * t) ^ rdx[0]));
+                const s16x4 p1 = tr_read(sP + rdoff[kk][1] + 16 * ((chP + 2 * t) ^ rdx[1]));
+                pf[t] = __builtin_bit_cast(vec8, (s16x8)__builtin_shufflevector(p0, p1, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const s16x4 q0 = tr_read(sQ + rdoff[kk][0] + 16 * ((chQ + 2 * t) ^ rdx[0]));
+                const s16x4 q1 = tr_read(sQ + rdoff[kk][1] + 16 * ((chQ + 2 * t) ^ rdx[1]));
+                qf[t] = __builtin_bit_cast(vec8, (s16x8)__builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[i][j] = T16<DT>::mfma16(qf[i], pf[j], acc[i][j]);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // lane holds, for tile (i, j): out[a = a0 + wa*128 + j*16 + r][b = b0 + wb*64 + i*16 + 4g .. +3]
+    float *o = p.out + (int64_t)blockIdx.y * p.csplit;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int a = a0 + wa * 128 + j * 16 + r;
+        if (a >= p.Na) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int b = b0 + wb * 64 + i * 16 + g * 4;
+            if (b + 3 < p.Nb) *(f32x4 *)(o + (int64_t)a * p.ldo + b) = acc[i][j];
+            else
+                for (int e = 0; e < 4; ++e)
+                    if (b + e < p.Nb) o[(int64_t)a * p.ldo + b + e] = acc[i][j][e];
+        }
+    }
+}
+
+// tile plan of the linear product: 256 x 256 when both extents fill such tiles with <= 7 % more padded area than 128 x 128
+int tn_tile(int Na, int Nb) {
+    static const int forced = [] { const char *e = getenv("HGR_TN_TILE"); return e ? atoi(e) : 0; }();
+    if (forced == 128 || forced == 256) return forced;
+    if (Na < 256 || Nb < 256) return 128;
+    const int64_t big = (int64_t)((Na + 255) / 256) * ((Nb + 255) / 256) * 65536, small = (int64_t)((Na + 127) / 128) * ((Nb + 127) / 128) * 16384;
+    return big * 100 <= small * 107 ? 256 : 128;
+}
+
 unsigned magic32(int d) { return (unsigned)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d); }
 
 int tn_launch(const void *P, int64_t ldp, const void *Q, int64_t ldq, float *partial, int64_t ldo,
@@ -189,8 +315,16 @@ int tn_launch(const void *P, int64_t ldp, const void *Q, int64_t ldq, float *par
     a.tiles_b = (Nb + 127) / 128;
     a.cH = H; a.cW = W; a.cC = C;
     a.mW = conv ? magic32(W) : 0; a.mH = conv ? magic32(H) : 0; a.mC = conv ? magic32(C) : 0;
-    dim3 grid((unsigned)(((Na + 127) / 128) * a.tiles_b), (unsigned)S);
     hipStream_t s = (hipStream_t)stream;
+    if (!conv && tn_tile(Na, Nb) == 256) {
+        a.tiles_b = (Nb + 255) / 256;
+        dim3 grid256((unsigned)(((Na + 255) / 256) * a.tiles_b), (unsigned)S);
+        if (dtype == HGR_BF16) hipLaunchKernelGGL((gemm_tn_256<HGR_BF16>), grid256, dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((gemm_tn_256<HGR_F16>), grid256, dim3(512), 0, s, a);
+        HGR_CHECK_LAUNCH(name);
+        return HGR_OK;
+    }
+    dim3 grid((unsigned)(((Na + 127) / 128) * a.tiles_b), (unsigned)S);
     if (conv) {
         if (dtype == HGR_BF16) hipLaunchKernelGGL((gemm_tn_128<HGR_BF16, true>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((gemm_tn_128<HGR_F16, true>), grid, dim3(256), 0, s, a);
@@ -203,6 +337,8 @@ int tn_launch(const void *P, int64_t ldp, const void *Q, int64_t ldq, float *par
 }
 
 }  // namespace
+
+extern "C" int hgr_gemm_tn_tile(int Na, int Nb) { return tn_tile(Na, Nb); }
 
 extern "C" int hgr_gemm_tn_splitk(const void *P, int64_t ldp, const void *Q, int64_t ldq, float *partial, int64_t ldo,
                                   int M, int Na, int Nb, int kc, int dtype, void *stream) {

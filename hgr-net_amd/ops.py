@@ -564,6 +564,13 @@ def splitk_slices(tiles: int, m: int, slots: int = 512) -> int:
     return best[1]
 
 
+def tn_slices(na: int, nb: int, m: int) -> int:
+    """Reduction slices of hgr_gemm_tn_splitk for a [na, nb] product over m rows, for the tile plan the library will run
+    (hgr_gemm_tn_tile: 256 x 256 tiles, one workgroup per CU, or 128 x 128, two per CU)."""
+    t = int(_lib.load().hgr_gemm_tn_tile(na, nb))
+    return splitk_slices(-(-na // t) * -(-nb // t), m, slots=256 if t == 256 else 512)
+
+
 def gemm_tn_splitk(p: torch.Tensor, q: torch.Tensor, partial: torch.Tensor, kc: int) -> torch.Tensor:
     """partial[s] [Na, Nb] = p[rows of slice s]^T . q[rows of slice s]; p [M, Na], q [M, Nb] 16-bit row-major."""
     assert p.dim() == 2 and q.dim() == 2 and p.stride(1) == 1 and q.stride(1) == 1 and p.dtype == q.dtype and p.shape[0] == q.shape[0]

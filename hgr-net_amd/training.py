@@ -112,7 +112,7 @@ class Engine:
                 and dy16.data_ptr() % 16 == 0 and xq.data_ptr() % 16 == 0:
             # operands as they lie in memory (hgr_gemm_tn_splitk): no transposed copies of dY and X
             gw = _grad(lin.weight).view(lin.n, lin.k)
-            s = ops.splitk_slices(-(-lin.n // 128) * -(-lin.k // 128), m)
+            s = ops.tn_slices(lin.n, lin.k, m)
             kc = _pad64(-(-m // s))
             s = -(-m // kc)
             need = s * lin.n * lin.k

@@ -177,7 +177,7 @@ class RNTower:
         k = 9 * conv[2] if conv else x16.shape[1]
         if not WGRAD_TN or cout % 8 or k % 8 or dy16.stride(0) % 8 or dy16.data_ptr() % 16 or x16.data_ptr() % 16 or not x16.is_contiguous():
             return False
-        s = ops.splitk_slices(-(-cout // 128) * -(-k // 128), m)
+        s = ops.splitk_slices(-(-cout // 128) * -(-k // 128), m) if conv else ops.tn_slices(cout, k, m)
         kc = _pad64(-(-m // s))
         s = -(-m // kc)
         part = self._tmp("part", (s, cout * k), torch.float32)

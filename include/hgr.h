@@ -281,6 +281,10 @@ int hgr_attnpool_attend(const float *q, const void *k, const void *v, void *out,
  */
 int hgr_gemm_tn_splitk(const void *P, int64_t ldp, const void *Q, int64_t ldq, float *partial, int64_t ldo,
                        int M, int Na, int Nb, int kc, int dtype, void *stream);
+/* Output tile edge (256 or 128) hgr_gemm_tn_splitk runs for an [Na, Nb] product: 256 x 256 tiles occupy a CU alone (size
+ * kc for ~256 workgroups per round), 128 x 128 tiles run two per CU (~512).  Pure function of the shape (HGR_TN_TILE=128|256
+ * in the environment pins it, for A/B runs); not an error code. */
+int hgr_gemm_tn_tile(int Na, int Nb);
 
 /* The same for a 3x3 / pad 1 / stride 1 convolution (every 3x3 of clip/model.py's Bottleneck and stem conv2/conv3):
  *   partial[s][co][(ky, kx, c)] = sum over pixels m of slice s of dY[m][co] * x[pixel m shifted by (ky-1, kx-1)][c]

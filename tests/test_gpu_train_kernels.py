@@ -347,7 +347,8 @@ def test_gemm_nt_splitk_partials(dt, m, n, k, kc):
 
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("m,na,nb,kc", [(64, 128, 128, 64), (200, 192, 128, 64), (1000, 40, 264, 256), (12800, 768, 768, 1280),
-                                        (777, 136, 72, 128), (4096, 3072, 768, 4096), (130, 8, 8, 64)])
+                                        (777, 136, 72, 128), (4096, 3072, 768, 4096), (130, 8, 8, 64),
+                                        (700, 1016, 760, 256), (8192, 1024, 4096, 2048), (333, 256, 256, 64)])     # the last three: 256 x 256 tiles, ragged edges
 def test_gemm_tn_splitk_exact(dt, m, na, nb, kc):
     """Weight gradient with untransposed operands: partial[s] = P[slice]^T . Q[slice].  Small-integer operands, so the
     fp32 accumulation is exact in any order: every slice must equal the fp64 product bit for bit (ragged M, Na, Nb;
@@ -357,6 +358,9 @@ def test_gemm_tn_splitk_exact(dt, m, na, nb, kc):
     pf[:, :na] = torch.randint(-2, 3, (m, na), generator=gen).to(dt)
     qf = torch.randint(-2, 3, (m, nb), generator=gen).to(dt)
     s = (m + kc - 1) // kc
+    from hgr_net_amd import _lib
+    if na >= 1016 or (na, nb) in ((768, 768), (3072, 768), (256, 256)):
+        assert _lib.load().hgr_gemm_tn_tile(na, nb) == 256
     part = torch.full((s, na, nb), 7.0, dtype=torch.float32, device=DEV)
     ops.gemm_tn_splitk(pf.to(DEV)[:, :na], qf.to(DEV), part, kc)
     for i in range(s):
