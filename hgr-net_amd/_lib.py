@@ -16,7 +16,7 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("HGR_LIB", _HERE / "lib" / "libhgr.so"))
 
 HGR_BF16, HGR_F16 = 0, 1
-EPI_NONE, EPI_BIAS, EPI_BIAS_QUICKGELU, EPI_BIAS_RESIDUAL, EPI_BIAS_RELU, EPI_BIAS_ADD16_RELU, EPI_ACCUM = 0, 1, 2, 3, 4, 5, 6
+EPI_NONE, EPI_BIAS, EPI_BIAS_QUICKGELU, EPI_BIAS_RESIDUAL, EPI_BIAS_RELU, EPI_BIAS_ADD16_RELU, EPI_ACCUM, EPI_QGELU_GRAD16 = 0, 1, 2, 3, 4, 5, 6, 7
 
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 

@@ -75,23 +75,31 @@ __device__ __forceinline__ float quick_gelu(float v) {
 }
 
 
+// d/dx of quick_gelu: s (1 + 1.702 x (1 - s)), s = sigmoid(1.702 x) - the expression of hgr_quickgelu16's backward
+__device__ __forceinline__ float quick_gelu_grad(float x) {
+    const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * x));
+    return s * (1.0f + 1.702f * x * (1.0f - s));
+}
+__host__ __device__ constexpr bool epi_has_bias(int epi) { return epi != HGR_EPI_NONE && epi != HGR_EPI_ACCUM && epi != HGR_EPI_QGELU_GRAD16; }
+__host__ __device__ constexpr bool epi_has_idn16(int epi) { return epi == HGR_EPI_BIAS_ADD16_RELU || epi == HGR_EPI_QGELU_GRAD16; }
+
 // One lane's 4 consecutive outputs C[m][n .. n+3] of an accumulator tile: bias / QuickGELU / residual,
 // then a 16-byte (fp32) or 8-byte (16-bit) store; scalar tail only at the N edge or for odd strides.
 template <int DT, int EPI, bool OUT32>
 __device__ __forceinline__ void store_quad(const GemmArgs &p, f32x4 v, int m, int n) {
     typedef typename T16<DT>::elem E;
     if (n + 3 < p.N && p.vec_ok) {
-        if (EPI != HGR_EPI_NONE && EPI != HGR_EPI_ACCUM) v += *(const f32x4 *)(p.bias + n);
+        if (epi_has_bias(EPI)) v += *(const f32x4 *)(p.bias + n);
         if (EPI == HGR_EPI_ACCUM) v += *(const f32x4 *)((const float *)p.C + (int64_t)m * p.ldc + n);
         if (EPI == HGR_EPI_BIAS_QUICKGELU) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
         }
         if (EPI == HGR_EPI_BIAS_RESIDUAL) v += *(const f32x4 *)(p.res + (int64_t)m * p.ldr + n);
-        if (EPI == HGR_EPI_BIAS_ADD16_RELU) {
+        if (epi_has_idn16(EPI)) {
             const typename T16<DT>::vec4 idn = *(const typename T16<DT>::vec4 *)((const E *)(const void *)p.res + (int64_t)m * p.ldr + n);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += (float)idn[e];
+            for (int e = 0; e < 4; ++e) v[e] = EPI == HGR_EPI_QGELU_GRAD16 ? v[e] * quick_gelu_grad((float)idn[e]) : v[e] + (float)idn[e];
         }
         if (EPI == HGR_EPI_BIAS_RELU || EPI == HGR_EPI_BIAS_ADD16_RELU) {
 #pragma unroll
@@ -103,11 +111,12 @@ __device__ __forceinline__ void store_quad(const GemmArgs &p, f32x4 v, int m, in
     }
     for (int e = 0; e < 4 && n + e < p.N; ++e) {
         float x = v[e];
-        if (EPI != HGR_EPI_NONE && EPI != HGR_EPI_ACCUM) x += p.bias[n + e];
+        if (epi_has_bias(EPI)) x += p.bias[n + e];
         if (EPI == HGR_EPI_ACCUM) x += ((const float *)p.C)[(int64_t)m * p.ldc + n + e];
         if (EPI == HGR_EPI_BIAS_QUICKGELU) x = quick_gelu(x);
         if (EPI == HGR_EPI_BIAS_RESIDUAL) x += p.res[(int64_t)m * p.ldr + n + e];
         if (EPI == HGR_EPI_BIAS_ADD16_RELU) x += (float)((const E *)(const void *)p.res)[(int64_t)m * p.ldr + n + e];
+        if (EPI == HGR_EPI_QGELU_GRAD16) x *= quick_gelu_grad((float)((const E *)(const void *)p.res)[(int64_t)m * p.ldr + n + e]);
         if (EPI == HGR_EPI_BIAS_RELU || EPI == HGR_EPI_BIAS_ADD16_RELU) x = fmaxf(x, 0.f);
         if (OUT32) ((float *)p.C)[(int64_t)m * p.ldc + n + e] = x;
         else ((E *)p.C)[(int64_t)m * p.ldc + n + e] = (E)x;
@@ -123,7 +132,7 @@ __device__ __forceinline__ f32x4 load_addend(const GemmArgs &p, int m, int n) {
     typedef typename T16<DT>::elem E;
     if (EPI == HGR_EPI_ACCUM) return *(const f32x4 *)((const float *)p.C + (int64_t)m * p.ldc + n);
     if (EPI == HGR_EPI_BIAS_RESIDUAL) return *(const f32x4 *)(p.res + (int64_t)m * p.ldr + n);
-    if (EPI == HGR_EPI_BIAS_ADD16_RELU) {
+    if (epi_has_idn16(EPI)) {
         const typename T16<DT>::vec4 idn = *(const typename T16<DT>::vec4 *)((const E *)(const void *)p.res + (int64_t)m * p.ldr + n);
         return (f32x4){(float)idn[0], (float)idn[1], (float)idn[2], (float)idn[3]};
     }
@@ -133,12 +142,16 @@ __device__ __forceinline__ f32x4 load_addend(const GemmArgs &p, int m, int n) {
 template <int DT, int EPI, bool OUT32>
 __device__ __forceinline__ void store_quad_full(const GemmArgs &p, f32x4 v, f32x4 bq, f32x4 addend, int m, int n) {
     typedef typename T16<DT>::elem E;
-    if (EPI != HGR_EPI_NONE && EPI != HGR_EPI_ACCUM) v += bq;
+    if (epi_has_bias(EPI)) v += bq;
     if (EPI == HGR_EPI_BIAS_QUICKGELU) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
     }
     if (EPI == HGR_EPI_ACCUM || EPI == HGR_EPI_BIAS_RESIDUAL || EPI == HGR_EPI_BIAS_ADD16_RELU) v += addend;
+    if (EPI == HGR_EPI_QGELU_GRAD16) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= quick_gelu_grad(addend[e]);
+    }
     if (EPI == HGR_EPI_BIAS_RELU || EPI == HGR_EPI_BIAS_ADD16_RELU) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -266,8 +279,8 @@ __global__ __launch_bounds__(NT) void gemm_nt_128(GemmArgs p) {
     // ONEK: the whole epilogue input (bias quads, first half of the identity) is requested together with the operands, so
     // a workgroup waits for memory once instead of three times (operands -> bias -> identity).
     typedef typename T16<DT>::elem E;
-    constexpr bool HAS_BIAS = EPI != HGR_EPI_NONE && EPI != HGR_EPI_ACCUM;
-    constexpr bool HAS_IDN = EPI == HGR_EPI_BIAS_ADD16_RELU;
+    constexpr bool HAS_BIAS = epi_has_bias(EPI);
+    constexpr bool HAS_IDN = epi_has_idn16(EPI);
     const bool full = p.vec_ok && m0 + BM <= p.M && n0 + BN <= p.N;
     const bool wide = !OUT32 && full && (p.ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 &&
                       (!HAS_IDN || ((p.ldr & 7) == 0 && (reinterpret_cast<uintptr_t>(p.res) & 15) == 0));
@@ -384,9 +397,9 @@ __global__ __launch_bounds__(NT) void gemm_nt_128(GemmArgs p) {
                 if (HAS_IDN) {
                     const typename T16<DT>::vec8 iv = __builtin_bit_cast(typename T16<DT>::vec8, idn[h][q]);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += (float)iv[e];
+                    for (int e = 0; e < 8; ++e) v[e] = EPI == HGR_EPI_QGELU_GRAD16 ? v[e] * quick_gelu_grad((float)iv[e]) : v[e] + (float)iv[e];
                 }
-                if (EPI == HGR_EPI_BIAS_RELU || HAS_IDN) {
+                if (EPI == HGR_EPI_BIAS_RELU || EPI == HGR_EPI_BIAS_ADD16_RELU) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
                 }
@@ -404,7 +417,7 @@ __global__ __launch_bounds__(NT) void gemm_nt_128(GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             bq[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (EPI != HGR_EPI_NONE && EPI != HGR_EPI_ACCUM) bq[i] = *(const f32x4 *)(p.bias + n0 + wn * 64 + i * 16 + g * 4);
+            if (epi_has_bias(EPI)) bq[i] = *(const f32x4 *)(p.bias + n0 + wn * 64 + i * 16 + g * 4);
         }
 #pragma unroll
         for (int jh = 0; jh < 2; ++jh) {       // batches of 8 quads: all addend loads first, then the stores
@@ -689,7 +702,7 @@ __global__ __launch_bounds__(NT256) void gemm_nt_256(GemmArgs p) {
             for (int j = 0; j < 2; ++j) {
                 const int n = n0 + wn * 64 + b * 32 + j * 16 + g * 4;
                 bq[b][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (EPI != HGR_EPI_NONE && EPI != HGR_EPI_ACCUM) {
+                if (epi_has_bias(EPI)) {
                     if (FULL || n + 3 < p.N) bq[b][j] = *(const f32x4 *)(p.bias + n);
                     else
                         for (int e = 0; e < 4; ++e) if (n + e < p.N) bq[b][j][e] = p.bias[n + e];
@@ -746,7 +759,7 @@ __global__ __launch_bounds__(NT256) void gemm_nt_256(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             bq[b][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (EPI != HGR_EPI_NONE && EPI != HGR_EPI_ACCUM) bq[b][j] = *(const f32x4 *)(p.bias + n0 + wn * 64 + b * 32 + j * 16 + g * 4);
+            if (epi_has_bias(EPI)) bq[b][j] = *(const f32x4 *)(p.bias + n0 + wn * 64 + b * 32 + j * 16 + g * 4);
         }
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -1090,7 +1103,7 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
         }
         return;
     }
-    constexpr bool HAS_BIAS = EPI != HGR_EPI_NONE && EPI != HGR_EPI_ACCUM;
+    constexpr bool HAS_BIAS = epi_has_bias(EPI);
     constexpr bool HAS_ADD = EPI == HGR_EPI_BIAS_RESIDUAL || EPI == HGR_EPI_ACCUM;
     const bool full = p.vec_ok && m0 + 256 <= p.M && n0 + 128 <= p.N;
     if (full && !OUT32 && (p.ldc & 7) == 0 && (EPI <= HGR_EPI_BIAS_QUICKGELU || EPI == HGR_EPI_BIAS_RELU)) {
@@ -1154,7 +1167,7 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
             *(u32x4 *)(cw + (cl + q * 8 * ldcB)) = *(const u32x4 *)(my + (q * 8 + rr) * RS + ch * 16);
         return;
     }
-    if (full && !OUT32 && EPI == HGR_EPI_BIAS_ADD16_RELU && (p.ldc & 7) == 0 && (p.ldr & 7) == 0) {
+    if (full && !OUT32 && epi_has_idn16(EPI) && (p.ldc & 7) == 0 && (p.ldr & 7) == 0) {
         // relu(acc + bias + 16-bit identity) -> 16 bit (bn3(conv3) ; out += identity ; relu, clip/model.py:46-52): the sum is
         // formed in fp32 and rounded once.  4 passes of 32 rows through the wave's LDS slice (fp32 rows of 256 B + 16 B pad);
         // on the way out a lane owns 8 consecutive columns of a row, so the identity is LOADED and the result STORED as
@@ -1165,7 +1178,7 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bq[b][j] = *(const f32x4 *)(p.bias + n0 + wn * 64 + b * 32 + j * 16 + g * 4);
+            for (int j = 0; j < 2; ++j) bq[b][j] = HAS_BIAS ? *(const f32x4 *)(p.bias + n0 + wn * 64 + b * 32 + j * 16 + g * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
         const int r8 = lane >> 3, c8 = lane & 7;
         const int64_t wrow = m0 + wm * 128, wcol = n0 + wn * 64;
         char *cw = (char *)p.C + (wrow * p.ldc + wcol) * 2;
@@ -1195,8 +1208,13 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
                 typename T16<DT>::vec8 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    o[e] = (E)fmaxf(lo[e] + (float)iv[e], 0.f);
-                    o[e + 4] = (E)fmaxf(hi[e] + (float)iv[e + 4], 0.f);
+                    if (EPI == HGR_EPI_QGELU_GRAD16) {          // dL/dpre = dL/dpost * g'(pre): the hgr_quickgelu16 backward, one rounding
+                        o[e] = (E)(lo[e] * quick_gelu_grad((float)iv[e]));
+                        o[e + 4] = (E)(hi[e] * quick_gelu_grad((float)iv[e + 4]));
+                    } else {
+                        o[e] = (E)fmaxf(lo[e] + (float)iv[e], 0.f);
+                        o[e + 4] = (E)fmaxf(hi[e] + (float)iv[e + 4], 0.f);
+                    }
                 }
                 *(u32x4 *)(cw + (cl + (rl + q * 8) * ldcB)) = __builtin_bit_cast(u32x4, o);
             }
@@ -1452,6 +1470,10 @@ void launch_dt(const GemmArgs &a, int epi, bool out32, dim3 grid, hipStream_t s,
         case HGR_EPI_BIAS_RELU: launch_epi<DT, HGR_EPI_BIAS_RELU>(a, out32, grid, s, big); break;
         case HGR_EPI_BIAS_ADD16_RELU: launch_epi<DT, HGR_EPI_BIAS_ADD16_RELU>(a, out32, grid, s, big); break;
         case HGR_EPI_ACCUM: launch_epi<DT, HGR_EPI_ACCUM>(a, out32, grid, s, big); break;
+        case HGR_EPI_QGELU_GRAD16:            // 16-bit output only (checked by the host entry)
+            if (big) hipLaunchKernelGGL((gemm_nt_256<DT, HGR_EPI_QGELU_GRAD16, false>), grid, dim3(NT256), 0, s, a);
+            else hipLaunchKernelGGL((gemm_nt_128<DT, HGR_EPI_QGELU_GRAD16, false>), grid, dim3(NT), 0, s, a);
+            break;
         default: launch_epi<DT, HGR_EPI_BIAS_RESIDUAL>(a, out32, grid, s, big); break;
     }
 }
@@ -1467,6 +1489,7 @@ void launch_duo(const GemmArgs &a, int epi, bool out32, dim3 grid, hipStream_t s
         case HGR_EPI_BIAS_RELU: HGR_DUO(HGR_EPI_BIAS_RELU); break;
         case HGR_EPI_BIAS_ADD16_RELU: hipLaunchKernelGGL((gemm_nt_duo<DT, HGR_EPI_BIAS_ADD16_RELU, false>), grid, dim3(NTD), 0, s, a); break;
         case HGR_EPI_ACCUM: hipLaunchKernelGGL((gemm_nt_duo<DT, HGR_EPI_ACCUM, true>), grid, dim3(NTD), 0, s, a); break;
+        case HGR_EPI_QGELU_GRAD16: hipLaunchKernelGGL((gemm_nt_duo<DT, HGR_EPI_QGELU_GRAD16, false>), grid, dim3(NTD), 0, s, a); break;
         default: hipLaunchKernelGGL((gemm_nt_duo<DT, HGR_EPI_BIAS_RESIDUAL, true>), grid, dim3(NTD), 0, s, a); break;
     }
 #undef HGR_DUO
@@ -1510,22 +1533,22 @@ extern "C" int hgr_gemm_nt(const void *A, int64_t lda, const void *W, int64_t ld
     HGR_REQUIRE(hgr_aligned(A, 16) && hgr_aligned(W, 16), "hgr_gemm_nt: A and W must be 16-byte aligned");
     HGR_REQUIRE(ldc >= N, "hgr_gemm_nt: ldc=%lld < N=%d", (long long)ldc, N);
     HGR_REQUIRE(dtype == HGR_BF16 || dtype == HGR_F16, "hgr_gemm_nt: bad dtype %d", dtype);
-    HGR_REQUIRE(epilogue >= HGR_EPI_NONE && epilogue <= HGR_EPI_ACCUM, "hgr_gemm_nt: bad epilogue %d", epilogue);
+    HGR_REQUIRE(epilogue >= HGR_EPI_NONE && epilogue <= HGR_EPI_QGELU_GRAD16, "hgr_gemm_nt: bad epilogue %d", epilogue);
     HGR_REQUIRE(epilogue != HGR_EPI_ACCUM || out_f32, "hgr_gemm_nt: ACCUM accumulates into an fp32 C");
-    HGR_REQUIRE(epilogue == HGR_EPI_NONE || epilogue == HGR_EPI_ACCUM || bias, "hgr_gemm_nt: epilogue %d needs bias", epilogue);
-    HGR_REQUIRE((epilogue != HGR_EPI_BIAS_RESIDUAL && epilogue != HGR_EPI_BIAS_ADD16_RELU) || (residual && ldr >= N), "hgr_gemm_nt: residual epilogue needs residual with ldr >= N");
-    HGR_REQUIRE(epilogue != HGR_EPI_BIAS_ADD16_RELU || !out_f32, "hgr_gemm_nt: ADD16_RELU writes 16-bit output");
+    HGR_REQUIRE(!epi_has_bias(epilogue) || bias, "hgr_gemm_nt: epilogue %d needs bias", epilogue);
+    HGR_REQUIRE((epilogue != HGR_EPI_BIAS_RESIDUAL && !epi_has_idn16(epilogue)) || (residual && ldr >= N), "hgr_gemm_nt: epilogue %d needs its second operand (residual / identity / pre-activation) with ldr >= N", epilogue);
+    HGR_REQUIRE(!epi_has_idn16(epilogue) || !out_f32, "hgr_gemm_nt: ADD16_RELU / QGELU_GRAD16 write 16-bit output");
     HGR_REQUIRE(hgr_aligned(C, out_f32 ? 4 : 2), "hgr_gemm_nt: C misaligned");
 
     bool vec = (ldc % 4 == 0) && hgr_aligned(C, out_f32 ? 16 : 8);
-    if (epilogue != HGR_EPI_NONE && epilogue != HGR_EPI_ACCUM) vec = vec && hgr_aligned(bias, 16);
+    if (epi_has_bias(epilogue)) vec = vec && hgr_aligned(bias, 16);
     if (epilogue == HGR_EPI_BIAS_RESIDUAL) vec = vec && (ldr % 4 == 0) && hgr_aligned(residual, 16);
-    if (epilogue == HGR_EPI_BIAS_ADD16_RELU) vec = vec && (ldr % 4 == 0) && hgr_aligned(residual, 8);
+    if (epi_has_idn16(epilogue)) vec = vec && (ldr % 4 == 0) && hgr_aligned(residual, 8);
     static int dbg = -1, split_env = -1;
     if (dbg < 0) { const char *e = getenv("HGR_GEMM_DBG"); dbg = e ? atoi(e) : 0; }
     if (split_env < 0) { const char *e = getenv("HGR_GEMM_SPLIT"); split_env = e ? atoi(e) : 1; }
     hipStream_t s = (hipStream_t)stream;
-    const size_t csz = out_f32 ? 4 : 2, rsz = (epilogue == HGR_EPI_BIAS_ADD16_RELU) ? 2 : 4;
+    const size_t csz = out_f32 ? 4 : 2, rsz = epi_has_idn16(epilogue) ? 2 : 4;
 
     // launch rows [m_lo, m_lo + m_cnt) with one tile size
     auto launch = [&](int m_lo, int m_cnt, bool big) {
@@ -1605,7 +1628,7 @@ extern "C" int hgr_gemm_nt(const void *A, int64_t lda, const void *W, int64_t ld
     const bool duo_fits = (N + 127) / 128 * 128 - N <= N / 8;
     if (duo_ok && (force == 2 || (force == 0 && tduo >= 256 && duo_fits))) launch_d();
     else if (force == 128 || K < 128) launch(0, M, false);
-    else if (epilogue == HGR_EPI_BIAS_ADD16_RELU && force != 256) launch(0, M, false);   // only the 128 kernel loads the identity / stores by full lines
+    else if (epi_has_idn16(epilogue) && force != 256) launch(0, M, false);   // only the 128 kernel loads the identity / stores by full lines
     else if (force == 256) launch(0, M, true);
     else if (cost_split < cost_big && cost_split < cost_small) { launch(0, m1, true); launch(m1, M - m1, false); }
     else launch(0, M, cost_big <= cost_small && t256 >= 128);

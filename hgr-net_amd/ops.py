@@ -8,7 +8,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import (EPI_ACCUM, EPI_BIAS, EPI_BIAS_ADD16_RELU, EPI_BIAS_QUICKGELU, EPI_BIAS_RELU, EPI_BIAS_RESIDUAL, EPI_NONE,
+from ._lib import (EPI_ACCUM, EPI_BIAS, EPI_BIAS_ADD16_RELU, EPI_BIAS_QUICKGELU, EPI_BIAS_RELU, EPI_BIAS_RESIDUAL, EPI_NONE, EPI_QGELU_GRAD16,
                    HGR_BF16, HGR_F16)
 
 # when a list, every gemm_nt call appends (name, start_event, end_event, algorithmic flops, algorithmic bytes, tag);
@@ -54,7 +54,7 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias: Optional[
     out32 = out.dtype == torch.float32
     assert out32 or out.dtype == a.dtype
     if residual is not None:
-        assert residual.stride(1) == 1 and residual.dtype == (a.dtype if epilogue == EPI_BIAS_ADD16_RELU else torch.float32)
+        assert residual.stride(1) == 1 and residual.dtype == (a.dtype if epilogue in (EPI_BIAS_ADD16_RELU, EPI_QGELU_GRAD16) else torch.float32)
     prof = PROFILE
     if prof is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

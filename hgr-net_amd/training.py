@@ -26,7 +26,7 @@ from typing import Callable, List, Optional
 import torch
 
 from . import ops
-from ._lib import EPI_ACCUM, EPI_BIAS, EPI_BIAS_RESIDUAL, EPI_NONE, HgrError
+from ._lib import EPI_ACCUM, EPI_BIAS, EPI_BIAS_RESIDUAL, EPI_NONE, EPI_QGELU_GRAD16, HgrError
 from .clip.model import VisionTransformer
 
 
@@ -34,6 +34,8 @@ import os
 
 # weight gradients from untransposed operands (hgr_gemm_tn_splitk); HGR_WGRAD=nt keeps the transposing route for A/B runs
 WGRAD_TN = os.environ.get("HGR_WGRAD", "tn") != "nt"
+# QuickGELU backward in the epilogue of the c_proj data-gradient GEMM; HGR_GELU_BWD_FUSED=0 keeps the separate pass for A/B runs
+GELU_BWD_FUSED = os.environ.get("HGR_GELU_BWD_FUSED", "1") != "0"
 
 
 def _pad64(n: int) -> int:
@@ -104,7 +106,8 @@ class Engine:
         ps = m.visual.patch_size
         self.conv = _Lin(m.visual.conv1.weight, None, dt, kpad=_pad64(3 * ps * ps))
 
-    def _linear_bwd(self, lin: _Lin, dy16: torch.Tensor, x16: torch.Tensor, m: int, need_dx: bool = True) -> Optional[torch.Tensor]:
+    def _linear_bwd(self, lin: _Lin, dy16: torch.Tensor, x16: torch.Tensor, m: int, need_dx: bool = True,
+                    gelu_pre: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
         """dW += dY^T X, db += colsum(dY); returns dX = dY W (16-bit) if wanted.  dy16 [m, n], x16 [m, k]."""
         dev, dt = self.dev, self.dt
         xq = x16[:, : lin.k] if x16.shape[1] != lin.k else x16
@@ -126,7 +129,7 @@ class Engine:
                 gw.view(-1).add_(part[0])
             if lin.bias is not None:
                 ops.colsum(dy16, _grad(lin.bias), self.scratch(((m + 511) // 512) * lin.n), accumulate=True)
-            return self._linear_dx(lin, dy16, m) if need_dx else None
+            return self._linear_dx(lin, dy16, m, gelu_pre) if need_dx else None
         mp = _pad64(m)
         alloc = torch.empty if mp == m else torch.zeros           # the pad columns must be zero, the rest is overwritten
         dyt = alloc(lin.n, mp, dtype=dt, device=dev)
@@ -158,13 +161,19 @@ class Engine:
             ops.gemm_nt(dyt, xt, gw, epilogue=EPI_ACCUM)
         if lin.bias is not None and not fused_bias:
             ops.colsum(dy16, _grad(lin.bias), self.scratch(((m + 511) // 512) * lin.n), accumulate=True)
-        return self._linear_dx(lin, dy16, m) if need_dx else None
+        return self._linear_dx(lin, dy16, m, gelu_pre) if need_dx else None
 
-    def _linear_dx(self, lin: _Lin, dy16: torch.Tensor, m: int) -> torch.Tensor:
+    def _linear_dx(self, lin: _Lin, dy16: torch.Tensor, m: int, gelu_pre: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """dX = dY W (16-bit).  With ``gelu_pre`` (the QuickGELU pre-activation that produced this layer's input) the GEMM's
+        epilogue multiplies by g'(pre): the result is the gradient w.r.t. the pre-activation, no separate activation pass."""
         dx = torch.empty(m, lin.k, dtype=self.dt, device=self.dev)
         if lin.n % 64:
             raise HgrError("backward GEMM needs the output width to be a multiple of 64")
-        ops.gemm_nt(dy16, lin.wt16[:, : lin.n] if lin.wt16.shape[1] == lin.n else lin.wt16, dx, n=lin.k)
+        wt = lin.wt16[:, : lin.n] if lin.wt16.shape[1] == lin.n else lin.wt16
+        if gelu_pre is not None:
+            ops.gemm_nt(dy16, wt, dx, residual=gelu_pre, epilogue=EPI_QGELU_GRAD16, n=lin.k)
+        else:
+            ops.gemm_nt(dy16, wt, dx, n=lin.k)
         return dx
 
     # -- transformer stack ---------------------------------------------------------------------
@@ -203,9 +212,12 @@ class Engine:
             # x2 = x1 + c_proj(gelu(c_fc(ln_2(x1))))
             dy = torch.empty(m, w, dtype=dt, device=dev)
             ops.cast16(dx, dy)
-            du = self._linear_bwd(k.w_proj, dy, u, m)
-            da = torch.empty_like(a)
-            ops.quickgelu16(a, da, du=du)
+            if GELU_BWD_FUSED:      # d(pre-activation) straight from the c_proj data-gradient GEMM (HGR_EPI_QGELU_GRAD16)
+                da = self._linear_bwd(k.w_proj, dy, u, m, gelu_pre=a)
+            else:
+                du = self._linear_bwd(k.w_proj, dy, u, m)
+                da = torch.empty_like(a)
+                ops.quickgelu16(a, da, du=du)
             dh2 = self._linear_bwd(k.w_fc, da, h2, m)
             ops.layernorm_bwd(dh2, x1, k.ln2.weight.data, dx, _grad(k.ln2.weight), _grad(k.ln2.bias), scr)
             # x1 = x0 + out_proj(attn(in_proj(ln_1(x0))))

@@ -43,7 +43,10 @@ typedef enum {
     HGR_EPI_BIAS_RELU = 4,      /* C = relu(A W^T + bias)            (conv + folded BN + ReLU: clip/model.py:43-44,137-138) */
     HGR_EPI_BIAS_ADD16_RELU = 5,/* C = relu(A W^T + bias + identity) (bn3(conv3) ; out += identity ; relu: clip/model.py:46-52);
                                    `residual` points at 16-bit values [M, ldr], 16-bit output only */
-    HGR_EPI_ACCUM = 6           /* C += A W^T, fp32 C                (weight gradients dW += dY^T X of loss.backward(), clip_tree.py:276) */
+    HGR_EPI_ACCUM = 6,          /* C += A W^T, fp32 C                (weight gradients dW += dY^T X of loss.backward(), clip_tree.py:276) */
+    HGR_EPI_QGELU_GRAD16 = 7    /* C = (A W^T) * g'(pre), g' = d/dx x*sigmoid(1.702x); pre = 16-bit [M, ldr] in `residual`, 16-bit C, no bias:
+                                   the gradient w.r.t. the QuickGELU pre-activation straight out of the c_proj data-gradient GEMM
+                                   (autograd of clip/model.py:162-164,177-180 behind clip_tree.py:276,280) */
 } hgr_epilogue_t;
 
 int hgr_abi_version(void);
@@ -57,7 +60,7 @@ const char *hgr_last_error(void);
  * `feats @ zsl_weights.T` at model/clip_tree.py:331.
  *   A, W      16-bit (`dtype`), leading dimensions lda/ldw in elements, both K-contiguous ("NT")
  *   C         fp32 if out_f32 else 16-bit (`dtype`), leading dimension ldc
- *   bias      fp32 [N] or NULL;  residual fp32 [M, ldr] (16-bit for HGR_EPI_BIAS_ADD16_RELU) or NULL;
+ *   bias      fp32 [N] or NULL;  residual fp32 [M, ldr] (16-bit for HGR_EPI_BIAS_ADD16_RELU / HGR_EPI_QGELU_GRAD16) or NULL;
  *             may alias C when element sizes match
  * Requirements: K % 64 == 0; lda, ldw % 8 == 0; A, W 16-byte aligned; M, N >= 1.
  */

@@ -386,3 +386,32 @@ def test_conv3x3_wgrad_splitk_vs_autograd(dt, b, h, w, c, cout, kc):
     part = torch.empty(s, cout, 9 * c, dtype=torch.float32, device=DEV)
     ops.conv3x3_wgrad_splitk(dyn, xn, part, b, h, w, c, kc)
     assert torch.equal(part.sum(0).cpu(), want)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("tile", [0, 128, 256, 2])
+@pytest.mark.parametrize("m,n,k", [(512, 256, 128), (1000, 328, 192), (2560, 3072, 768), (300, 64, 64)])
+def test_gemm_qgelu_grad16_epilogue(dt, tile, m, n, k):
+    """HGR_EPI_QGELU_GRAD16: C = (A W^T) * g'(pre) in one rounding, on every tile plan (ragged M / N included), against the
+    fp32 product times the closed form of d/dx x*sigmoid(1.702x) - and against the two-pass route it replaces
+    (GEMM -> 16 bit, hgr_quickgelu16 backward), which rounds twice."""
+    a = _rand((m, k), 3 * m + n, 0.5).to(dt)
+    w = _rand((n, k), 5 * n + k, 0.2).to(dt)
+    pre = _rand((m, n + 8), 7 * m + k, 1.5).to(dt)[:, :n]                      # strided pre-activation
+    prev = ops.gemm_set_tile(tile)
+    try:
+        out = torch.full((m, n), 7.0, dtype=dt, device=DEV)
+        ops.gemm_nt(a.to(DEV), w.to(DEV), out, residual=pre.to(DEV), epilogue=ops.EPI_QGELU_GRAD16)
+        plain = torch.empty(m, n, dtype=dt, device=DEV)
+        ops.gemm_nt(a.to(DEV), w.to(DEV), plain)
+    finally:
+        ops.gemm_set_tile(prev)
+    x = pre.float()
+    sg = torch.sigmoid(1.702 * x)
+    want = (a.float() @ w.float().t()) * sg * (1 + 1.702 * x * (1 - sg))
+    eps = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+    err = (out.float().cpu() - want).abs()
+    assert float((err - eps * want.abs()).max()) < 2e-3, float(err.max())                   # one rounding of the exact value (+ MFMA sum order)
+    two = torch.empty(m, n, dtype=dt, device=DEV)
+    ops.quickgelu16(pre.contiguous().to(DEV), two, du=plain)
+    assert float((out.float() - two.float()).abs().max()) <= 3 * eps * float(want.abs().max()) + 1e-3
