@@ -32,6 +32,7 @@ SIGNATURES = {
     "hgr_vit_embed_ln": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p],
     "hgr_layernorm": [_p, _p, _p, _p, _i, _i, _l, _p, _f, _i, _i, _p],
     "hgr_mha": [_p, _p, _i, _i, _i, _i, _i, _p],
+    "hgr_mha_stats": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
     "hgr_text_embed": [_p, _l, _p, _p, _p, _i, _i, _i, _i, _p],
     "hgr_eot_index": [_p, _l, _p, _i, _i, _p],
     "hgr_l2norm_rows": [_p, _p, _p, _i, _i, _i, _p],
@@ -53,6 +54,7 @@ SIGNATURES = {
     "hgr_layernorm_bwd": [_p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _l, _p, _f, _i, _p],
     "hgr_layernorm_bwd_scratch_floats": [_i, _i],
     "hgr_mha_bwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "hgr_mha_bwd_stats": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "hgr_ce_rows": [_p, _l, _p, _i, _i, _f, _p, _p, _l, _p],
     "hgr_l2norm_bwd": [_p, _p, _p, _i, _i, _i, _p],
     "hgr_matmul_f32": [_p, _l, _l, _p, _l, _l, _p, _l, _i, _i, _i, _f, _i, _p],

@@ -22,7 +22,7 @@ namespace {
 
 template <int DT, int KT, bool CAUSAL>
 __global__ __launch_bounds__(256) void mha_fwd(const typename T16<DT>::elem *__restrict__ qkv,
-                                               typename T16<DT>::elem *__restrict__ out, int L, int H) {
+                                               typename T16<DT>::elem *__restrict__ out, int L, int H, float2 *__restrict__ stats) {
     typedef typename T16<DT>::elem E;
     typedef typename T16<DT>::vec8 vec8;
     typedef typename T16<DT>::vec4 vec4;
@@ -104,6 +104,8 @@ __global__ __launch_bounds__(256) void mha_fwd(const typename T16<DT>::elem *__r
         sum += __shfl_xor(sum, 16);
         sum += __shfl_xor(sum, 32);
         const float inv = 1.0f / sum;
+        // training: the row's softmax statistics (max of the scaled scores, 1 / sum of exponentials) for hgr_mha_bwd_stats
+        if (stats && g == 0 && q < L) stats[((int64_t)b * H + h) * L + q] = make_float2(mx, inv);
 
         f32x4 o[4];
 #pragma unroll
@@ -134,33 +136,42 @@ __global__ __launch_bounds__(256) void mha_fwd(const typename T16<DT>::elem *__r
 }
 
 template <int DT, int KT>
-void launch_kt(const void *qkv, void *out, int B, int L, int H, bool causal, hipStream_t s) {
+void launch_kt(const void *qkv, void *out, int B, int L, int H, bool causal, hipStream_t s, float2 *stats) {
     typedef typename T16<DT>::elem E;
     dim3 grid(B * H), block(256);
-    if (causal) hipLaunchKernelGGL((mha_fwd<DT, KT, true>), grid, block, 0, s, (const E *)qkv, (E *)out, L, H);
-    else hipLaunchKernelGGL((mha_fwd<DT, KT, false>), grid, block, 0, s, (const E *)qkv, (E *)out, L, H);
+    if (causal) hipLaunchKernelGGL((mha_fwd<DT, KT, true>), grid, block, 0, s, (const E *)qkv, (E *)out, L, H, stats);
+    else hipLaunchKernelGGL((mha_fwd<DT, KT, false>), grid, block, 0, s, (const E *)qkv, (E *)out, L, H, stats);
 }
 
 template <int DT>
-void launch_dt(const void *qkv, void *out, int B, int L, int H, bool causal, hipStream_t s) {
+void launch_dt(const void *qkv, void *out, int B, int L, int H, bool causal, hipStream_t s, float2 *stats) {
     const int kt = (L + 31) / 32;
-    if (kt <= 1) launch_kt<DT, 1>(qkv, out, B, L, H, causal, s);
-    else if (kt <= 2) launch_kt<DT, 2>(qkv, out, B, L, H, causal, s);
-    else if (kt <= 3) launch_kt<DT, 3>(qkv, out, B, L, H, causal, s);
-    else if (kt <= 5) launch_kt<DT, 5>(qkv, out, B, L, H, causal, s);
-    else launch_kt<DT, 9>(qkv, out, B, L, H, causal, s);
+    if (kt <= 1) launch_kt<DT, 1>(qkv, out, B, L, H, causal, s, stats);
+    else if (kt <= 2) launch_kt<DT, 2>(qkv, out, B, L, H, causal, s, stats);
+    else if (kt <= 3) launch_kt<DT, 3>(qkv, out, B, L, H, causal, s, stats);
+    else if (kt <= 5) launch_kt<DT, 5>(qkv, out, B, L, H, causal, s, stats);
+    else launch_kt<DT, 9>(qkv, out, B, L, H, causal, s, stats);
 }
 
 }  // namespace
 
-extern "C" int hgr_mha(const void *qkv, void *out, int B, int L, int heads, int causal, int dtype, void *stream) {
-    HGR_REQUIRE(qkv && out, "hgr_mha: null operand");
-    HGR_REQUIRE(B >= 1 && heads >= 1 && L >= 1 && L <= 288, "hgr_mha: B=%d heads=%d L=%d unsupported (1 <= L <= 288)", B, heads, L);
-    HGR_REQUIRE((int64_t)B * heads < (1ll << 31), "hgr_mha: grid too large");
-    HGR_REQUIRE(hgr_aligned(qkv, 16) && hgr_aligned(out, 16), "hgr_mha: operands must be 16-byte aligned");
-    HGR_REQUIRE(dtype == HGR_BF16 || dtype == HGR_F16, "hgr_mha: bad dtype %d", dtype);
-    if (dtype == HGR_BF16) launch_dt<HGR_BF16>(qkv, out, B, L, heads, causal != 0, (hipStream_t)stream);
-    else launch_dt<HGR_F16>(qkv, out, B, L, heads, causal != 0, (hipStream_t)stream);
-    HGR_CHECK_LAUNCH("hgr_mha");
+static int mha_entry(const char *name, const void *qkv, void *out, float *stats, int B, int L, int heads, int causal, int dtype, void *stream) {
+    HGR_REQUIRE(qkv && out, "%s: null operand", name);
+    HGR_REQUIRE(B >= 1 && heads >= 1 && L >= 1 && L <= 288, "%s: B=%d heads=%d L=%d unsupported (1 <= L <= 288)", name, B, heads, L);
+    HGR_REQUIRE((int64_t)B * heads < (1ll << 31), "%s: grid too large", name);
+    HGR_REQUIRE(hgr_aligned(qkv, 16) && hgr_aligned(out, 16) && hgr_aligned(stats, 8), "%s: operands must be 16-byte aligned (stats: 8)", name);
+    HGR_REQUIRE(dtype == HGR_BF16 || dtype == HGR_F16, "%s: bad dtype %d", name, dtype);
+    if (dtype == HGR_BF16) launch_dt<HGR_BF16>(qkv, out, B, L, heads, causal != 0, (hipStream_t)stream, (float2 *)stats);
+    else launch_dt<HGR_F16>(qkv, out, B, L, heads, causal != 0, (hipStream_t)stream, (float2 *)stats);
+    HGR_CHECK_LAUNCH(name);
     return HGR_OK;
+}
+
+extern "C" int hgr_mha(const void *qkv, void *out, int B, int L, int heads, int causal, int dtype, void *stream) {
+    return mha_entry("hgr_mha", qkv, out, nullptr, B, L, heads, causal, dtype, stream);
+}
+
+extern "C" int hgr_mha_stats(const void *qkv, void *out, float *stats, int B, int L, int heads, int causal, int dtype, void *stream) {
+    HGR_REQUIRE(stats, "hgr_mha_stats: null stats");
+    return mha_entry("hgr_mha_stats", qkv, out, stats, B, L, heads, causal, dtype, stream);
 }

@@ -346,7 +346,8 @@ __device__ __forceinline__ void mm16_bt(f32x16 &acc, const typename T16<DT>::ele
 
 template <int DT, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void mha_bwd_tiled(const typename T16<DT>::elem *__restrict__ qkv, const typename T16<DT>::elem *__restrict__ outp,
-                                                        const typename T16<DT>::elem *__restrict__ dout, typename T16<DT>::elem *__restrict__ dqkv, int L, int H) {
+                                                        const typename T16<DT>::elem *__restrict__ dout, typename T16<DT>::elem *__restrict__ dqkv, int L, int H,
+                                                        const float2 *__restrict__ stats) {
     typedef typename T16<DT>::elem E;
     typedef typename T16<DT>::vec8 vec8;
     typedef typename T16<DT>::vec4 vec4;
@@ -426,6 +427,7 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_tiled(const typename T16<DT>::
             acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2);
             if (part == 0) { rD[qi * 64 + row] = acc; rM[qi * 64 + row] = -INFINITY; rLinv[qi * 64 + row] = 0.f; }
         }
+        if (stats) continue;                                    // block-uniform: the forward kept the row statistics (hgr_mha_stats)
         vec8 pk[2];
         fetch(pk, base + W, ld, 0);
         for (int kj = 0; kj < nb; ++kj) {
@@ -457,7 +459,15 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_tiled(const typename T16<DT>::
         }
     }
     __syncthreads();
-    for (int i = tid; i < nb * 64; i += 256) rLinv[i] = (i < L && rLinv[i] > 0.f) ? 1.0f / rLinv[i] : 0.f;
+    if (stats) {
+        const float2 *st = stats + ((int64_t)b * H + h) * L;
+        for (int i = tid; i < nb * 64; i += 256) {
+            const float2 v = i < L ? st[i] : make_float2(0.f, 0.f);
+            rM[i] = v.x; rLinv[i] = v.y;
+        }
+    } else {
+        for (int i = tid; i < nb * 64; i += 256) rLinv[i] = (i < L && rLinv[i] > 0.f) ? 1.0f / rLinv[i] : 0.f;
+    }
     __syncthreads();
 
     // ---- sweep 1: dK, dV per key block, dQ of every query block accumulated in registers -------------------------------------------------
@@ -935,13 +945,15 @@ extern "C" int64_t hgr_layernorm_bwd_scratch_floats(int rows, int W) {
     return 2 * nw * W + ((nw + 511) / 512) * W;
 }
 
-extern "C" int hgr_mha_bwd(const void *qkv, const void *out, const void *dout, void *dqkv, int B, int L, int heads, int causal, int dtype, void *stream) {
-    HGR_REQUIRE(qkv && out && dout && dqkv && B >= 1 && heads >= 1, "hgr_mha_bwd: bad arguments");
-    HGR_REQUIRE(L >= 1 && L <= 320, "hgr_mha_bwd: L=%d unsupported (L <= 320)", L);
-    DT_OK("hgr_mha_bwd");
+static int mha_bwd_entry(const char *name, const void *qkv, const void *out, const void *dout, void *dqkv, const float *stats,
+                         int B, int L, int heads, int causal, int dtype, void *stream) {
+    HGR_REQUIRE(qkv && out && dout && dqkv && B >= 1 && heads >= 1, "%s: bad arguments", name);
+    HGR_REQUIRE(L >= 1 && L <= 320, "%s: L=%d unsupported (L <= 320)", name, L);
+    HGR_REQUIRE(hgr_aligned(stats, 8), "%s: stats must be 8-byte aligned", name);
+    HGR_REQUIRE(dtype == HGR_BF16 || dtype == HGR_F16, "%s: bad dtype %d", name, dtype);
     hipStream_t s = (hipStream_t)stream;
     const dim3 g(B * heads);
-    if (L <= 32) {
+    if (L <= 32) {           // one 32 x 32 block per (batch, head): the statistics are recomputed in registers, `stats` is not needed
         if (dtype == HGR_BF16) {
             if (causal) hipLaunchKernelGGL((mha_bwd_wave<HGR_BF16, true>), g, dim3(64), 0, s, (const __bf16 *)qkv, (const __bf16 *)dout, (__bf16 *)dqkv, L, heads);
             else hipLaunchKernelGGL((mha_bwd_wave<HGR_BF16, false>), g, dim3(64), 0, s, (const __bf16 *)qkv, (const __bf16 *)dout, (__bf16 *)dqkv, L, heads);
@@ -951,16 +963,27 @@ extern "C" int hgr_mha_bwd(const void *qkv, const void *out, const void *dout, v
         }
     }
     else {
+        const float2 *st = (const float2 *)stats;
 #define HGR_MT(CAUS)                                                                                                              \
     do {                                                                                                                          \
-        if (dtype == HGR_BF16) hipLaunchKernelGGL((mha_bwd_tiled<HGR_BF16, CAUS>), g, dim3(256), 0, s, (const __bf16 *)qkv, (const __bf16 *)out, (const __bf16 *)dout, (__bf16 *)dqkv, L, heads); \
-        else hipLaunchKernelGGL((mha_bwd_tiled<HGR_F16, CAUS>), g, dim3(256), 0, s, (const _Float16 *)qkv, (const _Float16 *)out, (const _Float16 *)dout, (_Float16 *)dqkv, L, heads); \
+        if (dtype == HGR_BF16) hipLaunchKernelGGL((mha_bwd_tiled<HGR_BF16, CAUS>), g, dim3(256), 0, s, (const __bf16 *)qkv, (const __bf16 *)out, (const __bf16 *)dout, (__bf16 *)dqkv, L, heads, st); \
+        else hipLaunchKernelGGL((mha_bwd_tiled<HGR_F16, CAUS>), g, dim3(256), 0, s, (const _Float16 *)qkv, (const _Float16 *)out, (const _Float16 *)dout, (_Float16 *)dqkv, L, heads, st); \
     } while (0)
         if (causal) HGR_MT(true); else HGR_MT(false);
 #undef HGR_MT
     }
-    HGR_CHECK_LAUNCH("hgr_mha_bwd");
+    HGR_CHECK_LAUNCH(name);
     return HGR_OK;
+}
+
+extern "C" int hgr_mha_bwd(const void *qkv, const void *out, const void *dout, void *dqkv, int B, int L, int heads, int causal, int dtype, void *stream) {
+    return mha_bwd_entry("hgr_mha_bwd", qkv, out, dout, dqkv, nullptr, B, L, heads, causal, dtype, stream);
+}
+
+extern "C" int hgr_mha_bwd_stats(const void *qkv, const void *out, const void *dout, void *dqkv, const float *stats,
+                                 int B, int L, int heads, int causal, int dtype, void *stream) {
+    HGR_REQUIRE(stats, "hgr_mha_bwd_stats: null stats");
+    return mha_bwd_entry("hgr_mha_bwd_stats", qkv, out, dout, dqkv, stats, B, L, heads, causal, dtype, stream);
 }
 
 extern "C" int hgr_ce_rows(const float *logits, int64_t ld, const int32_t *labels, int rows, int n, float gscale, float *loss_rows, float *dlogits, int64_t ldd, void *stream) {

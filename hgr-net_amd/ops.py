@@ -206,8 +206,13 @@ def layernorm(x: torch.Tensor, gamma, beta, out: torch.Tensor, rows: Optional[in
     return out
 
 
-def mha(qkv: torch.Tensor, out: torch.Tensor, b: int, l: int, heads: int, causal: bool) -> torch.Tensor:
+def mha(qkv: torch.Tensor, out: torch.Tensor, b: int, l: int, heads: int, causal: bool, stats: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``stats`` fp32 [b, heads, l, 2]: also keep every row's softmax statistics (max, 1 / sum) for mha_bwd (training forward)."""
     assert qkv.is_contiguous() and out.is_contiguous() and qkv.shape[1] == 3 * heads * 64 and out.shape[1] == heads * 64
+    if stats is not None:
+        assert stats.dtype == torch.float32 and stats.is_contiguous() and stats.numel() == b * heads * l * 2
+        _lib.call("hgr_mha_stats", _dev(qkv), _dev(out), _dev(stats), b, l, heads, 1 if causal else 0, DT_OF[qkv.dtype], _stream())
+        return out
     _lib.call("hgr_mha", _dev(qkv), _dev(out), b, l, heads, 1 if causal else 0, DT_OF[qkv.dtype], _stream())
     return out
 
@@ -502,8 +507,14 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, dx: to
               rows, w, row_mul, _dev(row_idx), eps, HGR_BF16 if f32 else DT_OF[dy.dtype], _stream())
 
 
-def mha_bwd(qkv: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, dqkv: torch.Tensor, b: int, l: int, heads: int, causal: bool) -> torch.Tensor:
+def mha_bwd(qkv: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, dqkv: torch.Tensor, b: int, l: int, heads: int, causal: bool,
+            stats: Optional[torch.Tensor] = None) -> torch.Tensor:
     assert qkv.is_contiguous() and out.is_contiguous() and dout.is_contiguous() and dqkv.is_contiguous()
+    if stats is not None:
+        assert stats.dtype == torch.float32 and stats.is_contiguous() and stats.numel() == b * heads * l * 2
+        _lib.call("hgr_mha_bwd_stats", _dev(qkv), _dev(out), _dev(dout), _dev(dqkv), _dev(stats), b, l, heads, 1 if causal else 0,
+                  DT_OF[qkv.dtype], _stream())
+        return dqkv
     _lib.call("hgr_mha_bwd", _dev(qkv), _dev(out), _dev(dout), _dev(dqkv), b, l, heads, 1 if causal else 0, DT_OF[qkv.dtype], _stream())
     return dqkv
 

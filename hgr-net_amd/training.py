@@ -188,7 +188,8 @@ class Engine:
             qkv = torch.empty(m, 3 * w, dtype=dt, device=dev)
             ops.gemm_nt(h1, k.w_in.w16, qkv, bias=k.w_in.b32, epilogue=EPI_BIAS)
             att = torch.empty(m, w, dtype=dt, device=dev)
-            ops.mha(qkv, att, b, l, heads, causal)
+            st = torch.empty(b, heads, l, 2, dtype=torch.float32, device=dev) if l > 32 else None     # softmax row statistics for mha_bwd
+            ops.mha(qkv, att, b, l, heads, causal, stats=st)
             x1 = torch.empty_like(x)
             ops.gemm_nt(att, k.w_out.w16, x1, bias=k.w_out.b32, residual=x, epilogue=EPI_BIAS_RESIDUAL)
             h2 = torch.empty(m, w, dtype=dt, device=dev)
@@ -199,7 +200,7 @@ class Engine:
             ops.quickgelu16(a, u)
             x2 = torch.empty_like(x)
             ops.gemm_nt(u, k.w_proj.w16, x2, bias=k.w_proj.b32, residual=x1, epilogue=EPI_BIAS_RESIDUAL)
-            saves.append((x, h1, qkv, att, x1, h2, a, u))
+            saves.append((x, h1, qkv, att, x1, h2, a, u, st))
             x = x2
         return x, saves
 
@@ -208,7 +209,7 @@ class Engine:
         m, w = dx.shape
         dt, dev = self.dt, self.dev
         scr = self.scratch(ops.layernorm_bwd_scratch(m, w))
-        for k, (x0, h1, qkv, att, x1, h2, a, u) in zip(reversed(blocks), reversed(saves)):
+        for k, (x0, h1, qkv, att, x1, h2, a, u, st) in zip(reversed(blocks), reversed(saves)):
             # x2 = x1 + c_proj(gelu(c_fc(ln_2(x1))))
             dy = torch.empty(m, w, dtype=dt, device=dev)
             ops.cast16(dx, dy)
@@ -224,7 +225,7 @@ class Engine:
             ops.cast16(dx, dy)
             datt = self._linear_bwd(k.w_out, dy, att, m)
             dqkv = torch.empty_like(qkv)
-            ops.mha_bwd(qkv, att, datt, dqkv, b, l, heads, causal)
+            ops.mha_bwd(qkv, att, datt, dqkv, b, l, heads, causal, stats=st)
             dh1 = self._linear_bwd(k.w_in, dqkv, h1, m)
             ops.layernorm_bwd(dh1, x0, k.ln1.weight.data, dx, _grad(k.ln1.weight), _grad(k.ln1.bias), scr)
         return dx

@@ -142,6 +142,10 @@ int hgr_layernorm(const float *x, const float *gamma, const float *beta, void *y
  * (row = b*L + t); out 16-bit [B*L, W].  causal != 0 masks key > query.  1 <= L <= 288.
  */
 int hgr_mha(const void *qkv, void *out, int B, int L, int heads, int causal, int dtype, void *stream);
+/* The same, and per (batch, head, query) the softmax statistics of the row: stats[((b * heads + h) * L + q) * 2] = max of the
+ * scaled scores, [.. + 1] = 1 / sum of exp(score - max) (fp32 [B, heads, L, 2], 8-byte aligned).  The training forward keeps
+ * them so that hgr_mha_bwd_stats does not recompute Q K^T for the statistics (what autograd's saved softmax output holds). */
+int hgr_mha_stats(const void *qkv, void *out, float *stats, int B, int L, int heads, int causal, int dtype, void *stream);
 
 /*
  * Text embedding (clip/model.py:340-342): x[i*L + t] = token_embedding[tokens[i, t]] + positional[t],
@@ -331,6 +335,10 @@ int64_t hgr_layernorm_bwd_scratch_floats(int rows, int W);
  * 16-bit.  Short sequences (L <= 32) use per-output fp32 loops; longer ones a tiled flash-style kernel on the exact-fp32
  * MFMA that recomputes P from row statistics (nothing L x L is stored). */
 int hgr_mha_bwd(const void *qkv, const void *out, const void *dout, void *dqkv, int B, int L, int heads, int causal, int dtype, void *stream);
+/* The same with the row statistics hgr_mha_stats wrote for this qkv (same B, L, heads, causal): identical results, one sweep
+ * over the score blocks less.  (L <= 32 runs the single-block kernel, which does not read them.) */
+int hgr_mha_bwd_stats(const void *qkv, const void *out, const void *dout, void *dqkv, const float *stats,
+                      int B, int L, int heads, int causal, int dtype, void *stream);
 
 /*
  * ---- ModifiedResNet tower in training (clip/model.py:10-150 under model/clip_tree.py:222-281; the reference's README

@@ -164,6 +164,18 @@ def test_mha_bwd_vs_autograd(dt, L, causal):
     ops.mha_bwd(qkv.to(DEV), o.detach().to(dt).to(DEV), do.to(DEV), dqkv, b, L, heads, causal)
     tol = 3e-2 if dt == torch.bfloat16 else 4e-3
     assert (dqkv.float().cpu() - q.grad).abs().max() < tol * max(1.0, float(q.grad.abs().max()))
+    # with the row statistics the forward kept (hgr_mha_stats / hgr_mha_bwd_stats): the same forward output, and the same gradient up to
+    # the last-bit differences of the statistics (the forward sums Q K^T in another MFMA shape than the backward's recomputation)
+    st = torch.full((b, heads, L, 2), float("nan"), device=DEV)
+    o2 = torch.empty(b * L, w, dtype=dt, device=DEV)
+    ops.mha(qkv.to(DEV), o2, b, L, heads, causal, stats=st)
+    o1 = torch.empty_like(o2)
+    ops.mha(qkv.to(DEV), o1, b, L, heads, causal)
+    assert torch.equal(o1, o2) and bool(torch.isfinite(st).all())
+    dq2 = torch.empty_like(dqkv)
+    ops.mha_bwd(qkv.to(DEV), o.detach().to(dt).to(DEV), do.to(DEV), dq2, b, L, heads, causal, stats=st)
+    assert (dq2.float().cpu() - q.grad).abs().max() < tol * max(1.0, float(q.grad.abs().max()))
+    assert float((dq2.float() - dqkv.float()).abs().max()) <= (2.0 ** -6 if dt == torch.bfloat16 else 2.0 ** -9) * max(1.0, float(q.grad.abs().max()))
 
 
 def test_ce_l2norm_matmul_scatter():
