@@ -75,6 +75,11 @@ __device__ __forceinline__ float quick_gelu(float v) {
 }
 
 
+// the expression hgr_quickgelu16 (hgr_train.hip) evaluates, operation for operation: the dual-output forward must give its bits
+__device__ __forceinline__ float quick_gelu_train(float x) {
+    const float z = 1.702f * x;
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z));
+}
 // d/dx of quick_gelu: s (1 + 1.702 x (1 - s)), s = sigmoid(1.702 x) - the expression of hgr_quickgelu16's backward
 __device__ __forceinline__ float quick_gelu_grad(float x) {
     const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * x));
@@ -1162,6 +1167,24 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
             for (int q = 0; q < 16; ++q) store16_sc1(cw + (cl + q * 8 * ldcB), *(const u32x4 *)(my + (q * 8 + rr) * RS + ch * 16));
             return;
         }
+        if (LN == 4) {
+            // training forward of the MLP: C keeps the pre-activation (backward needs it), ln_xh gets QuickGELU of the ROUNDED
+            // pre-activation - the bits hgr_quickgelu16 would produce from C in a second pass, without that pass
+            char *gw = (char *)p.ln_xh + ((int64_t)(m0 + wm * 128) * p.ln_ldx + n0 + wn * 64) * 2;
+            const unsigned ldgB = (unsigned)p.ln_ldx * 2u;
+            const unsigned gl = (unsigned)rr * ldgB + ch * 16;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const u32x4 v = *(const u32x4 *)(my + (q * 8 + rr) * RS + ch * 16);
+                *(u32x4 *)(cw + (cl + q * 8 * ldcB)) = v;
+                const vec8 h = __builtin_bit_cast(vec8, v);
+                vec8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (E)quick_gelu_train((float)h[e]);
+                *(u32x4 *)(gw + (gl + q * 8 * ldgB)) = __builtin_bit_cast(u32x4, o);
+            }
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < 16; ++q)
             *(u32x4 *)(cw + (cl + q * 8 * ldcB)) = *(const u32x4 *)(my + (q * 8 + rr) * RS + ch * 16);
@@ -1424,6 +1447,28 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
                     *(f16x4 *)((_Float16 *)p.ln_xl + at) = nl;
                     if (cq == 0) *(float2 *)(p.ln_stats + (row * p.ln_slots + (n0 >> 6) + wn) * 2) = make_float2(s1, s2);
                 }
+            }
+        }
+        return;
+    }
+    if (LN == 4) {
+        // edge tile of the dual-output forward (rows beyond M; N is a multiple of 128 by the host's contract)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wm * 128 + a * 64 + i * 16 + r;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + wn * 64 + b * 32 + j * 16 + g * 4;
+                const f32x4 v = acc[a][b][i][j] + *(const f32x4 *)(p.bias + n);
+                const typename T16<DT>::vec4 pre = cvt4<DT>(v[0], v[1], v[2], v[3]);
+                *(typename T16<DT>::vec4 *)((E *)p.C + (int64_t)m * p.ldc + n) = pre;
+                *(typename T16<DT>::vec4 *)((E *)p.ln_xh + (int64_t)m * p.ln_ldx + n) =
+                    cvt4<DT>(quick_gelu_train((float)pre[0]), quick_gelu_train((float)pre[1]), quick_gelu_train((float)pre[2]), quick_gelu_train((float)pre[3]));
             }
         }
         return;
@@ -1800,6 +1845,22 @@ extern "C" int hgr_gemm_nt_ln(const void *X16, int64_t ldx, const void *Wfold, i
         else hipLaunchKernelGGL((gemm_nt_duo<HGR_F16, HGR_EPI_BIAS, false, 2>), grid, dim3(NTD), 0, s, a);
     }
     HGR_CHECK_LAUNCH("hgr_gemm_nt_ln");
+    return HGR_OK;
+}
+
+extern "C" int hgr_gemm_nt_bias_gelu_dual(const void *A, int64_t lda, const void *W, int64_t ldw, void *pre, int64_t ldpre, void *post, int64_t ldpost,
+                                          const float *bias, int M, int N, int K, int dtype, void *stream) {
+    if (int rc = ln_common_checks("hgr_gemm_nt_bias_gelu_dual", A, lda, W, ldw, M, N, K, dtype)) return rc;
+    HGR_REQUIRE(pre && post && bias, "hgr_gemm_nt_bias_gelu_dual: null pre / post / bias");
+    HGR_REQUIRE(ldpre >= N && ldpost >= N && ldpre % 8 == 0 && ldpost % 8 == 0 && ldpre < (1 << 20) && ldpost < (1 << 20) && hgr_aligned(pre, 16) && hgr_aligned(post, 16) && hgr_aligned(bias, 16),
+                "hgr_gemm_nt_bias_gelu_dual: pre / post / bias must be 16-byte aligned, leading dimensions >= N, %% 8 == 0, < 2^20");
+    GemmArgs a;
+    ln_args(a, A, lda, W, ldw, pre, ldpre, M, N, K);
+    a.bias = bias; a.ln_xh = post; a.ln_ldx = ldpost;
+    dim3 grid((unsigned)(a.tiles_m * a.tiles_n));
+    if (dtype == HGR_BF16) hipLaunchKernelGGL((gemm_nt_duo<HGR_BF16, HGR_EPI_BIAS, false, 4>), grid, dim3(NTD), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((gemm_nt_duo<HGR_F16, HGR_EPI_BIAS, false, 4>), grid, dim3(NTD), 0, (hipStream_t)stream, a);
+    HGR_CHECK_LAUNCH("hgr_gemm_nt_bias_gelu_dual");
     return HGR_OK;
 }
 

@@ -98,6 +98,21 @@ def gemm_nt_res_stats(a: torch.Tensor, w: torch.Tensor, xh: torch.Tensor, xl: to
     _prof_end(ev, 2.0 * m * n * k, 2 * m * k + 2 * n * k + 8 * m * n, tag)
 
 
+def gemm_nt_bias_gelu_dual(a: torch.Tensor, w: torch.Tensor, pre: torch.Tensor, post: torch.Tensor, bias: torch.Tensor) -> None:
+    """pre = a @ w^T + bias, post = QuickGELU(pre as rounded), both 16-bit, one launch (training forward of the MLP)."""
+    assert a.dim() == 2 and w.dim() == 2 and a.dtype == w.dtype == pre.dtype == post.dtype and a.stride(1) == w.stride(1) == pre.stride(1) == post.stride(1) == 1
+    m, k = a.shape
+    n = w.shape[0]
+    assert w.shape[1] == k and pre.shape == (m, n) and post.shape == (m, n) and bias.dtype == torch.float32 and bias.numel() == n
+    _lib.call("hgr_gemm_nt_bias_gelu_dual", _dev(a), a.stride(0), _dev(w), w.stride(0), _dev(pre), pre.stride(0), _dev(post), post.stride(0),
+              _dev(bias), m, n, k, DT_OF[a.dtype], _stream())
+
+
+def gelu_dual_ok(m: int, n: int, k: int, lda: int, ldw: int) -> bool:
+    """Shape contract of hgr_gemm_nt_bias_gelu_dual (the 256 x 128 tile kernel: whole column tiles, 32-bit operand offsets)."""
+    return n % 128 == 0 and k % 64 == 0 and k >= 128 and m * lda * 2 < (1 << 32) and n * ldw * 2 < (1 << 32)
+
+
 def gemm_nt_ln(x16: torch.Tensor, wfold: torch.Tensor, out: torch.Tensor, ln_s: torch.Tensor, ln_c: torch.Tensor, stats: torch.Tensor,
                eps: float = 1e-5, quickgelu: bool = False, tag: str = "") -> torch.Tensor:
     """out (16-bit) = act(LayerNorm(x) @ W^T + b) from the un-normalised 16-bit rows x16, the gamma-folded weight and the

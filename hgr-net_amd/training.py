@@ -36,6 +36,7 @@ import os
 WGRAD_TN = os.environ.get("HGR_WGRAD", "tn") != "nt"
 # QuickGELU backward in the epilogue of the c_proj data-gradient GEMM; HGR_GELU_BWD_FUSED=0 keeps the separate pass for A/B runs
 GELU_BWD_FUSED = os.environ.get("HGR_GELU_BWD_FUSED", "1") != "0"
+GELU_FWD_FUSED = os.environ.get("HGR_GELU_FWD_FUSED", "1") != "0"     # c_fc forward writes pre-activation and activation in one launch
 
 
 def _pad64(n: int) -> int:
@@ -195,9 +196,12 @@ class Engine:
             h2 = torch.empty(m, w, dtype=dt, device=dev)
             ops.layernorm(x1, k.ln2.weight.data, k.ln2.bias.data, h2)
             a = torch.empty(m, 4 * w, dtype=dt, device=dev)
-            ops.gemm_nt(h2, k.w_fc.w16, a, bias=k.w_fc.b32, epilogue=EPI_BIAS)
             u = torch.empty_like(a)
-            ops.quickgelu16(a, u)
+            if GELU_FWD_FUSED and ops.gelu_dual_ok(m, 4 * w, k.w_fc.w16.shape[1], h2.stride(0), k.w_fc.w16.stride(0)) and m >= 256:
+                ops.gemm_nt_bias_gelu_dual(h2, k.w_fc.w16, a, u, k.w_fc.b32)          # pre-activation and activation from one GEMM
+            else:
+                ops.gemm_nt(h2, k.w_fc.w16, a, bias=k.w_fc.b32, epilogue=EPI_BIAS)
+                ops.quickgelu16(a, u)
             x2 = torch.empty_like(x)
             ops.gemm_nt(u, k.w_proj.w16, x2, bias=k.w_proj.b32, residual=x1, epilogue=EPI_BIAS_RESIDUAL)
             saves.append((x, h1, qkv, att, x1, h2, a, u, st))

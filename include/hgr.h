@@ -459,6 +459,13 @@ int hgr_gemm_nt_res_stats(const void *A, int64_t lda, const void *W, int64_t ldw
 int hgr_gemm_nt_ln(const void *XH, int64_t ldx, const void *Wfold, int64_t ldw, void *C, int64_t ldc,
                    const float *ln_s, const float *ln_c, const float *stats, float eps,
                    int M, int N, int K, int dtype, int act, void *stream);
+
+/* Training forward of the QuickGELU MLP (clip/model.py:177-180 under autograd): one GEMM, two 16-bit outputs -
+ *   pre  [M, ldpre]  = A W^T + bias                (kept for the backward: HGR_EPI_QGELU_GRAD16 / hgr_quickgelu16 read it)
+ *   post [M, ldpost] = g(pre as rounded to 16 bit)  (the input of c_proj) - the bits hgr_quickgelu16 would write from `pre`.
+ * Same shape contract as hgr_gemm_nt_ln (N % 128 == 0, K >= 128, operands below 4 GB). */
+int hgr_gemm_nt_bias_gelu_dual(const void *A, int64_t lda, const void *W, int64_t ldw, void *pre, int64_t ldpre, void *post, int64_t ldpost,
+                               const float *bias, int M, int N, int K, int dtype, void *stream);
 /* hgr_vit_embed_ln whose output rows leave as the pair + slot statistics (input of the first block) */
 int hgr_vit_embed_ln_stats(const float *patches, const float *class_embedding, const float *positional_embedding,
                            const float *gamma, const float *beta, void *xh, void *xl, float *stats,

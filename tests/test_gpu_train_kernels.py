@@ -427,3 +427,21 @@ def test_gemm_qgelu_grad16_epilogue(dt, tile, m, n, k):
     two = torch.empty(m, n, dtype=dt, device=DEV)
     ops.quickgelu16(pre.contiguous().to(DEV), two, du=plain)
     assert float((out.float() - two.float()).abs().max()) <= 3 * eps * float(want.abs().max()) + 1e-3
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("m,n,k", [(512, 256, 128), (1000, 384, 192), (2560, 3072, 768), (77, 128, 128)])
+def test_gemm_nt_bias_gelu_dual_equals_two_passes(dt, m, n, k):
+    """hgr_gemm_nt_bias_gelu_dual: the pre-activation equals hgr_gemm_nt(+bias) bit for bit and the activation equals
+    hgr_quickgelu16 of it bit for bit (ragged last row panel included)."""
+    a = _rand((m, k), 3 * m + n, 0.5).to(dt).to(DEV)
+    w = _rand((n, k), 5 * n + k, 0.2).to(dt).to(DEV)
+    bias = _rand((n,), 11 * n, 0.3).to(DEV)
+    pre = torch.full((m, n), 7.0, dtype=dt, device=DEV)
+    post = torch.full((m, n), 7.0, dtype=dt, device=DEV)
+    ops.gemm_nt_bias_gelu_dual(a, w, pre, post, bias)
+    ref = torch.empty(m, n, dtype=dt, device=DEV)
+    ops.gemm_nt(a, w, ref, bias=bias, epilogue=ops.EPI_BIAS)
+    act = torch.empty_like(ref)
+    ops.quickgelu16(ref, act)
+    assert torch.equal(pre, ref) and torch.equal(post, act)
