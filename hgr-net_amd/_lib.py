@@ -52,6 +52,7 @@ SIGNATURES = {
     "hgr_cast16": [_p, _p, _l, _i, _p],
     "hgr_quickgelu16": [_p, _p, _p, _l, _i, _i, _p],
     "hgr_layernorm_bwd": [_p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _l, _p, _f, _i, _p],
+    "hgr_layernorm_bwd_cast": [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _l, _p, _f, _i, _p],
     "hgr_layernorm_bwd_scratch_floats": [_i, _i],
     "hgr_mha_bwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "hgr_mha_bwd_stats": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],

@@ -208,7 +208,8 @@ __global__ __launch_bounds__(256) void gelu16(const typename T16<DT>::elem *__re
 template <int DT, bool DYF32, int NV>
 __global__ __launch_bounds__(256) void layernorm_bwd(const void *__restrict__ dy, const float *__restrict__ x, const float *__restrict__ gamma,
                                                      float *__restrict__ dx, float *__restrict__ pg, float *__restrict__ pb,
-                                                     int rows, int W, int64_t row_mul, const int32_t *__restrict__ row_idx, float eps) {
+                                                     int rows, int W, int64_t row_mul, const int32_t *__restrict__ row_idx, float eps,
+                                                     typename T16<DT>::elem *__restrict__ dx16) {
     typedef typename T16<DT>::elem E;
     const int lane = threadIdx.x & 63;
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
@@ -273,6 +274,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd(const void *__restrict__ dy
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] += rstd * (g[i][e] - mg - v[i][e] * mgx);
                 dxr[c] = o;
+                // the updated gradient also as the 16-bit operand of the next data-/weight-gradient GEMMs (what hgr_cast16 of dx gives)
+                if (dx16) ((typename T16<DT>::vec4 *)(dx16 + src * W))[c] = cvt4<DT>(o[0], o[1], o[2], o[3]);
             }
         }
     }
@@ -914,11 +917,12 @@ extern "C" int hgr_quickgelu16(const void *a, const void *du, void *out, int64_t
     return HGR_OK;
 }
 
-extern "C" int hgr_layernorm_bwd(const void *dy, int dy_f32, const float *x, const float *gamma, float *dx, float *dgamma, float *dbeta, float *scratch,
-                                 int rows, int W, int64_t row_mul, const int32_t *row_idx, float eps, int dtype, void *stream) {
-    HGR_REQUIRE(dy && x && gamma && dx && dgamma && dbeta && scratch, "hgr_layernorm_bwd: null operand");
-    HGR_REQUIRE(rows >= 1 && W >= 4 && W % 4 == 0 && W <= 4096 && row_mul >= 1, "hgr_layernorm_bwd: rows=%d W=%d unsupported", rows, W);
-    DT_OK("hgr_layernorm_bwd");
+static int layernorm_bwd_entry(const char *name, const void *dy, int dy_f32, const float *x, const float *gamma, float *dx, void *dx16, float *dgamma, float *dbeta,
+                               float *scratch, int rows, int W, int64_t row_mul, const int32_t *row_idx, float eps, int dtype, void *stream) {
+    HGR_REQUIRE(dy && x && gamma && dx && dgamma && dbeta && scratch, "%s: null operand", name);
+    HGR_REQUIRE(rows >= 1 && W >= 4 && W % 4 == 0 && W <= 4096 && row_mul >= 1, "%s: rows=%d W=%d unsupported", name, rows, W);
+    HGR_REQUIRE(dtype == HGR_BF16 || dtype == HGR_F16, "%s: bad dtype %d", name, dtype);
+    HGR_REQUIRE(hgr_aligned(dx16, 8), "%s: dx16 must be 8-byte aligned", name);
     const int blocks = rows < 4 * 512 ? (rows + 3) / 4 : 512;          // <= 2048 waves, each leaves one partial row
     const int nw = blocks * 4;
     float *pg = scratch, *pb = scratch + (int64_t)nw * W;
@@ -927,16 +931,28 @@ extern "C" int hgr_layernorm_bwd(const void *dy, int dy_f32, const float *x, con
     const int nvl = (W / 4 + 63) / 64;
 #define HGR_LNB(NVV)                                                                                                             \
     do {                                                                                                                         \
-        if (dy_f32) hipLaunchKernelGGL((layernorm_bwd<HGR_BF16, true, NVV>), dim3(blocks), dim3(256), 0, s, dy, x, gamma, dx, pg, pb, rows, W, row_mul, row_idx, eps); \
-        else if (dtype == HGR_BF16) hipLaunchKernelGGL((layernorm_bwd<HGR_BF16, false, NVV>), dim3(blocks), dim3(256), 0, s, dy, x, gamma, dx, pg, pb, rows, W, row_mul, row_idx, eps); \
-        else hipLaunchKernelGGL((layernorm_bwd<HGR_F16, false, NVV>), dim3(blocks), dim3(256), 0, s, dy, x, gamma, dx, pg, pb, rows, W, row_mul, row_idx, eps); \
+        if (dy_f32 && dtype == HGR_BF16) hipLaunchKernelGGL((layernorm_bwd<HGR_BF16, true, NVV>), dim3(blocks), dim3(256), 0, s, dy, x, gamma, dx, pg, pb, rows, W, row_mul, row_idx, eps, (__bf16 *)dx16); \
+        else if (dy_f32) hipLaunchKernelGGL((layernorm_bwd<HGR_F16, true, NVV>), dim3(blocks), dim3(256), 0, s, dy, x, gamma, dx, pg, pb, rows, W, row_mul, row_idx, eps, (_Float16 *)dx16); \
+        else if (dtype == HGR_BF16) hipLaunchKernelGGL((layernorm_bwd<HGR_BF16, false, NVV>), dim3(blocks), dim3(256), 0, s, dy, x, gamma, dx, pg, pb, rows, W, row_mul, row_idx, eps, (__bf16 *)dx16); \
+        else hipLaunchKernelGGL((layernorm_bwd<HGR_F16, false, NVV>), dim3(blocks), dim3(256), 0, s, dy, x, gamma, dx, pg, pb, rows, W, row_mul, row_idx, eps, (_Float16 *)dx16); \
     } while (0)
     if (nvl <= 1) HGR_LNB(1); else if (nvl <= 2) HGR_LNB(2); else if (nvl <= 4) HGR_LNB(4); else if (nvl <= 8) HGR_LNB(8); else HGR_LNB(16);
 #undef HGR_LNB
-    HGR_CHECK_LAUNCH("hgr_layernorm_bwd");
+    HGR_CHECK_LAUNCH(name);
     int rc = hgr_colsum(pg, W, nw, W, 1, HGR_BF16, dgamma, 1, 1.0f, cs, stream);
     if (rc) return rc;
     return hgr_colsum(pb, W, nw, W, 1, HGR_BF16, dbeta, 1, 1.0f, cs, stream);
+}
+
+extern "C" int hgr_layernorm_bwd(const void *dy, int dy_f32, const float *x, const float *gamma, float *dx, float *dgamma, float *dbeta, float *scratch,
+                                 int rows, int W, int64_t row_mul, const int32_t *row_idx, float eps, int dtype, void *stream) {
+    return layernorm_bwd_entry("hgr_layernorm_bwd", dy, dy_f32, x, gamma, dx, nullptr, dgamma, dbeta, scratch, rows, W, row_mul, row_idx, eps, dtype, stream);
+}
+
+extern "C" int hgr_layernorm_bwd_cast(const void *dy, int dy_f32, const float *x, const float *gamma, float *dx, void *dx16, float *dgamma, float *dbeta,
+                                      float *scratch, int rows, int W, int64_t row_mul, const int32_t *row_idx, float eps, int dtype, void *stream) {
+    HGR_REQUIRE(dx16, "hgr_layernorm_bwd_cast: null dx16");
+    return layernorm_bwd_entry("hgr_layernorm_bwd_cast", dy, dy_f32, x, gamma, dx, dx16, dgamma, dbeta, scratch, rows, W, row_mul, row_idx, eps, dtype, stream);
 }
 
 extern "C" int64_t hgr_layernorm_bwd_scratch_floats(int rows, int W) {

@@ -512,12 +512,18 @@ def layernorm_bwd_scratch(rows: int, w: int) -> int:
 
 
 def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, dx: torch.Tensor, dgamma: torch.Tensor, dbeta: torch.Tensor,
-                  scratch: torch.Tensor, rows: Optional[int] = None, row_mul: int = 1, row_idx: Optional[torch.Tensor] = None, eps: float = 1e-5) -> None:
-    """dx[src rows] += dLN; dgamma += ...; dbeta += ...  (all fp32, accumulate)."""
+                  scratch: torch.Tensor, rows: Optional[int] = None, row_mul: int = 1, row_idx: Optional[torch.Tensor] = None, eps: float = 1e-5,
+                  dx16: Optional[torch.Tensor] = None) -> None:
+    """dx[src rows] += dLN; dgamma += ...; dbeta += ...  (all fp32, accumulate).  ``dx16``: also the updated dx rows as a 16-bit copy."""
     w = x.shape[-1]
     rows = dy.shape[0] if rows is None else rows
     f32 = dy.dtype == torch.float32
     assert scratch.numel() >= layernorm_bwd_scratch(rows, w) and dy.is_contiguous()
+    if dx16 is not None:
+        assert dx16.is_contiguous() and dx16.shape == dx.shape and (f32 or dx16.dtype == dy.dtype)
+        _lib.call("hgr_layernorm_bwd_cast", _dev(dy), 1 if f32 else 0, _dev(x), _dev(gamma), _dev(dx), _dev(dx16), _dev(dgamma), _dev(dbeta), _dev(scratch),
+                  rows, w, row_mul, _dev(row_idx), eps, DT_OF[dx16.dtype], _stream())
+        return
     _lib.call("hgr_layernorm_bwd", _dev(dy), 1 if f32 else 0, _dev(x), _dev(gamma), _dev(dx), _dev(dgamma), _dev(dbeta), _dev(scratch),
               rows, w, row_mul, _dev(row_idx), eps, HGR_BF16 if f32 else DT_OF[dy.dtype], _stream())
 

@@ -213,10 +213,10 @@ class Engine:
         m, w = dx.shape
         dt, dev = self.dt, self.dev
         scr = self.scratch(ops.layernorm_bwd_scratch(m, w))
+        dy = torch.empty(m, w, dtype=dt, device=dev)
+        ops.cast16(dx, dy)               # later 16-bit copies of dx come out of the LayerNorm backward that updates it
         for k, (x0, h1, qkv, att, x1, h2, a, u, st) in zip(reversed(blocks), reversed(saves)):
             # x2 = x1 + c_proj(gelu(c_fc(ln_2(x1))))
-            dy = torch.empty(m, w, dtype=dt, device=dev)
-            ops.cast16(dx, dy)
             if GELU_BWD_FUSED:      # d(pre-activation) straight from the c_proj data-gradient GEMM (HGR_EPI_QGELU_GRAD16)
                 da = self._linear_bwd(k.w_proj, dy, u, m, gelu_pre=a)
             else:
@@ -224,14 +224,13 @@ class Engine:
                 da = torch.empty_like(a)
                 ops.quickgelu16(a, da, du=du)
             dh2 = self._linear_bwd(k.w_fc, da, h2, m)
-            ops.layernorm_bwd(dh2, x1, k.ln2.weight.data, dx, _grad(k.ln2.weight), _grad(k.ln2.bias), scr)
+            ops.layernorm_bwd(dh2, x1, k.ln2.weight.data, dx, _grad(k.ln2.weight), _grad(k.ln2.bias), scr, dx16=dy)
             # x1 = x0 + out_proj(attn(in_proj(ln_1(x0))))
-            ops.cast16(dx, dy)
             datt = self._linear_bwd(k.w_out, dy, att, m)
             dqkv = torch.empty_like(qkv)
             ops.mha_bwd(qkv, att, datt, dqkv, b, l, heads, causal, stats=st)
             dh1 = self._linear_bwd(k.w_in, dqkv, h1, m)
-            ops.layernorm_bwd(dh1, x0, k.ln1.weight.data, dx, _grad(k.ln1.weight), _grad(k.ln1.bias), scr)
+            ops.layernorm_bwd(dh1, x0, k.ln1.weight.data, dx, _grad(k.ln1.weight), _grad(k.ln1.bias), scr, dx16=dy)
         return dx
 
     # -- image tower (ViT) ----------------------------------------------------------------------

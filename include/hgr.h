@@ -329,6 +329,11 @@ int hgr_quickgelu16(const void *a, const void *du, void *out, int64_t n, int bac
 int hgr_layernorm_bwd(const void *dy, int dy_f32, const float *x, const float *gamma, float *dx, float *dgamma,
                       float *dbeta, float *scratch, int rows, int W, int64_t row_mul, const int32_t *row_idx,
                       float eps, int dtype, void *stream);
+/* The same, and the rows it touched of the UPDATED dx also as a 16-bit copy dx16[src row][W] (= hgr_cast16 of those rows):
+ * the next GEMMs of the backward chain take the gradient in 16 bit, this saves the separate conversion pass. */
+int hgr_layernorm_bwd_cast(const void *dy, int dy_f32, const float *x, const float *gamma, float *dx, void *dx16, float *dgamma,
+                           float *dbeta, float *scratch, int rows, int W, int64_t row_mul, const int32_t *row_idx, float eps,
+                           int dtype, void *stream);
 int64_t hgr_layernorm_bwd_scratch_floats(int rows, int W);
 
 /* Attention backward for hgr_mha (L <= 320): dqkv [B*L, 3W] from qkv, the forward output `out` and dout [B*L, W], all

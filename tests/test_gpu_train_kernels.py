@@ -145,6 +145,25 @@ def test_layernorm_bwd(w):
 
 
 @pytest.mark.parametrize("dt", DTS)
+def test_layernorm_bwd_cast_equals_bwd_then_cast16(dt):
+    """hgr_layernorm_bwd_cast: dx, dgamma, dbeta as hgr_layernorm_bwd; the 16-bit copy equals hgr_cast16 of the updated dx."""
+    rows, w = 300, 768
+    x = _rand((rows, w), 71, 1.0).to(DEV)
+    dy = _rand((rows, w), 72, 0.5).to(dt).to(DEV)
+    g = (_rand((w,), 73, 0.2) + 1.0).to(DEV)
+    dx0 = _rand((rows, w), 74, 0.3).to(DEV)
+    scratch = torch.empty(ops.layernorm_bwd_scratch(rows, w), device=DEV)
+    dx1, dg1, db1 = dx0.clone(), torch.zeros(w, device=DEV), torch.zeros(w, device=DEV)
+    ops.layernorm_bwd(dy, x, g, dx1, dg1, db1, scratch)
+    c1 = torch.empty(rows, w, dtype=dt, device=DEV)
+    ops.cast16(dx1, c1)
+    dx2, dg2, db2 = dx0.clone(), torch.zeros(w, device=DEV), torch.zeros(w, device=DEV)
+    c2 = torch.full((rows, w), 7.0, dtype=dt, device=DEV)
+    ops.layernorm_bwd(dy, x, g, dx2, dg2, db2, scratch, dx16=c2)
+    assert torch.equal(dx1, dx2) and torch.equal(dg1, dg2) and torch.equal(db1, db2) and torch.equal(c1, c2)
+
+
+@pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("L,causal", [(5, True), (16, True), (1, True), (12, False), (29, True), (32, True), (32, False), (50, False), (64, False), (37, True),
                                       (77, True), (65, False), (130, True), (257, False)])
 def test_mha_bwd_vs_autograd(dt, L, causal):
