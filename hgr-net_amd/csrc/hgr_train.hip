@@ -361,7 +361,9 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_tiled(const typename T16<DT>::
                 sDS = (TileP)(smem + 4 * TB), sDSt = (TileP)(smem + 5 * TB), sPt = (TileP)(smem + 6 * TB);
     float (*const sS)[65] = (float (*)[65])(smem + 4 * TB);      // sweep 0 only: fp32 scores over the (then unused) dS / dS^T tiles
     static_assert(64 * 65 * 4 <= 2 * TB, "score block must fit the two tiles it aliases");
-    __shared__ float rM[320], rLinv[320], rD[320];
+    __shared__ __attribute__((aligned(16))) float rM[320];
+    __shared__ __attribute__((aligned(16))) float rLinv[320];
+    __shared__ __attribute__((aligned(16))) float rD[320];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
     const int r32 = lane & 31, hh = lane >> 5;
     const int b = blockIdx.x / H, h = blockIdx.x - b * H;
@@ -504,24 +506,26 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_tiled(const typename T16<DT>::
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {                      // 4 consecutive rows of this lane's column per step
                 vec4 p4, d4;
+                const int rr0 = wr * 32 + HGR_ACC_ROW(g4 * 4, hh);     // a multiple of 4: the 4 rows' statistics are one 16-byte LDS read each
+                const f32x4 m4 = *(const f32x4 *)&rM[qi * 64 + rr0], l4 = *(const f32x4 *)&rLinv[qi * 64 + rr0], dd4 = *(const f32x4 *)&rD[qi * 64 + rr0];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int g = g4 * 4 + e;
-                    const int rr = wr * 32 + HGR_ACC_ROW(g, hh), q = qi * 64 + rr;
+                    const int rr = rr0 + e, q = qi * 64 + rr;
                     const float sc = score(sacc[g], q, kj * 64 + cc);
-                    const float pv = (sc > -INFINITY) ? __expf(sc - rM[q]) * rLinv[q] : 0.f;
-                    const float dsv = pv * (dp[g] - rD[q]) * 0.125f;
+                    const float pv = (sc > -INFINITY) ? __expf(sc - m4[e]) * l4[e] : 0.f;
+                    const float dsv = pv * (dp[g] - dd4[e]) * 0.125f;
                     p4[e] = (E)pv; d4[e] = (E)dsv;
                     sDS[rr][cc] = (E)dsv;
                 }
-                const int rr0 = wr * 32 + HGR_ACC_ROW(g4 * 4, hh);
                 *(vec4 *)&sPt[cc][rr0] = p4;                      // transposed images: [key][query]
                 *(vec4 *)&sDSt[cc][rr0] = d4;
             }
             __syncthreads();
             mm16_bt<DT>(dv, sPt, wr * 32, sO, wc * 32, lane);     // dV += P^T dO      (rows = keys, columns = d; k = queries)
             mm16_bt<DT>(dk, sDSt, wr * 32, sQ, wc * 32, lane);    // dK += dS^T Q
-            mm16_bt<DT>(dq[qi], sDS, wr * 32, sK, wc * 32, lane); // dQ_i += dS K      (k = keys)
+            mm16_bt<DT>(dq[qi], sDS, wr * 32, sK, wc * 32, lane); // dQ_i += dS K      (k = keys; reading dS through the transposing read
+                                                                  // too, out of its [key][query] image, measured 7 % slower than this row-major copy)
         }
         write_rows(dqb + W, ld, kj * 64, dk);
         write_rows(dqb + 2 * W, ld, kj * 64, dv);
