@@ -79,6 +79,17 @@ int main() {
     EXPECT_FAIL(hgr_sumsq(nullptr, 16, f32, nullptr));
     EXPECT_FAIL(hgr_adamw(nullptr, f32, f32, f32, 16, 1e-3f, 0.9f, 0.999f, 1e-8f, 0.f, 1, nullptr, 1.f, 1.f, nullptr));
     EXPECT_OK(hgr_layernorm_bwd_scratch_floats(1000, 768));
+    // this round's training entries
+    EXPECT_FAIL(hgr_gemm_nt(h16, 64, h16, 64, h16, 64, nullptr, nullptr, 0, 4, 4, 64, HGR_F16, HGR_EPI_QGELU_GRAD16, 0, nullptr));   // pre-activation missing
+    EXPECT_FAIL(hgr_gemm_nt(h16, 64, h16, 64, f32, 64, nullptr, h16, 64, 4, 4, 64, HGR_F16, HGR_EPI_QGELU_GRAD16, 1, nullptr));       // fp32 output
+    EXPECT_FAIL(hgr_gemm_nt_bias_gelu_dual(h16, 128, h16, 128, h16, 100, h16, 128, f32, 4, 100, 128, HGR_F16, nullptr));               // N % 128
+    EXPECT_FAIL(hgr_gemm_nt_bias_gelu_dual(h16, 128, h16, 128, h16, 128, nullptr, 128, f32, 4, 128, 128, HGR_F16, nullptr));           // post missing
+    EXPECT_FAIL(hgr_mha_stats(h16, h16, nullptr, 1, 50, 12, 0, HGR_F16, nullptr));
+    EXPECT_FAIL(hgr_mha_bwd_stats(h16, h16, h16, h16, nullptr, 1, 50, 12, 0, HGR_F16, nullptr));
+    EXPECT_FAIL(hgr_mha_bwd_stats(h16, h16, h16, h16, f32, 1, 400, 12, 0, HGR_F16, nullptr));                                           // L > 320
+    EXPECT_FAIL(hgr_layernorm_bwd_cast(h16, 0, f32, f32, f32, nullptr, f32, f32, f32, 4, 64, 1, nullptr, 1e-5f, HGR_F16, nullptr));
+    EXPECT_FAIL(hgr_layernorm_bwd_cast(h16, 0, f32, f32, f32, h16, f32, f32, f32, 4, 6, 1, nullptr, 1e-5f, HGR_F16, nullptr));         // W % 4
+    EXPECT_OK(hgr_gemm_tn_tile(3072, 768) == 256 && hgr_gemm_tn_tile(200, 4096) == 128 && hgr_gemm_tn_tile(640, 640) == 128 ? 0 : -1);
     // collectives without a communicator / with bad arguments (librccl may be absent: both outcomes are failures by contract)
     EXPECT_FAIL(hgr_allreduce(f32, f32, 16, HGR_COMM_F32, HGR_COMM_SUM, nullptr));
     EXPECT_FAIL(hgr_allgather(f32, f32, 16, 99, nullptr));
