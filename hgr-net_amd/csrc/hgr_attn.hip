@@ -12,13 +12,17 @@
 //   O^T = V^T . P^T : the exponentiated accumulators ARE the B operand of the second product after
 //                    a 16-bit convert (accumulator-as-operand, cdna_hip_programming.md section 3):
 //                    k-slot j of lane-group g in 32-key step s is key 32s + 16(j>>2) + 4g + (j&3),
-//                    so the A operand reads V^T with the same key permutation (two 8-byte LDS reads
-//                    of a transposed V image).  No LDS round trip for P.
+//                    so the A operand reads V^T with the same key permutation: two transposing LDS reads
+//                    (ds_read_b64_tr_b16) of the row-major V tile - V is staged as it lies in memory, no
+//                    transposed image is written.  No LDS round trip for P.
 // Output lane layout: 4 consecutive head dims of one query -> 8-byte stores.
 // HBM-bound in practice (reads 3W, writes W 16-bit values per token), the MFMA work is ~1 % of a layer.
 #include "hgr_common.h"
 
 namespace {
+
+typedef __attribute__((ext_vector_type(4))) short mha_s16x4;
+typedef __attribute__((ext_vector_type(8))) short mha_s16x8;
 
 template <int DT, int KT, bool CAUSAL>
 __global__ __launch_bounds__(256) void mha_fwd(const typename T16<DT>::elem *__restrict__ qkv,
@@ -27,9 +31,16 @@ __global__ __launch_bounds__(256) void mha_fwd(const typename T16<DT>::elem *__r
     typedef typename T16<DT>::vec8 vec8;
     typedef typename T16<DT>::vec4 vec4;
     constexpr int LP = KT * 32;        // keys padded to the MFMA k-step
-    constexpr int VS = LP + 4;         // V^T row stride in elements (8-byte aligned rows, spreads banks)
+    // V^T fragments: for short sequences (<= 64 keys: ViT-B/32, the attention pool, prompts) V is staged as it lies in memory and the
+    // fragments come out of ds_read_b64_tr_b16 (29.5 vs 35 us at ViT-B/32 batch 512: no scalar transposing LDS stores on the
+    // kernel's one critical path); for long sequences the transposed image wins (ViT-L/14, 257 keys: 646 vs 710 us at batch 512 -
+    // the staging is amortised over 17 query tiles, the plain 8-byte reads are cheaper than the transposing ones)
+    constexpr bool VTR = KT <= 2;
+    constexpr int VR = 72;             // VTR: V row stride in elements (144 B: the 4-row x 32-byte blocks of a transposing read spread over the banks)
+    constexpr int VS = LP + 4;         // else: V^T row stride in elements (8-byte aligned rows, spreads banks)
     __shared__ __attribute__((aligned(16))) char sK[LP * 128];
-    __shared__ __attribute__((aligned(16))) E sVt[64 * VS];
+    __shared__ __attribute__((aligned(16))) E sV[VTR ? LP * VR : 64 * VS];
+    E *const sVt = sV;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
@@ -56,8 +67,10 @@ __global__ __launch_bounds__(256) void mha_fwd(const typename T16<DT>::elem *__r
 #pragma unroll
             for (int e = 0; e < 8; ++e) { kv[e] = (E)0.f; vv[e] = (E)0.f; }
         *(vec8 *)(sK + row * 128 + ((c ^ (row & 7)) * 16)) = kv;
+        if (VTR) *(vec8 *)(sV + row * VR + c * 8) = vv;
+        else
 #pragma unroll
-        for (int e = 0; e < 8; ++e) sVt[(c * 8 + e) * VS + row] = vv[e];
+            for (int e = 0; e < 8; ++e) sVt[(c * 8 + e) * VS + row] = vv[e];
     }
     __syncthreads();
 
@@ -117,12 +130,21 @@ __global__ __launch_bounds__(256) void mha_fwd(const typename T16<DT>::elem *__r
             for (int e = 0; e < 4; ++e) { pf[e] = (E)acc[2 * s][e]; pf[4 + e] = (E)acc[2 * s + 1][e]; }
 #pragma unroll
             for (int td = 0; td < 4; ++td) {
-                const E *vr = sVt + (td * 16 + r) * VS + s * 32 + g * 4;
-                const vec4 lo = *(const vec4 *)vr;
-                const vec4 hi = *(const vec4 *)(vr + 16);
+                // A operand = V^T[d = 16 td + r][keys 32 s + 4 g .. + 3, 32 s + 16 + 4 g .. + 3]: lane 4 q + pp of the 16-lane group g
+                // supplies (key row 32 s + 4 g + q, columns 16 td + 4 pp ..) and receives the 4 keys of column 16 td + (lane & 15)
                 vec8 vf;
+                if (VTR) {
+                    const E *vb = sV + (s * 32 + g * 4 + (r >> 2)) * VR + td * 16 + (r & 3) * 4;
+                    const mha_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AS3 mha_s16x4 *)vb);
+                    const mha_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AS3 mha_s16x4 *)(vb + 16 * VR));
+                    vf = __builtin_bit_cast(vec8, (mha_s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                } else {
+                    const E *vr = sVt + (td * 16 + r) * VS + s * 32 + g * 4;
+                    const vec4 lo = *(const vec4 *)vr;
+                    const vec4 hi = *(const vec4 *)(vr + 16);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = hi[e]; }
+                    for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = hi[e]; }
+                }
                 o[td] = T16<DT>::mfma16(vf, pf, o[td]);
             }
         }
