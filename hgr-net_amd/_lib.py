@@ -107,6 +107,9 @@ class HgrError(RuntimeError):
 _lib = None
 
 
+ABI_VERSION = 2          # HGR_ABI_VERSION of include/hgr.h this wrapper was written against
+
+
 def load() -> C.CDLL:
     """Load libhgr.so once; raise (never fall back) when it is absent."""
     global _lib
@@ -122,8 +125,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)            # AttributeError if the .so does not export a declared symbol
         fn.argtypes = argtypes
         fn.restype = _l if name.endswith(("_scratch_floats", "_workspace_bytes")) else _i
-    if lib.hgr_abi_version() != 1:
-        raise HgrError(f"libhgr.so ABI {lib.hgr_abi_version()} != 1")
+    if lib.hgr_abi_version() != ABI_VERSION:
+        raise HgrError(f"libhgr.so ABI {lib.hgr_abi_version()} != {ABI_VERSION} (include/hgr.h): stale build, run `make -C {_HERE / 'csrc'}`")
     _lib = lib
     return lib
 
