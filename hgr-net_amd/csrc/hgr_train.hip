@@ -542,13 +542,27 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_tiled(const typename T16<DT>::
 // v_mfma_f32_32x32x16 with the operands staged once in LDS (rows past L zero-filled): S = Q K^T and dP = dO V^T (k = 64),
 // the row softmax and D = rowsum(P * dP) by shuffles inside the 32-lane halves of the accumulator layout (a lane owns one
 // key column and 16 query rows), then dV = P^T dO, dK = dS^T Q, dQ = dS K (k = 32) on 16-bit P / dS images written from
-// the accumulators.  No barriers (one wave), 41 KB of LDS, 3 waves per CU.
+// the accumulators.  No barriers (one wave), 26 KB of LDS (the transposed operands come from ds_read_b64_tr_b16), 6 waves per CU.
 template <int DT>
 __device__ __forceinline__ void mm16k(f32x16 &acc, const typename T16<DT>::elem *A, int lda, const typename T16<DT>::elem *B, int ldb, int ksteps, int lane) {
     typedef typename T16<DT>::vec8 vec8;
     const int r = lane & 31, kh = lane >> 5;
     for (int kk = 0; kk < ksteps; ++kk)
         acc = T16<DT>::mfma32(*(const vec8 *)(A + r * lda + kk * 16 + kh * 8), *(const vec8 *)(B + r * ldb + kk * 16 + kh * 8), acc);
+}
+
+// mm16k with the B operand read out of a row-major [k][n] tile by the transposing LDS read (see mm16_bt): acc[m][n] += sum_k A[m][k] Bt[k][bcol + n]
+template <int DT>
+__device__ __forceinline__ void mm16k_bt(f32x16 &acc, const typename T16<DT>::elem *A, int lda, const typename T16<DT>::elem *Bt, int ldb, int bcol, int ksteps, int lane) {
+    typedef typename T16<DT>::vec8 vec8;
+    const int r = lane & 31, kh = lane >> 5, l16 = lane & 15;
+    const int q = l16 >> 2, c = bcol + ((lane >> 4) & 1) * 16 + (l16 & 3) * 4;
+    for (int kk = 0; kk < ksteps; ++kk) {
+        const int k0 = kk * 16 + kh * 8;
+        const tr_s16x4 b0 = tr_read64(Bt + (k0 + q) * ldb + c), b1 = tr_read64(Bt + (k0 + 4 + q) * ldb + c);
+        const vec8 bf = __builtin_bit_cast(vec8, (tr_s16x8)__builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+        acc = T16<DT>::mfma32(*(const vec8 *)(A + r * lda + kk * 16 + kh * 8), bf, acc);
+    }
 }
 
 template <int DT, bool CAUSAL>
@@ -558,8 +572,9 @@ __global__ __launch_bounds__(64) void mha_bwd_wave(const typename T16<DT>::elem 
     typedef typename T16<DT>::vec8 vec8;
     typedef typename T16<DT>::vec4 vec4;
     constexpr int LR = 72, LT = 40;                 // row strides (elements): [32][72] row images, [64][40] / [32][40] transposed images
-    __shared__ __attribute__((aligned(16))) E sQ[32 * LR], sK[32 * LR], sV[32 * LR], sO[32 * LR], sQt[64 * LT], sKt[64 * LT], sOt[64 * LT],
-        sDS[32 * LT], sDSt[32 * LT], sPt[32 * LT];
+    // Q^T, K^T, dO^T are never staged: the k = 32 products read them out of the row-major tiles with ds_read_b64_tr_b16 (mm16k_bt):
+    // 26 instead of 41 KB of LDS (6 instead of 3 workgroups per CU) and no 2-byte transposing stores
+    __shared__ __attribute__((aligned(16))) E sQ[32 * LR], sK[32 * LR], sV[32 * LR], sO[32 * LR], sDS[32 * LT], sDSt[32 * LT], sPt[32 * LT];
     const int lane = threadIdx.x, r32 = lane & 31, hh = lane >> 5;
     const int b = blockIdx.x / H, h = blockIdx.x - b * H;
     const int W = H * 64;
@@ -579,8 +594,6 @@ __global__ __launch_bounds__(64) void mha_bwd_wave(const typename T16<DT>::elem 
             for (int e = 0; e < 8; ++e) { q[e] = (E)0.f; k[e] = (E)0.f; v[e] = (E)0.f; o[e] = (E)0.f; }
         }
         *(vec8 *)&sQ[r * LR + c] = q; *(vec8 *)&sK[r * LR + c] = k; *(vec8 *)&sV[r * LR + c] = v; *(vec8 *)&sO[r * LR + c] = o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { sQt[(c + e) * LT + r] = q[e]; sKt[(c + e) * LT + r] = k[e]; sOt[(c + e) * LT + r] = o[e]; }
     }
     __syncthreads();
     f32x16 sacc = {0.f}, dp = {0.f};
@@ -624,9 +637,9 @@ __global__ __launch_bounds__(64) void mha_bwd_wave(const typename T16<DT>::elem 
 #pragma unroll
     for (int half = 0; half < 2; ++half) {          // the 64 head dimensions as two blocks of 32 columns
         f32x16 dq = {0.f}, dk = {0.f}, dv = {0.f};
-        mm16k<DT>(dq, sDS, LT, sKt + half * 32 * LT, LT, 2, lane);      // dQ[q][d] = sum_j dS[q][j] K[j][d]
-        mm16k<DT>(dk, sDSt, LT, sQt + half * 32 * LT, LT, 2, lane);     // dK[j][d] = sum_q dS[q][j] Q[q][d]
-        mm16k<DT>(dv, sPt, LT, sOt + half * 32 * LT, LT, 2, lane);      // dV[j][d] = sum_q P[q][j] dO[q][d]
+        mm16k_bt<DT>(dq, sDS, LT, sK, LR, half * 32, 2, lane);          // dQ[q][d] = sum_j dS[q][j] K[j][d]
+        mm16k_bt<DT>(dk, sDSt, LT, sQ, LR, half * 32, 2, lane);         // dK[j][d] = sum_q dS[q][j] Q[q][d]
+        mm16k_bt<DT>(dv, sPt, LT, sO, LR, half * 32, 2, lane);          // dV[j][d] = sum_q P[q][j] dO[q][d]
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
             const int row = HGR_ACC_ROW(g, hh);

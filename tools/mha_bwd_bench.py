@@ -39,3 +39,16 @@ for name, L, heads in (("L14", 257, 16), ("B16", 197, 12), ("B32", 50, 12)):
     fl = 4.0 * L * L * 64 * heads * batch
     print(json.dumps({"shape": name, "batch": batch, "L": L, "heads": heads, "fwd_us": round(tf, 1), "fwd_tflops": round(fl / tf / 1e6, 1),
                       "bwd_us": round(tb, 1), "bwd_tflops_2.5x": round(2.5 * fl / tb / 1e6, 1)}), flush=True)
+
+# text-tower shape of the training bench: ~3 552 distinct prompts x 23 tokens (L <= 32: the one-wave-per-head kernel), causal
+for name, n, L, heads in (("txt B32", 3552, 23, 8), ("txt L14", 3552, 23, 12)):
+    w = heads * 64
+    qkv = (torch.randn(n * L, 3 * w, device="cuda") * 0.7).to(dt)
+    do = (torch.randn(n * L, w, device="cuda") * 0.5).to(dt)
+    out = torch.empty(n * L, w, dtype=dt, device="cuda")
+    dqkv = torch.empty_like(qkv)
+    ops.mha(qkv, out, n, L, heads, True)
+    g = lambda: ops.mha_bwd(qkv, out, do, dqkv, n, L, heads, True)
+    g()
+    tb = min(timeit(g) for _ in range(3))
+    print(json.dumps({"shape": name, "prompts": n, "L": L, "heads": heads, "bwd_us": round(tb, 1)}), flush=True)
