@@ -330,7 +330,8 @@ def test_batch512_forward_through_graph_vs_oracle_subsample(arch, nodes, tmp_pat
     tokens = synth.make_tokens(nodes, 11, cfg["vocab_size"])
     model = tree_model(_opts(tmp_path, edges), splits["all"], splits["rest"], node_tokens=tokens,
                        clip_model=build_model(sd, image_dtype="f16", text_dtype="f16").to(DEV))
-    assert model.use_graph
+    if not model.use_graph:
+        pytest.skip("HGR_GRAPH=0: this test is about the graph-replayed path")
     model.update_classifier()
     img = synth.images(512, cfg["image_resolution"], 4321)
     dimg = img.to(DEV)
