@@ -1008,7 +1008,7 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
         }
         if (MODE <= 1) issueW(oW1, DUO_W1, t + 1);
         if (MODE == 0) issueA(oA0, DUO_A0, t + 2, 0);
-        HGR_RBAR();                                                     // ph4 reads nothing new
+        __builtin_amdgcn_sched_barrier(0);                              // no barrier here: nothing is refilled before ph4's barrier that ph3 reads
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
