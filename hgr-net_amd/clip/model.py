@@ -173,9 +173,11 @@ IMG_STREAMS_MIN_ROWS = 8192
 LN_FUSED = os.environ.get("HGR_LN_FUSED", "1") != "0"     # HGR_LN_FUSED=0: separate LayerNorm launches (the first build's path), for A/B runs
 
 
-def ln_fusable(w: int) -> bool:
-    """The LayerNorm-folded GEMM pair needs the row width to be a multiple of 128 (two 64-column statistic slots per load)."""
-    return LN_FUSED and w % 128 == 0
+def ln_fusable(w: int, m: int = 0) -> bool:
+    """The LayerNorm-folded GEMM pair needs the row width to be a multiple of 128 (two 64-column statistic slots per load) and
+    32-bit operand offsets: its widest A operand is u16 [m, 4w] in 16 bit, which must stay below 4 GB (ViT-L/14@336 above ~900
+    images does not: those batches take the unfused LayerNorm + hgr_gemm_nt route, whose 128 / 256 tile kernels use 64-bit rows)."""
+    return LN_FUSED and w % 128 == 0 and m * 4 * w * 2 < 2 ** 32
 
 
 def _run_blocks(x: Optional[torch.Tensor], blocks, heads: int, b: int, l: int, causal: bool, dt: torch.dtype, ws: _Workspace, tag: str,
@@ -488,7 +490,7 @@ class CLIP(nn.Module):
         pe = ws.get(tag + ".pe", (b * gg, w), torch.float32, dev)
         ops.gemm_nt(patches, p["conv_w_nhwc"] if u8 else p["conv_w"], pe, tag="patch")
         cls16 = ws.get(tag + ".cls16", (b, w), dt, dev)
-        if ln_fusable(w):
+        if ln_fusable(w, b * l):
             xh = ws.get(tag + ".xh", (b * l, w), dt, dev)
             xl = ws.get(tag + ".xl", (b * l, w), torch.float16, dev)
             stats = ws.get(tag + ".stats", (b * l, w // 64, 2), torch.float32, dev)
@@ -533,7 +535,7 @@ class CLIP(nn.Module):
             if ctx is not None:
                 ops.ctx_splice(x, ctx.detach().float().contiguous(), p["tpos"], c, l)
             f16 = ws.get("t.f16", (c, w), dt, dev)
-            if ln_fusable(w):
+            if ln_fusable(w, c * l):
                 xh = ws.get("t.xh", (c * l, w), dt, dev)
                 xl = ws.get("t.xl", (c * l, w), torch.float16, dev)
                 stats = ws.get("t.stats", (c * l, w // 64, 2), torch.float32, dev)

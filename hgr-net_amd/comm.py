@@ -3,8 +3,10 @@
 row slices, all-reduce of the metric counters / the flat gradient buffer, broadcast of parameters.
 
 The reference has no distributed code.  ``torch.distributed`` (backend "nccl" = RCCL) stays the default
-transport of bench.py / main.py; this module is what a host that does not carry PyTorch's process groups binds, and it is
-selected in this package with HGR_COMM=native.  Bootstrap: rank 0 draws the 128-byte unique id and ships it over any side
+transport of bench.py / main.py; this module is what a host that does not carry PyTorch's process groups binds.  In this
+package HGR_COMM=native selects it for the blocking exchanges - the class-matrix all-gather (parallel.all_gather_rows), the
+counter all-reduce (Evaluator.counters), FusedAdamW.allreduce and parallel.allreduce_grads; the overlapped gradient buckets
+(FusedAdamW.allreduce_part) stay on torch.distributed's asynchronous work handles.  Bootstrap: rank 0 draws the 128-byte unique id and ships it over any side
 channel - here an existing torch.distributed group (gloo is enough) or a file."""
 from __future__ import annotations
 
@@ -45,23 +47,56 @@ def init_from_torch(group=None) -> None:
     init(rank, world, box[0])
 
 
-def init_from_file(path: str, rank: int, world: int, timeout_s: float = 120.0) -> None:
-    """Bootstrap over a shared file: rank 0 writes the id (atomically), the others wait for it."""
+def _run_nonce(nonce: Optional[str]) -> bytes:
+    """16 bytes that identify THIS run: every rank derives them from what the launcher gave all of them (an explicit
+    `nonce`, else HGR_COMM_NONCE, else MASTER_ADDR:MASTER_PORT + torchelastic's run id)."""
+    import hashlib
+    if nonce is None:
+        nonce = os.environ.get("HGR_COMM_NONCE") or ":".join(os.environ.get(k, "") for k in ("MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"))
+    return hashlib.sha256(nonce.encode()).digest()[:16]
+
+
+def init_from_file(path: str, rank: int, world: int, timeout_s: float = 120.0, nonce: Optional[str] = None) -> None:
+    """Bootstrap over a shared file: rank 0 removes whatever an earlier run left at `path`, then publishes
+    run-nonce + unique id atomically; the others wait for a file that carries THIS run's nonce (a stale or foreign id
+    file is ignored instead of being fed to ncclCommInitRank, which would hang with no diagnostic).  The file is removed
+    by rank 0's destroy()."""
+    tagb = _run_nonce(nonce)
     if rank == 0:
-        tmp = path + ".tmp"
+        try:
+            os.unlink(path)
+        except FileNotFoundError:
+            pass
+        tmp = f"{path}.{os.getpid()}.tmp"
         with open(tmp, "wb") as f:
-            f.write(unique_id())
+            f.write(tagb + unique_id())
         os.replace(tmp, path)
+        _published.append(path)
     t0 = time.time()
-    while not os.path.exists(path):
+    while True:
+        try:
+            blob = open(path, "rb").read()
+        except FileNotFoundError:
+            blob = b""
+        if len(blob) == 16 + ID_BYTES and blob[:16] == tagb:
+            break
         if time.time() - t0 > timeout_s:
-            raise _lib.HgrError(f"hgr comm: no unique id at {path} after {timeout_s}s")
+            what = "no unique id" if not blob else "only a stale unique id (another run's nonce)"
+            raise _lib.HgrError(f"hgr comm: {what} at {path} after {timeout_s}s")
         time.sleep(0.05)
-    init(rank, world, open(path, "rb").read())
+    init(rank, world, blob[16:])
+
+
+_published: list = []
 
 
 def destroy() -> None:
     _lib.call("hgr_comm_destroy")
+    while _published:                                   # rank 0: the id file of this run is of no further use
+        try:
+            os.unlink(_published.pop())
+        except OSError:
+            pass
 
 
 def world() -> int:

@@ -1,0 +1,176 @@
+// Shared pieces of the NT GEMM family (hgr_gemm_128 / _256 / _duo .hip + the host entry points in hgr_gemm.hip):
+// the argument block, the epilogue helpers and the wait / barrier macros of the counted-vmcnt pipelines.
+//
+// C[M,N] = epilogue(A[M,K] . W[N,K]^T) on the gfx950 matrix cores.  Both operands are K-contiguous (activations row-major,
+// nn.Linear weights [out, in]), so a lane's MFMA fragment (8 consecutive k of one row) is one 16-byte LDS read for either operand.
+// W is fed as the MFMA "A" operand and the activations as "B", i.e. a wave computes C^T tiles: the 4 accumulator registers of a
+// lane are 4 CONSECUTIVE n of one output row m, so bias / residual / stores are 8- or 16-byte vector accesses.
+// Staging is LDS-DMA (global_load_lds_dwordx4) into a lane-linear image of 128-byte rows; the bank-conflict swizzle
+// chunk' = chunk ^ (row & 7) is applied on the per-lane SOURCE address and again on the ds_read address (cdna_hip_programming.md
+// rule 21).  Block -> tile maps are XCD-aware (blocks b, b + 8 share an L2) with a grouped raster.
+#pragma once
+#include "hgr_common.h"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace hgr_gemm {
+
+constexpr int BK = 64;
+
+struct GemmArgs {
+    const char *A; int64_t lda;
+    const char *W; int64_t ldw;
+    void *C; int64_t ldc;
+    const float *bias;
+    const float *res; int64_t ldr;
+    int M, N, K;
+    int tiles_m, tiles_n;
+    int m_fastest;   // 1: consecutive tile ids walk M first (W panel shared), 0: walk N first
+    int vec_ok;      // C / residual rows allow 4-element vector access
+    int dbg;         // diagnostics only (HGR_GEMM_DBG): 1 = skip MFMAs, 2 = skip LDS-DMA issue, 3 = skip epilogue
+    // implicit-GEMM 3x3 convolution (CONV kernels only): A is an NHWC image [B, H, W, C], pad 1
+    int cH, cW, cC, cStride, cHo, cWo;
+    unsigned cMagic;  // ceil(2^32 / cC): __umulhi(k, cMagic) == k / cC for every k < 9 * cC + 64 (k * cC < 2^32)
+    // split-K (gemm_nt_128 only): blockIdx.y = split s works on K columns [s * kc, min(K, (s + 1) * kc)) and writes its own
+    // fp32 partial C + s * csplit elements; 0 = off
+    int kc; int64_t csplit;
+    // LayerNorm folded into the GEMMs around it (gemm_nt_duo only, LN template parameter):
+    //   producer (LN = 1, x += A W^T + b): the residual stream is kept as a 16-bit pair (hi, lo) with x = hi + lo - 4 bytes per
+    //            element like fp32, and hi IS the next GEMM's A operand; per row and 64-column slot it also emits the partial
+    //            (sum, sum of squares) of the new values -> ln_stats [M][ln_slots][2]
+    //   consumer (LN = 2, y = LN(x) W^T + b): A is the un-normalised 16-bit x, W the gamma-folded weight,
+    //            y = rstd_m (acc - mean_m ln_s[n]) + ln_c[n] with row statistics from ln_stats (K = row width)
+    float *ln_stats; int ln_slots; float ln_eps;
+    void *ln_xh, *ln_xl; int64_t ln_ldx;      // producer: the residual stream as a 16-bit PAIR, x = hi + lo (hi in the MFMA type, lo f16)
+    const float *ln_s, *ln_c;
+    int group;       // gemm_nt_duo: row (or column) panels per raster group (HGR_GEMM_GROUP, default 4)
+    // fused evaluation (LN = 3, hgr_logits_eval): W = level-sorted, level-aligned class matrix, so every 64-column slice (one
+    // wave's share of a tile) lies inside ONE hierarchy level.  Nothing of C is written; per (row, slice) the epilogue emits
+    // the best train column as an orderable key and the largest value over the test columns.
+    unsigned long long *ev_key; float *ev_tmax, *ev_m2; int *ev_p1; const int *ev_tpos, *ev_epos; int ev_slices;
+};
+
+
+// 16 zero bytes every out-of-bounds conv tap (and the K padding) is loaded from; one copy per translation unit (no -fgpu-rdc)
+static __device__ __attribute__((aligned(16))) unsigned int hgr_zero_page[4] = {0u, 0u, 0u, 0u};
+
+// x * sigmoid(1.702 x) with v_exp_f32 + v_rcp_f32 (1 ulp each): an IEEE fp32 divide costs ~10 VALU ops per
+// element and, at 128 elements per lane, dominated the c_fc epilogue (measured 88 us of a 206 us launch).
+__device__ __forceinline__ float quick_gelu(float v) {
+    return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * v));
+}
+
+
+// the expression hgr_quickgelu16 (hgr_train.hip) evaluates, operation for operation: the dual-output forward must give its bits
+__device__ __forceinline__ float quick_gelu_train(float x) {
+    const float z = 1.702f * x;
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z));
+}
+// d/dx of quick_gelu: s (1 + 1.702 x (1 - s)), s = sigmoid(1.702 x) - the expression of hgr_quickgelu16's backward
+__device__ __forceinline__ float quick_gelu_grad(float x) {
+    const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * x));
+    return s * (1.0f + 1.702f * x * (1.0f - s));
+}
+__host__ __device__ constexpr bool epi_has_bias(int epi) { return epi != HGR_EPI_NONE && epi != HGR_EPI_ACCUM && epi != HGR_EPI_QGELU_GRAD16; }
+__host__ __device__ constexpr bool epi_has_idn16(int epi) { return epi == HGR_EPI_BIAS_ADD16_RELU || epi == HGR_EPI_QGELU_GRAD16; }
+
+// One lane's 4 consecutive outputs C[m][n .. n+3] of an accumulator tile: bias / QuickGELU / residual,
+// then a 16-byte (fp32) or 8-byte (16-bit) store; scalar tail only at the N edge or for odd strides.
+template <int DT, int EPI, bool OUT32>
+__device__ __forceinline__ void store_quad(const GemmArgs &p, f32x4 v, int m, int n) {
+    typedef typename T16<DT>::elem E;
+    if (n + 3 < p.N && p.vec_ok) {
+        if (epi_has_bias(EPI)) v += *(const f32x4 *)(p.bias + n);
+        if (EPI == HGR_EPI_ACCUM) v += *(const f32x4 *)((const float *)p.C + (int64_t)m * p.ldc + n);
+        if (EPI == HGR_EPI_BIAS_QUICKGELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
+        }
+        if (EPI == HGR_EPI_BIAS_RESIDUAL) v += *(const f32x4 *)(p.res + (int64_t)m * p.ldr + n);
+        if (epi_has_idn16(EPI)) {
+            const typename T16<DT>::vec4 idn = *(const typename T16<DT>::vec4 *)((const E *)(const void *)p.res + (int64_t)m * p.ldr + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = EPI == HGR_EPI_QGELU_GRAD16 ? v[e] * quick_gelu_grad((float)idn[e]) : v[e] + (float)idn[e];
+        }
+        if (EPI == HGR_EPI_BIAS_RELU || EPI == HGR_EPI_BIAS_ADD16_RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (OUT32) *(f32x4 *)((float *)p.C + (int64_t)m * p.ldc + n) = v;
+        else *(typename T16<DT>::vec4 *)((E *)p.C + (int64_t)m * p.ldc + n) = cvt4<DT>(v[0], v[1], v[2], v[3]);
+        return;
+    }
+    for (int e = 0; e < 4 && n + e < p.N; ++e) {
+        float x = v[e];
+        if (epi_has_bias(EPI)) x += p.bias[n + e];
+        if (EPI == HGR_EPI_ACCUM) x += ((const float *)p.C)[(int64_t)m * p.ldc + n + e];
+        if (EPI == HGR_EPI_BIAS_QUICKGELU) x = quick_gelu(x);
+        if (EPI == HGR_EPI_BIAS_RESIDUAL) x += p.res[(int64_t)m * p.ldr + n + e];
+        if (EPI == HGR_EPI_BIAS_ADD16_RELU) x += (float)((const E *)(const void *)p.res)[(int64_t)m * p.ldr + n + e];
+        if (EPI == HGR_EPI_QGELU_GRAD16) x *= quick_gelu_grad((float)((const E *)(const void *)p.res)[(int64_t)m * p.ldr + n + e]);
+        if (EPI == HGR_EPI_BIAS_RELU || EPI == HGR_EPI_BIAS_ADD16_RELU) x = fmaxf(x, 0.f);
+        if (OUT32) ((float *)p.C)[(int64_t)m * p.ldc + n + e] = x;
+        else ((E *)p.C)[(int64_t)m * p.ldc + n + e] = (E)x;
+    }
+}
+
+// Interior-tile forms (the caller guarantees vec_ok and that the whole quad is inside C).  The quad's second addend
+// (fp32 residual, 16-bit identity or the old C for ACCUM) is loaded by load_addend() and handed to store_quad_full():
+// callers fetch a batch of addends, then store the batch.  Interleaved load / store pairs serialise completely -
+// residual and C may alias, so hipcc keeps every load behind the previous store with a vmcnt(0) between them.
+template <int DT, int EPI>
+__device__ __forceinline__ f32x4 load_addend(const GemmArgs &p, int m, int n) {
+    typedef typename T16<DT>::elem E;
+    if (EPI == HGR_EPI_ACCUM) return *(const f32x4 *)((const float *)p.C + (int64_t)m * p.ldc + n);
+    if (EPI == HGR_EPI_BIAS_RESIDUAL) return *(const f32x4 *)(p.res + (int64_t)m * p.ldr + n);
+    if (epi_has_idn16(EPI)) {
+        const typename T16<DT>::vec4 idn = *(const typename T16<DT>::vec4 *)((const E *)(const void *)p.res + (int64_t)m * p.ldr + n);
+        return (f32x4){(float)idn[0], (float)idn[1], (float)idn[2], (float)idn[3]};
+    }
+    return (f32x4){0.f, 0.f, 0.f, 0.f};
+}
+
+template <int DT, int EPI, bool OUT32>
+__device__ __forceinline__ void store_quad_full(const GemmArgs &p, f32x4 v, f32x4 bq, f32x4 addend, int m, int n) {
+    typedef typename T16<DT>::elem E;
+    if (epi_has_bias(EPI)) v += bq;
+    if (EPI == HGR_EPI_BIAS_QUICKGELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
+    }
+    if (EPI == HGR_EPI_ACCUM || EPI == HGR_EPI_BIAS_RESIDUAL || EPI == HGR_EPI_BIAS_ADD16_RELU) v += addend;
+    if (EPI == HGR_EPI_QGELU_GRAD16) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= quick_gelu_grad(addend[e]);
+    }
+    if (EPI == HGR_EPI_BIAS_RELU || EPI == HGR_EPI_BIAS_ADD16_RELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    if (OUT32) *(f32x4 *)((float *)p.C + (int64_t)m * p.ldc + n) = v;
+    else *(typename T16<DT>::vec4 *)((E *)p.C + (int64_t)m * p.ldc + n) = cvt4<DT>(v[0], v[1], v[2], v[3]);
+}
+
+
+// R interval end: my share of the piece the NEXT read interval needs has landed (counted vmcnt), my own
+// ds_reads are complete (so the slot they read may be refilled), then the barrier.  M interval end: barrier.
+#define HGR_RWAIT(N) do { __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define HGR_RBAR() do { __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define HGR_MBAR() do { __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+
+// ---- launchers, one per translation unit (the kernels are templates; host code selects by value) ------------------------
+enum { V128_PLAIN = 0, V128_TALL = 1, V128_CONV = 2, V128_CONV_TALL = 3 };
+// gemm_nt_128 family.  PLAIN: epi any (K == 64 with 16-bit bias epilogues takes the one-stage variant); TALL: 256 x 64 tiles,
+// epi = BIAS_RELU, 16-bit out; CONV / CONV_TALL: implicit-GEMM 3x3 convolution, epi = BIAS_RELU or NONE, 16-bit out.
+void launch_128(const GemmArgs &a, int dtype, int epi, bool out32, int variant, dim3 grid, hipStream_t s);
+// gemm_nt_256: plain (any epi) or the implicit-GEMM convolution (BIAS_RELU, 16-bit out)
+void launch_256(const GemmArgs &a, int dtype, int epi, bool out32, bool conv, dim3 grid, hipStream_t s);
+// gemm_nt_duo: ln = 0 plain (any epi), 1 LayerNorm producer, 2 LayerNorm consumer (epi BIAS / BIAS_QUICKGELU), 3 evaluation
+// consumers (hgr_logits_eval), 4 dual output (pre-activation + QuickGELU)
+void launch_duo(const GemmArgs &a, int dtype, int epi, bool out32, int ln, dim3 grid, hipStream_t s);
+
+}  // namespace hgr_gemm

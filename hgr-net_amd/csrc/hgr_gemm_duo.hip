@@ -1,0 +1,722 @@
+// =================================================================================================
+// gemm_nt_duo: 256 (M) x 128 (N) x 64 tile, 256 threads = 4 waves as 2 (M) x 2 (N); a wave owns 128 x 64, the register
+// tile of gemm_nt_256 (128 accumulators, 4 quadrant phases per K-tile).  TWO workgroups share a CU: 80 KB of LDS and
+// <= 256 registers per wave each, one wave of each workgroup per SIMD.
+//
+// Why: at one workgroup per CU nothing overlaps a tile's prologue (first operand pieces) and epilogue (bias / fp32
+// residual loads, stores): ~14 us of a ~35 us tile at K = 768, and a whole round of 256 tiles stores (and, for the
+// residual epilogue, re-reads) its 33 - 67 MB in one burst.  A wave's stores and its LDS-DMA loads share one in-order
+// vmcnt, so a single persistent workgroup cannot hide them either (finding 3).  Two independent
+// workgroups per CU can: while one is in its epilogue or waits for operands, the other one's waves own the matrix
+// pipes of the same SIMDs.  No ping-pong groups inside a workgroup, so ONE barrier per phase (4 per K-tile).
+//
+// LDS: A0 (m-half-0 rows of both wave rows, 16 KB) and A1 (m-half 1) double-buffered, W0 / W1 (n-half 0 / 1 rows of both
+// wave columns, 8 KB each) single-buffered: 2 x 32 + 16 = 80 KB.  A piece's slot is refilled in the phase after the
+// barrier that follows its last read:
+//     ph1 reads W0(t), A0(t)   issues A1(t+1) x4           waits vmcnt(8)  : W1(t) landed
+//     ph2 reads W1(t)          issues W0(t+1) x2           waits vmcnt(14) : A1(t) landed
+//     ph3 reads A1(t)          issues W1(t+1) x2, A0(t+2) first half x2    (ph4 reads nothing new)
+//     ph4                      issues A0(t+2) second half x2   waits vmcnt(6) : W0(t+1), A0(t+1) landed
+// (xN = global_load_lds_dwordx4 instructions per thread; the counts are "my N youngest may still be in flight").
+// The activations are prefetched 5 - 7 phases ahead, the weights (L2 / MALL resident panels shared by every row panel)
+// 3 phases ahead; if a piece is late the partner workgroup's MFMAs fill the gap.
+// =================================================================================================
+#include "hgr_gemm_common.h"
+
+namespace hgr_gemm {
+
+constexpr int NTD = 256;
+constexpr int DUO_A0 = 0, DUO_A1 = 32768, DUO_W0 = 65536, DUO_W1 = 73728, DUO_LDS = 81920;
+
+// 16-byte store that does not keep the line in the XCD's L2 (sc1: write-through, line dropped): a tile's output is never
+// re-read by this launch, and 64 tiles in flight per XCD write as many bytes as the L2 holds (experiment: HGR_GEMM_DBG=8)
+__device__ __forceinline__ void store16_sc1(void *ptr, u32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
+}
+
+template <int DT, int EPI, bool OUT32, int LN = 0>
+__global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
+    typedef typename T16<DT>::vec8 vec8;
+    typedef typename T16<DT>::elem E;
+    if (p.kc) {                                   // split-K (see gemm_nt_128)
+        const int sp = blockIdx.y;
+        p.A += (int64_t)sp * p.kc * 2; p.W += (int64_t)sp * p.kc * 2;
+        p.C = (char *)p.C + (int64_t)sp * p.csplit * 4;
+        p.K = min(p.kc, p.K - sp * p.kc);
+    }
+    __shared__ __attribute__((aligned(1024))) char smem[DUO_LDS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 15, g = lane >> 4;
+
+    const int nwg = gridDim.x;
+    const int orig = blockIdx.x;
+    const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    const int GROUP = p.group;    // default 4: 64 tiles in flight per XCD = 4 row panels of 256 x 16 column panels of 128
+    int tm, tn;
+    if (p.m_fastest) {
+        const int per = GROUP * p.tiles_m, grp = wg / per, first = grp * GROUP;
+        const int gs = min(GROUP, p.tiles_n - first), loc = wg - grp * per;
+        tn = first + loc % gs; tm = loc / gs;
+    } else {
+        const int per = GROUP * p.tiles_n, grp = wg / per, first = grp * GROUP;
+        const int gs = min(GROUP, p.tiles_m - first), loc = wg - grp * per;
+        tm = first + loc % gs; tn = loc / gs;
+    }
+    const int m0 = tm * 256, n0 = tn * 128;
+
+    // per-lane source offsets (bytes from A / W; operands are < 4 GB, checked on the host) of the LDS-DMA instructions of
+    // one K-tile: 4 per A piece (32 piece rows each), 2 per W piece.  Piece row pr of A0 = tile row (pr / 64) * 128 + pr % 64,
+    // of W0 = tile row (pr / 32) * 64 + pr % 32; A1 / W1 = the same rows + 64 / + 32.  Source chunk ^= row & 7 (rule 21).
+    unsigned oA0[4], oA1[4], oW0[2], oW1[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int id = (i * 4 + wave) * 64 + lane;
+        const int pr = id >> 3, c = (id & 7) ^ (pr & 7);
+        const int ra = (pr >> 6) * 128 + (pr & 63);
+        oA0[i] = (unsigned)(((int64_t)min(m0 + ra, p.M - 1) * p.lda + c * 8) * 2);
+        oA1[i] = (unsigned)(((int64_t)min(m0 + ra + 64, p.M - 1) * p.lda + c * 8) * 2);
+        if (i < 2) {
+            const int rw = (pr >> 5) * 64 + (pr & 31);
+            oW0[i] = (unsigned)(((int64_t)min(n0 + rw, p.N - 1) * p.ldw + c * 8) * 2);
+            oW1[i] = (unsigned)(((int64_t)min(n0 + rw + 32, p.N - 1) * p.ldw + c * 8) * 2);
+        }
+    }
+    char *const ldsw = smem + wave * 1024;
+    // halves of an A piece: instructions [2h, 2h + 2)
+    auto issueA = [&](const unsigned (&off)[4], int slot_base, int t, int h) {
+        const char *base = p.A + (int64_t)t * 128;
+        char *dst = ldsw + slot_base + (t & 1) * 16384;
+#pragma unroll
+        for (int i = 2 * h; i < 2 * h + 2; ++i)
+            __builtin_amdgcn_global_load_lds((const AS1 void *)(base + off[i]), (AS3 void *)(dst + i * 4096), 16, 0, 0);
+    };
+    auto issueW = [&](const unsigned (&off)[2], int slot_base, int t) {
+        const char *base = p.W + (int64_t)t * 128;
+        char *dst = ldsw + slot_base;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((const AS1 void *)(base + off[i]), (AS3 void *)(dst + i * 4096), 16, 0, 0);
+    };
+
+    f32x4 acc[2][2][4][2];      // [m-half][n-half][m tile][n tile]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[a][b][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // LN consumer: thread t finalises the statistics of tile row t from the producer's per-slot partial sums.  Called in the
+    // epilogue, where its loads travel together with the bias / ln_s / ln_c loads (one exposed round trip per tile, covered
+    // by the partner workgroup); at kernel entry it would delay the first LDS-DMA by a memory round trip.
+    auto ln_row_stats = [&]() {
+        const f32x4 *sp = (const f32x4 *)(p.ln_stats + (int64_t)min(m0 + tid, p.M - 1) * p.ln_slots * 2);
+        float s1 = 0.f, s2 = 0.f;
+        // the usual row widths get all their loads issued back to back (a load inside a run-time loop is waited for on the spot:
+        // six dependent L2 round trips for width 768)
+        auto fixed = [&](auto nq_tag) {
+            constexpr int NQ = decltype(nq_tag)::value;
+            f32x4 t[NQ];
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) t[i] = sp[i];
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) { s1 += t[i][0] + t[i][2]; s2 += t[i][1] + t[i][3]; }
+        };
+        switch (p.ln_slots) {
+            case 4: fixed(std::integral_constant<int, 2>()); break;      // width 256
+            case 8: fixed(std::integral_constant<int, 4>()); break;      // 512
+            case 10: fixed(std::integral_constant<int, 5>()); break;     // 640
+            case 12: fixed(std::integral_constant<int, 6>()); break;     // 768
+            case 16: fixed(std::integral_constant<int, 8>()); break;     // 1024
+            default:
+                for (int i = 0; i < p.ln_slots / 2; ++i) { const f32x4 t = sp[i]; s1 += t[0] + t[2]; s2 += t[1] + t[3]; }
+        }
+        const float inv = 1.0f / (float)p.K;
+        const float mean = s1 * inv;
+        return make_float2(mean, rsqrtf(fmaxf(s2 * inv - mean * mean, 0.f) + p.ln_eps));
+    };
+    const int nk = p.K / 64;    // >= 2 (host guarantees)
+    // prologue in steady-state order: A0(0), A1(0), W0(0), W1(0), A0(1)
+    issueA(oA0, DUO_A0, 0, 0); issueA(oA0, DUO_A0, 0, 1);
+    issueA(oA1, DUO_A1, 0, 0); issueA(oA1, DUO_A1, 0, 1);
+    issueW(oW0, DUO_W0, 0); issueW(oW1, DUO_W1, 0);
+    issueA(oA0, DUO_A0, 1, 0); issueA(oA0, DUO_A0, 1, 1);
+    HGR_RWAIT(6);               // A0(0), W0(0) landed
+
+    const int offA = (wm * 64 + r) * 128;      // + m tile * 2048, within pieces A0 / A1
+    const int offW = (wn * 32 + r) * 128;      // + n tile * 2048, within pieces W0 / W1
+    const int sw0 = ((0 + g) ^ (r & 7)) * 16, sw1 = ((4 + g) ^ (r & 7)) * 16;
+    vec8 af[4][2], wf0[2][2], wf1[2][2];
+
+    // MODE 0: steady state (t + 2 < nk), 1: second-last K-tile, 2: last K-tile
+    auto ktile = [&](int t, auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        const char *bufA0 = smem + DUO_A0 + (t & 1) * 16384, *bufA1 = smem + DUO_A1 + (t & 1) * 16384;
+        // ---- ph1: Q(0,0) ----
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            wf0[j][0] = *(const vec8 *)(smem + DUO_W0 + offW + j * 2048 + sw0);
+            wf0[j][1] = *(const vec8 *)(smem + DUO_W0 + offW + j * 2048 + sw1);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            af[i][0] = *(const vec8 *)(bufA0 + offA + i * 2048 + sw0);
+            af[i][1] = *(const vec8 *)(bufA0 + offA + i * 2048 + sw1);
+        }
+        if (MODE <= 1) { issueA(oA1, DUO_A1, t + 1, 0); issueA(oA1, DUO_A1, t + 1, 1); }
+        if (MODE <= 1) HGR_RWAIT(8); else HGR_RWAIT(0);                 // W1(t) landed
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[0][0][i][j] = T16<DT>::mfma16(wf0[j][kk], af[i][kk], acc[0][0][i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        // ---- ph2: Q(0,1) ----
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            wf1[j][0] = *(const vec8 *)(smem + DUO_W1 + offW + j * 2048 + sw0);
+            wf1[j][1] = *(const vec8 *)(smem + DUO_W1 + offW + j * 2048 + sw1);
+        }
+        if (MODE <= 1) issueW(oW0, DUO_W0, t + 1);
+        if (MODE <= 1) HGR_RWAIT(14); else HGR_RBAR();                  // A1(t) landed
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[0][1][i][j] = T16<DT>::mfma16(wf1[j][kk], af[i][kk], acc[0][1][i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        // ---- ph3: Q(1,1) ----
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            af[i][0] = *(const vec8 *)(bufA1 + offA + i * 2048 + sw0);
+            af[i][1] = *(const vec8 *)(bufA1 + offA + i * 2048 + sw1);
+        }
+        if (MODE <= 1) issueW(oW1, DUO_W1, t + 1);
+        if (MODE == 0) issueA(oA0, DUO_A0, t + 2, 0);
+        __builtin_amdgcn_sched_barrier(0);                              // no barrier here: nothing is refilled before ph4's barrier that ph3 reads
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[1][1][i][j] = T16<DT>::mfma16(wf1[j][kk], af[i][kk], acc[1][1][i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        // ---- ph4: Q(1,0) ----
+        if (MODE == 0) issueA(oA0, DUO_A0, t + 2, 1);
+        if (MODE == 0) HGR_RWAIT(6); else if (MODE == 1) HGR_RWAIT(2);  // W0(t+1), A0(t+1) landed
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[1][0][i][j] = T16<DT>::mfma16(wf0[j][kk], af[i][kk], acc[1][0][i][j]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    for (int t = 0; t < nk - 2; ++t) ktile(t, std::integral_constant<int, 0>());
+    ktile(nk - 2, std::integral_constant<int, 1>());
+    ktile(nk - 1, std::integral_constant<int, 2>());
+    HGR_MBAR();                 // every wave's LDS reads are done, no DMA in flight: the staging area is free
+    // the epilogue is VALU / LDS work next to the partner workgroup's MFMA clusters (priority 1): run it above them, or its
+    // instructions only get the issue slots the matrix stream leaves over (HGR_GEMM_DBG bit 16 = off, for A/B runs)
+    if (!(p.dbg & 16)) __builtin_amdgcn_s_setprio(3);
+
+    // tile (a, b, i, j) of this lane holds C[m][n .. n+3],  m = m0 + wm*128 + a*64 + i*16 + r,  n = n0 + wn*64 + b*32 + j*16 + g*4
+    if (LN == 3) {
+        // Evaluation consumers in place of the C store (main.py:136-176 consuming model/clip_tree.py:331).  This wave's 128 rows x
+        // 64 columns are slice s = n0 / 64 + wn of every row; a lane holds, per row, 16 of the 64 columns (4 quads), the other
+        // 48 sit in the lanes r + 16, r + 32, r + 48.  key = (orderable(value) << 32) | (0x7fffffff - train position): unsigned
+        // max = "larger value, then smaller position" (the tie rule of logits[:, train_index].topk); 0 = no train column.
+        const int sl = (n0 >> 6) + wn;
+        int tp[2][2][4], ep[2][2][4];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + b * 32 + j * 16 + g * 4;
+            const int4 t4 = *(const int4 *)(p.ev_tpos + n), e4 = *(const int4 *)(p.ev_epos + n);
+            tp[b][j][0] = t4.x; tp[b][j][1] = t4.y; tp[b][j][2] = t4.z; tp[b][j][3] = t4.w;
+            ep[b][j][0] = e4.x; ep[b][j][1] = e4.y; ep[b][j][2] = e4.z; ep[b][j][3] = e4.w;
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned long long key = 0ull;
+            // per 16-column group (b, j) of the slice: largest test value, the test position of one element attaining it, and
+            // the second largest value (multiplicity counted: m2 == m1 when the maximum is attained twice)
+            f32x4 m1, m2;
+            int p1[4];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float x[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = acc[a][b][i][j][e] + 0.0f;             // -0 -> +0, as the row sweep of hgr_eval_rows does
+                    const unsigned u = __float_as_uint(v);
+                    const unsigned long long k2 = ((unsigned long long)(u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u)) << 32) | (unsigned)(0x7fffffff - tp[b][j][e]);
+                    if (tp[b][j][e] >= 0 && k2 > key) key = k2;
+                    x[e] = ep[b][j][e] >= 0 ? v : -INFINITY;
+                }
+                const float hi01 = fmaxf(x[0], x[1]), lo01 = fminf(x[0], x[1]), hi23 = fmaxf(x[2], x[3]), lo23 = fminf(x[2], x[3]);
+                const float top = fmaxf(hi01, hi23);
+                m1[b * 2 + j] = top;
+                m2[b * 2 + j] = fmaxf(fminf(hi01, hi23), fmaxf(lo01, lo23));
+                p1[b * 2 + j] = x[0] == top ? ep[b][j][0] : x[1] == top ? ep[b][j][1] : x[2] == top ? ep[b][j][2] : ep[b][j][3];
+            }
+#pragma unroll
+            for (int o = 16; o <= 32; o <<= 1) {
+                const unsigned hi = __shfl_xor((unsigned)(key >> 32), o), lo = __shfl_xor((unsigned)key, o);
+                const unsigned long long x = ((unsigned long long)hi << 32) | lo;
+                key = x > key ? x : key;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float o1 = __shfl_xor(m1[q], o), o2 = __shfl_xor(m2[q], o);
+                    const int op = __shfl_xor(p1[q], o);
+                    m2[q] = fmaxf(fminf(m1[q], o1), fmaxf(m2[q], o2));
+                    p1[q] = o1 > m1[q] ? op : p1[q];
+                    m1[q] = fmaxf(m1[q], o1);
+                }
+            }
+            const int m = m0 + wm * 128 + a * 64 + i * 16 + r;
+            if (g == 0 && m < p.M) {
+                const int64_t at = (int64_t)m * p.ev_slices + sl;
+                p.ev_key[at] = key;
+                *(f32x4 *)(p.ev_tmax + at * 4) = m1;
+                *(int4 *)(p.ev_p1 + at * 4) = make_int4(p1[0], p1[1], p1[2], p1[3]);
+                *(f32x4 *)(p.ev_m2 + at * 4) = m2;
+            }
+        }
+        return;
+    }
+    constexpr bool HAS_BIAS = epi_has_bias(EPI);
+    constexpr bool HAS_ADD = EPI == HGR_EPI_BIAS_RESIDUAL || EPI == HGR_EPI_ACCUM;
+    const bool full = p.vec_ok && m0 + 256 <= p.M && n0 + 128 <= p.N;
+    if (full && !OUT32 && (p.ldc & 7) == 0 && (EPI <= HGR_EPI_BIAS_QUICKGELU || EPI == HGR_EPI_BIAS_RELU)) {
+        // 16-bit output: the wave's 128 x 64 tile through its private LDS slice (rows of 128 B + 16 B pad), then full
+        // 128-byte lines with 16-byte stores (8 lanes per row, 8 rows per instruction)
+        constexpr int RS = 144;
+        char *my = smem + wave * (128 * RS);
+        f32x4 bq[2][2], lsq[2][2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + wn * 64 + b * 32 + j * 16 + g * 4;
+                if (LN == 2) { bq[b][j] = *(const f32x4 *)(p.ln_c + n); lsq[b][j] = *(const f32x4 *)(p.ln_s + n); }
+                else bq[b][j] = HAS_BIAS ? *(const f32x4 *)(p.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        float2 *lnrow = (float2 *)(smem + 4 * 128 * RS);      // 256 x (mean, rstd) behind the four staging slices
+        if (LN == 2) {
+            lnrow[tid] = ln_row_stats();
+            __syncthreads();
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+        float2 mr = make_float2(0.f, 1.f);
+        if (LN == 2) mr = lnrow[wm * 128 + a * 64 + i * 16 + r];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f32x4 v;
+            if (LN == 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(mr.y, acc[a][b][i][j][e] - mr.x * lsq[b][j][e], bq[b][j][e]);
+            } else v = acc[a][b][i][j] + bq[b][j];
+            if (EPI == HGR_EPI_BIAS_QUICKGELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
+            }
+            if (EPI == HGR_EPI_BIAS_RELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            *(typename T16<DT>::vec4 *)(my + (a * 64 + i * 16 + r) * RS + (b * 32 + j * 16 + g * 4) * 2) = cvt4<DT>(v[0], v[1], v[2], v[3]);
+        }
+        }
+        // addresses = wave-uniform 64-bit base + 32-bit per-lane byte offset (one VALU add per store; a 64-bit row * ldc product
+        // per access costs ~6 VALU instructions, and this epilogue competes with the partner workgroup for issue slots)
+        const int ch = lane & 7, rr = lane >> 3;
+        char *cw = (char *)p.C + ((int64_t)(m0 + wm * 128) * p.ldc + n0 + wn * 64) * 2;
+        const unsigned ldcB = (unsigned)p.ldc * 2u;
+        const unsigned cl = (unsigned)rr * ldcB + ch * 16;
+        if (p.dbg & 8) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) store16_sc1(cw + (cl + q * 8 * ldcB), *(const u32x4 *)(my + (q * 8 + rr) * RS + ch * 16));
+            return;
+        }
+        if (LN == 4) {
+            // training forward of the MLP: C keeps the pre-activation (backward needs it), ln_xh gets QuickGELU of the ROUNDED
+            // pre-activation - the bits hgr_quickgelu16 would produce from C in a second pass, without that pass
+            char *gw = (char *)p.ln_xh + ((int64_t)(m0 + wm * 128) * p.ln_ldx + n0 + wn * 64) * 2;
+            const unsigned ldgB = (unsigned)p.ln_ldx * 2u;
+            const unsigned gl = (unsigned)rr * ldgB + ch * 16;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const u32x4 v = *(const u32x4 *)(my + (q * 8 + rr) * RS + ch * 16);
+                *(u32x4 *)(cw + (cl + q * 8 * ldcB)) = v;
+                const vec8 h = __builtin_bit_cast(vec8, v);
+                vec8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (E)quick_gelu_train((float)h[e]);
+                *(u32x4 *)(gw + (gl + q * 8 * ldgB)) = __builtin_bit_cast(u32x4, o);
+            }
+            return;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            *(u32x4 *)(cw + (cl + q * 8 * ldcB)) = *(const u32x4 *)(my + (q * 8 + rr) * RS + ch * 16);
+        return;
+    }
+    if (full && !OUT32 && epi_has_idn16(EPI) && (p.ldc & 7) == 0 && (p.ldr & 7) == 0) {
+        // relu(acc + bias + 16-bit identity) -> 16 bit (bn3(conv3) ; out += identity ; relu, clip/model.py:46-52): the sum is
+        // formed in fp32 and rounded once.  4 passes of 32 rows through the wave's LDS slice (fp32 rows of 256 B + 16 B pad);
+        // on the way out a lane owns 8 consecutive columns of a row, so the identity is LOADED and the result STORED as
+        // 16 bytes per lane over whole 128-byte lines (8 lanes per row, 8 rows per instruction).
+        constexpr int RS = 272;
+        char *my = smem + wave * (32 * RS);
+        f32x4 bq[2][2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bq[b][j] = HAS_BIAS ? *(const f32x4 *)(p.bias + n0 + wn * 64 + b * 32 + j * 16 + g * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int r8 = lane >> 3, c8 = lane & 7;
+        const int64_t wrow = m0 + wm * 128, wcol = n0 + wn * 64;
+        char *cw = (char *)p.C + (wrow * p.ldc + wcol) * 2;
+        const char *iw = (const char *)p.res + (wrow * p.ldr + wcol) * 2;
+        const unsigned ldcB = (unsigned)p.ldc * 2u, ldiB = (unsigned)p.ldr * 2u;
+        const unsigned cl = r8 * ldcB + c8 * 16, il = r8 * ldiB + c8 * 16;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int ih = 0; ih < 2; ++ih) {
+            const int rl = a * 64 + ih * 32;
+            u32x4 idn[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) idn[q] = *(const u32x4 *)(iw + (il + (rl + q * 8) * ldiB));
+#pragma unroll
+            for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                *(f32x4 *)(my + (i2 * 16 + r) * RS + (b * 32 + j * 16 + g * 4) * 4) = acc[a][b][ih * 2 + i2][j] + bq[b][j];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 lo = *(const f32x4 *)(my + (q * 8 + r8) * RS + c8 * 32);
+                const f32x4 hi = *(const f32x4 *)(my + (q * 8 + r8) * RS + c8 * 32 + 16);
+                const typename T16<DT>::vec8 iv = __builtin_bit_cast(typename T16<DT>::vec8, idn[q]);
+                typename T16<DT>::vec8 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (EPI == HGR_EPI_QGELU_GRAD16) {          // dL/dpre = dL/dpost * g'(pre): the hgr_quickgelu16 backward, one rounding
+                        o[e] = (E)(lo[e] * quick_gelu_grad((float)iv[e]));
+                        o[e + 4] = (E)(hi[e] * quick_gelu_grad((float)iv[e + 4]));
+                    } else {
+                        o[e] = (E)fmaxf(lo[e] + (float)iv[e], 0.f);
+                        o[e + 4] = (E)fmaxf(hi[e] + (float)iv[e + 4], 0.f);
+                    }
+                }
+                *(u32x4 *)(cw + (cl + (rl + q * 8) * ldcB)) = __builtin_bit_cast(u32x4, o);
+            }
+        }
+        return;
+    }
+    if (full && OUT32 && (EPI == HGR_EPI_NONE || EPI == HGR_EPI_BIAS || HAS_ADD) &&
+        (LN == 1 || ((p.ldc & 3) == 0 && (!HAS_ADD || EPI == HGR_EPI_ACCUM || (p.ldr & 3) == 0)))) {
+        // fp32 output (+ fp32 residual / old C): 4 passes of 32 rows through the wave's private LDS slice (rows of 256 B +
+        // 16 B pad); every global access is then 16 bytes per lane over whole 256-byte row segments (2 full lines per row,
+        // 4 rows per instruction) instead of 64-byte fragments of 16 rows.  The pass's 8 addend loads are issued before its
+        // LDS round trip; residual and C may alias: a pass loads before it stores, and passes touch disjoint rows.
+        constexpr int RS = 272;
+        char *my = smem + wave * (32 * RS);
+        f32x4 bq[2][2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                bq[b][j] = HAS_BIAS ? *(const f32x4 *)(p.bias + n0 + wn * 64 + b * 32 + j * 16 + g * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int rq = lane >> 4, cq = lane & 15;           // row-in-group and 16-byte column chunk of this lane on the way out
+        // every global address below = wave-uniform 64-bit base + 32-bit per-lane byte offset (see the 16-bit epilogue)
+        const int64_t wrow = m0 + wm * 128, wcol = n0 + wn * 64;
+        if (LN == 1) {
+            // Producer of a folded LayerNorm.  The residual stream lives in memory as a 16-bit pair: x = hi + lo, hi = x rounded to
+            // the MFMA type (= the A operand of the next GEMM, no second copy of the stream), lo = f16(x - hi): |x - hi - lo| <=
+            // 2^-11 |x - hi| (2^-22 |x| with f16 hi, 2^-19 |x| with bf16 hi), far below the 16-bit rounding of every GEMM input.
+            // Same bytes as an fp32 read-modify-write.  Plus this wave's 64-column share of the rows' LayerNorm statistics; the
+            // 16 reduction chains of a pass (8 row groups x {sum, sum of squares}) advance stage by stage (DPP latencies overlap).
+            typedef typename T16<DT>::vec4 hvec4;
+            char *hw = (char *)p.ln_xh + (wrow * p.ln_ldx + wcol) * 2;
+            char *lw = (char *)p.ln_xl + (wrow * p.ln_ldx + wcol) * 2;
+            char *sw = (char *)(p.ln_stats + (wrow * p.ln_slots + (n0 >> 6) + wn) * 2);
+            const unsigned ldxB = (unsigned)p.ln_ldx * 2u, ldsB = (unsigned)p.ln_slots * 8u;
+            const unsigned xl = rq * ldxB + cq * 8, sl = rq * ldsB;
+            // the old pair of pass P + 1 is requested before pass P stores (passes touch disjoint rows; the compiler cannot hoist
+            // the loads itself, the pointers alias): one exposed memory round trip per tile instead of four
+            hvec4 ohb[2][8];
+            f16x4 olb[2][8];
+            auto pair_load = [&](int buf, int rl) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    ohb[buf][q] = *(const hvec4 *)(hw + (xl + (rl + q * 4) * ldxB));
+                    olb[buf][q] = *(const f16x4 *)(lw + (xl + (rl + q * 4) * ldxB));
+                }
+            };
+            pair_load(0, 0);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int ih = 0; ih < 2; ++ih) {
+                const int rl = a * 64 + ih * 32;
+                const int pb = ih;                               // pass a * 2 + ih uses buffer ih
+                hvec4 (&oh)[8] = ohb[pb];
+                f16x4 (&ol)[8] = olb[pb];
+                if (a * 2 + ih > 0 && (p.dbg & 64)) pair_load(pb, rl);        // HGR_GEMM_DBG bit 64: every pass loads for itself (A/B runs)
+#pragma unroll
+                for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    *(f32x4 *)(my + (i2 * 16 + r) * RS + (b * 32 + j * 16 + g * 4) * 4) = acc[a][b][ih * 2 + i2][j] + bq[b][j];
+                if (a * 2 + ih < 3 && !(p.dbg & 64)) pair_load(pb ^ 1, rl + 32);
+                f32x4 vq[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    vq[q] = *(const f32x4 *)(my + (q * 4 + rq) * RS + cq * 16);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) vq[q][e] += (float)oh[q][e] + (float)ol[q][e];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const hvec4 nh = cvt4<DT>(vq[q][0], vq[q][1], vq[q][2], vq[q][3]);
+                    f16x4 nl;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) nl[e] = (_Float16)(vq[q][e] - (float)nh[e]);
+                    *(hvec4 *)(hw + (xl + (rl + q * 4) * ldxB)) = nh;
+                    *(f16x4 *)(lw + (xl + (rl + q * 4) * ldxB)) = nl;
+                }
+                if (p.dbg & 32) continue;
+                float s1[8], s2[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    s1[q] = (vq[q][0] + vq[q][1]) + (vq[q][2] + vq[q][3]);
+                    s2[q] = (vq[q][0] * vq[q][0] + vq[q][1] * vq[q][1]) + (vq[q][2] * vq[q][2] + vq[q][3] * vq[q][3]);
+                }
+#define HGR_DPP_STAGE(CTRL) _Pragma("unroll") for (int q = 0; q < 8; ++q) { \
+                    s1[q] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1[q]), CTRL, 0xF, 0xF, true)); \
+                    s2[q] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s2[q]), CTRL, 0xF, 0xF, true)); }
+                HGR_DPP_STAGE(0xB1) HGR_DPP_STAGE(0x4E) HGR_DPP_STAGE(0x141) HGR_DPP_STAGE(0x140)
+#undef HGR_DPP_STAGE
+                if (cq == 0) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) *(float2 *)(sw + (sl + (rl + q * 4) * ldsB)) = make_float2(s1[q], s2[q]);
+                }
+            }
+            return;
+        }
+        const float *addp = EPI == HGR_EPI_ACCUM ? (const float *)p.C : p.res;
+        const int64_t ldadd = EPI == HGR_EPI_ACCUM ? p.ldc : p.ldr;
+        char *cw = (char *)p.C + (wrow * p.ldc + wcol) * 4;
+        const char *aw = (const char *)addp + (wrow * ldadd + wcol) * 4;
+        const unsigned ldcB = (unsigned)p.ldc * 4u, ldaB = (unsigned)ldadd * 4u;
+        const unsigned cl = rq * ldcB + cq * 16, al = rq * ldaB + cq * 16;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int ih = 0; ih < 2; ++ih) {
+            const int rl = a * 64 + ih * 32;                 // first row of the pass inside the wave's 128 rows
+            f32x4 ad[8];
+            if (HAS_ADD) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) ad[q] = *(const f32x4 *)(aw + (al + (rl + q * 4) * ldaB));
+            }
+#pragma unroll
+            for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                *(f32x4 *)(my + (i2 * 16 + r) * RS + (b * 32 + j * 16 + g * 4) * 4) = acc[a][b][ih * 2 + i2][j] + bq[b][j];
+            f32x4 vq[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                vq[q] = *(const f32x4 *)(my + (q * 4 + rq) * RS + cq * 16);
+                if (HAS_ADD) vq[q] += ad[q];
+            }
+            if (p.dbg & 8) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) store16_sc1(cw + (cl + (rl + q * 4) * ldcB), __builtin_bit_cast(u32x4, vq[q]));
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) *(f32x4 *)(cw + (cl + (rl + q * 4) * ldcB)) = vq[q];
+            }
+        }
+        return;
+    }
+    if (LN == 2) {
+        // edge tile of an LN consumer (rows beyond M; N is a multiple of 128 by the host's contract): same arithmetic, guarded rows
+        float2 *lnrow = (float2 *)smem;
+        lnrow[tid] = ln_row_stats();
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wm * 128 + a * 64 + i * 16 + r;
+            const float2 mr = lnrow[wm * 128 + a * 64 + i * 16 + r];
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + wn * 64 + b * 32 + j * 16 + g * 4;
+                const f32x4 sq = *(const f32x4 *)(p.ln_s + n), cq4 = *(const f32x4 *)(p.ln_c + n);
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = fmaf(mr.y, acc[a][b][i][j][e] - mr.x * sq[e], cq4[e]);
+                    if (EPI == HGR_EPI_BIAS_QUICKGELU) v[e] = quick_gelu(v[e]);
+                }
+                store_quad<DT, HGR_EPI_NONE, OUT32>(p, v, m, n);
+            }
+        }
+        return;
+    }
+    if (LN == 1) {
+        // edge tile of an LN producer: the same pass structure with guarded rows (a partial last row panel)
+        typedef typename T16<DT>::vec4 hvec4;
+        constexpr int RS = 272;
+        char *my = smem + wave * (32 * RS);
+        const int rq = lane >> 4, cq = lane & 15;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int ih = 0; ih < 2; ++ih) {
+            const int row0 = m0 + wm * 128 + a * 64 + ih * 32;
+#pragma unroll
+            for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                *(f32x4 *)(my + (i2 * 16 + r) * RS + (b * 32 + j * 16 + g * 4) * 4) =
+                    acc[a][b][ih * 2 + i2][j] + *(const f32x4 *)(p.bias + n0 + wn * 64 + b * 32 + j * 16 + g * 4);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int64_t row = row0 + q * 4 + rq;
+                f32x4 v = *(const f32x4 *)(my + (q * 4 + rq) * RS + cq * 16);
+                const bool ok = row < p.M;
+                const int64_t at = row * p.ln_ldx + n0 + wn * 64 + cq * 4;
+                if (ok) {
+                    const hvec4 oh = *(const hvec4 *)((const E *)p.ln_xh + at);
+                    const f16x4 ol = *(const f16x4 *)((const _Float16 *)p.ln_xl + at);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += (float)oh[e] + (float)ol[e];
+                }
+                const float s1 = row16_sum((v[0] + v[1]) + (v[2] + v[3]));
+                const float s2 = row16_sum((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]));
+                if (ok) {
+                    const hvec4 nh = cvt4<DT>(v[0], v[1], v[2], v[3]);
+                    f16x4 nl;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) nl[e] = (_Float16)(v[e] - (float)nh[e]);
+                    *(hvec4 *)((E *)p.ln_xh + at) = nh;
+                    *(f16x4 *)((_Float16 *)p.ln_xl + at) = nl;
+                    if (cq == 0) *(float2 *)(p.ln_stats + (row * p.ln_slots + (n0 >> 6) + wn) * 2) = make_float2(s1, s2);
+                }
+            }
+        }
+        return;
+    }
+    if (LN == 4) {
+        // edge tile of the dual-output forward (rows beyond M; N is a multiple of 128 by the host's contract)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wm * 128 + a * 64 + i * 16 + r;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + wn * 64 + b * 32 + j * 16 + g * 4;
+                const f32x4 v = acc[a][b][i][j] + *(const f32x4 *)(p.bias + n);
+                const typename T16<DT>::vec4 pre = cvt4<DT>(v[0], v[1], v[2], v[3]);
+                *(typename T16<DT>::vec4 *)((E *)p.C + (int64_t)m * p.ldc + n) = pre;
+                *(typename T16<DT>::vec4 *)((E *)p.ln_xh + (int64_t)m * p.ln_ldx + n) =
+                    cvt4<DT>(quick_gelu_train((float)pre[0]), quick_gelu_train((float)pre[1]), quick_gelu_train((float)pre[2]), quick_gelu_train((float)pre[3]));
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 128 + a * 64 + i * 16 + r;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + b * 32 + j * 16 + g * 4;
+            if (n < p.N) store_quad<DT, EPI, OUT32>(p, acc[a][b][i][j], m, n);
+        }
+    }
+}
+
+namespace {
+template <int DT>
+void launch_duo_dt(const GemmArgs &a, int epi, bool out32, int ln, dim3 grid, hipStream_t s) {
+    switch (ln) {
+        case 1: hipLaunchKernelGGL((gemm_nt_duo<DT, HGR_EPI_BIAS_RESIDUAL, true, 1>), grid, dim3(NTD), 0, s, a); return;
+        case 2:
+            if (epi == HGR_EPI_BIAS_QUICKGELU) hipLaunchKernelGGL((gemm_nt_duo<DT, HGR_EPI_BIAS_QUICKGELU, false, 2>), grid, dim3(NTD), 0, s, a);
+            else hipLaunchKernelGGL((gemm_nt_duo<DT, HGR_EPI_BIAS, false, 2>), grid, dim3(NTD), 0, s, a);
+            return;
+        case 3: hipLaunchKernelGGL((gemm_nt_duo<DT, HGR_EPI_NONE, true, 3>), grid, dim3(NTD), 0, s, a); return;
+        case 4: hipLaunchKernelGGL((gemm_nt_duo<DT, HGR_EPI_BIAS, false, 4>), grid, dim3(NTD), 0, s, a); return;
+        default: break;
+    }
+#define HGR_DUO(E) do { if (out32) hipLaunchKernelGGL((gemm_nt_duo<DT, E, true>), grid, dim3(NTD), 0, s, a); \
+                        else hipLaunchKernelGGL((gemm_nt_duo<DT, E, false>), grid, dim3(NTD), 0, s, a); } while (0)
+    switch (epi) {
+        case HGR_EPI_NONE: HGR_DUO(HGR_EPI_NONE); break;
+        case HGR_EPI_BIAS: HGR_DUO(HGR_EPI_BIAS); break;
+        case HGR_EPI_BIAS_QUICKGELU: HGR_DUO(HGR_EPI_BIAS_QUICKGELU); break;
+        case HGR_EPI_BIAS_RELU: HGR_DUO(HGR_EPI_BIAS_RELU); break;
+        case HGR_EPI_BIAS_ADD16_RELU: hipLaunchKernelGGL((gemm_nt_duo<DT, HGR_EPI_BIAS_ADD16_RELU, false>), grid, dim3(NTD), 0, s, a); break;
+        case HGR_EPI_ACCUM: hipLaunchKernelGGL((gemm_nt_duo<DT, HGR_EPI_ACCUM, true>), grid, dim3(NTD), 0, s, a); break;
+        case HGR_EPI_QGELU_GRAD16: hipLaunchKernelGGL((gemm_nt_duo<DT, HGR_EPI_QGELU_GRAD16, false>), grid, dim3(NTD), 0, s, a); break;
+        default: hipLaunchKernelGGL((gemm_nt_duo<DT, HGR_EPI_BIAS_RESIDUAL, true>), grid, dim3(NTD), 0, s, a); break;
+    }
+#undef HGR_DUO
+}
+}  // namespace
+
+void launch_duo(const GemmArgs &a, int dtype, int epi, bool out32, int ln, dim3 grid, hipStream_t s) {
+    if (dtype == HGR_BF16) launch_duo_dt<HGR_BF16>(a, epi, out32, ln, grid, s);
+    else launch_duo_dt<HGR_F16>(a, epi, out32, ln, grid, s);
+}
+
+}  // namespace hgr_gemm

@@ -103,7 +103,12 @@ class Evaluator:
         if group is not None:
             import torch.distributed as dist
             acc = acc.clone()
-            dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
+            from .parallel import native_comm
+            nc = native_comm() if acc.is_cuda else None
+            if nc is not None:
+                nc.allreduce(acc)                        # hgr_allreduce (fp64 sum) on the current stream
+            else:
+                dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
         return dict(zip(COUNTERS, acc.cpu().tolist()))
 
     def summary(self, group=None) -> str:

@@ -117,10 +117,12 @@ def train(opts, epoch, model, train_loader, num_batches, optimizer, optimizer2, 
         loss = model.train_batch(imgs, targets, opts.training_method, opts.sample_strategy)
         if group is not None and not overlapped:          # first step: the trainer did not exist before train_batch built it
             optimizer.allreduce(group)
-            if optimizer2 is not None and model.layer_weight.grad is not None:
-                import torch.distributed as dist          # <= 13 floats: keep the ranks' layer weights identical
-                dist.all_reduce(model.layer_weight.grad, op=dist.ReduceOp.SUM, group=group)
-                model.layer_weight.grad.div_(dist.get_world_size(group))
+        if group is not None and optimizer2 is not None and model.layer_weight.grad is not None:
+            # EVERY step, overlapped or not: layer_weight is not in the flat gradient buffer the hooks all-reduce, and ranks
+            # that step it with their local gradient weight the CE terms differently from then on (<= 13 floats)
+            import torch.distributed as dist
+            dist.all_reduce(model.layer_weight.grad, op=dist.ReduceOp.SUM, group=group)
+            model.layer_weight.grad.div_(dist.get_world_size(group))
         optimizer.step()                                  # clip_grad_norm_(params, 1.0) + AdamW, main.py:87-91
         if optimizer2 is not None:
             optimizer2.step()
@@ -181,6 +183,9 @@ def main(argv=None):
         torch.cuda.set_device(opts.device)
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{opts.device}"))
         group = dist.group.WORLD
+        if os.environ.get("HGR_COMM") == "native":              # C-ABI RCCL collectives for the blocking exchanges (hgr_net_amd.comm)
+            from . import comm
+            comm.init_from_torch(group)
     return run(opts, group=group)
 
 

@@ -21,6 +21,17 @@ import torch
 import torch.distributed as dist
 
 
+def native_comm():
+    """The libhgr RCCL communicator (hgr_net_amd.comm) when HGR_COMM=native selected it and it has been initialised
+    (bench.py / main.py do that right after the process group exists: the group only bootstraps the unique id); else None
+    and torch.distributed carries the collectives."""
+    import os
+    if os.environ.get("HGR_COMM") != "native":
+        return None
+    from . import comm
+    return comm if comm.active() else None
+
+
 def shard_bounds(n: int, world: int, rank: int) -> Tuple[int, int]:
     """Contiguous [lo, hi) of rank's rows; the first n % world ranks get one extra row."""
     q, r = divmod(n, world)
@@ -34,8 +45,11 @@ def all_gather_rows(local: torch.Tensor, n: int, group=None) -> torch.Tensor:
     sizes = [shard_bounds(n, world, r)[1] - shard_bounds(n, world, r)[0] for r in range(world)]
     tail = tuple(local.shape[1:])
     full = torch.empty((n,) + tail, dtype=local.dtype, device=local.device)
+    nc = native_comm() if local.is_cuda else None
     if len(set(sizes)) == 1:
-        if local.is_cuda:
+        if nc is not None:
+            nc.allgather(local.contiguous(), full.view((world,) + tuple(local.shape)))   # hgr_allgather: RCCL through the C ABI
+        elif local.is_cuda:
             dist.all_gather_into_tensor(full, local.contiguous(), group=group)   # one in-place RCCL all-gather
         else:
             dist.all_gather(list(full.chunk(world)), local.contiguous(), group=group)
@@ -44,8 +58,11 @@ def all_gather_rows(local: torch.Tensor, n: int, group=None) -> torch.Tensor:
     mx = max(sizes)
     pad = torch.zeros((mx,) + tail, dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
-    buf = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(buf, pad, group=group)
+    if nc is not None:
+        buf = list(nc.allgather(pad))
+    else:
+        buf = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(buf, pad, group=group)
     lo = 0
     for r in range(world):
         full[lo: lo + sizes[r]] = buf[r][: sizes[r]]
@@ -90,7 +107,11 @@ def allreduce_grads(params, group=None, bucket_bytes: int = 64 << 20) -> None:
         if not bucket:
             return
         flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p.data)).reshape(-1).float() for p in bucket])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        nc = native_comm() if flat.is_cuda else None
+        if nc is not None:
+            nc.allreduce(flat)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
         flat.mul_(1.0 / world)
         off = 0
         for p in bucket:

@@ -526,8 +526,13 @@ class FusedAdamW:
         import torch.distributed as dist
         self._relink()
         step = max(1, bucket_bytes // 4)
+        from .parallel import native_comm
+        nc = native_comm()
         for lo in range(0, self.gflat.numel(), step):
-            dist.all_reduce(self.gflat[lo: lo + step], op=dist.ReduceOp.SUM, group=group)
+            if nc is not None:
+                nc.allreduce(self.gflat[lo: lo + step])                      # hgr_allreduce: RCCL through the C ABI, current stream
+            else:
+                dist.all_reduce(self.gflat[lo: lo + step], op=dist.ReduceOp.SUM, group=group)
         self.grad_scale = 1.0 / dist.get_world_size(group)
 
     @torch.no_grad()

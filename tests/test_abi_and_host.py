@@ -282,3 +282,30 @@ def test_host_asan_build_of_the_abi_shim():
         pytest.skip("ASan driver not built (HGR_ASAN_TEST=1 builds it)")
     p = subprocess.run([str(drv)], capture_output=True, text=True, timeout=300, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1"))
     assert p.returncode == 0 and "0 failures" in p.stdout, p.stdout[-1500:] + p.stderr[-1500:]
+
+
+def test_comm_file_bootstrap_ignores_a_stale_id_file(tmp_path, monkeypatch):
+    """Round-2 advisor finding: a unique-id file left by an earlier run must not be fed to ncclCommInitRank.  The file carries the
+    run's nonce; rank 0 replaces whatever it finds, a waiting rank accepts only a file with THIS run's nonce and times out with a
+    diagnostic on a foreign one; rank 0's destroy() removes the file.  (No RCCL call: unique_id / init are stand-ins here.)"""
+    from hgr_net_amd import _lib, comm
+    seen = []
+    monkeypatch.setattr(comm, "unique_id", lambda: b"\x07" * comm.ID_BYTES)
+    monkeypatch.setattr(comm, "init", lambda rank, world, uid: seen.append((rank, world, bytes(uid))))
+    monkeypatch.setattr(_lib, "call", lambda *a, **k: 0)
+    path = str(tmp_path / "uid.bin")
+    with open(path, "wb") as f:                                   # what an earlier run left behind: same size, other nonce
+        f.write(comm._run_nonce("earlier run") + b"\x09" * comm.ID_BYTES)
+    with pytest.raises(_lib.HgrError, match="stale"):
+        comm.init_from_file(path, rank=1, world=2, timeout_s=0.3, nonce="this run")
+    assert not seen
+    comm.init_from_file(path, rank=0, world=2, timeout_s=5.0, nonce="this run")       # replaces the stale file
+    comm.init_from_file(path, rank=1, world=2, timeout_s=5.0, nonce="this run")
+    assert seen == [(0, 2, b"\x07" * comm.ID_BYTES), (1, 2, b"\x07" * comm.ID_BYTES)]
+    comm.destroy()
+    assert not os.path.exists(path)
+    os.environ.pop("HGR_COMM_NONCE", None)
+    monkeypatch.setenv("MASTER_PORT", "29512")
+    a = comm._run_nonce(None)
+    monkeypatch.setenv("MASTER_PORT", "29513")
+    assert a != comm._run_nonce(None) and len(a) == 16

@@ -212,7 +212,7 @@ def test_config0_rn50_n1000_batch32_vs_cpu_oracle(tmp_path):
     lg = model(img.to(DEV), None).cpu().numpy()
     zsl = tree_ref.update_classifier(sd, tokens, trim=True)
     zerr = float(np.abs(model.zsl_weights.float().cpu().numpy() - zsl.numpy()).max())
-    print(f"[measured] ViT-B/32 N=1000 zsl_weights max |HIP - oracle| = {zerr:.2e}")
+    print(f"[measured] RN50 N=1000 zsl_weights max |HIP - oracle| = {zerr:.2e}")
     assert zerr < 1e-3, zerr
     ref = tree_ref.forward(sd, img, zsl).numpy()
     err = float(np.abs(lg - ref).max())
@@ -360,6 +360,44 @@ def test_batch512_forward_through_graph_vs_oracle_subsample(arch, nodes, tmp_pat
     assert err_full < 1e-3, f"{arch} batch 512: max |logit - full oracle| = {err_full:.3e}"
     print(f"\n[batch512 {arch}] max|logit-oracle| {err:.2e} (image oracle x HIP class matrix), {err_full:.2e} (both towers oracle, 2048 cols); "
           f"hit@1 equal {int(same.sum())}/48, decidable {int(decidable.sum())}, equal&decidable {int((same & decidable).sum())}")
+    # (3) the route bench.py TIMES - Evaluator.add_images -> tree_model.forward_eval -> hgr_logits_eval (no logits written) - at this
+    #     size through the real towers (main.py:136-176 consuming clip_tree.py:331): its top-20 / top-1 / per-level ids are, bit for
+    #     bit, those of forward() + hgr_eval_rows, and equal the ids derived from the ORACLE's logits wherever the oracle decides
+    #     by more than 2 x the measured logit error
+    ev = evaluate.Evaluator(model)
+    assert ev.fused_ok()
+    plan = ops.LogitsEvalPlan(ev.index)
+    lv_f, p1_f, pk_f = [t.clone() for t in model.forward_eval(dimg, plan, 20)]      # capture + replay
+    lv_f2, p1_f2, pk_f2 = model.forward_eval(dimg, plan, 20)                        # pure replay
+    assert torch.equal(lv_f, lv_f2) and torch.equal(p1_f, p1_f2) and torch.equal(pk_f, pk_f2)
+    lv_u, p1_u, pk_u = ops.eval_rows(lg, ev.index, 20)
+    assert torch.equal(pk_f, pk_u), "top-20 ids of the fused route differ from forward() + hgr_eval_rows"
+    assert torch.equal(p1_f, p1_u) and torch.equal(lv_f, lv_u)
+    tr = model.train_index.cpu()
+    depth = model.depth32.cpu().long()
+    pk_s, p1_s, lv_s = pk_f[rows.to(DEV)].cpu().long(), p1_f[rows.to(DEV)].cpu().long()[:, 0], lv_f[rows.to(DEV)].cpu().long()
+    top21 = ref[:, te].topk(21, dim=1)
+    gaps = top21.values[:, :-1] - top21.values[:, 1:]
+    dec20 = (gaps > 2 * err).all(dim=1)
+    assert bool((pk_s[dec20] == te[top21.indices[:, :20]][dec20]).all())
+    prefix = (gaps > 2 * err).long().cumprod(dim=1)                 # ranks decided so far: the decidable prefix of every row must agree
+    assert bool(((pk_s == te[top21.indices[:, :20]]) | (prefix == 0)).all())
+    t2 = ref[:, tr].topk(2, dim=1)
+    dec1 = (t2.values[:, 0] - t2.values[:, 1]) > 2 * err
+    assert bool((p1_s[dec1] == tr[t2.indices[:, 0]][dec1]).all())
+    lv_checked = 0
+    for l in range(ev.n_levels):
+        cols_l = tr[depth[tr] == l]
+        if cols_l.numel() < 2:
+            continue
+        v = ref[:, cols_l].topk(2, dim=1)
+        d_l = (v.values[:, 0] - v.values[:, 1]) > 2 * err
+        assert bool((lv_s[d_l, l] == cols_l[v.indices[:, 0]][d_l]).all()), f"level {l}"
+        lv_checked += int(d_l.sum())
+    assert lv_checked >= 48
+    print(f"[batch512 {arch}] fused route == forward() + eval_rows bit for bit on 512 rows; vs oracle ids: top-20 rows fully decidable "
+          f"{int(dec20.sum())}/48 equal, decided rank prefixes equal on all 48, train top-1 decidable {int(dec1.sum())}/48 equal, "
+          f"{lv_checked} decidable (row, level) arg-max ids equal")
 
 
 def test_graphs_survive_a_workspace_reallocation(golden_dir, tmp_path):

@@ -1,6 +1,6 @@
 """Child process of tests/test_gpu_multirank.py: one rank of a data-parallel evaluation / OM training step.
 
-    python dp_worker.py <eval|train> <out.pt>          (RANK / WORLD_SIZE / MASTER_* from the environment)
+    python dp_worker.py <eval|train|adaptive> <out.pt>  (RANK / WORLD_SIZE / MASTER_* from the environment)
 
 With HGR_TEST_ONE_GPU=1 every rank uses cuda:0 and the gloo backend (RCCL refuses two ranks on one device; the
 driver's real multi-GPU runs use RCCL).  WORLD_SIZE=1 runs the same code with no process group: the 1-rank reference
@@ -35,8 +35,49 @@ group = None
 if world > 1:
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group("gloo" if one_gpu else "nccl")
+    dist.init_process_group("gloo" if one_gpu else "nccl", **({} if one_gpu else {"device_id": torch.device(dev)}))
     group = dist.group.WORLD
+
+if mode == "native":
+    # libhgr's own RCCL communicator (include/hgr.h "Data-parallel collectives", hgr_net_amd.comm) against torch.distributed on the
+    # same data: all-reduce (sum, max; fp32 / fp64 / int32), all-gather, broadcast.  One rank per DEVICE (RCCL refuses two ranks
+    # on one); world 1 still goes through dlopen(librccl), ncclCommInitRank and the enum mapping of every call.
+    import torch.distributed as dist
+    from hgr_net_amd import comm
+    if group is None:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(dev))
+        group = dist.group.WORLD
+    comm.init_from_torch(group)
+    assert comm.active() and comm.world() == world and comm.rank() == rank
+    g = torch.Generator(device="cpu").manual_seed(100 + rank)
+    res = {}
+    for dt in (torch.float32, torch.float64, torch.int32):
+        x = (torch.randn(4099, generator=g) * 100).to(dt).to(dev)
+        for op, top in ((comm.SUM, dist.ReduceOp.SUM), (comm.MAX, dist.ReduceOp.MAX)):
+            a, b = x.clone(), x.clone()
+            comm.allreduce(a, op)
+            dist.all_reduce(b, op=top, group=group)
+            torch.cuda.synchronize()
+            res[f"allreduce_{dt}_{op}"] = bool(torch.equal(a, b)) if dt == torch.int32 or op == comm.MAX else bool(torch.allclose(a, b, rtol=1e-6, atol=1e-4))
+    loc = torch.randn(7, 33, generator=g).to(dev).half()
+    out = comm.allgather(loc)
+    ref = [torch.empty_like(loc) for _ in range(world)]
+    dist.all_gather(ref, loc, group=group)
+    torch.cuda.synchronize()
+    res["allgather"] = bool(torch.equal(out, torch.stack(ref)))
+    t = torch.full((1025,), float(rank + 1), device=dev)
+    comm.broadcast(t, root=world - 1)
+    torch.cuda.synchronize()
+    res["broadcast"] = bool((t == float(world)).all())
+    comm.destroy()
+    assert not comm.active()
+    if rank == 0:
+        torch.save(res, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(0)
 
 cfg = synth.CLIP_CONFIGS["small-vit"]
 sd = synth.clip_state_dict(cfg, 0)
@@ -48,7 +89,7 @@ tokens = synth.make_tokens(n, 11, cfg["vocab_size"])
 tmp = tempfile.mkdtemp(prefix="hgr_dp_")
 gp = os.path.join(tmp, "g.json")
 json.dump(edges, open(gp, "w"))
-opts = types.SimpleNamespace(device=dev, folder=tmp, exp_name="HGR", weights="equal", out_ratio=0.5, in_ratio=0.5, from_epoch=-1,
+opts = types.SimpleNamespace(device=dev, folder=tmp, exp_name="HGR", weights="adaptive" if mode == "adaptive" else "equal", out_ratio=0.5, in_ratio=0.5, from_epoch=-1,
                              graph_path=gp, arch="synthetic", fetch=False, load=False, load_path="none", scale=1.0, num_compare=12, k=1,
                              sample_strategy="topk", weighting="both", train_dtype="bf16")
 model = tree_model(opts, splits["all"], splits["rest"], node_tokens=tokens, clip_model=build_model(sd).to(dev))
@@ -69,6 +110,32 @@ if mode == "eval":
     summary = ev.summary(group)
     if rank == 0:
         torch.save({"counters": counters, "summary": summary, "zsl": model.zsl_weights.cpu()}, out_path)
+elif mode == "adaptive":
+    # hgr_net_amd.main.train itself (main.py:72-101) for THREE steps with --weights adaptive: from the second step on the CLIP
+    # gradients travel through the overlapped hooks, and layer_weight.grad (not in the flat buffer) must still be averaged
+    # on every step or the ranks' layer weights drift apart (round-2 advisor finding)
+    from hgr_net_amd import main as drv
+    from hgr_net_amd.training import FusedAdamW
+    from hgr_net_amd.utils import cosine_lr
+    opts.ref_quirks, opts.training_method, opts.sample_strategy, opts.print_freq = False, "OM", "topk", 10 ** 9
+    params = [p for nm, p in model.named_parameters() if p.requires_grad and nm != "layer_weight"]
+    opt = FusedAdamW(params, lr=1e-6, max_norm=1.0)
+    opt2 = torch.optim.SGD([model.layer_weight], lr=0.5)           # a large step: un-averaged gradients would show at once
+    lw0 = model.layer_weight.detach().clone()
+    steps, gb = 3, 8
+    random.seed(5)
+    loader = drv.synthetic_loader(model, model.train_index.tolist(), steps, gb // world, seed=3, rank=rank, world=world, shard_batch=True)
+    drv.train(opts, 0, model, loader, steps, opt, opt2, cosine_lr(opt, 1e-6, 0, steps), dev, group)
+    torch.cuda.synchronize()
+    lw = model.layer_weight.detach().clone()
+    every = [lw.cpu()]
+    if group is not None:
+        import torch.distributed as dist
+        box = [torch.empty_like(lw) for _ in range(world)]
+        dist.all_gather(box, lw)
+        every = [b.cpu() for b in box]
+    if rank == 0:
+        torch.save({"layer_weight": every, "initial": lw0.cpu()}, out_path)
 else:
     # one OM step on ONE single-class global batch sharded over the ranks with identical sampling seeds (H7)
     from hgr_net_amd.training import FusedAdamW
