@@ -24,6 +24,7 @@ _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 SIGNATURES = {
     "hgr_gemm_nt": [_p, _l, _p, _l, _p, _l, _p, _p, _l, _i, _i, _i, _i, _i, _i, _p],
     "hgr_gemm_set_tile": [_i],
+    "hgr_gemm_set_tail": [_i, _i],
     "hgr_im2col_patches": [_p, _p, _i, _i, _i, _i, _i, _p],
     "hgr_im2col_patches_ex": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "hgr_vit_assemble": [_p, _p, _p, _i, _i, _i, _p],
@@ -81,6 +82,7 @@ SIGNATURES = {
     "hgr_bn_unfold_grad": [_p, _l, _p, _p, _p, _p, _p, _f, _p, _p, _p, _i, _i, _i, _p],
     "hgr_csr_group_aggregate": [_p, _l, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _p, _p, _l, _i, _f, _i, _p],
     "hgr_gemm_nt_res_stats": [_p, _l, _p, _l, _p, _p, _l, _p, _p, _i, _i, _i, _i, _p],
+    "hgr_gemm_nt_res_stats_guard": [_p, _l, _p, _l, _p, _p, _l, _p, _p, _f, _p, _i, _i, _i, _i, _p],
     "hgr_gemm_nt_ln": [_p, _l, _p, _l, _p, _l, _p, _p, _p, _f, _i, _i, _i, _i, _i, _p],
     "hgr_gemm_nt_bias_gelu_dual": [_p, _l, _p, _l, _p, _l, _p, _l, _p, _i, _i, _i, _i, _p],
     "hgr_vit_embed_ln_stats": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p],

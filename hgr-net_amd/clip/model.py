@@ -181,7 +181,8 @@ def ln_fusable(w: int, m: int = 0) -> bool:
 
 
 def _run_blocks(x: Optional[torch.Tensor], blocks, heads: int, b: int, l: int, causal: bool, dt: torch.dtype, ws: _Workspace, tag: str,
-                taps: Optional[dict] = None, tap_prefix: str = "", pair=None, stats: Optional[torch.Tensor] = None):
+                taps: Optional[dict] = None, tap_prefix: str = "", pair=None, stats: Optional[torch.Tensor] = None,
+                flag: Optional[torch.Tensor] = None):
     """The residual stack (clip/model.py:185-188 per block).
 
     Fused form (``pair`` = (xh, xl): the residual stream as a 16-bit pair, x = xh + xl, with its LayerNorm slot statistics in
@@ -189,6 +190,7 @@ def _run_blocks(x: Optional[torch.Tensor], blocks, heads: int, b: int, l: int, c
     per block and no LayerNorm pass:
         QKV = LN-folded GEMM(xh) -> attention -> (xh, xl) += out GEMM (+ stats) -> u = LN-folded GEMM(xh, QuickGELU)
         -> (xh, xl) += proj GEMM (+ stats)
+    ``flag``: the producers' range guard (ops.gemm_nt_res_stats), see CLIP._ln_check.
     Otherwise, on the fp32 stream x [b*l, w]: LN -> QKV GEMM(+bias) -> attention -> out GEMM(+bias, +residual) -> LN -> fc
     GEMM(+bias, QuickGELU) -> proj GEMM(+bias, +residual): 7 launches per block."""
     m, w = (pair[0] if pair is not None else x).shape
@@ -201,9 +203,9 @@ def _run_blocks(x: Optional[torch.Tensor], blocks, heads: int, b: int, l: int, c
         for i, k in enumerate(blocks):
             ops.gemm_nt_ln(xh, k.wf_in, qkv, k.s_in, k.c_in, stats, k.eps1, tag="qkv")
             ops.mha(qkv, att, b, l, heads, causal)
-            ops.gemm_nt_res_stats(att, k.w_out, xh, xl, k.b_out, stats, tag="out")
+            ops.gemm_nt_res_stats(att, k.w_out, xh, xl, k.b_out, stats, tag="out", flag=flag)
             ops.gemm_nt_ln(xh, k.wf_fc, u16, k.s_fc, k.c_fc, stats, k.eps2, quickgelu=True, tag="fc")
-            ops.gemm_nt_res_stats(u16, k.w_proj, xh, xl, k.b_proj, stats, tag="proj")
+            ops.gemm_nt_res_stats(u16, k.w_proj, xh, xl, k.b_proj, stats, tag="proj", flag=flag)
             if taps is not None:
                 taps[f"{tap_prefix}.resblocks.{i}"] = (xh.float() + xl.float()).view(b, l, w)
         return None
@@ -383,6 +385,50 @@ class CLIP(nn.Module):
         self.text_chunk = 8192          # prompts per text-tower pass (bounds the workspace; result is chunk-invariant)
         self._prep: dict = {}
         self._ws = _Workspace()
+        # LayerNorm folding keeps the residual stream's high half in 16 bit; the reference keeps LayerNorm in fp32 because trained
+        # checkpoints carry outlier channels (clip/model.py:153-159).  Range guard: every producer GEMM reports a 64-column slot whose
+        # sum of squares leaves the safe range (or is inf / NaN) into _ln_flags[tower]; a tower whose flag trips runs unfused from
+        # then on (fp32 stream + separate LayerNorm launches = HGR_LN_FUSED=0 for that tower).
+        self._ln_flags: Optional[torch.Tensor] = None
+        self._ln_off: set = set()
+        self._ln_checked: dict = {}
+
+    # -- LayerNorm-folding range guard ------------------------------------------------------------
+    def _ln_flag(self, tower: str, dev) -> torch.Tensor:
+        if self._ln_flags is None or self._ln_flags.device != torch.device(dev):
+            self._ln_flags = torch.zeros(2, dtype=torch.int32, device=dev)
+        i = 0 if tower == "v" else 1
+        return self._ln_flags[i:i + 1]
+
+    def ln_guard_tripped(self) -> dict:
+        """{tower: largest offending slot sum of squares (inf / nan included)} of the towers whose folded residual stream left the
+        guarded range since the flags were last cleared; empty = in range.  One small D2H copy (synchronises)."""
+        if self._ln_flags is None:
+            return {}
+        bits = self._ln_flags.cpu().numpy().view(np.uint32)
+        vals = bits.view(np.float32)
+        return {t: float(vals[i]) for i, t in enumerate(("image", "text")) if bits[i]}
+
+    def _ln_check(self, tower: str, dev) -> bool:
+        """After the FIRST folded pass of a tower under the current weights (never inside a graph capture): read its flag; when it
+        tripped, switch the tower to the unfused path for good, say so, and tell the caller to recompute.  Later passes are not
+        checked in the hot loop (no synchronisation there); Evaluator.summary() reads the flags once more at the end."""
+        fp = self._prep.get("fp")
+        if self._ln_checked.get(tower) == fp or torch.cuda.is_current_stream_capturing():
+            return False
+        self._ln_checked[tower] = fp
+        i = 0 if tower == "v" else 1
+        bits = int(self._ln_flags[i].item()) & 0xFFFFFFFF
+        if not bits:
+            return False
+        worst = float(np.array([bits], dtype=np.uint32).view(np.float32)[0])
+        import warnings
+        warnings.warn(f"hgr_net_amd: the {'image' if tower == 'v' else 'text'} tower's residual stream left the range the 16-bit LayerNorm-folded path "
+                      f"is guarded for (a 64-column slot with sum of squares {worst:g} > {ops.LN_GUARD_SUMSQ:g}): this tower now runs with the fp32 "
+                      f"stream and separate LayerNorm launches (the HGR_LN_FUSED=0 path).")
+        self._ln_off.add(tower)
+        self._ln_flags[i] = 0
+        return True
 
     # -- reference surface ---------------------------------------------------------------------
     @property
@@ -449,7 +495,9 @@ class CLIP(nn.Module):
         out = torch.empty((b, v.output_dim), dtype=torch.float32, device=dev)
         ns = IMG_STREAMS if (taps is None and b >= 2 * IMG_STREAMS and b * (r // v.patch_size) ** 2 >= IMG_STREAMS_MIN_ROWS) else 1
         if ns == 1:
-            self._vit_forward(image, p, out, "v", taps, u8)
+            fused = self._vit_forward(image, p, out, "v", taps, u8)
+            if fused and self._ln_check("v", dev):
+                self._vit_forward(image, p, out, "v", taps, u8)          # the guard tripped: once more on the unfused path
             return out
         # The batch in ``ns`` independent slices on ``ns`` streams: the residual stack is a strict chain of launches, and a
         # launch whose tile count is not a multiple of the chip's workgroup slots ends in a partly empty round (N = 768 at
@@ -474,8 +522,9 @@ class CLIP(nn.Module):
             have.append(torch.cuda.Stream(device=dev))
         return have[:n]
 
-    def _vit_forward(self, image: torch.Tensor, p: dict, out: torch.Tensor, tag: str, taps: Optional[dict], u8: bool) -> None:
-        """VisionTransformer.forward (clip/model.py:219-236) of one slice of the batch on the current stream, features into ``out``."""
+    def _vit_forward(self, image: torch.Tensor, p: dict, out: torch.Tensor, tag: str, taps: Optional[dict], u8: bool) -> bool:
+        """VisionTransformer.forward (clip/model.py:219-236) of one slice of the batch on the current stream, features into ``out``.
+        Returns whether the LayerNorm-folded path ran."""
         v = self.visual
         dt, ws, dev = self.image_dtype, self._ws, image.device
         b, r = image.shape[0], v.input_resolution
@@ -490,14 +539,15 @@ class CLIP(nn.Module):
         pe = ws.get(tag + ".pe", (b * gg, w), torch.float32, dev)
         ops.gemm_nt(patches, p["conv_w_nhwc"] if u8 else p["conv_w"], pe, tag="patch")
         cls16 = ws.get(tag + ".cls16", (b, w), dt, dev)
-        if ln_fusable(w, b * l):
+        fused = ln_fusable(w, b * l) and "v" not in self._ln_off
+        if fused:
             xh = ws.get(tag + ".xh", (b * l, w), dt, dev)
             xl = ws.get(tag + ".xl", (b * l, w), torch.float16, dev)
             stats = ws.get(tag + ".stats", (b * l, w // 64, 2), torch.float32, dev)
             ops.vit_embed_ln_stats(pe, p["cls"], p["pos"], p["ln_pre"][0], p["ln_pre"][1], xh, xl, stats, b, gg)
             if taps is not None:
                 taps["visual.ln_pre"] = (xh.float() + xl.float()).view(b, l, w)
-            _run_blocks(None, p["vblocks"], w // 64, b, l, False, dt, ws, tag, taps, "visual.transformer", (xh, xl), stats)
+            _run_blocks(None, p["vblocks"], w // 64, b, l, False, dt, ws, tag, taps, "visual.transformer", (xh, xl), stats, self._ln_flag("v", dev))
             cls32 = ws.get(tag + ".cls32", (b, w), torch.float32, dev)
             ops.pair_rows_f32(xh, xl, cls32, row_mul=l)                          # the class tokens back in fp32 for ln_post
             ops.layernorm(cls32, p["ln_post"][0], p["ln_post"][1], cls16, rows=b)
@@ -509,6 +559,7 @@ class CLIP(nn.Module):
             _run_blocks(x, p["vblocks"], w // 64, b, l, False, dt, ws, tag, taps, "visual.transformer")
             ops.layernorm(x, p["ln_post"][0], p["ln_post"][1], cls16, rows=b, row_mul=l)
         ops.gemm_nt(cls16, p["proj_t"], out)
+        return fused
 
     @torch.no_grad()
     def encode_text(self, text: torch.Tensor, trim: bool = True, ctx: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -527,7 +578,8 @@ class CLIP(nn.Module):
         eot = torch.empty(n, dtype=torch.int32, device=dev)
         ops.eot_index(text, eot)
         l = int(eot.max().item()) + 1 if trim else ctx_len
-        for s in range(0, n, self.text_chunk):
+        s = 0
+        while s < n:
             e = min(n, s + self.text_chunk)
             c = e - s
             x = ws.get("t.x", (c * l, w), torch.float32, dev)
@@ -535,12 +587,15 @@ class CLIP(nn.Module):
             if ctx is not None:
                 ops.ctx_splice(x, ctx.detach().float().contiguous(), p["tpos"], c, l)
             f16 = ws.get("t.f16", (c, w), dt, dev)
-            if ln_fusable(w, c * l):
+            fused = ln_fusable(w, c * l) and "t" not in self._ln_off
+            if fused:
                 xh = ws.get("t.xh", (c * l, w), dt, dev)
                 xl = ws.get("t.xl", (c * l, w), torch.float16, dev)
                 stats = ws.get("t.stats", (c * l, w // 64, 2), torch.float32, dev)
                 ops.row_stats16(x, xh, xl, stats)
-                _run_blocks(None, p["tblocks"], w // 64, c, l, True, dt, ws, "t", pair=(xh, xl), stats=stats)
+                _run_blocks(None, p["tblocks"], w // 64, c, l, True, dt, ws, "t", pair=(xh, xl), stats=stats, flag=self._ln_flag("t", dev))
+                if self._ln_check("t", dev):
+                    continue                                             # the guard tripped: this chunk once more, unfused
                 e32 = ws.get("t.e32", (c, w), torch.float32, dev)
                 ops.pair_rows_f32(xh, xl, e32, row_mul=l, row_idx=eot[s:e])       # the EOT rows back in fp32 for ln_final
                 ops.layernorm(e32, p["ln_final"][0], p["ln_final"][1], f16, rows=c)
@@ -548,6 +603,7 @@ class CLIP(nn.Module):
                 _run_blocks(x, p["tblocks"], w // 64, c, l, True, dt, ws, "t")
                 ops.layernorm(x, p["ln_final"][0], p["ln_final"][1], f16, rows=c, row_mul=l, row_idx=eot[s:e])
             ops.gemm_nt(f16, p["tproj_t"], out[s:e])
+            s = e
         return out
 
     def forward(self, image, text):

@@ -21,6 +21,64 @@ int duo_dbg() {
     return d;
 }
 
+// Tail plan of gemm_nt_duo.  The chip runs 512 of its workgroups at a time (2 per CU); a launch of T > 512 full tiles that is not
+// a whole number of rounds ends in a partly empty round: the N = 768 residual producers of ViT-B/32 at batch 512 (600 tiles) spent
+// 25 - 29 % of their time with 88 workgroups on the chip (tools/round_staircase.py).  The plan gives the LAST row panels to half
+// tiles (128 x 128, dispatched after the full tiles): work of half the size fills the slots the full tiles free first.  Chosen by
+// list-scheduling the two tile kinds on 512 slots (a half tile priced at HGR_DUO_HALF_COST = 0.55 of a full one: half the MFMAs, the
+// same per-tile overhead) over the candidate panel counts; HGR_DUO_TAIL=0 switches it off, HGR_DUO_PB=n forces n full panels.
+struct DuoPlan { int big_panels, nbig, tiles_m_half, grid; };
+int tail_env = -2, pb_env = -2;              // hgr_gemm_set_tail / HGR_DUO_TAIL, HGR_DUO_PB
+double half_cost = 0.55;
+DuoPlan duo_plan(int M, int N, bool allow_tail) {
+    if (tail_env == -2) {
+        const char *e = getenv("HGR_DUO_TAIL"); tail_env = e ? atoi(e) : 1;
+        const char *f = getenv("HGR_DUO_PB"); pb_env = f ? atoi(f) : -1;
+        const char *h = getenv("HGR_DUO_HALF_COST"); if (h && atof(h) > 0.1) half_cost = atof(h);
+    }
+    const int tiles_m = (M + 255) / 256, tiles_n = (N + 127) / 128, S = 512;
+    const int64_t T = (int64_t)tiles_m * tiles_n;
+    DuoPlan best{tiles_m, (int)T, 0, (int)T};
+    if (!allow_tail || !tail_env || T <= S || T % S == 0) return best;
+    auto makespan = [&](int pb) {
+        const int64_t nb = (int64_t)pb * tiles_n;
+        const int mh = M - pb * 256;
+        int64_t nh = mh > 0 ? (int64_t)((mh + 127) / 128) * tiles_n : 0;
+        const int64_t q = nb / S, rem = nb % S;
+        double tE = (double)q, tL = (double)q + 1.0;         // S - rem slots are free at q, rem slots at q + 1
+        int64_t nE = S - rem, nL = rem;
+        double end = rem ? tL : tE;
+        if (!nb) end = 0.0;
+        while (nh > 0) {
+            const bool useE = nE > 0 && (nL == 0 || tE <= tL);
+            double &t = useE ? tE : tL;
+            const int64_t k = useE ? nE : nL;
+            t += half_cost;
+            if (t > end) end = t;
+            nh -= k;
+        }
+        return end;
+    };
+    int pick = tiles_m;
+    double bm = makespan(tiles_m);
+    if (pb_env >= 0) pick = pb_env < tiles_m ? pb_env : tiles_m;
+    else
+        for (int pb = tiles_m - 1; pb >= 0 && pb >= tiles_m - 96; --pb) {
+            const double m = makespan(pb);
+            if (m < bm - 1e-9) { bm = m; pick = pb; }
+        }
+    if (pick == tiles_m) return best;
+    const int mh = M - pick * 256;
+    best.big_panels = pick; best.nbig = pick * tiles_n; best.tiles_m_half = (mh + 127) / 128;
+    best.grid = best.nbig + best.tiles_m_half * tiles_n;
+    return best;
+}
+void duo_apply_plan(GemmArgs &a, bool allow_tail, dim3 &grid) {
+    const DuoPlan pl = duo_plan(a.M, a.N, allow_tail);
+    a.nbig = pl.nbig; a.big_panels = pl.big_panels; a.tiles_m_half = pl.tiles_m_half;
+    grid = dim3((unsigned)pl.grid);
+}
+
 // tile plan override (hgr_gemm_set_tile); HGR_GEMM_TILE=128|256|2 sets the initial value
 int g_force_tile = -1;
 int hgr_gemm_force_tile() {
@@ -29,6 +87,14 @@ int hgr_gemm_force_tile() {
 }
 
 }  // namespace
+
+extern "C" int hgr_gemm_set_tail(int enabled, int full_panels) {
+    HGR_REQUIRE((enabled == 0 || enabled == 1) && full_panels >= -1, "hgr_gemm_set_tail: enabled must be 0 or 1, full_panels >= -1 (-1 = choose), got %d, %d", enabled, full_panels);
+    duo_plan(1, 1, false);                       // reads the environment once, so that it cannot overwrite this call later
+    const int prev = tail_env;
+    tail_env = enabled; pb_env = full_panels;
+    return prev;
+}
 
 extern "C" int hgr_gemm_set_tile(int tile) {
     HGR_REQUIRE(tile == 0 || tile == 128 || tile == 256 || tile == 2, "hgr_gemm_set_tile: tile must be 0, 128, 256 or 2 (256 x 128 tiles, two workgroups per CU), got %d", tile);
@@ -121,7 +187,9 @@ extern "C" int hgr_gemm_nt(const void *A, int64_t lda, const void *W, int64_t ld
         a.tiles_m = (M + 255) / 256; a.tiles_n = (N + 127) / 128;
         a.m_fastest = ((int64_t)N * K > (int64_t)M * K) ? 1 : 0;
         a.vec_ok = vec ? 1 : 0; a.dbg = dbg; a.kc = 0; a.csplit = 0; a.group = duo_group();
-        launch_duo(a, dtype, epilogue, out_f32 != 0, 0, dim3((unsigned)(a.tiles_m * a.tiles_n)), s);
+        dim3 grid;
+        duo_apply_plan(a, true, grid);
+        launch_duo(a, dtype, epilogue, out_f32 != 0, 0, grid, s);
     };
     // Plan choice for the shapes gemm_nt_duo covers: measured (tools/gemm_plan_ab.py, same-process A/B, f16, one MI355X; bit-identical
     // outputs): qkv 97 -> 91 us, out-proj 59 -> 49, c_fc 136 -> 124, c_proj 145 -> 126, patch 124 -> 118, class logits 24.7 -> 20.7,
@@ -242,13 +310,20 @@ void ln_args(GemmArgs &a, const void *A, int64_t lda, const void *W, int64_t ldw
     a.M = M; a.N = N; a.K = K; a.tiles_m = (M + 255) / 256; a.tiles_n = N / 128;
     a.m_fastest = ((int64_t)N * K > (int64_t)M * K) ? 1 : 0; a.vec_ok = 1; a.dbg = duo_dbg(); a.kc = 0; a.csplit = 0; a.group = duo_group();
     a.cH = a.cW = a.cC = a.cStride = a.cHo = a.cWo = 0; a.cMagic = 0;
-    a.ln_stats = nullptr; a.ln_slots = 0; a.ln_eps = 0.f; a.ln_xh = a.ln_xl = nullptr; a.ln_ldx = 0; a.ln_s = a.ln_c = nullptr;
+    a.ln_stats = nullptr; a.ln_slots = 0; a.ln_eps = 0.f; a.ln_xh = a.ln_xl = nullptr; a.ln_ldx = 0; a.ln_s = a.ln_c = nullptr; a.ln_flag = nullptr; a.ln_guard = 0.f;
 }
 }  // namespace
 
 extern "C" int hgr_gemm_nt_res_stats(const void *A, int64_t lda, const void *W, int64_t ldw, void *xh, void *xl, int64_t ldx,
                                      const float *bias, float *stats, int M, int N, int K, int dtype, void *stream) {
+    return hgr_gemm_nt_res_stats_guard(A, lda, W, ldw, xh, xl, ldx, bias, stats, 0.f, nullptr, M, N, K, dtype, stream);
+}
+
+extern "C" int hgr_gemm_nt_res_stats_guard(const void *A, int64_t lda, const void *W, int64_t ldw, void *xh, void *xl, int64_t ldx,
+                                           const float *bias, float *stats, float guard_sumsq, uint32_t *flag,
+                                           int M, int N, int K, int dtype, void *stream) {
     if (int rc = ln_common_checks("hgr_gemm_nt_res_stats", A, lda, W, ldw, M, N, K, dtype)) return rc;
+    HGR_REQUIRE(!flag || (guard_sumsq > 0.f && hgr_aligned(flag, 4)), "hgr_gemm_nt_res_stats_guard: flag needs guard_sumsq > 0 and 4-byte alignment");
     HGR_REQUIRE(xh && xl && bias && stats, "hgr_gemm_nt_res_stats: null xh / xl / bias / stats");
     HGR_REQUIRE(ldx >= N && ldx % 4 == 0 && ldx < (1 << 20) && hgr_aligned(xh, 8) && hgr_aligned(xl, 8), "hgr_gemm_nt_res_stats: xh / xl must be 8-byte aligned, ldx %% 4 == 0, ldx < 2^20");
     HGR_REQUIRE(hgr_aligned(bias, 16) && hgr_aligned(stats, 8), "hgr_gemm_nt_res_stats: bias must be 16-byte, stats 8-byte aligned");
@@ -256,7 +331,10 @@ extern "C" int hgr_gemm_nt_res_stats(const void *A, int64_t lda, const void *W, 
     ln_args(a, A, lda, W, ldw, nullptr, 0, M, N, K);
     a.bias = bias;
     a.ln_stats = stats; a.ln_slots = N / 64; a.ln_xh = xh; a.ln_xl = xl; a.ln_ldx = ldx;
-    launch_duo(a, dtype, HGR_EPI_BIAS_RESIDUAL, true, 1, dim3((unsigned)(a.tiles_m * a.tiles_n)), (hipStream_t)stream);
+    a.ln_flag = flag; a.ln_guard = guard_sumsq;
+    dim3 grid;
+    duo_apply_plan(a, true, grid);
+    launch_duo(a, dtype, HGR_EPI_BIAS_RESIDUAL, true, 1, grid, (hipStream_t)stream);
     HGR_CHECK_LAUNCH("hgr_gemm_nt_res_stats");
     return HGR_OK;
 }
@@ -273,7 +351,9 @@ extern "C" int hgr_gemm_nt_ln(const void *X16, int64_t ldx, const void *Wfold, i
     GemmArgs a;
     ln_args(a, X16, ldx, Wfold, ldw, C, ldc, M, N, K);
     a.ln_stats = const_cast<float *>(stats); a.ln_slots = K / 64; a.ln_eps = eps; a.ln_s = ln_s; a.ln_c = ln_c;
-    launch_duo(a, dtype, act ? HGR_EPI_BIAS_QUICKGELU : HGR_EPI_BIAS, false, 2, dim3((unsigned)(a.tiles_m * a.tiles_n)), (hipStream_t)stream);
+    dim3 grid;
+    duo_apply_plan(a, true, grid);
+    launch_duo(a, dtype, act ? HGR_EPI_BIAS_QUICKGELU : HGR_EPI_BIAS, false, 2, grid, (hipStream_t)stream);
     HGR_CHECK_LAUNCH("hgr_gemm_nt_ln");
     return HGR_OK;
 }
@@ -287,7 +367,9 @@ extern "C" int hgr_gemm_nt_bias_gelu_dual(const void *A, int64_t lda, const void
     GemmArgs a;
     ln_args(a, A, lda, W, ldw, pre, ldpre, M, N, K);
     a.bias = bias; a.ln_xh = post; a.ln_ldx = ldpost;
-    launch_duo(a, dtype, HGR_EPI_BIAS, false, 4, dim3((unsigned)(a.tiles_m * a.tiles_n)), (hipStream_t)stream);
+    dim3 grid;
+    duo_apply_plan(a, true, grid);
+    launch_duo(a, dtype, HGR_EPI_BIAS, false, 4, grid, (hipStream_t)stream);
     HGR_CHECK_LAUNCH("hgr_gemm_nt_bias_gelu_dual");
     return HGR_OK;
 }
@@ -323,7 +405,9 @@ extern "C" int hgr_logits_eval(const void *feat16, const void *zsl_perm16, int r
     a.ev_p1 = (int *)((char *)workspace + (size_t)rows * S * 24);
     a.ev_m2 = (float *)((char *)workspace + (size_t)rows * S * 40);
     a.ev_tpos = tpos_perm; a.ev_epos = epos_perm; a.ev_slices = S;
-    launch_duo(a, dtype, HGR_EPI_NONE, true, 3, dim3((unsigned)(a.tiles_m * a.tiles_n)), (hipStream_t)stream);
+    dim3 grid;
+    duo_apply_plan(a, false, grid);                    // the evaluation epilogue owns whole 256-row tiles
+    launch_duo(a, dtype, HGR_EPI_NONE, true, 3, grid, (hipStream_t)stream);
     HGR_CHECK_LAUNCH("hgr_logits_eval (tile stage)");
     return hgr_logits_eval_rows_launch(feat16, zsl_perm16, D, S, a.ev_key, a.ev_tmax, a.ev_p1, a.ev_m2, level_first, n_levels, filler_pos, train_cols, n_train,
                                        epos_perm, test_cols, n_test, k, out_level, out_top1, out_topk, rows, dtype, stream);

@@ -43,7 +43,13 @@ struct GemmArgs {
     float *ln_stats; int ln_slots; float ln_eps;
     void *ln_xh, *ln_xl; int64_t ln_ldx;      // producer: the residual stream as a 16-bit PAIR, x = hi + lo (hi in the MFMA type, lo f16)
     const float *ln_s, *ln_c;
+    // producer range guard: when a 64-column slot's sum of squares exceeds ln_guard (or is inf / NaN) its bit pattern is
+    // atomicMax'ed into *ln_flag (0 = the stream stayed in range); null = no guard
+    unsigned *ln_flag; float ln_guard;
     int group;       // gemm_nt_duo: row (or column) panels per raster group (HGR_GEMM_GROUP, default 4)
+    // gemm_nt_duo tail plan (duo_plan): blocks [0, nbig) = full 256 x 128 tiles on row panels [0, big_panels), the remaining blocks =
+    // 128 x 128 half tiles on the rows behind them (tiles_m_half panels of 128 rows).  No tail: nbig = grid, big_panels = tiles_m.
+    int nbig, big_panels, tiles_m_half;
     // fused evaluation (LN = 3, hgr_logits_eval): W = level-sorted, level-aligned class matrix, so every 64-column slice (one
     // wave's share of a tile) lies inside ONE hierarchy level.  Nothing of C is written; per (row, slice) the epilogue emits
     // the best train column as an orderable key and the largest value over the test columns.

@@ -34,40 +34,19 @@ __device__ __forceinline__ void store16_sc1(void *ptr, u32x4 v) {
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
 }
 
-template <int DT, int EPI, bool OUT32, int LN = 0>
-__global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
+// One output tile.  MH = 2: the 256 (M) x 128 (N) tile described above.  MH = 1: a HALF tile, 128 x 128 (m-half 0 only: a wave owns
+// 64 x 64, two phases per K-tile) for the row panels that do not fill a whole round of the chip's 512 workgroup slots - see
+// duo_plan() on the host side and the half-tile schedule below.
+template <int DT, int EPI, bool OUT32, int LN, int MH>
+__device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const int m0, const int n0) {
     typedef typename T16<DT>::vec8 vec8;
     typedef typename T16<DT>::elem E;
-    if (p.kc) {                                   // split-K (see gemm_nt_128)
-        const int sp = blockIdx.y;
-        p.A += (int64_t)sp * p.kc * 2; p.W += (int64_t)sp * p.kc * 2;
-        p.C = (char *)p.C + (int64_t)sp * p.csplit * 4;
-        p.K = min(p.kc, p.K - sp * p.kc);
-    }
-    __shared__ __attribute__((aligned(1024))) char smem[DUO_LDS];
-
+    constexpr int WR = 64 * MH;                    // rows of the tile one wave row owns
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 15, g = lane >> 4;
-
-    const int nwg = gridDim.x;
-    const int orig = blockIdx.x;
-    const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
-    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-    const int GROUP = p.group;    // default 4: 64 tiles in flight per XCD = 4 row panels of 256 x 16 column panels of 128
-    int tm, tn;
-    if (p.m_fastest) {
-        const int per = GROUP * p.tiles_m, grp = wg / per, first = grp * GROUP;
-        const int gs = min(GROUP, p.tiles_n - first), loc = wg - grp * per;
-        tn = first + loc % gs; tm = loc / gs;
-    } else {
-        const int per = GROUP * p.tiles_n, grp = wg / per, first = grp * GROUP;
-        const int gs = min(GROUP, p.tiles_m - first), loc = wg - grp * per;
-        tm = first + loc % gs; tn = loc / gs;
-    }
-    const int m0 = tm * 256, n0 = tn * 128;
 
     // per-lane source offsets (bytes from A / W; operands are < 4 GB, checked on the host) of the LDS-DMA instructions of
     // one K-tile: 4 per A piece (32 piece rows each), 2 per W piece.  Piece row pr of A0 = tile row (pr / 64) * 128 + pr % 64,
@@ -77,7 +56,7 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
     for (int i = 0; i < 4; ++i) {
         const int id = (i * 4 + wave) * 64 + lane;
         const int pr = id >> 3, c = (id & 7) ^ (pr & 7);
-        const int ra = (pr >> 6) * 128 + (pr & 63);
+        const int ra = MH == 2 ? (pr >> 6) * 128 + (pr & 63) : pr;          // half tile: piece row = tile row
         oA0[i] = (unsigned)(((int64_t)min(m0 + ra, p.M - 1) * p.lda + c * 8) * 2);
         oA1[i] = (unsigned)(((int64_t)min(m0 + ra + 64, p.M - 1) * p.lda + c * 8) * 2);
         if (i < 2) {
@@ -103,9 +82,9 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
             __builtin_amdgcn_global_load_lds((const AS1 void *)(base + off[i]), (AS3 void *)(dst + i * 4096), 16, 0, 0);
     };
 
-    f32x4 acc[2][2][4][2];      // [m-half][n-half][m tile][n tile]
+    f32x4 acc[MH][2][4][2];     // [m-half][n-half][m tile][n tile]
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < MH; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -143,92 +122,167 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
         return make_float2(mean, rsqrtf(fmaxf(s2 * inv - mean * mean, 0.f) + p.ln_eps));
     };
     const int nk = p.K / 64;    // >= 2 (host guarantees)
-    // prologue in steady-state order: A0(0), A1(0), W0(0), W1(0), A0(1)
-    issueA(oA0, DUO_A0, 0, 0); issueA(oA0, DUO_A0, 0, 1);
-    issueA(oA1, DUO_A1, 0, 0); issueA(oA1, DUO_A1, 0, 1);
-    issueW(oW0, DUO_W0, 0); issueW(oW1, DUO_W1, 0);
-    issueA(oA0, DUO_A0, 1, 0); issueA(oA0, DUO_A0, 1, 1);
-    HGR_RWAIT(6);               // A0(0), W0(0) landed
-
     const int offA = (wm * 64 + r) * 128;      // + m tile * 2048, within pieces A0 / A1
     const int offW = (wn * 32 + r) * 128;      // + n tile * 2048, within pieces W0 / W1
     const int sw0 = ((0 + g) ^ (r & 7)) * 16, sw1 = ((4 + g) ^ (r & 7)) * 16;
     vec8 af[4][2], wf0[2][2], wf1[2][2];
+    if constexpr (MH == 2) {
+        // prologue in steady-state order: A0(0), A1(0), W0(0), W1(0), A0(1)
+        issueA(oA0, DUO_A0, 0, 0); issueA(oA0, DUO_A0, 0, 1);
+        issueA(oA1, DUO_A1, 0, 0); issueA(oA1, DUO_A1, 0, 1);
+        issueW(oW0, DUO_W0, 0); issueW(oW1, DUO_W1, 0);
+        issueA(oA0, DUO_A0, 1, 0); issueA(oA0, DUO_A0, 1, 1);
+        HGR_RWAIT(6);               // A0(0), W0(0) landed
 
-    // MODE 0: steady state (t + 2 < nk), 1: second-last K-tile, 2: last K-tile
-    auto ktile = [&](int t, auto mode_tag) {
-        constexpr int MODE = decltype(mode_tag)::value;
-        const char *bufA0 = smem + DUO_A0 + (t & 1) * 16384, *bufA1 = smem + DUO_A1 + (t & 1) * 16384;
-        // ---- ph1: Q(0,0) ----
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            wf0[j][0] = *(const vec8 *)(smem + DUO_W0 + offW + j * 2048 + sw0);
-            wf0[j][1] = *(const vec8 *)(smem + DUO_W0 + offW + j * 2048 + sw1);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            af[i][0] = *(const vec8 *)(bufA0 + offA + i * 2048 + sw0);
-            af[i][1] = *(const vec8 *)(bufA0 + offA + i * 2048 + sw1);
-        }
-        if (MODE <= 1) { issueA(oA1, DUO_A1, t + 1, 0); issueA(oA1, DUO_A1, t + 1, 1); }
-        if (MODE <= 1) HGR_RWAIT(8); else HGR_RWAIT(0);                 // W1(t) landed
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[0][0][i][j] = T16<DT>::mfma16(wf0[j][kk], af[i][kk], acc[0][0][i][j]);
-        __builtin_amdgcn_s_setprio(0);
-        // ---- ph2: Q(0,1) ----
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            wf1[j][0] = *(const vec8 *)(smem + DUO_W1 + offW + j * 2048 + sw0);
-            wf1[j][1] = *(const vec8 *)(smem + DUO_W1 + offW + j * 2048 + sw1);
-        }
-        if (MODE <= 1) issueW(oW0, DUO_W0, t + 1);
-        if (MODE <= 1) HGR_RWAIT(14); else HGR_RBAR();                  // A1(t) landed
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[0][1][i][j] = T16<DT>::mfma16(wf1[j][kk], af[i][kk], acc[0][1][i][j]);
-        __builtin_amdgcn_s_setprio(0);
-        // ---- ph3: Q(1,1) ----
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            af[i][0] = *(const vec8 *)(bufA1 + offA + i * 2048 + sw0);
-            af[i][1] = *(const vec8 *)(bufA1 + offA + i * 2048 + sw1);
-        }
-        if (MODE <= 1) issueW(oW1, DUO_W1, t + 1);
-        if (MODE == 0) issueA(oA0, DUO_A0, t + 2, 0);
-        __builtin_amdgcn_sched_barrier(0);                              // no barrier here: nothing is refilled before ph4's barrier that ph3 reads
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[1][1][i][j] = T16<DT>::mfma16(wf1[j][kk], af[i][kk], acc[1][1][i][j]);
-        __builtin_amdgcn_s_setprio(0);
-        // ---- ph4: Q(1,0) ----
-        if (MODE == 0) issueA(oA0, DUO_A0, t + 2, 1);
-        if (MODE == 0) HGR_RWAIT(6); else if (MODE == 1) HGR_RWAIT(2);  // W0(t+1), A0(t+1) landed
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[1][0][i][j] = T16<DT>::mfma16(wf0[j][kk], af[i][kk], acc[1][0][i][j]);
-        __builtin_amdgcn_s_setprio(0);
-    };
 
-    for (int t = 0; t < nk - 2; ++t) ktile(t, std::integral_constant<int, 0>());
-    ktile(nk - 2, std::integral_constant<int, 1>());
-    ktile(nk - 1, std::integral_constant<int, 2>());
+        // MODE 0: steady state (t + 2 < nk), 1: second-last K-tile, 2: last K-tile
+        auto ktile = [&](int t, auto mode_tag) {
+            constexpr int MODE = decltype(mode_tag)::value;
+            const char *bufA0 = smem + DUO_A0 + (t & 1) * 16384, *bufA1 = smem + DUO_A1 + (t & 1) * 16384;
+            // ---- ph1: Q(0,0) ----
+    #pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                wf0[j][0] = *(const vec8 *)(smem + DUO_W0 + offW + j * 2048 + sw0);
+                wf0[j][1] = *(const vec8 *)(smem + DUO_W0 + offW + j * 2048 + sw1);
+            }
+    #pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i][0] = *(const vec8 *)(bufA0 + offA + i * 2048 + sw0);
+                af[i][1] = *(const vec8 *)(bufA0 + offA + i * 2048 + sw1);
+            }
+            if (MODE <= 1) { issueA(oA1, DUO_A1, t + 1, 0); issueA(oA1, DUO_A1, t + 1, 1); }
+            if (MODE <= 1) HGR_RWAIT(8); else HGR_RWAIT(0);                 // W1(t) landed
+            __builtin_amdgcn_s_setprio(1);
+    #pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+    #pragma unroll
+                for (int i = 0; i < 4; ++i)
+    #pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[0][0][i][j] = T16<DT>::mfma16(wf0[j][kk], af[i][kk], acc[0][0][i][j]);
+            __builtin_amdgcn_s_setprio(0);
+            // ---- ph2: Q(0,1) ----
+    #pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                wf1[j][0] = *(const vec8 *)(smem + DUO_W1 + offW + j * 2048 + sw0);
+                wf1[j][1] = *(const vec8 *)(smem + DUO_W1 + offW + j * 2048 + sw1);
+            }
+            if (MODE <= 1) issueW(oW0, DUO_W0, t + 1);
+            if (MODE <= 1) HGR_RWAIT(14); else HGR_RBAR();                  // A1(t) landed
+            __builtin_amdgcn_s_setprio(1);
+    #pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+    #pragma unroll
+                for (int i = 0; i < 4; ++i)
+    #pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[0][1][i][j] = T16<DT>::mfma16(wf1[j][kk], af[i][kk], acc[0][1][i][j]);
+            __builtin_amdgcn_s_setprio(0);
+            // ---- ph3: Q(1,1) ----
+    #pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i][0] = *(const vec8 *)(bufA1 + offA + i * 2048 + sw0);
+                af[i][1] = *(const vec8 *)(bufA1 + offA + i * 2048 + sw1);
+            }
+            if (MODE <= 1) issueW(oW1, DUO_W1, t + 1);
+            if (MODE == 0) issueA(oA0, DUO_A0, t + 2, 0);
+            __builtin_amdgcn_sched_barrier(0);                              // no barrier here: nothing is refilled before ph4's barrier that ph3 reads
+            __builtin_amdgcn_s_setprio(1);
+    #pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+    #pragma unroll
+                for (int i = 0; i < 4; ++i)
+    #pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[1][1][i][j] = T16<DT>::mfma16(wf1[j][kk], af[i][kk], acc[1][1][i][j]);
+            __builtin_amdgcn_s_setprio(0);
+            // ---- ph4: Q(1,0) ----
+            if (MODE == 0) issueA(oA0, DUO_A0, t + 2, 1);
+            if (MODE == 0) HGR_RWAIT(6); else if (MODE == 1) HGR_RWAIT(2);  // W0(t+1), A0(t+1) landed
+            __builtin_amdgcn_s_setprio(1);
+    #pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+    #pragma unroll
+                for (int i = 0; i < 4; ++i)
+    #pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[1][0][i][j] = T16<DT>::mfma16(wf0[j][kk], af[i][kk], acc[1][0][i][j]);
+            __builtin_amdgcn_s_setprio(0);
+        };
+
+        for (int t = 0; t < nk - 2; ++t) ktile(t, std::integral_constant<int, 0>());
+        ktile(nk - 2, std::integral_constant<int, 1>());
+        ktile(nk - 1, std::integral_constant<int, 2>());
+    } else {
+        // Half tile (128 x 128): two phases per K-tile, 8 LDS-DMA instructions per thread per K-tile.  LDS: A (16 KB) in THREE
+        // buffers at 0 / 16 K / 32 K (the activations come from HBM / Infinity Cache: prefetched two K-tiles ahead), W0 and W1
+        // (8 KB each) in TWO buffers each at 48 K.. (L2-resident weight panels, one K-tile ahead): 80 KB like the full tile.
+        //     ph1(t) reads W0(t), A(t)   issues W1(t+1) x2, A(t+2) x4   waits vmcnt(12) : W1(t) landed
+        //     ph2(t) reads W1(t)         issues W0(t+2) x2              waits vmcnt(8)  : A(t+1), W0(t+1) landed
+        // issue order ... W1(t), A(t+1) | W0(t+1) | W1(t+1), A(t+2) | W0(t+2) ...: a count = "my N youngest may still be in flight".
+        constexpr int HW0 = 49152, HW1 = 65536;
+        auto issueAh = [&](int t, int buf) {
+            const char *base = p.A + (int64_t)t * 128;
+            char *dst = ldsw + buf * 16384;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_global_load_lds((const AS1 void *)(base + oA0[i]), (AS3 void *)(dst + i * 4096), 16, 0, 0);
+        };
+        auto issueWh = [&](const unsigned (&off)[2], int slot_base, int t) {
+            const char *base = p.W + (int64_t)t * 128;
+            char *dst = ldsw + slot_base + (t & 1) * 8192;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                __builtin_amdgcn_global_load_lds((const AS1 void *)(base + off[i]), (AS3 void *)(dst + i * 4096), 16, 0, 0);
+        };
+        // prologue in steady-state order: A(0), W0(0), W1(0), A(1), W0(1)
+        issueAh(0, 0); issueWh(oW0, HW0, 0); issueWh(oW1, HW1, 0); issueAh(1, 1); issueWh(oW0, HW0, 1);
+        HGR_RWAIT(8);               // A(0), W0(0) landed
+        int ab = 0;                 // t % 3
+        auto ktile = [&](int t, auto mode_tag) {
+            constexpr int MODE = decltype(mode_tag)::value;      // 0: steady state (t + 2 < nk), 1: second-last K-tile, 2: last K-tile
+            const char *bufA = smem + ab * 16384;
+            const char *bufW0 = smem + HW0 + (t & 1) * 8192, *bufW1 = smem + HW1 + (t & 1) * 8192;
+            // ---- ph1: Q(0,0) ----
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                wf0[j][0] = *(const vec8 *)(bufW0 + offW + j * 2048 + sw0);
+                wf0[j][1] = *(const vec8 *)(bufW0 + offW + j * 2048 + sw1);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i][0] = *(const vec8 *)(bufA + offA + i * 2048 + sw0);
+                af[i][1] = *(const vec8 *)(bufA + offA + i * 2048 + sw1);
+            }
+            if (MODE <= 1) issueWh(oW1, HW1, t + 1);
+            if (MODE == 0) issueAh(t + 2, ab == 0 ? 2 : ab - 1);            // (t + 2) % 3: last read in ph1(t - 1), behind its barrier
+            if (MODE == 0) HGR_RWAIT(12); else if (MODE == 1) HGR_RWAIT(8); else HGR_RWAIT(0);      // W1(t) landed
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[0][0][i][j] = T16<DT>::mfma16(wf0[j][kk], af[i][kk], acc[0][0][i][j]);
+            __builtin_amdgcn_s_setprio(0);
+            // ---- ph2: Q(0,1) ----
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                wf1[j][0] = *(const vec8 *)(bufW1 + offW + j * 2048 + sw0);
+                wf1[j][1] = *(const vec8 *)(bufW1 + offW + j * 2048 + sw1);
+            }
+            if (MODE == 0) issueWh(oW0, HW0, t + 2);                        // buffer t & 1: W0(t) was read in ph1, behind its barrier
+            if (MODE == 0) HGR_RWAIT(8); else if (MODE == 1) HGR_RWAIT(2); else HGR_RBAR();         // A(t+1), W0(t+1) landed
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[0][1][i][j] = T16<DT>::mfma16(wf1[j][kk], af[i][kk], acc[0][1][i][j]);
+            __builtin_amdgcn_s_setprio(0);
+            ab = ab == 2 ? 0 : ab + 1;
+        };
+        for (int t = 0; t < nk - 2; ++t) ktile(t, std::integral_constant<int, 0>());
+        ktile(nk - 2, std::integral_constant<int, 1>());
+        ktile(nk - 1, std::integral_constant<int, 2>());
+    }
     HGR_MBAR();                 // every wave's LDS reads are done, no DMA in flight: the staging area is free
     // the epilogue is VALU / LDS work next to the partner workgroup's MFMA clusters (priority 1): run it above them, or its
     // instructions only get the issue slots the matrix stream leaves over (HGR_GEMM_DBG bit 16 = off, for A/B runs)
@@ -252,7 +306,7 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
             ep[b][j][0] = e4.x; ep[b][j][1] = e4.y; ep[b][j][2] = e4.z; ep[b][j][3] = e4.w;
         }
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < MH; ++a)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             unsigned long long key = 0ull;
@@ -293,7 +347,7 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
                     m1[q] = fmaxf(m1[q], o1);
                 }
             }
-            const int m = m0 + wm * 128 + a * 64 + i * 16 + r;
+            const int m = m0 + wm * WR + a * 64 + i * 16 + r;
             if (g == 0 && m < p.M) {
                 const int64_t at = (int64_t)m * p.ev_slices + sl;
                 p.ev_key[at] = key;
@@ -306,8 +360,8 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
     }
     constexpr bool HAS_BIAS = epi_has_bias(EPI);
     constexpr bool HAS_ADD = EPI == HGR_EPI_BIAS_RESIDUAL || EPI == HGR_EPI_ACCUM;
-    const bool full = p.vec_ok && m0 + 256 <= p.M && n0 + 128 <= p.N;
-    if (full && !OUT32 && (p.ldc & 7) == 0 && (EPI <= HGR_EPI_BIAS_QUICKGELU || EPI == HGR_EPI_BIAS_RELU)) {
+    const bool full = p.vec_ok && m0 + 2 * WR <= p.M && n0 + 128 <= p.N;
+    if (full && !OUT32 && (p.ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 && (EPI <= HGR_EPI_BIAS_QUICKGELU || EPI == HGR_EPI_BIAS_RELU)) {
         // 16-bit output: the wave's 128 x 64 tile through its private LDS slice (rows of 128 B + 16 B pad), then full
         // 128-byte lines with 16-byte stores (8 lanes per row, 8 rows per instruction)
         constexpr int RS = 144;
@@ -327,11 +381,11 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
             __syncthreads();
         }
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < MH; ++a)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
         float2 mr = make_float2(0.f, 1.f);
-        if (LN == 2) mr = lnrow[wm * 128 + a * 64 + i * 16 + r];
+        if (LN == 2) mr = lnrow[wm * WR + a * 64 + i * 16 + r];
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -355,22 +409,22 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
         // addresses = wave-uniform 64-bit base + 32-bit per-lane byte offset (one VALU add per store; a 64-bit row * ldc product
         // per access costs ~6 VALU instructions, and this epilogue competes with the partner workgroup for issue slots)
         const int ch = lane & 7, rr = lane >> 3;
-        char *cw = (char *)p.C + ((int64_t)(m0 + wm * 128) * p.ldc + n0 + wn * 64) * 2;
+        char *cw = (char *)p.C + ((int64_t)(m0 + wm * WR) * p.ldc + n0 + wn * 64) * 2;
         const unsigned ldcB = (unsigned)p.ldc * 2u;
         const unsigned cl = (unsigned)rr * ldcB + ch * 16;
         if (p.dbg & 8) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) store16_sc1(cw + (cl + q * 8 * ldcB), *(const u32x4 *)(my + (q * 8 + rr) * RS + ch * 16));
+            for (int q = 0; q < 8 * MH; ++q) store16_sc1(cw + (cl + q * 8 * ldcB), *(const u32x4 *)(my + (q * 8 + rr) * RS + ch * 16));
             return;
         }
         if (LN == 4) {
             // training forward of the MLP: C keeps the pre-activation (backward needs it), ln_xh gets QuickGELU of the ROUNDED
             // pre-activation - the bits hgr_quickgelu16 would produce from C in a second pass, without that pass
-            char *gw = (char *)p.ln_xh + ((int64_t)(m0 + wm * 128) * p.ln_ldx + n0 + wn * 64) * 2;
+            char *gw = (char *)p.ln_xh + ((int64_t)(m0 + wm * WR) * p.ln_ldx + n0 + wn * 64) * 2;
             const unsigned ldgB = (unsigned)p.ln_ldx * 2u;
             const unsigned gl = (unsigned)rr * ldgB + ch * 16;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
+            for (int q = 0; q < 8 * MH; ++q) {
                 const u32x4 v = *(const u32x4 *)(my + (q * 8 + rr) * RS + ch * 16);
                 *(u32x4 *)(cw + (cl + q * 8 * ldcB)) = v;
                 const vec8 h = __builtin_bit_cast(vec8, v);
@@ -382,11 +436,11 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
             return;
         }
 #pragma unroll
-        for (int q = 0; q < 16; ++q)
+        for (int q = 0; q < 8 * MH; ++q)
             *(u32x4 *)(cw + (cl + q * 8 * ldcB)) = *(const u32x4 *)(my + (q * 8 + rr) * RS + ch * 16);
         return;
     }
-    if (full && !OUT32 && epi_has_idn16(EPI) && (p.ldc & 7) == 0 && (p.ldr & 7) == 0) {
+    if (full && !OUT32 && epi_has_idn16(EPI) && (p.ldc & 7) == 0 && (p.ldr & 7) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.res) & 15) == 0) {
         // relu(acc + bias + 16-bit identity) -> 16 bit (bn3(conv3) ; out += identity ; relu, clip/model.py:46-52): the sum is
         // formed in fp32 and rounded once.  4 passes of 32 rows through the wave's LDS slice (fp32 rows of 256 B + 16 B pad);
         // on the way out a lane owns 8 consecutive columns of a row, so the identity is LOADED and the result STORED as
@@ -399,13 +453,13 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) bq[b][j] = HAS_BIAS ? *(const f32x4 *)(p.bias + n0 + wn * 64 + b * 32 + j * 16 + g * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
         const int r8 = lane >> 3, c8 = lane & 7;
-        const int64_t wrow = m0 + wm * 128, wcol = n0 + wn * 64;
+        const int64_t wrow = m0 + wm * WR, wcol = n0 + wn * 64;
         char *cw = (char *)p.C + (wrow * p.ldc + wcol) * 2;
         const char *iw = (const char *)p.res + (wrow * p.ldr + wcol) * 2;
         const unsigned ldcB = (unsigned)p.ldc * 2u, ldiB = (unsigned)p.ldr * 2u;
         const unsigned cl = r8 * ldcB + c8 * 16, il = r8 * ldiB + c8 * 16;
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < MH; ++a)
 #pragma unroll
         for (int ih = 0; ih < 2; ++ih) {
             const int rl = a * 64 + ih * 32;
@@ -456,7 +510,7 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
                 bq[b][j] = HAS_BIAS ? *(const f32x4 *)(p.bias + n0 + wn * 64 + b * 32 + j * 16 + g * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
         const int rq = lane >> 4, cq = lane & 15;           // row-in-group and 16-byte column chunk of this lane on the way out
         // every global address below = wave-uniform 64-bit base + 32-bit per-lane byte offset (see the 16-bit epilogue)
-        const int64_t wrow = m0 + wm * 128, wcol = n0 + wn * 64;
+        const int64_t wrow = m0 + wm * WR, wcol = n0 + wn * 64;
         if (LN == 1) {
             // Producer of a folded LayerNorm.  The residual stream lives in memory as a 16-bit pair: x = hi + lo, hi = x rounded to
             // the MFMA type (= the A operand of the next GEMM, no second copy of the stream), lo = f16(x - hi): |x - hi - lo| <=
@@ -481,8 +535,9 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
                 }
             };
             pair_load(0, 0);
+            unsigned gbits = 0u;                                  // range guard: largest slot sum of squares seen (as bits: inf / NaN rank highest)
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < MH; ++a)
 #pragma unroll
             for (int ih = 0; ih < 2; ++ih) {
                 const int rl = a * 64 + ih * 32;
@@ -497,7 +552,7 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     *(f32x4 *)(my + (i2 * 16 + r) * RS + (b * 32 + j * 16 + g * 4) * 4) = acc[a][b][ih * 2 + i2][j] + bq[b][j];
-                if (a * 2 + ih < 3 && !(p.dbg & 64)) pair_load(pb ^ 1, rl + 32);
+                if (a * 2 + ih < 2 * MH - 1 && !(p.dbg & 64)) pair_load(pb ^ 1, rl + 32);
                 f32x4 vq[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
@@ -519,7 +574,8 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     s1[q] = (vq[q][0] + vq[q][1]) + (vq[q][2] + vq[q][3]);
-                    s2[q] = (vq[q][0] * vq[q][0] + vq[q][1] * vq[q][1]) + (vq[q][2] * vq[q][2] + vq[q][3] * vq[q][3]);
+                    // explicit fused form: the full-tile and the edge-tile path must round alike (hipcc contracts a*a + b*b as it likes)
+                    s2[q] = __builtin_fmaf(vq[q][0], vq[q][0], vq[q][1] * vq[q][1]) + __builtin_fmaf(vq[q][2], vq[q][2], vq[q][3] * vq[q][3]);
                 }
 #define HGR_DPP_STAGE(CTRL) _Pragma("unroll") for (int q = 0; q < 8; ++q) { \
                     s1[q] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1[q]), CTRL, 0xF, 0xF, true)); \
@@ -528,9 +584,13 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
 #undef HGR_DPP_STAGE
                 if (cq == 0) {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) *(float2 *)(sw + (sl + (rl + q * 4) * ldsB)) = make_float2(s1[q], s2[q]);
+                    for (int q = 0; q < 8; ++q) {
+                        *(float2 *)(sw + (sl + (rl + q * 4) * ldsB)) = make_float2(s1[q], s2[q]);
+                        gbits = max(gbits, __float_as_uint(s2[q]));
+                    }
                 }
             }
+            if (p.ln_flag && gbits > __float_as_uint(p.ln_guard)) atomicMax(p.ln_flag, gbits);
             return;
         }
         const float *addp = EPI == HGR_EPI_ACCUM ? (const float *)p.C : p.res;
@@ -540,7 +600,7 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
         const unsigned ldcB = (unsigned)p.ldc * 4u, ldaB = (unsigned)ldadd * 4u;
         const unsigned cl = rq * ldcB + cq * 16, al = rq * ldaB + cq * 16;
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < MH; ++a)
 #pragma unroll
         for (int ih = 0; ih < 2; ++ih) {
             const int rl = a * 64 + ih * 32;                 // first row of the pass inside the wave's 128 rows
@@ -578,11 +638,11 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
         lnrow[tid] = ln_row_stats();
         __syncthreads();
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < MH; ++a)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int m = m0 + wm * 128 + a * 64 + i * 16 + r;
-            const float2 mr = lnrow[wm * 128 + a * 64 + i * 16 + r];
+            const int m = m0 + wm * WR + a * 64 + i * 16 + r;
+            const float2 mr = lnrow[wm * WR + a * 64 + i * 16 + r];
             if (m >= p.M) continue;
 #pragma unroll
             for (int b = 0; b < 2; ++b)
@@ -608,10 +668,10 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
         char *my = smem + wave * (32 * RS);
         const int rq = lane >> 4, cq = lane & 15;
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < MH; ++a)
 #pragma unroll
         for (int ih = 0; ih < 2; ++ih) {
-            const int row0 = m0 + wm * 128 + a * 64 + ih * 32;
+            const int row0 = m0 + wm * WR + a * 64 + ih * 32;
 #pragma unroll
             for (int i2 = 0; i2 < 2; ++i2)
 #pragma unroll
@@ -633,7 +693,7 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
                     for (int e = 0; e < 4; ++e) v[e] += (float)oh[e] + (float)ol[e];
                 }
                 const float s1 = row16_sum((v[0] + v[1]) + (v[2] + v[3]));
-                const float s2 = row16_sum((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]));
+                const float s2 = row16_sum(__builtin_fmaf(v[0], v[0], v[1] * v[1]) + __builtin_fmaf(v[2], v[2], v[3] * v[3]));
                 if (ok) {
                     const hvec4 nh = cvt4<DT>(v[0], v[1], v[2], v[3]);
                     f16x4 nl;
@@ -642,6 +702,7 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
                     *(hvec4 *)((E *)p.ln_xh + at) = nh;
                     *(f16x4 *)((_Float16 *)p.ln_xl + at) = nl;
                     if (cq == 0) *(float2 *)(p.ln_stats + (row * p.ln_slots + (n0 >> 6) + wn) * 2) = make_float2(s1, s2);
+                    if (cq == 0 && p.ln_flag && __float_as_uint(s2) > __float_as_uint(p.ln_guard)) atomicMax(p.ln_flag, __float_as_uint(s2));
                 }
             }
         }
@@ -650,10 +711,10 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
     if (LN == 4) {
         // edge tile of the dual-output forward (rows beyond M; N is a multiple of 128 by the host's contract)
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < MH; ++a)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int m = m0 + wm * 128 + a * 64 + i * 16 + r;
+            const int m = m0 + wm * WR + a * 64 + i * 16 + r;
             if (m >= p.M) continue;
 #pragma unroll
             for (int b = 0; b < 2; ++b)
@@ -670,10 +731,10 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
         return;
     }
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < MH; ++a)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 128 + a * 64 + i * 16 + r;
+        const int m = m0 + wm * WR + a * 64 + i * 16 + r;
         if (m >= p.M) continue;
 #pragma unroll
         for (int b = 0; b < 2; ++b)
@@ -682,6 +743,43 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
             const int n = n0 + wn * 64 + b * 32 + j * 16 + g * 4;
             if (n < p.N) store_quad<DT, EPI, OUT32>(p, acc[a][b][i][j], m, n);
         }
+    }
+}
+
+// Block -> tile.  Blocks [0, p.nbig) are full tiles on the first p.big_panels row panels of 256; blocks [p.nbig, gridDim.x) are
+// half tiles on the remaining rows (128-row panels): dispatched last, they fill the slots the last, partly empty round of full
+// tiles would leave idle with work of half the size.  Each region has its own XCD-aware grouped raster.
+template <int DT, int EPI, bool OUT32, int LN = 0>
+__global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
+    if (p.kc) {                                   // split-K (see gemm_nt_128)
+        const int sp = blockIdx.y;
+        p.A += (int64_t)sp * p.kc * 2; p.W += (int64_t)sp * p.kc * 2;
+        p.C = (char *)p.C + (int64_t)sp * p.csplit * 4;
+        p.K = min(p.kc, p.K - sp * p.kc);
+    }
+    __shared__ __attribute__((aligned(1024))) char smem[DUO_LDS];
+    const bool half = LN != 3 && (int)blockIdx.x >= p.nbig;
+    const int nwg = half ? (int)gridDim.x - p.nbig : p.nbig;
+    const int orig = half ? (int)blockIdx.x - p.nbig : (int)blockIdx.x;
+    const int tiles_m = half ? p.tiles_m_half : p.big_panels;
+    const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    const int GROUP = p.group;    // default 4: 64 tiles in flight per XCD = 4 row panels of 256 x 16 column panels of 128
+    int tm, tn;
+    if (p.m_fastest) {
+        const int per = GROUP * tiles_m, grp = wg / per, first = grp * GROUP;
+        const int gs = min(GROUP, p.tiles_n - first), loc = wg - grp * per;
+        tn = first + loc % gs; tm = loc / gs;
+    } else {
+        const int per = GROUP * p.tiles_n, grp = wg / per, first = grp * GROUP;
+        const int gs = min(GROUP, tiles_m - first), loc = wg - grp * per;
+        tm = first + loc % gs; tn = loc / gs;
+    }
+    if constexpr (LN == 3) {
+        duo_tile<DT, EPI, OUT32, LN, 2>(p, smem, tm * 256, tn * 128);
+    } else {
+        if (half) duo_tile<DT, EPI, OUT32, LN, 1>(p, smem, p.big_panels * 256 + tm * 128, tn * 128);
+        else duo_tile<DT, EPI, OUT32, LN, 2>(p, smem, tm * 256, tn * 128);
     }
 }
 

@@ -779,23 +779,35 @@ extern "C" int hgr_level_argmax(const float *logits, int64_t ld, const int32_t *
 namespace {
 // T1 / T2 / T4 bookkeeping of one batch (main.py:139-148,157-160,177-191) from the outputs of eval_rows: one block, integer
 // counts reduced in a fixed order, then the nine double-precision counters of the evaluation are advanced in place.
-__global__ __launch_bounds__(256) void eval_counters(const int32_t *__restrict__ pred, int k, const int64_t *__restrict__ targets, int target,
-                                                     const int32_t *__restrict__ top1, const int32_t *__restrict__ lv, int n_levels,
-                                                     const int32_t *__restrict__ parents, const int32_t *__restrict__ levels, int L,
-                                                     double *__restrict__ acc, int B) {
-    __shared__ unsigned s_red[4][8];
+__global__ __launch_bounds__(1024) void eval_counters(const int32_t *__restrict__ pred, int k, const int64_t *__restrict__ targets, int target,
+                                                      const int32_t *__restrict__ top1, const int32_t *__restrict__ lv, int n_levels,
+                                                      const int32_t *__restrict__ parents, const int32_t *__restrict__ levels, int L,
+                                                      double *__restrict__ acc, int B) {
+    // One row per thread (batch 512 = one pass of the 1024-thread block) and every load of a row requested before the first
+    // compare: the first version walked two rows per thread with its loads under the compares, a chain of dependent L2 round
+    // trips that made this 0.1 MB kernel the 11 us tail of every evaluation step.
+    __shared__ unsigned s_red[16][8];
     unsigned cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // hits@1,2,5,10,20, hits_all, edges (or first-level matches when L == 1), points
-    for (int r = threadIdx.x; r < B; r += 256) {
+    for (int r = threadIdx.x; r < B; r += 1024) {
         const int tgt = targets ? (int)targets[r] : target;
-        int j = k;
-        for (int i = k - 1; i >= 0; --i)
-            if (pred[(int64_t)r * k + i] == tgt) j = i;         // first match (ids are distinct: at most one)
-        cnt[0] += j < 1; cnt[1] += j < 2; cnt[2] += j < 5; cnt[3] += j < 10; cnt[4] += j < 20;
+        int pr[32], lvv[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) pr[i] = i < k ? pred[(int64_t)r * k + i] : -1;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) lvv[i] = i < L ? lv[(int64_t)r * n_levels + levels[i]] : -1;
         const int t1 = top1[r];
+        int j = k;
+#pragma unroll
+        for (int i = 31; i >= 0; --i)
+            if (i < k && pr[i] == tgt) j = i;                   // first match (ids are distinct: at most one)
+        cnt[0] += j < 1; cnt[1] += j < 2; cnt[2] += j < 5; cnt[3] += j < 10; cnt[4] += j < 20;
         bool prev = false;
-        for (int i = 0; i < L; ++i) {
-            cnt[5] += t1 == parents[i];
-            const bool m = lv[(int64_t)r * n_levels + levels[i]] == parents[i];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            if (i >= L) break;
+            const int pa = parents[i];
+            cnt[5] += t1 == pa;
+            const bool m = lvv[i] == pa;
             cnt[7] += m;
             if (L == 1) cnt[6] += m;
             else if (i > 0) cnt[6] += (m && prev);
@@ -812,7 +824,10 @@ __global__ __launch_bounds__(256) void eval_counters(const int32_t *__restrict__
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned t[8];
-        for (int c = 0; c < 8; ++c) t[c] = s_red[0][c] + s_red[1][c] + s_red[2][c] + s_red[3][c];
+        for (int c = 0; c < 8; ++c) {
+            t[c] = 0;
+            for (int w = 0; w < 16; ++w) t[c] += s_red[w][c];
+        }
         for (int c = 0; c < 6; ++c) acc[c] += (double)t[c];
         acc[6] += L > 1 ? (double)t[6] / (double)(L - 1) : (double)t[6];
         acc[7] += (double)t[7] / (double)L;
@@ -824,8 +839,8 @@ __global__ __launch_bounds__(256) void eval_counters(const int32_t *__restrict__
 extern "C" int hgr_eval_counters(const int32_t *pred, int k, const int64_t *targets, int target, const int32_t *top1, const int32_t *lv,
                                  int n_levels, const int32_t *parents, const int32_t *levels, int L, double *acc, int rows, void *stream) {
     HGR_REQUIRE(pred && top1 && lv && parents && levels && acc, "hgr_eval_counters: null operand");
-    HGR_REQUIRE(rows >= 1 && k >= 1 && k <= 32 && L >= 1 && n_levels >= 1, "hgr_eval_counters: bad sizes rows=%d k=%d L=%d", rows, k, L);
-    hipLaunchKernelGGL(eval_counters, dim3(1), dim3(256), 0, (hipStream_t)stream, pred, k, targets, target, top1, lv, n_levels, parents, levels, L, acc, rows);
+    HGR_REQUIRE(rows >= 1 && k >= 1 && k <= 32 && L >= 1 && L <= 32 && n_levels >= 1, "hgr_eval_counters: bad sizes rows=%d k=%d L=%d (k, L <= 32)", rows, k, L);
+    hipLaunchKernelGGL(eval_counters, dim3(1), dim3(1024), 0, (hipStream_t)stream, pred, k, targets, target, top1, lv, n_levels, parents, levels, L, acc, rows);
     HGR_CHECK_LAUNCH("hgr_eval_counters");
     return HGR_OK;
 }

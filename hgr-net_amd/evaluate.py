@@ -114,6 +114,10 @@ class Evaluator:
     def summary(self, group=None) -> str:
         """The string main.test prints and logs (main.py:205-216)."""
         c = self.counters(group)
+        tripped = getattr(self.model.clip_model, "ln_guard_tripped", lambda: {})()
+        if tripped:                                        # activations left the guarded 16-bit range AFTER the first-pass check
+            import warnings
+            warnings.warn(f"hgr_net_amd: LayerNorm-folding range guard tripped during this evaluation {tripped}: rerun with HGR_LN_FUSED=0")
         n = c["num_sample"]
         s, _ = count_acc({k: c[f"hits@{k}"] for k in TOPK}, n)
         out = "\n" + s

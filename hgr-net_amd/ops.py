@@ -83,18 +83,29 @@ def _prof_end(ev, flops, byts, tag):
         PROFILE.append(("gemm_nt", ev[0], ev[1], float(flops), float(byts), tag))
 
 
+# Range guard of the LayerNorm-folded residual stream (hgr_gemm_nt_res_stats_guard): a 64-column slot whose sum of squares exceeds
+# LN_GUARD_SUMSQ = 16384^2 could hold an element beyond a quarter of the f16 range (65504); below it every |x| <= 16384.
+LN_GUARD_SUMSQ = 16384.0 ** 2
+
+
 def gemm_nt_res_stats(a: torch.Tensor, w: torch.Tensor, xh: torch.Tensor, xl: torch.Tensor, bias: torch.Tensor, stats: torch.Tensor,
-                      tag: str = "") -> None:
+                      tag: str = "", flag: Optional[torch.Tensor] = None) -> None:
     """(xh, xl) += a @ w^T + bias on the residual stream kept as a 16-bit pair (x = xh + xl, xh in the MFMA type = the next GEMM's
     A operand, xl f16) and, for the LayerNorm that follows, stats[m, slot] = (sum, sum of squares) of every 64-column slot of the
-    new row (hgr_gemm_nt_res_stats)."""
+    new row (hgr_gemm_nt_res_stats).  `flag` (uint32 / int32 [1], zeroed by the caller): range guard, non-zero afterwards when a
+    slot's sum of squares exceeded LN_GUARD_SUMSQ or was inf / NaN (hgr_gemm_nt_res_stats_guard)."""
     m, k = a.shape
     n = w.shape[0]
     assert a.dtype == w.dtype == xh.dtype and xl.dtype == torch.float16 and xh.shape == xl.shape == (m, n) and xh.stride() == xl.stride()
     assert stats.dtype == torch.float32 and stats.numel() >= m * (n // 64) * 2 and a.stride(1) == w.stride(1) == xh.stride(1) == 1
     ev = _prof_begin()
-    _lib.call("hgr_gemm_nt_res_stats", _dev(a), a.stride(0), _dev(w), w.stride(0), _dev(xh), _dev(xl), xh.stride(0), _dev(bias),
-              _dev(stats), m, n, k, DT_OF[a.dtype], _stream())
+    if flag is None:
+        _lib.call("hgr_gemm_nt_res_stats", _dev(a), a.stride(0), _dev(w), w.stride(0), _dev(xh), _dev(xl), xh.stride(0), _dev(bias),
+                  _dev(stats), m, n, k, DT_OF[a.dtype], _stream())
+    else:
+        assert flag.numel() == 1 and flag.element_size() == 4
+        _lib.call("hgr_gemm_nt_res_stats_guard", _dev(a), a.stride(0), _dev(w), w.stride(0), _dev(xh), _dev(xl), xh.stride(0), _dev(bias),
+                  _dev(stats), LN_GUARD_SUMSQ, _dev(flag), m, n, k, DT_OF[a.dtype], _stream())
     _prof_end(ev, 2.0 * m * n * k, 2 * m * k + 2 * n * k + 8 * m * n, tag)
 
 
@@ -152,6 +163,15 @@ def gemm_set_tile(tile: int) -> int:
     prev = lib.hgr_gemm_set_tile(int(tile))
     if prev < 0:
         raise _lib.HgrError(f"hgr_gemm_set_tile failed ({prev}): {lib.hgr_last_error().decode()}")
+    return prev
+
+
+def gemm_set_tail(enabled: bool, full_panels: int = -1) -> int:
+    """Tail plan of the 256 x 128 tile kernel on / off (hgr_gemm_set_tail); returns the previous setting."""
+    lib = _lib.load()
+    prev = lib.hgr_gemm_set_tail(1 if enabled else 0, int(full_panels))
+    if prev < 0:
+        raise _lib.HgrError(f"hgr_gemm_set_tail failed ({prev}): {lib.hgr_last_error().decode()}")
     return prev
 
 

@@ -11,7 +11,7 @@
  *   - plain pointers and sizes only; every tensor argument is a raw DEVICE pointer, row-major;
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); every call is asynchronous
  *     and stream-ordered, never synchronises and allocates no device memory.  The only process-wide mutable state is
- *     (a) the development knob hgr_gemm_set_tile (tile-plan override for A/B runs and tests; default = cost model) and
+ *     (a) the development knobs hgr_gemm_set_tile / hgr_gemm_set_tail (tile-plan overrides for A/B runs and tests) and
  *     (b) the optional RCCL communicator created / destroyed explicitly by hgr_comm_init / hgr_comm_destroy;
  *   - returns 0 on success, a negative HGR_E* code otherwise; hgr_last_error() returns the message of
  *     the last failure on the calling thread.  Arguments are validated on the host before any launch
@@ -77,6 +77,16 @@ int hgr_gemm_nt(const void *A, int64_t lda, const void *W, int64_t ldw, void *C,
  * shape under each plan.  Returns the previous value, or a negative HGR_E* code for any other argument.
  */
 int hgr_gemm_set_tile(int tile);
+
+/*
+ * Tail plan of the 256 x 128 tile kernel (hgr_gemm_nt and the LayerNorm-folded forms below): a launch whose tile count is not a
+ * whole number of rounds of the chip's 512 workgroup slots gives its LAST row panels to 128 x 128 half tiles, dispatched after
+ * the full tiles, so that the last round is not left to a few workgroups.  enabled = 1 (default; HGR_DUO_TAIL)
+ * / 0; full_panels = -1 lets the host's list-scheduling model choose how many 256-row panels stay on full tiles, n >= 0 forces
+ * it (measurement sweeps; HGR_DUO_PB).  Every output element sums K in the same order on either tile: results are bit-identical.
+ * Process-wide development knob like hgr_gemm_set_tile.  Returns the previous `enabled`.
+ */
+int hgr_gemm_set_tail(int enabled, int full_panels);
 
 /*
  * Patch extraction for the ViT stem: image fp32 NCHW [B,3,R,R] -> rows [B*g*g, Kp] of 16-bit
@@ -461,6 +471,18 @@ int hgr_adamw(float *p, const float *g, float *m, float *v, int64_t n, float lr,
 /* (xh, xl) += A W^T + bias  (the residual add of clip/model.py:186-187 on the pair, in place), stats = slot partials of the new rows */
 int hgr_gemm_nt_res_stats(const void *A, int64_t lda, const void *W, int64_t ldw, void *xh, void *xl, int64_t ldx,
                           const float *bias, float *stats, int M, int N, int K, int dtype, void *stream);
+
+/*
+ * The same with a RANGE GUARD on the residual stream.  The reference keeps LayerNorm in fp32 (clip/model.py:153-159) because trained
+ * CLIP residual streams carry outlier channels; here the stream's high half xh is 16-bit, so a value beyond the f16 range would
+ * become inf.  Whenever a 64-column slot's sum of squares of the NEW rows exceeds guard_sumsq - or is inf / NaN - its bit pattern
+ * is atomicMax'ed into *flag (zeroed by the caller; it stays 0 while every |x| <= sqrt(guard_sumsq)).  Nearly free: the slot sums
+ * exist anyway, and no atomic is issued while the stream is in range.  The host reads the flag at its next synchronisation point
+ * and falls back to the unfused fp32 stream (hgr_net_amd.clip.model: CLIP.ln_guard_tripped).  flag = NULL: no guard.
+ */
+int hgr_gemm_nt_res_stats_guard(const void *A, int64_t lda, const void *W, int64_t ldw, void *xh, void *xl, int64_t ldx,
+                                const float *bias, float *stats, float guard_sumsq, uint32_t *flag,
+                                int M, int N, int K, int dtype, void *stream);
 /* C (16-bit) = act( rstd_m (XH Wfold^T - mean_m ln_s) + ln_c ), act: 0 none (ln_1 -> in_proj), 1 QuickGELU (ln_2 -> c_fc -> gelu);
  * K = row width, mean / rstd from `stats` ([M][K/64][2], as written by the producers), eps of the LayerNorm */
 int hgr_gemm_nt_ln(const void *XH, int64_t ldx, const void *Wfold, int64_t ldw, void *C, int64_t ldc,

@@ -576,6 +576,61 @@ def test_gemm_nt_res_stats(dt, m, n, k):
 
 
 @pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("m,n,k,panels", [(25600, 768, 768, -1), (25600, 768, 3072, -1), (25600, 2304, 768, -1), (25523, 768, 128, -1),
+                                           (25600, 768, 192, 0), (25600, 768, 256, 1), (25600, 768, 256, 99), (26000, 1536, 256, -1)])
+def test_gemm_tail_plan_is_bit_identical(dt, m, n, k, panels):
+    """The tail plan of the 256 x 128 tile kernel (half tiles on the last row panels, hgr_gemm_set_tail) against the
+    all-full-tile launch of the same call: every output element sums K in the same order on either tile, so every entry point that
+    rides the kernel - plain 16-bit / fp32 epilogues, the LayerNorm producer (pair + slot statistics) and consumer, the dual-output
+    forward - must give the same BITS on random data.  ViT-B/32 tower shapes at batch 512 (600 / 1800 tiles on 512 slots), a ragged
+    M (last half panel partly empty, last full panel absent), 2- and 3-K-tile reductions (the prologue / drain forms of the
+    half-tile pipeline), forced panel counts 0 (all half tiles), 1 and tiles_m - 1."""
+    g = torch.Generator(device=DEV).manual_seed(m + n + k)               # device-side random operands: the hash generator of synth
+    rnd = lambda shape, scale=1.0: scale * torch.randn(shape, generator=g, device=DEV)      # would spend minutes on 10^8 values
+    a, w = rnd((m, k)).to(dt), rnd((n, k), 0.1).to(dt)
+    bias, x0 = rnd((n,)), rnd((m, n), 2.0)
+    xh0, xl0 = _pair(x0, dt)
+    gamma_s, c = rnd((n,)), rnd((n,))
+    xk = rnd((m, k), 1.5) if k % 128 == 0 else None
+
+    def run():
+        out = {}
+        o16 = torch.empty(m, n, dtype=dt, device=DEV)
+        ops.gemm_nt(a, w, o16, bias=bias, epilogue=EPI_BIAS_QUICKGELU)
+        out["gelu16"] = o16
+        o32 = x0.clone()
+        ops.gemm_nt(a, w, o32, bias=bias, residual=o32, epilogue=EPI_BIAS_RESIDUAL)
+        out["res32"] = o32
+        xh, xl = xh0.clone(), xl0.clone()
+        stats = torch.zeros((m, n // 64, 2), dtype=torch.float32, device=DEV)
+        ops.gemm_nt_res_stats(a, w, xh, xl, bias, stats)
+        out["xh"], out["xl"], out["stats"] = xh, xl, stats
+        if k % 128 == 0:
+            # consumer on ITS operand shape: rows of width k with statistics of their own
+            kh, kl = _pair(xk, dt)
+            st = torch.empty((m, k // 64, 2), dtype=torch.float32, device=DEV)
+            ops.row_stats16(xk, kh, kl, st)
+            y = torch.empty(m, n, dtype=dt, device=DEV)
+            ops.gemm_nt_ln(kh, w, y, gamma_s, c, st, 1e-5, quickgelu=True)
+            out["ln"] = y
+        if ops.gelu_dual_ok(m, n, k, a.stride(0), w.stride(0)):
+            pre, post = torch.empty(m, n, dtype=dt, device=DEV), torch.empty(m, n, dtype=dt, device=DEV)
+            ops.gemm_nt_bias_gelu_dual(a, w, pre, post, bias)
+            out["pre"], out["post"] = pre, post
+        return out
+
+    prev = ops.gemm_set_tail(False)
+    try:
+        full = run()
+        ops.gemm_set_tail(True, min(panels, (m + 255) // 256 - 1) if panels >= 0 else -1)
+        tail = run()
+    finally:
+        ops.gemm_set_tail(bool(prev))
+    for key in full:
+        assert torch.equal(full[key], tail[key]), key
+
+
+@pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("gelu", [False, True])
 @pytest.mark.parametrize("m,n,k", [(512, 384, 128), (1000, 2304, 768), (25600, 3072, 768), (300, 128, 1024)])
 def test_gemm_nt_ln(dt, gelu, m, n, k):

@@ -1,0 +1,159 @@
+"""GPU: the LayerNorm-folded path (hgr_gemm_nt_ln / hgr_gemm_nt_res_stats, residual stream as a 16-bit pair) under the activation
+statistics of TRAINED CLIP checkpoints, which the hash-seeded weights of the other tests do not have: a few residual channels carry
+values 50 - 300 x the row's standard deviation, rows have a mean of the order of their deviation, a few LayerNorm gains are ~10 x
+the rest.  The reference keeps LayerNorm in fp32 for exactly this reason (clip/model.py:153-159).  Checked: (1) folded == unfused ==
+fp32 oracle within the 16-bit operand tolerance, no inf / NaN; (2) the range guard of the producer GEMM (hgr_gemm_nt_res_stats_guard)
+and the automatic fall-back of the model to the fp32 stream when a checkpoint exceeds what the 16-bit stream can hold."""
+import json
+import types
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from hgr_net_amd import ops, synth
+from hgr_net_amd.clip.model import build_model
+from hgr_net_amd.model import tree_model
+from oracle import clip_ref, tree_ref
+
+DEV = "cuda"
+
+
+def _checkpoint_like(cfg, outlier, mean_shift=0.6, gain=10.0):
+    """small-vit weights with trained-checkpoint statistics: every block's c_proj bias pushes three channels by a share of
+    (+0.2, -0.5, +1.0) x `outlier` (so the outliers build up along the depth like in CLIP's towers) and all channels by `mean_shift`;
+    three gains of every LayerNorm are `gain` x the rest."""
+    sd = {k: v.clone() for k, v in synth.clip_state_dict(cfg, 0).items()}
+    for tower, width, n in (("visual.transformer", cfg["vision_width"], cfg["vision_layers"]),
+                            ("transformer", cfg["transformer_width"], cfg["transformer_layers"])):
+        ch = torch.tensor([3, 77 % width, width - 5])
+        for i in range(n):
+            pre = f"{tower}.resblocks.{i}."
+            sd[pre + "mlp.c_proj.bias"][ch] += torch.tensor([0.2, -0.5, 1.0]) * outlier / n
+            sd[pre + "mlp.c_proj.bias"] += mean_shift / n
+            for ln in ("ln_1", "ln_2"):
+                sd[pre + ln + ".weight"][torch.tensor([1, 40 % width, width - 2])] *= gain
+    return sd
+
+
+def _unit(x):
+    return x / x.norm(dim=-1, keepdim=True)
+
+
+def _stream_stats(sd, img):
+    """what the residual stream of the oracle looks like under these weights: max |x| / row std and max |row mean| / row std"""
+    taps = {}
+    clip_ref.encode_image(sd, img, taps=taps)
+    worst_out, worst_mean = 0.0, 0.0
+    for k, v in taps.items():
+        if "resblocks" in k:
+            x = v.reshape(-1, v.shape[-1]).double()
+            sdv = x.std(dim=1, keepdim=True)
+            core = x.abs().median(dim=1, keepdim=True).values * 1.4826           # robust row scale (outliers excluded)
+            worst_out = max(worst_out, float((x.abs() / core).max()))
+            worst_mean = max(worst_mean, float((x.mean(dim=1, keepdim=True).abs() / core).max()))
+            del sdv
+    return worst_out, worst_mean
+
+
+@pytest.mark.parametrize("outlier,mean_shift", [(60.0, 0.6), (300.0, 3.0)])
+def test_folded_layernorm_under_checkpoint_like_statistics(outlier, mean_shift, tmp_path):
+    cfg = synth.CLIP_CONFIGS["small-vit"]
+    sd = _checkpoint_like(cfg, outlier, mean_shift)
+    img = synth.images(6, cfg["image_resolution"], 21)
+    tok = synth.make_tokens(40, 11, cfg["vocab_size"])
+    out_ratio, mean_ratio = _stream_stats(sd, img)
+    assert out_ratio > 40 and mean_ratio > 0.3, (out_ratio, mean_ratio)          # the stress the test is about is really there
+    ref_i, ref_t = clip_ref.encode_image(sd, img), clip_ref.encode_text(sd, tok, trim=True)
+    res = {}
+    for mode in ("folded", "unfused"):
+        model = build_model(sd).to(DEV)
+        if mode == "unfused":
+            model._ln_off = {"v", "t"}
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")                                        # the guard must NOT trip at these magnitudes
+            fi, ft = model.encode_image(img.to(DEV)).cpu(), model.encode_text(tok.to(DEV)).cpu()
+        assert torch.isfinite(fi).all() and torch.isfinite(ft).all()
+        assert model.ln_guard_tripped() == {} and (model._ln_off == set() if mode == "folded" else True)
+        res[mode] = (float((_unit(fi) - _unit(ref_i)).abs().max()), float((_unit(ft) - _unit(ref_t)).abs().max()))
+    print(f"\n[LN stress, outlier {outlier:g}] stream: max |x| / row scale {out_ratio:.0f}, max |mean| / row scale {mean_ratio:.2f}; "
+          f"max |unit feature - oracle| image / text: folded {res['folded'][0]:.2e} / {res['folded'][1]:.2e}, unfused {res['unfused'][0]:.2e} / {res['unfused'][1]:.2e}")
+    for mode in res:
+        assert res[mode][0] < 1e-3 and res[mode][1] < 1e-3, (mode, res[mode])
+    # the folded form may not cost more than 3 x the unfused path's own 16-bit error (plus a floor of 1e-4)
+    assert res["folded"][0] <= 3 * res["unfused"][0] + 1e-4 and res["folded"][1] <= 3 * res["unfused"][1] + 1e-4, res
+
+    # ... and through the tree model: logits within the north-star's 1e-3 of the oracle
+    from hgr_net_amd.hierarchy import build_hierarchy
+    edges = synth.make_dag(200, depth=8, seed=7, multi_parent=0.05)
+    h = build_hierarchy(edges)
+    splits = synth.make_splits(h.nodes, [len(c) == 0 for c in h.p2c], 60, 100, 13)
+    tokens = synth.make_tokens(len(h.nodes), 11, cfg["vocab_size"])
+    gp = tmp_path / "g.json"
+    json.dump(edges, open(gp, "w"))
+    opts = types.SimpleNamespace(device=DEV, folder=str(tmp_path), exp_name="HGR", weights="equal", out_ratio=0.25, in_ratio=0.5, from_epoch=-1,
+                                 graph_path=str(gp), arch="synthetic", fetch=False, load=False, load_path="none", scale=1.0)
+    tm = tree_model(opts, splits["all"], splits["rest"], node_tokens=tokens, clip_model=build_model(sd).to(DEV))
+    tm.update_classifier()
+    lg = tm(img.to(DEV), None).cpu()
+    ref = tree_ref.forward(sd, img, tree_ref.update_classifier(sd, tokens, trim=True))
+    err = float((lg - ref).abs().max())
+    assert torch.isfinite(lg).all() and err < 1e-3, err
+
+
+def test_range_guard_flag_of_the_producer_gemm():
+    """hgr_gemm_nt_res_stats_guard: the flag stays 0 while every slot's sum of squares is <= the guard, becomes the offending sum's
+    bit pattern otherwise (largest one), and reports inf / NaN - on full tiles, on the ragged edge path and on half tiles."""
+    g = torch.Generator(device=DEV).manual_seed(5)
+    for m in (25600, 300):                                          # tail plan (full + half tiles) and a single ragged tile
+        n, k = 768, 128
+        a = torch.randn((m, k), generator=g, device=DEV).half()
+        w = (0.05 * torch.randn((n, k), generator=g, device=DEV)).half()
+        bias = torch.zeros(n, device=DEV)
+        stats = torch.empty((m, n // 64, 2), dtype=torch.float32, device=DEV)
+        for case in ("in range", "large", "nan"):
+            x0 = torch.randn((m, n), generator=g, device=DEV)
+            row, col = m - 7, 700
+            if case == "large":
+                x0[row, col] = 3.0e4
+            xh, xl = x0.half(), (x0 - x0.half().float()).half()
+            if case == "nan":
+                xl[row, col] = float("nan")
+            flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+            ops.gemm_nt_res_stats(a, w, xh, xl, bias, stats, flag=flag)
+            bits = int(flag.item()) & 0xFFFFFFFF
+            val = float(np.array([bits], dtype=np.uint32).view(np.float32)[0])
+            if case == "in range":
+                assert bits == 0, (m, val)
+            elif case == "large":
+                assert val > ops.LN_GUARD_SUMSQ and abs(val - float(stats[row, col // 64, 1])) <= 1e-6 * val, (m, val)
+            else:
+                assert np.isnan(val), (m, bits)
+
+
+def test_model_falls_back_to_the_fp32_stream_when_the_guard_trips(tmp_path):
+    """A checkpoint whose residual stream exceeds the f16 range (one channel pushed to ~1e5: xh would be inf): the first folded pass
+    trips the guard, the model warns, switches that tower to the fp32 stream + separate LayerNorm launches, recomputes, and the
+    result is finite and equal to the oracle's to the 16-bit operand tolerance; the text tower, in range, stays folded."""
+    cfg = synth.CLIP_CONFIGS["small-vit"]
+    sd = _checkpoint_like(cfg, 60.0)
+    last = cfg["vision_layers"] - 1
+    sd[f"visual.transformer.resblocks.{last - 1}.mlp.c_proj.bias"][9] += 1.0e5
+    img = synth.images(4, cfg["image_resolution"], 22)
+    tok = synth.make_tokens(16, 11, cfg["vocab_size"])
+    model = build_model(sd).to(DEV)
+    with pytest.warns(UserWarning, match="range"):
+        fi = model.encode_image(img.to(DEV)).cpu()
+    assert model._ln_off == {"v"} and model.ln_guard_tripped() == {}
+    ft = model.encode_text(tok.to(DEV)).cpu()
+    assert model._ln_off == {"v"}
+    ref_i, ref_t = clip_ref.encode_image(sd, img), clip_ref.encode_text(sd, tok, trim=True)
+    assert torch.isfinite(fi).all() and float((_unit(fi) - _unit(ref_i)).abs().max()) < 2e-3
+    assert float((_unit(ft) - _unit(ref_t)).abs().max()) < 1e-3
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        again = model.encode_image(img.to(DEV)).cpu()               # second call: no folded pass, no warning, same bits
+    assert torch.equal(again, fi)
