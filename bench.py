@@ -341,6 +341,8 @@ def train_mode(a, model, cfg, h, rank, world, group, ranks_seen, dev, real_stdou
                 "peak_memory_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
         if dp_check is not None:
             line["dp_check"] = dp_check
+            if not dp_check["ok"]:
+                log(f"[bench] dp_check FAILED: {json.dumps(dp_check)}")
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if group is not None:
@@ -672,6 +674,8 @@ def main():
                 "planted_signal": planted}
         if dp_check is not None:
             line["dp_check"] = dp_check
+            if not dp_check["ok"]:
+                log(f"[bench] dp_check FAILED: {json.dumps(dp_check)}")
         default_run = a.arch == ARCH and a.batch == BATCH and a.nodes == N_NODES and world == 1 and group is None
         if a.secondary and not a.is_secondary and default_run:
             # BASELINE configs[2] and configs[4] beside the headline, each as a child process after the headline measurement is over

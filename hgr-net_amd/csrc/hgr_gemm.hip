@@ -40,6 +40,10 @@ DuoPlan duo_plan(int M, int N, bool allow_tail) {
     const int64_t T = (int64_t)tiles_m * tiles_n;
     DuoPlan best{tiles_m, (int)T, 0, (int)T};
     if (!allow_tail || !tail_env || T <= S || T % S == 0) return best;
+    // measured (tools/tail_sweep.py, ViT-B/32 tower launches at batch 512, cold operands): last round 15 - 17 % full (out, proj, patch:
+    // 600 / 588 tiles) -13 %, -14.5 %, -11 %; last round 52 % full (qkv, 1800 tiles) +-0; 69 % full (fc, 2400 tiles) +2 %: a
+    // half-full last round already overlaps well, and half tiles stage fewer flops per byte
+    if (pb_env < 0 && (T % S) * 100 > 45 * (int64_t)S) return best;
     auto makespan = [&](int pb) {
         const int64_t nb = (int64_t)pb * tiles_n;
         const int mh = M - pb * 256;

@@ -67,7 +67,7 @@ def main():
         if sweep:
             full_rounds = (tiles_m * tiles_n) // 512
             base = (full_rounds * 512) // tiles_n
-            for pb in sorted({max(0, base - 8), max(0, base - 4), max(0, base - 2), base - 1, base, base + 1, min(tiles_m - 1, base + 2), min(tiles_m - 1, base + 4)}):
+            for pb in sorted({0, base // 2, max(0, base - 8), max(0, base - 2), base - 1, base, base + 1}):
                 if 0 <= pb < tiles_m:
                     arms.append((f"pb{pb}", (True, pb)))
         best = {a: [] for a, _ in arms}
