@@ -23,13 +23,6 @@
 // =================================================================================================
 #include "hgr_gemm_common.h"
 
-#ifndef HGR_PAIR16
-#define HGR_PAIR16 1
-#endif
-#ifndef HGR_DUO_ILV
-#define HGR_DUO_ILV 0        // 1: the LDS-DMA instructions of a phase are issued INSIDE its MFMA cluster (one per 4 MFMAs), see ktile_ilv
-#endif
-
 namespace hgr_gemm {
 
 constexpr int NTD = 256;
@@ -213,79 +206,9 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
             __builtin_amdgcn_s_setprio(0);
         };
 
-        // Variant (HGR_DUO_ILV): the same pieces in the same issue order, but each phase issues its LDS-DMA instructions from INSIDE
-        // its MFMA cluster, one per group of 4 MFMAs, instead of in front of the phase's wait: the matrix pipe keeps running while
-        // the wave pays the DMA issue cost (60 - 185 cycles per instruction, MI355X_MICROARCH.md).  A phase's wait now precedes its
-        // own issues, so the counts drop by what the phase issues: 8 -> 4, 14 -> 12, 6 -> 4 (last K-tiles: unchanged 4 / 12 / 2, 0).
-        auto issueA1 = [&](const unsigned (&off)[4], int slot_base, int t, int i) {
-            __builtin_amdgcn_global_load_lds((const AS1 void *)(p.A + (int64_t)t * 128 + off[i]), (AS3 void *)(ldsw + slot_base + (t & 1) * 16384 + i * 4096), 16, 0, 0);
-        };
-        auto issueW1 = [&](const unsigned (&off)[2], int slot_base, int t, int i) {
-            __builtin_amdgcn_global_load_lds((const AS1 void *)(p.W + (int64_t)t * 128 + off[i]), (AS3 void *)(ldsw + slot_base + i * 4096), 16, 0, 0);
-        };
-        auto cluster = [&](f32x4 (&q)[4][2], vec8 (&wf)[2][2], auto issue) {
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int ip = 0; ip < 2; ++ip) {
-#pragma unroll
-                    for (int i = 2 * ip; i < 2 * ip + 2; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) q[i][j] = T16<DT>::mfma16(wf[j][kk], af[i][kk], q[i][j]);
-                    issue(kk * 2 + ip);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            __builtin_amdgcn_s_setprio(0);
-        };
-        auto ktile_ilv = [&](int t, auto mode_tag) {
-            constexpr int MODE = decltype(mode_tag)::value;
-            const char *bufA0 = smem + DUO_A0 + (t & 1) * 16384, *bufA1 = smem + DUO_A1 + (t & 1) * 16384;
-            // ---- ph1: Q(0,0), issues A1(t+1) x4 ----
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                wf0[j][0] = *(const vec8 *)(smem + DUO_W0 + offW + j * 2048 + sw0);
-                wf0[j][1] = *(const vec8 *)(smem + DUO_W0 + offW + j * 2048 + sw1);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                af[i][0] = *(const vec8 *)(bufA0 + offA + i * 2048 + sw0);
-                af[i][1] = *(const vec8 *)(bufA0 + offA + i * 2048 + sw1);
-            }
-            if (MODE <= 1) HGR_RWAIT(4); else HGR_RWAIT(0);                 // W1(t) landed
-            cluster(acc[0][0], wf0, [&](int grp) { if (MODE <= 1) issueA1(oA1, DUO_A1, t + 1, grp); });
-            // ---- ph2: Q(0,1), issues W0(t+1) x2 ----
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                wf1[j][0] = *(const vec8 *)(smem + DUO_W1 + offW + j * 2048 + sw0);
-                wf1[j][1] = *(const vec8 *)(smem + DUO_W1 + offW + j * 2048 + sw1);
-            }
-            if (MODE <= 1) HGR_RWAIT(12); else HGR_RBAR();                  // A1(t) landed
-            cluster(acc[0][1], wf1, [&](int grp) { if (MODE <= 1 && (grp & 1) == 0) issueW1(oW0, DUO_W0, t + 1, grp >> 1); });
-            // ---- ph3: Q(1,1), issues W1(t+1) x2, A0(t+2) first half x2; no barrier (nothing ph3 reads is refilled before ph4's) ----
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                af[i][0] = *(const vec8 *)(bufA1 + offA + i * 2048 + sw0);
-                af[i][1] = *(const vec8 *)(bufA1 + offA + i * 2048 + sw1);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            cluster(acc[1][1], wf1, [&](int grp) {
-                if (MODE <= 1 && grp < 2) issueW1(oW1, DUO_W1, t + 1, grp);
-                if (MODE == 0 && grp >= 2) issueA1(oA0, DUO_A0, t + 2, grp - 2);
-            });
-            // ---- ph4: Q(1,0), issues A0(t+2) second half x2 ----
-            if (MODE == 0) HGR_RWAIT(4); else if (MODE == 1) HGR_RWAIT(2);  // W0(t+1), A0(t+1) landed
-            cluster(acc[1][0], wf0, [&](int grp) { if (MODE == 0 && (grp & 1) == 0) issueA1(oA0, DUO_A0, t + 2, 2 + (grp >> 1)); });
-        };
-        if constexpr (HGR_DUO_ILV) {
-            for (int t = 0; t < nk - 2; ++t) ktile_ilv(t, std::integral_constant<int, 0>());
-            ktile_ilv(nk - 2, std::integral_constant<int, 1>());
-            ktile_ilv(nk - 1, std::integral_constant<int, 2>());
-        } else {
-            for (int t = 0; t < nk - 2; ++t) ktile(t, std::integral_constant<int, 0>());
-            ktile(nk - 2, std::integral_constant<int, 1>());
-            ktile(nk - 1, std::integral_constant<int, 2>());
-        }
+        for (int t = 0; t < nk - 2; ++t) ktile(t, std::integral_constant<int, 0>());
+        ktile(nk - 2, std::integral_constant<int, 1>());
+        ktile(nk - 1, std::integral_constant<int, 2>());
     } else {
         // Half tile (128 x 128): two phases per K-tile, 8 LDS-DMA instructions per thread per K-tile.  LDS: A (16 KB) in THREE
         // buffers at 0 / 16 K / 32 K (the activations come from HBM / Infinity Cache: prefetched two K-tiles ahead), W0 and W1
@@ -594,110 +517,33 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
             // 2^-11 |x - hi| (2^-22 |x| with f16 hi, 2^-19 |x| with bf16 hi), far below the 16-bit rounding of every GEMM input.
             // Same bytes as an fp32 read-modify-write.  Plus this wave's 64-column share of the rows' LayerNorm statistics; the
             // 16 reduction chains of a pass (8 row groups x {sum, sum of squares}) advance stage by stage (DPP latencies overlap).
-            typedef typename T16<DT>::vec4 hvec4;
-            if constexpr (HGR_PAIR16) {
-                // 16-byte accesses on the pair (T21 of the CDNA guide: a row-per-lane epilogue is store-ISSUE bound): a lane owns 8
-                // consecutive columns of a row (8 lanes per row, 8 rows per instruction), i.e. ONE 16-byte load / store per half of the
-                // pair where the first version issued two of 8 bytes: 64 instead of 128 global memory instructions per thread and
-                // tile.  The slot sums pair the same values as the 4-column form stage by stage (a lane's 8 columns = the first
-                // exchange of two 4-column lanes), so the statistics keep their bits (-DHGR_PAIR16=0 builds the 8-byte form, for A/B runs).
-                char *hw = (char *)p.ln_xh + (wrow * p.ln_ldx + wcol) * 2;
-                char *lw = (char *)p.ln_xl + (wrow * p.ln_ldx + wcol) * 2;
-                char *sw = (char *)(p.ln_stats + (wrow * p.ln_slots + (n0 >> 6) + wn) * 2);
-                const int r8 = lane >> 3, c8 = lane & 7;
-                const unsigned ldxB = (unsigned)p.ln_ldx * 2u, ldsB = (unsigned)p.ln_slots * 8u;
-                const unsigned xo = r8 * ldxB + c8 * 16, so = r8 * ldsB;
-                u32x4 ohb[2][4], olb[2][4];
-                auto pair_load = [&](int buf, int rl) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        ohb[buf][q] = *(const u32x4 *)(hw + (xo + (rl + q * 8) * ldxB));
-                        olb[buf][q] = *(const u32x4 *)(lw + (xo + (rl + q * 8) * ldxB));
-                    }
-                };
-                pair_load(0, 0);
-                unsigned gbits = 0u;                              // range guard: largest slot sum of squares seen (as bits: inf / NaN rank highest)
-#pragma unroll
-                for (int a = 0; a < MH; ++a)
-#pragma unroll
-                for (int ih = 0; ih < 2; ++ih) {
-                    const int rl = a * 64 + ih * 32;
-                    const int pb = ih;                           // pass a * 2 + ih uses buffer ih
-#pragma unroll
-                    for (int i2 = 0; i2 < 2; ++i2)
-#pragma unroll
-                    for (int b = 0; b < 2; ++b)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        *(f32x4 *)(my + (i2 * 16 + r) * RS + (b * 32 + j * 16 + g * 4) * 4) = acc[a][b][ih * 2 + i2][j] + bq[b][j];
-                    if (a * 2 + ih < 2 * MH - 1) pair_load(pb ^ 1, rl + 32);
-                    float s1[4], s2[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f32x4 lo4 = *(const f32x4 *)(my + (q * 8 + r8) * RS + c8 * 32);
-                        const f32x4 hi4 = *(const f32x4 *)(my + (q * 8 + r8) * RS + c8 * 32 + 16);
-                        const vec8 oh = __builtin_bit_cast(vec8, ohb[pb][q]);
-                        const f16x8 ol = __builtin_bit_cast(f16x8, olb[pb][q]);
-                        float v[8];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            v[e] = lo4[e] + ((float)oh[e] + (float)ol[e]);
-                            v[e + 4] = hi4[e] + ((float)oh[e + 4] + (float)ol[e + 4]);
-                        }
-                        vec8 nh;
-                        f16x8 nl;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) { nh[e] = (E)v[e]; nl[e] = (_Float16)(v[e] - (float)nh[e]); }
-                        *(u32x4 *)(hw + (xo + (rl + q * 8) * ldxB)) = __builtin_bit_cast(u32x4, nh);
-                        *(u32x4 *)(lw + (xo + (rl + q * 8) * ldxB)) = __builtin_bit_cast(u32x4, nl);
-                        s1[q] = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-                        s2[q] = (__builtin_fmaf(v[0], v[0], v[1] * v[1]) + __builtin_fmaf(v[2], v[2], v[3] * v[3])) +
-                                (__builtin_fmaf(v[4], v[4], v[5] * v[5]) + __builtin_fmaf(v[6], v[6], v[7] * v[7]));
-                    }
-                    if (p.dbg & 32) continue;
-#define HGR_DPP_STAGE8(CTRL) _Pragma("unroll") for (int q = 0; q < 4; ++q) { \
-                        s1[q] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1[q]), CTRL, 0xF, 0xF, true)); \
-                        s2[q] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s2[q]), CTRL, 0xF, 0xF, true)); }
-                    HGR_DPP_STAGE8(0xB1) HGR_DPP_STAGE8(0x4E) HGR_DPP_STAGE8(0x141)
-#undef HGR_DPP_STAGE8
-                    if (c8 == 0) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            *(float2 *)(sw + (so + (rl + q * 8) * ldsB)) = make_float2(s1[q], s2[q]);
-                            gbits = max(gbits, __float_as_uint(s2[q]));
-                        }
-                    }
-                }
-                if (p.ln_flag && gbits > __float_as_uint(p.ln_guard)) atomicMax(p.ln_flag, gbits);
-                return;
-            }
+            // 16-byte accesses on the pair (T21 of the CDNA guide: a row-per-lane epilogue is store-ISSUE bound): a lane owns 8
+            // consecutive columns of a row (8 lanes per row, 8 rows per instruction), i.e. ONE 16-byte load / store per half of the
+            // pair where the first version issued two of 8 bytes: 64 instead of 128 global memory instructions per thread and
+            // tile.  The slot sums pair the same values as the 4-column form stage by stage (a lane's 8 columns = the first
+            // exchange of two 4-column lanes), so the statistics keep their bits.  Measured against the 8-byte form, same box, interleaved: out 69.1 -> 64.6 us, proj 146 -> 140 us, image tower 6.04 -> 5.89 ms.
             char *hw = (char *)p.ln_xh + (wrow * p.ln_ldx + wcol) * 2;
             char *lw = (char *)p.ln_xl + (wrow * p.ln_ldx + wcol) * 2;
             char *sw = (char *)(p.ln_stats + (wrow * p.ln_slots + (n0 >> 6) + wn) * 2);
+            const int r8 = lane >> 3, c8 = lane & 7;
             const unsigned ldxB = (unsigned)p.ln_ldx * 2u, ldsB = (unsigned)p.ln_slots * 8u;
-            const unsigned xl = rq * ldxB + cq * 8, sl = rq * ldsB;
-            // the old pair of pass P + 1 is requested before pass P stores (passes touch disjoint rows; the compiler cannot hoist
-            // the loads itself, the pointers alias): one exposed memory round trip per tile instead of four
-            hvec4 ohb[2][8];
-            f16x4 olb[2][8];
+            const unsigned xo = r8 * ldxB + c8 * 16, so = r8 * ldsB;
+            u32x4 ohb[2][4], olb[2][4];
             auto pair_load = [&](int buf, int rl) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    ohb[buf][q] = *(const hvec4 *)(hw + (xl + (rl + q * 4) * ldxB));
-                    olb[buf][q] = *(const f16x4 *)(lw + (xl + (rl + q * 4) * ldxB));
+                for (int q = 0; q < 4; ++q) {
+                    ohb[buf][q] = *(const u32x4 *)(hw + (xo + (rl + q * 8) * ldxB));
+                    olb[buf][q] = *(const u32x4 *)(lw + (xo + (rl + q * 8) * ldxB));
                 }
             };
             pair_load(0, 0);
-            unsigned gbits = 0u;                                  // range guard: largest slot sum of squares seen (as bits: inf / NaN rank highest)
+            unsigned gbits = 0u;                              // range guard: largest slot sum of squares seen (as bits: inf / NaN rank highest)
 #pragma unroll
             for (int a = 0; a < MH; ++a)
 #pragma unroll
             for (int ih = 0; ih < 2; ++ih) {
                 const int rl = a * 64 + ih * 32;
-                const int pb = ih;                               // pass a * 2 + ih uses buffer ih
-                hvec4 (&oh)[8] = ohb[pb];
-                f16x4 (&ol)[8] = olb[pb];
-                if (a * 2 + ih > 0 && (p.dbg & 64)) pair_load(pb, rl);        // HGR_GEMM_DBG bit 64: every pass loads for itself (A/B runs)
+                const int pb = ih;                           // pass a * 2 + ih uses buffer ih
 #pragma unroll
                 for (int i2 = 0; i2 < 2; ++i2)
 #pragma unroll
@@ -705,40 +551,40 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     *(f32x4 *)(my + (i2 * 16 + r) * RS + (b * 32 + j * 16 + g * 4) * 4) = acc[a][b][ih * 2 + i2][j] + bq[b][j];
-                if (a * 2 + ih < 2 * MH - 1 && !(p.dbg & 64)) pair_load(pb ^ 1, rl + 32);
-                f32x4 vq[8];
+                if (a * 2 + ih < 2 * MH - 1) pair_load(pb ^ 1, rl + 32);
+                float s1[4], s2[4];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    vq[q] = *(const f32x4 *)(my + (q * 4 + rq) * RS + cq * 16);
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 lo4 = *(const f32x4 *)(my + (q * 8 + r8) * RS + c8 * 32);
+                    const f32x4 hi4 = *(const f32x4 *)(my + (q * 8 + r8) * RS + c8 * 32 + 16);
+                    const vec8 oh = __builtin_bit_cast(vec8, ohb[pb][q]);
+                    const f16x8 ol = __builtin_bit_cast(f16x8, olb[pb][q]);
+                    float v[8];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) vq[q][e] += (float)oh[q][e] + (float)ol[q][e];
-                }
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = lo4[e] + ((float)oh[e] + (float)ol[e]);
+                        v[e + 4] = hi4[e] + ((float)oh[e + 4] + (float)ol[e + 4]);
+                    }
+                    vec8 nh;
+                    f16x8 nl;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const hvec4 nh = cvt4<DT>(vq[q][0], vq[q][1], vq[q][2], vq[q][3]);
-                    f16x4 nl;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) nl[e] = (_Float16)(vq[q][e] - (float)nh[e]);
-                    *(hvec4 *)(hw + (xl + (rl + q * 4) * ldxB)) = nh;
-                    *(f16x4 *)(lw + (xl + (rl + q * 4) * ldxB)) = nl;
+                    for (int e = 0; e < 8; ++e) { nh[e] = (E)v[e]; nl[e] = (_Float16)(v[e] - (float)nh[e]); }
+                    *(u32x4 *)(hw + (xo + (rl + q * 8) * ldxB)) = __builtin_bit_cast(u32x4, nh);
+                    *(u32x4 *)(lw + (xo + (rl + q * 8) * ldxB)) = __builtin_bit_cast(u32x4, nl);
+                    s1[q] = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+                    s2[q] = (__builtin_fmaf(v[0], v[0], v[1] * v[1]) + __builtin_fmaf(v[2], v[2], v[3] * v[3])) +
+                            (__builtin_fmaf(v[4], v[4], v[5] * v[5]) + __builtin_fmaf(v[6], v[6], v[7] * v[7]));
                 }
                 if (p.dbg & 32) continue;
-                float s1[8], s2[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    s1[q] = (vq[q][0] + vq[q][1]) + (vq[q][2] + vq[q][3]);
-                    // explicit fused form: the full-tile and the edge-tile path must round alike (hipcc contracts a*a + b*b as it likes)
-                    s2[q] = __builtin_fmaf(vq[q][0], vq[q][0], vq[q][1] * vq[q][1]) + __builtin_fmaf(vq[q][2], vq[q][2], vq[q][3] * vq[q][3]);
-                }
-#define HGR_DPP_STAGE(CTRL) _Pragma("unroll") for (int q = 0; q < 8; ++q) { \
+#define HGR_DPP_STAGE8(CTRL) _Pragma("unroll") for (int q = 0; q < 4; ++q) { \
                     s1[q] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1[q]), CTRL, 0xF, 0xF, true)); \
                     s2[q] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s2[q]), CTRL, 0xF, 0xF, true)); }
-                HGR_DPP_STAGE(0xB1) HGR_DPP_STAGE(0x4E) HGR_DPP_STAGE(0x141) HGR_DPP_STAGE(0x140)
-#undef HGR_DPP_STAGE
-                if (cq == 0) {
+                HGR_DPP_STAGE8(0xB1) HGR_DPP_STAGE8(0x4E) HGR_DPP_STAGE8(0x141)
+#undef HGR_DPP_STAGE8
+                if (c8 == 0) {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        *(float2 *)(sw + (sl + (rl + q * 4) * ldsB)) = make_float2(s1[q], s2[q]);
+                    for (int q = 0; q < 4; ++q) {
+                        *(float2 *)(sw + (so + (rl + q * 8) * ldsB)) = make_float2(s1[q], s2[q]);
                         gbits = max(gbits, __float_as_uint(s2[q]));
                     }
                 }

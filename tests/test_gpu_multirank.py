@@ -27,7 +27,8 @@ def _bench(n, extra):
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     if p.returncode != 0 and any(w in p.stderr for w in ("Address already in use", "RendezvousConnectionError", "DistNetworkError")):
         pytest.skip("could not set up a local rendezvous on this box")
-    assert p.returncode == 0, p.stderr[-2000:]
+    why = [l for l in p.stderr.splitlines() if "dp_check FAILED" in l or "Error" in l][:6]
+    assert p.returncode == 0, "\n".join(why) + "\n" + p.stderr[-1500:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-500:]                      # rank 0 prints exactly one JSON line
     return json.loads(lines[0])
