@@ -790,14 +790,45 @@ __global__ __launch_bounds__(256) void embed_scatter_add(const int64_t *__restri
 }
 
 // ---- sum of squares (global grad norm) and fused AdamW with the clip factor read from device memory -----------------
+// Deterministic: every block leaves its partial in g_sumsq_part, the block that draws the last ticket adds the partials in index
+// order.  (The first version atomicAdd'ed the block sums into *out: the order, hence the last bits of the global gradient norm,
+// hence of the clip factor and of every weight, differed from run to run and from RANK to RANK - data-parallel replicas drifted
+// apart by ulps per step; found by bench.py's dp_check.)  One agent-scope release per block and one acquire in the last block
+// (cdna_hip_programming.md, Guideline 16).  The scratch is process-wide: launches of hgr_sumsq must be stream-ordered with each other.
+__device__ float g_sumsq_part[1024];
+__device__ unsigned g_sumsq_ticket = 0;
 __global__ __launch_bounds__(256) void sumsq(const float *__restrict__ x, int64_t n, float *__restrict__ out) {
     __shared__ float s[4];
+    __shared__ unsigned s_last;
     float acc = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) acc += x[i] * x[i];
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, s[0] + s[1] + s[2] + s[3]);
+    if (threadIdx.x == 0) {
+        g_sumsq_part[blockIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_last = __hip_atomic_fetch_add(&g_sumsq_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    // fixed order: thread t sums partials t, t + 256, ... ; then the wave / block tree above
+    float tot = 0.f;
+    for (unsigned b = threadIdx.x; b < gridDim.x; b += 256) tot += __hip_atomic_load(&g_sumsq_part[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    tot = wave_sum(tot);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = tot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *out += (s[0] + s[1]) + (s[2] + s[3]);
+        __hip_atomic_store(&g_sumsq_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 // torch.optim.AdamW semantics: p *= 1 - lr*wd ; m, v EMA ; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps).
 // `sumsq_total` (may be NULL) holds the squared global grad norm: grads are scaled by min(1, max_norm/(norm+1e-6))

@@ -255,6 +255,24 @@ def test_adamw_and_clip_match_torch():
     assert torch.allclose(p.cpu(), p_ref.detach(), rtol=1e-5, atol=1e-6)
 
 
+def test_sumsq_is_bit_deterministic_and_accumulates():
+    """The global gradient norm must have the same BITS on every data-parallel rank (and run to run): the clip factor multiplies
+    every gradient, so a last-bit difference makes the replicas' weights drift apart (found by bench.py's dp_check: gradient buffers
+    identical after the all-reduce, weights not).  hgr_sumsq: per-block partials + a fixed-order final sum by the last block; over
+    150 M values (the ViT-B/32 CLIP parameter count: 1024 blocks), a ragged size, and accumulation into a non-zero total."""
+    g = torch.Generator(device=DEV).manual_seed(9)
+    for n in (151_277_313, 1000, 262_144 * 3 + 17):
+        x = torch.randn(n, generator=g, device=DEV)
+        tots = []
+        for rep in range(6):
+            tot = torch.full((1,), 0.5 if rep == 5 else 0.0, device=DEV)
+            ops.sumsq(x, tot)
+            tots.append(float(tot.item()))
+        assert len(set(tots[:5])) == 1, tots
+        ref = float((x.double() ** 2).sum())
+        assert abs(tots[0] - ref) <= 2e-6 * ref and abs(tots[5] - 0.5 - ref) <= 2e-6 * ref, (tots, ref)
+
+
 # ---- ModifiedResNet tower backward pieces (training_rn.py) ---------------------------------------------------------
 @pytest.mark.parametrize("dt", DTS)
 def test_relu_add_avgpool_attnpool_backward_kernels(dt):
