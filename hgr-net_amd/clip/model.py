@@ -516,32 +516,6 @@ class CLIP(nn.Module):
             main.wait_stream(st)
         return out
 
-    @torch.no_grad()
-    def prestage_patches(self, image: Optional[torch.Tensor], slot: int = 0, stream=None) -> Optional[torch.cuda.Event]:
-        """Unfold the NEXT batch's patch matrix ahead of its forward (hgr_im2col_patches into a buffer of its own, `slot` in {0, 1}),
-        optionally on a side `stream`, so that the HBM-bound unfold (75 us at ViT-B/32, batch 512) runs beside the previous batch's
-        MFMA-bound kernels instead of in front of its own patch GEMM.  The next encode_image of exactly this tensor then starts at
-        the patch GEMM.  Returns the event the consumer stream must wait for; prestage_patches(None) drops the staging."""
-        if image is None:
-            self.__dict__.pop("_prestaged", None)
-            return None
-        v = self.visual
-        p = self._prepared()
-        ps = v.patch_size
-        b, g = image.shape[0], v.input_resolution // ps
-        u8 = image.dtype == torch.uint8
-        buf = self._ws.get(f"v.patches.pre{slot}", (b * g * g, p["kp"]), self.image_dtype, image.device)
-        st = stream if stream is not None else torch.cuda.current_stream()
-        with torch.cuda.stream(st):
-            if u8:
-                ops.im2col_patches_u8(image, buf, ps)
-            else:
-                ops.im2col_patches(image, buf, ps)
-            ev = torch.cuda.Event()
-            ev.record(st)
-        self.__dict__["_prestaged"] = ((image.data_ptr(), tuple(image.shape), image.dtype), buf)
-        return ev
-
     def _side_streams(self, n: int, dev):
         have = self.__dict__.setdefault("_streams", [])
         while len(have) < n:
@@ -557,15 +531,11 @@ class CLIP(nn.Module):
         ps = v.patch_size
         g = r // ps
         gg, l, w = g * g, g * g + 1, v.conv1.weight.shape[0]
-        pre = self.__dict__.get("_prestaged")
-        if pre is not None and pre[0] == (image.data_ptr(), tuple(image.shape), image.dtype) and tag == "v":
-            patches = pre[1]                              # the patch matrix of THIS input was unfolded ahead of time (prestage_patches)
+        patches = ws.get(tag + ".patches", (b * gg, p["kp"]), dt, dev)
+        if u8:
+            ops.im2col_patches_u8(image, patches, ps)
         else:
-            patches = ws.get(tag + ".patches", (b * gg, p["kp"]), dt, dev)
-            if u8:
-                ops.im2col_patches_u8(image, patches, ps)
-            else:
-                ops.im2col_patches(image, patches, ps)
+            ops.im2col_patches(image, patches, ps)
         pe = ws.get(tag + ".pe", (b * gg, w), torch.float32, dev)
         ops.gemm_nt(patches, p["conv_w_nhwc"] if u8 else p["conv_w"], pe, tag="patch")
         cls16 = ws.get(tag + ".cls16", (b, w), dt, dev)
