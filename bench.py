@@ -319,6 +319,16 @@ def train_mode(a, model, cfg, h, rank, world, group, ranks_seen, dev, real_stdou
         dp_check = {"ok": bool(ok), "ranks_seen": dist.get_world_size(group), "grad_buffer_checksum_equal": all(g == gs[0] for g in gs),
                     "weights_checksum_equal": all(w == ws_[0] for w in ws_), "negatives_equal": all(c == cs[0] for c in cs),
                     "loss_per_rank": losses, "loss_global_mean": sum(losses) / world}
+    traffic, traffic_src = None, "null: no PMC summary of this kernel build / configuration under profiles/"
+    if a.arch == "ViT-L/14" and a.n_ctx == 16 and a.batch == 256:
+        sys.path.insert(0, str(ROOT / "tools"))
+        from pmc_summary import kernel_source_hash
+        for pmc in sorted((ROOT / "profiles").glob("r*pmc_summary.json"), reverse=True):
+            d = json.load(open(pmc))
+            if d.get("kernel_source_hash") == kernel_source_hash() and d.get("config") == "train_l14":
+                traffic = d["tower_gemm"]["hbm_bytes_per_launch"]
+                traffic_src = f"HBM bytes per GEMM launch (gemm_nt / gemm_tn, rocprofv3 PMC, profiles/{pmc.name})"
+                break
     picks = model._trainer.last_contra
     uniq = len({i for ids, _ in picks for i in ids})
     l_txt = int(model.node_tokens[:, :].argmax(dim=-1).max().item()) + 1
@@ -333,7 +343,7 @@ def train_mode(a, model, cfg, h, rank, world, group, ranks_seen, dev, real_stdou
                                        f"{len(picks)} inner steps x <= 257 prompts ({uniq} distinct, {l_txt} tokens), batch {a.batch}/GPU",
                            "global_batch": a.batch * world, "parallelism": f"dp{world}", "weights": "random-init (hash-seeded)"},
                 "roofline": {"kernel": "whole step (forward + backward GEMMs of both towers)", "bound": "mfma", "achieved": round(fl / (ms * 1e-3) / 1e12, 1),
-                             "peak": PEAK_TFLOPS_BF16, "unit": "TFLOP/s", "frac": round(fl / (ms * 1e-3) / 1e12 / PEAK_TFLOPS_BF16, 4), "traffic": None,
+                             "peak": PEAK_TFLOPS_BF16, "unit": "TFLOP/s", "frac": round(fl / (ms * 1e-3) / 1e12 / PEAK_TFLOPS_BF16, 4), "traffic": traffic, "traffic_unit": traffic_src,
                              "flops_per_step": fl, "note": "3 x forward FLOPs of the executed passes (per rank)"},
                 "cpu_baseline": None, "loss_first": loss0, "loss_last": loss,
                 "parity": {"note": "the true-dimension OM step is checked against oracle/train_ref in tests/test_gpu_training.py "
@@ -522,17 +532,19 @@ def main():
             # cannot be read from inside the process, so a committed summary is quoted ONLY if it was measured on this very
             # build of the kernels (its recorded source hash == tools/pmc_summary.py:kernel_source_hash() now); else null.
             traffic, traffic_src = None, "null: no PMC summary of this kernel build under profiles/ (tools/profile_round.sh regenerates it)"
-            if a.arch == ARCH and a.batch == BATCH and a.nodes == N_NODES:
+            want = "vitb32" if (a.arch == ARCH and a.batch == BATCH and a.nodes == N_NODES) else \
+                   "rn50" if (a.arch == "RN50" and a.batch == BATCH and a.nodes == 20842) else None
+            if want:
                 sys.path.insert(0, str(ROOT / "tools"))
                 from pmc_summary import kernel_source_hash
                 now = kernel_source_hash()
-                for pmc in sorted((ROOT / "profiles").glob("r*_pmc_summary.json"), reverse=True):
+                for pmc in sorted((ROOT / "profiles").glob("r*pmc_summary.json"), reverse=True):
                     d = json.load(open(pmc))
-                    if d.get("kernel_source_hash") == now:
+                    if d.get("kernel_source_hash") == now and d.get("config", "vitb32") == want:
                         traffic = d["tower_gemm"]["hbm_bytes_per_launch"]
                         traffic_src = f"HBM bytes per launch (rocprofv3 PMC, profiles/{pmc.name}, kernel sources {now})"
                         break
-            roof = {"kernel": "gemm_nt_256 / gemm_nt_128 (image-tower GEMMs: qkv, out, fc, proj, patch)" if a.arch.startswith("ViT") else "gemm_nt_256 / gemm_nt_128 (image-tower 1x1 GEMMs and implicit-GEMM 3x3 convolutions)", "bound": "mfma",
+            roof = {"kernel": "gemm_nt_duo (image-tower GEMMs: qkv, out, fc, proj, patch)" if a.arch.startswith("ViT") else "gemm_nt_256 / gemm_nt_128 (image-tower 1x1 GEMMs and implicit-GEMM 3x3 convolutions)", "bound": "mfma",
                     "achieved": round(ach, 1), "peak": PEAK_TFLOPS_BF16, "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS_BF16, 4),
                     "traffic": traffic, "traffic_unit": traffic_src,
                     "algorithmic_bytes_per_launch": round(sum(b for _, _, b in tower) / len(tower)),

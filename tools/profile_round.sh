@@ -21,14 +21,14 @@ cd /tmp
 python3 "$ROOT/bench.py" $ARGS > "$OUT/bench.json" 2> "$OUT/bench.err"
 echo "[profile] bench done: $(cut -c1-200 "$OUT/bench.json")"
 
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o "$TAG" -- python3 "$ROOT/bench.py" $ARGS --no-cpu-baseline --no-pcie \
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o "$TAG" -- python3 "$ROOT/bench.py" $ARGS --no-cpu-baseline --no-pcie --no-secondary \
     > "$OUT/bench_under_rocprof.json" 2> "$OUT/rocprof_stats.err"
 echo "[profile] kernel-trace stats done"
 
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o fetch -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-pcie \
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o fetch -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-pcie --no-secondary \
     > /dev/null 2> "$OUT/rocprof_fetch.err"
 echo "[profile] FETCH_SIZE pass done"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o write -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-pcie \
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o write -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-pcie --no-secondary \
     > /dev/null 2> "$OUT/rocprof_write.err"
 echo "[profile] WRITE_SIZE pass done"
 
@@ -39,6 +39,26 @@ python3 "$ROOT/tools/pmc_summary.py" "$TAG" "$STATS" "$FETCH" "$WRITE"
 cp "$STATS" "$ROOT/profiles/${TAG}_vitb32_kernel_stats.csv"
 cp "$OUT/bench.json" "$ROOT/profiles/${TAG}_vitb32_bench.json"
 cp "$OUT/bench_under_rocprof.json" "$ROOT/profiles/${TAG}_vitb32_bench_under_rocprof.json"
+# the other two BASELINE configs the default bench line carries as `secondary` (configs[2] RN50 + hierarchy, configs[4] ViT-L/14 + CoOp
+# OM training step): kernel-trace statistics and the two PMC passes of each (PROFILE_SECONDARY=0 skips them)
+profile_config() {   # <name> <bench args...>
+    local NAME=$1; shift
+    rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${NAME}_stats" -o "$TAG" -- python3 "$ROOT/bench.py" "$@" \
+        > "$OUT/${NAME}_bench_under_rocprof.json" 2> "$OUT/${NAME}_rocprof_stats.err"
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/${NAME}_pmc_fetch" -o fetch -- python3 "$ROOT/bench.py" "$@" > /dev/null 2> "$OUT/${NAME}_rocprof_fetch.err"
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/${NAME}_pmc_write" -o write -- python3 "$ROOT/bench.py" "$@" > /dev/null 2> "$OUT/${NAME}_rocprof_write.err"
+    local S=$(find "$OUT/${NAME}_stats" -name "*kernel_stats.csv" | head -1)
+    local F=$(find "$OUT/${NAME}_pmc_fetch" -name "*counter_collection.csv" | head -1)
+    local W=$(find "$OUT/${NAME}_pmc_write" -name "*counter_collection.csv" | head -1)
+    python3 "$ROOT/tools/pmc_summary.py" "$TAG" "$S" "$F" "$W" "$NAME"
+    cp "$S" "$ROOT/profiles/${TAG}_${NAME}_kernel_stats.csv"
+    cp "$OUT/${NAME}_bench_under_rocprof.json" "$ROOT/profiles/${TAG}_${NAME}_bench_under_rocprof.json"
+    echo "[profile] $NAME done"
+}
+if [ "${PROFILE_SECONDARY:-1}" != "0" ]; then
+    profile_config rn50 --arch RN50 --nodes 20842 --steps 8 --warmup 2 --no-pcie --no-cpu-baseline --secondary
+    profile_config train_l14 --mode train --arch ViT-L/14 --n-ctx 16 --batch 256 --steps 2 --warmup 1 --secondary
+fi
 # profiles/ on the box is outside gpurun_out/: ship copies back through it
 mkdir -p "$OUT/profiles" && cp "$ROOT/profiles/${TAG}"_* "$OUT/profiles/"
 echo "[profile] summaries in gpurun_out/$TAG/profiles/ (copy into profiles/ and commit)"
