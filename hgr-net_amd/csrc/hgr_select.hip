@@ -787,6 +787,14 @@ __global__ __launch_bounds__(1024) void eval_counters(const int32_t *__restrict_
     // compare: the first version walked two rows per thread with its loads under the compares, a chain of dependent L2 round
     // trips that made this 0.1 MB kernel the 11 us tail of every evaluation step.
     __shared__ unsigned s_red[16][8];
+    __shared__ int s_par[32], s_lev[32];
+    // the target's path (ancestors, their levels) through LDS: read as uniform values inside the per-level loop they became a chain
+    // of scalar loads, one L2 / HBM round trip per level (the arrays are views into a CSR nobody else touches: always cold)
+    if (threadIdx.x < 32) {
+        s_par[threadIdx.x] = threadIdx.x < L ? parents[threadIdx.x] : -1;
+        s_lev[threadIdx.x] = threadIdx.x < L ? levels[threadIdx.x] : 0;
+    }
+    __syncthreads();
     unsigned cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // hits@1,2,5,10,20, hits_all, edges (or first-level matches when L == 1), points
     for (int r = threadIdx.x; r < B; r += 1024) {
         const int tgt = targets ? (int)targets[r] : target;
@@ -794,7 +802,7 @@ __global__ __launch_bounds__(1024) void eval_counters(const int32_t *__restrict_
 #pragma unroll
         for (int i = 0; i < 32; ++i) pr[i] = i < k ? pred[(int64_t)r * k + i] : -1;
 #pragma unroll
-        for (int i = 0; i < 32; ++i) lvv[i] = i < L ? lv[(int64_t)r * n_levels + levels[i]] : -1;
+        for (int i = 0; i < 32; ++i) lvv[i] = i < L ? lv[(int64_t)r * n_levels + s_lev[i]] : -1;
         const int t1 = top1[r];
         int j = k;
 #pragma unroll
@@ -804,10 +812,10 @@ __global__ __launch_bounds__(1024) void eval_counters(const int32_t *__restrict_
         bool prev = false;
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
-            if (i >= L) break;
-            const int pa = parents[i];
-            cnt[5] += t1 == pa;
-            const bool m = lvv[i] == pa;
+            const int pa = s_par[i];
+            const bool live = i < L;
+            cnt[5] += live && t1 == pa;
+            const bool m = live && lvv[i] == pa;
             cnt[7] += m;
             if (L == 1) cnt[6] += m;
             else if (i > 0) cnt[6] += (m && prev);
