@@ -170,6 +170,7 @@ class _Workspace:
 # ViT image batches of at least IMG_STREAMS_MIN_ROWS patch rows run as HGR_IMG_STREAMS independent slices on as many streams
 IMG_STREAMS = max(1, int(os.environ.get("HGR_IMG_STREAMS", "1")))
 IMG_STREAMS_MIN_ROWS = 8192
+CLS_LAST = os.environ.get("HGR_CLS_LAST", "1") != "0"      # HGR_CLS_LAST=0: the last image block runs out_proj / MLP on every token (A/B runs, tests)
 LN_FUSED = os.environ.get("HGR_LN_FUSED", "1") != "0"     # HGR_LN_FUSED=0: separate LayerNorm launches (the first build's path), for A/B runs
 
 
@@ -182,7 +183,7 @@ def ln_fusable(w: int, m: int = 0) -> bool:
 
 def _run_blocks(x: Optional[torch.Tensor], blocks, heads: int, b: int, l: int, causal: bool, dt: torch.dtype, ws: _Workspace, tag: str,
                 taps: Optional[dict] = None, tap_prefix: str = "", pair=None, stats: Optional[torch.Tensor] = None,
-                flag: Optional[torch.Tensor] = None):
+                flag: Optional[torch.Tensor] = None, cls_only_last: bool = False):
     """The residual stack (clip/model.py:185-188 per block).
 
     Fused form (``pair`` = (xh, xl): the residual stream as a 16-bit pair, x = xh + xl, with its LayerNorm slot statistics in
@@ -191,6 +192,10 @@ def _run_blocks(x: Optional[torch.Tensor], blocks, heads: int, b: int, l: int, c
         QKV = LN-folded GEMM(xh) -> attention -> (xh, xl) += out GEMM (+ stats) -> u = LN-folded GEMM(xh, QuickGELU)
         -> (xh, xl) += proj GEMM (+ stats)
     ``flag``: the producers' range guard (ops.gemm_nt_res_stats), see CLIP._ln_check.
+    ``cls_only_last`` (image tower): the visual head reads ONLY the class token of the last block's output
+    (``x = self.ln_post(x[:, 0, :])``, clip/model.py:231), and out_proj / ln_2 / the MLP act on every token independently (:186-187), so
+    the last block runs them on the b class-token rows alone - strided views into the same pair, same kernels, the same bits for
+    those rows; its attention still sees every key and value.  The other rows of (xh, xl) keep the previous block's values.
     Otherwise, on the fp32 stream x [b*l, w]: LN -> QKV GEMM(+bias) -> attention -> out GEMM(+bias, +residual) -> LN -> fc
     GEMM(+bias, QuickGELU) -> proj GEMM(+bias, +residual): 7 launches per block."""
     m, w = (pair[0] if pair is not None else x).shape
@@ -203,6 +208,14 @@ def _run_blocks(x: Optional[torch.Tensor], blocks, heads: int, b: int, l: int, c
         for i, k in enumerate(blocks):
             ops.gemm_nt_ln(xh, k.wf_in, qkv, k.s_in, k.c_in, stats, k.eps1, tag="qkv")
             ops.mha(qkv, att, b, l, heads, causal)
+            if cls_only_last and i == len(blocks) - 1 and l > 1:
+                ch, cl, ca = xh.view(b, l, w)[:, 0, :], xl.view(b, l, w)[:, 0, :], att.view(b, l, w)[:, 0, :]      # row stride l * w
+                st_c = ws.get(tag + ".stats_cls", (b, w // 64, 2), torch.float32, dev)
+                u_c = ws.get(tag + ".u16_cls", (b, 4 * w), dt, dev)
+                ops.gemm_nt_res_stats(ca, k.w_out, ch, cl, k.b_out, st_c, tag="out_cls", flag=flag)
+                ops.gemm_nt_ln(ch, k.wf_fc, u_c, k.s_fc, k.c_fc, st_c, k.eps2, quickgelu=True, tag="fc_cls")
+                ops.gemm_nt_res_stats(u_c, k.w_proj, ch, cl, k.b_proj, st_c, tag="proj_cls", flag=flag)
+                break
             ops.gemm_nt_res_stats(att, k.w_out, xh, xl, k.b_out, stats, tag="out", flag=flag)
             ops.gemm_nt_ln(xh, k.wf_fc, u16, k.s_fc, k.c_fc, stats, k.eps2, quickgelu=True, tag="fc")
             ops.gemm_nt_res_stats(u16, k.w_proj, xh, xl, k.b_proj, stats, tag="proj", flag=flag)
@@ -547,7 +560,8 @@ class CLIP(nn.Module):
             ops.vit_embed_ln_stats(pe, p["cls"], p["pos"], p["ln_pre"][0], p["ln_pre"][1], xh, xl, stats, b, gg)
             if taps is not None:
                 taps["visual.ln_pre"] = (xh.float() + xl.float()).view(b, l, w)
-            _run_blocks(None, p["vblocks"], w // 64, b, l, False, dt, ws, tag, taps, "visual.transformer", (xh, xl), stats, self._ln_flag("v", dev))
+            _run_blocks(None, p["vblocks"], w // 64, b, l, False, dt, ws, tag, taps, "visual.transformer", (xh, xl), stats, self._ln_flag("v", dev),
+                        cls_only_last=taps is None and CLS_LAST)
             cls32 = ws.get(tag + ".cls32", (b, w), torch.float32, dev)
             ops.pair_rows_f32(xh, xl, cls32, row_mul=l)                          # the class tokens back in fp32 for ln_post
             ops.layernorm(cls32, p["ln_post"][0], p["ln_post"][1], cls16, rows=b)

@@ -400,6 +400,25 @@ def test_batch512_forward_through_graph_vs_oracle_subsample(arch, nodes, tmp_pat
           f"{lv_checked} decidable (row, level) arg-max ids equal")
 
 
+@pytest.mark.parametrize("arch,batch", [("small-vit", 5), ("ViT-B/32", 24)])
+def test_last_block_on_class_tokens_only_gives_the_same_bits(arch, batch):
+    """The visual head reads only the class token of the last block (clip/model.py:231: ln_post(x[:, 0, :])); out_proj, ln_2 and the
+    MLP are per-token (clip/model.py:186-187), so the last block runs them on the class-token rows alone (strided views of the pair,
+    same kernels).  Features must equal, bit for bit, the ones computed with every token carried through the last block."""
+    from hgr_net_amd.clip import model as clip_model
+    cfg = synth.CLIP_CONFIGS[arch]
+    m = build_model(synth.clip_state_dict(cfg, 0)).to(DEV)
+    img = synth.images(batch, cfg["image_resolution"], 77).to(DEV)
+    assert clip_model.CLS_LAST
+    fast = m.encode_image(img).clone()
+    clip_model.CLS_LAST = False
+    try:
+        full = m.encode_image(img).clone()
+    finally:
+        clip_model.CLS_LAST = True
+    assert torch.isfinite(fast).all() and torch.equal(fast, full)
+
+
 def test_graphs_survive_a_workspace_reallocation(golden_dir, tmp_path):
     """a direct encode_image call with a LARGER batch between two graphed forwards re-allocates the shared
     workspace; the old graph must not be replayed on the freed buffers (workspace epoch is part of the graph key)."""
