@@ -157,6 +157,14 @@ class _Workspace:
         self._b: Dict[str, torch.Tensor] = {}
         self.epoch = 0          # bumped whenever a buffer is (re)allocated: captured HIP graphs hold the old pointers
 
+    def const(self, name: str, build) -> torch.Tensor:
+        """A small constant device tensor built once (index vectors): never re-created inside a graph capture."""
+        t = self._b.get("const." + name)
+        if t is None:
+            t = self._b["const." + name] = build()
+            self.epoch += 1
+        return t
+
     def get(self, name: str, shape, dtype, device) -> torch.Tensor:
         n = int(np.prod(shape))
         t = self._b.get(name)
@@ -206,10 +214,20 @@ def _run_blocks(x: Optional[torch.Tensor], blocks, heads: int, b: int, l: int, c
     if pair is not None:
         xh, xl = pair
         for i, k in enumerate(blocks):
-            ops.gemm_nt_ln(xh, k.wf_in, qkv, k.s_in, k.c_in, stats, k.eps1, tag="qkv")
+            last_cls = cls_only_last and i == len(blocks) - 1 and l > 1
+            if last_cls:
+                # keys and values of every token, queries of the class tokens only (the one attention row that is read)
+                ch, cl = xh.view(b, l, w)[:, 0, :], xl.view(b, l, w)[:, 0, :]                  # row stride l * w
+                ops.gemm_nt_ln(xh, k.wf_in[w:], qkv[:, w:], k.s_in[w:], k.c_in[w:], stats, k.eps1, tag="kv")
+                st_q = ws.get(tag + ".stats_q", (b, w // 64, 2), torch.float32, dev)
+                idx = ws.const(f"cls_rows.{b}.{l}", lambda: (torch.arange(b, dtype=torch.int32, device=dev) * l).contiguous())
+                ops.rows_gather(stats.view(b * l, -1), idx, st_q.view(b, -1))                   # the class rows' ln_1 statistics, compact
+                ops.gemm_nt_ln(ch, k.wf_in[:w], qkv.view(b, l, 3 * w)[:, 0, :w], k.s_in[:w], k.c_in[:w], st_q, k.eps1, tag="q_cls")
+            else:
+                ops.gemm_nt_ln(xh, k.wf_in, qkv, k.s_in, k.c_in, stats, k.eps1, tag="qkv")
             ops.mha(qkv, att, b, l, heads, causal)
-            if cls_only_last and i == len(blocks) - 1 and l > 1:
-                ch, cl, ca = xh.view(b, l, w)[:, 0, :], xl.view(b, l, w)[:, 0, :], att.view(b, l, w)[:, 0, :]      # row stride l * w
+            if last_cls:
+                ca = att.view(b, l, w)[:, 0, :]
                 st_c = ws.get(tag + ".stats_cls", (b, w // 64, 2), torch.float32, dev)
                 u_c = ws.get(tag + ".u16_cls", (b, 4 * w), dt, dev)
                 ops.gemm_nt_res_stats(ca, k.w_out, ch, cl, k.b_out, st_c, tag="out_cls", flag=flag)

@@ -3,7 +3,8 @@
 process-wide knob, replayed interleaved in ONE process (CDNA guide rule 24): what a kernel change is worth INSIDE the step.
 
     step_knob_ab.py tail           tail plan of gemm_nt_duo off / on (hgr_gemm_set_tail)
-    step_knob_ab.py env NAME v1 v2 ...   an environment knob the host code re-reads per call (e.g. HGR_PATCH_IMPLICIT 0 1)
+    step_knob_ab.py env NAME v1 v2 ...   an environment knob the host code re-reads per call
+    step_knob_ab.py attr MODULE NAME v1 v2 ...   a module-level switch read at call time (e.g. attr hgr_net_amd.clip.model CLS_LAST 0 1)
 """
 import json
 import os
@@ -44,6 +45,10 @@ what = sys.argv[1] if len(sys.argv) > 1 else "tail"
 from hgr_net_amd import ops
 if what == "tail":
     arms = [("tail_off", lambda: ops.gemm_set_tail(False)), ("tail_on", lambda: ops.gemm_set_tail(True, -1))]
+elif what == "attr":
+    import importlib
+    mod, name, vals = importlib.import_module(sys.argv[2]), sys.argv[3], sys.argv[4:]
+    arms = [(f"{name}={v}", (lambda v=v: setattr(mod, name, type(getattr(mod, name))(int(v))))) for v in vals]
 else:
     name, vals = sys.argv[2], sys.argv[3:]
     arms = [(f"{name}={v}", (lambda v=v: os.environ.__setitem__(name, v))) for v in vals]
