@@ -33,6 +33,7 @@ SIGNATURES = {
     "hgr_vit_embed_ln": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p],
     "hgr_layernorm": [_p, _p, _p, _p, _i, _i, _l, _p, _f, _i, _i, _p],
     "hgr_mha": [_p, _p, _i, _i, _i, _i, _i, _p],
+    "hgr_mha_rows": [_p, _p, _i, _i, _i, _i, _i, _i, _p],
     "hgr_mha_stats": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
     "hgr_text_embed": [_p, _l, _p, _p, _p, _i, _i, _i, _i, _p],
     "hgr_eot_index": [_p, _l, _p, _i, _i, _p],

@@ -225,7 +225,7 @@ def _run_blocks(x: Optional[torch.Tensor], blocks, heads: int, b: int, l: int, c
                 ops.gemm_nt_ln(ch, k.wf_in[:w], qkv.view(b, l, 3 * w)[:, 0, :w], k.s_in[:w], k.c_in[:w], st_q, k.eps1, tag="q_cls")
             else:
                 ops.gemm_nt_ln(xh, k.wf_in, qkv, k.s_in, k.c_in, stats, k.eps1, tag="qkv")
-            ops.mha(qkv, att, b, l, heads, causal)
+            ops.mha(qkv, att, b, l, heads, causal, q_rows=1 if last_cls else 0)
             if last_cls:
                 ca = att.view(b, l, w)[:, 0, :]
                 st_c = ws.get(tag + ".stats_cls", (b, w // 64, 2), torch.float32, dev)

@@ -26,7 +26,7 @@ typedef __attribute__((ext_vector_type(8))) short mha_s16x8;
 
 template <int DT, int KT, bool CAUSAL>
 __global__ __launch_bounds__(256) void mha_fwd(const typename T16<DT>::elem *__restrict__ qkv,
-                                               typename T16<DT>::elem *__restrict__ out, int L, int H, float2 *__restrict__ stats) {
+                                               typename T16<DT>::elem *__restrict__ out, int L, int H, float2 *__restrict__ stats, int QL) {
     typedef typename T16<DT>::elem E;
     typedef typename T16<DT>::vec8 vec8;
     typedef typename T16<DT>::vec4 vec4;
@@ -51,9 +51,12 @@ __global__ __launch_bounds__(256) void mha_fwd(const typename T16<DT>::elem *__r
 
     // this wave's first query tile is requested together with K / V: one memory round trip per workgroup, not two (with
     // L <= 64 - ViT-B/32, the attention pool, trimmed prompts - a wave has exactly one tile and the kernel is one round trip)
+    // QL = number of leading query rows whose output is wanted (L: all; 1: the class token of a ViT's last block, the only row its
+    // head reads): query tiles beyond QL are neither loaded nor computed, rows beyond it are not stored; the rows that are stored
+    // go through exactly the same instructions on the same data
     vec8 q0n, q1n;
     {
-        const int qrow = min(wave * 16 + r, L - 1);
+        const int qrow = min(wave * 16 + r, QL - 1);       // rows beyond QL are never stored: their lanes re-read row QL - 1 (a cache hit)
         q0n = *(const vec8 *)(base + qrow * ld + g * 8);
         q1n = *(const vec8 *)(base + qrow * ld + 32 + g * 8);
     }
@@ -75,11 +78,11 @@ __global__ __launch_bounds__(256) void mha_fwd(const typename T16<DT>::elem *__r
     __syncthreads();
 
     const int sw0 = ((0 + g) ^ (r & 7)) * 16, sw1 = ((4 + g) ^ (r & 7)) * 16;
-    for (int qt = wave; qt * 16 < L; qt += 4) {
+    for (int qt = wave; qt * 16 < QL; qt += 4) {
         const int q = qt * 16 + r;
         const vec8 q0 = q0n, q1 = q1n;
-        if ((qt + 4) * 16 < L) {                   // the next tile's queries travel while this tile is computed
-            const int qrow = min(q + 64, L - 1);
+        if ((qt + 4) * 16 < QL) {                  // the next tile's queries travel while this tile is computed
+            const int qrow = min(q + 64, QL - 1);
             q0n = *(const vec8 *)(base + qrow * ld + g * 8);
             q1n = *(const vec8 *)(base + qrow * ld + 32 + g * 8);
         }
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(256) void mha_fwd(const typename T16<DT>::elem *__r
         sum += __shfl_xor(sum, 32);
         const float inv = 1.0f / sum;
         // training: the row's softmax statistics (max of the scaled scores, 1 / sum of exponentials) for hgr_mha_bwd_stats
-        if (stats && g == 0 && q < L) stats[((int64_t)b * H + h) * L + q] = make_float2(mx, inv);
+        if (stats && g == 0 && q < QL) stats[((int64_t)b * H + h) * L + q] = make_float2(mx, inv);
 
         f32x4 o[4];
 #pragma unroll
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(256) void mha_fwd(const typename T16<DT>::elem *__r
                 o[td] = T16<DT>::mfma16(vf, pf, o[td]);
             }
         }
-        if (q < L) {
+        if (q < QL) {
             E *orow = out + ((int64_t)b * L + q) * W + h * 64 + g * 4;
 #pragma unroll
             for (int td = 0; td < 4; ++td)
@@ -158,39 +161,46 @@ __global__ __launch_bounds__(256) void mha_fwd(const typename T16<DT>::elem *__r
 }
 
 template <int DT, int KT>
-void launch_kt(const void *qkv, void *out, int B, int L, int H, bool causal, hipStream_t s, float2 *stats) {
+void launch_kt(const void *qkv, void *out, int B, int L, int H, bool causal, hipStream_t s, float2 *stats, int ql) {
     typedef typename T16<DT>::elem E;
     dim3 grid(B * H), block(256);
-    if (causal) hipLaunchKernelGGL((mha_fwd<DT, KT, true>), grid, block, 0, s, (const E *)qkv, (E *)out, L, H, stats);
-    else hipLaunchKernelGGL((mha_fwd<DT, KT, false>), grid, block, 0, s, (const E *)qkv, (E *)out, L, H, stats);
+    if (causal) hipLaunchKernelGGL((mha_fwd<DT, KT, true>), grid, block, 0, s, (const E *)qkv, (E *)out, L, H, stats, ql);
+    else hipLaunchKernelGGL((mha_fwd<DT, KT, false>), grid, block, 0, s, (const E *)qkv, (E *)out, L, H, stats, ql);
 }
 
 template <int DT>
-void launch_dt(const void *qkv, void *out, int B, int L, int H, bool causal, hipStream_t s, float2 *stats) {
+void launch_dt(const void *qkv, void *out, int B, int L, int H, bool causal, hipStream_t s, float2 *stats, int ql) {
     const int kt = (L + 31) / 32;
-    if (kt <= 1) launch_kt<DT, 1>(qkv, out, B, L, H, causal, s, stats);
-    else if (kt <= 2) launch_kt<DT, 2>(qkv, out, B, L, H, causal, s, stats);
-    else if (kt <= 3) launch_kt<DT, 3>(qkv, out, B, L, H, causal, s, stats);
-    else if (kt <= 5) launch_kt<DT, 5>(qkv, out, B, L, H, causal, s, stats);
-    else launch_kt<DT, 9>(qkv, out, B, L, H, causal, s, stats);
+    if (kt <= 1) launch_kt<DT, 1>(qkv, out, B, L, H, causal, s, stats, ql);
+    else if (kt <= 2) launch_kt<DT, 2>(qkv, out, B, L, H, causal, s, stats, ql);
+    else if (kt <= 3) launch_kt<DT, 3>(qkv, out, B, L, H, causal, s, stats, ql);
+    else if (kt <= 5) launch_kt<DT, 5>(qkv, out, B, L, H, causal, s, stats, ql);
+    else launch_kt<DT, 9>(qkv, out, B, L, H, causal, s, stats, ql);
 }
 
 }  // namespace
 
-static int mha_entry(const char *name, const void *qkv, void *out, float *stats, int B, int L, int heads, int causal, int dtype, void *stream) {
+static int mha_entry(const char *name, const void *qkv, void *out, float *stats, int B, int L, int heads, int causal, int dtype, void *stream, int q_rows = 0) {
     HGR_REQUIRE(qkv && out, "%s: null operand", name);
     HGR_REQUIRE(B >= 1 && heads >= 1 && L >= 1 && L <= 288, "%s: B=%d heads=%d L=%d unsupported (1 <= L <= 288)", name, B, heads, L);
     HGR_REQUIRE((int64_t)B * heads < (1ll << 31), "%s: grid too large", name);
     HGR_REQUIRE(hgr_aligned(qkv, 16) && hgr_aligned(out, 16) && hgr_aligned(stats, 8), "%s: operands must be 16-byte aligned (stats: 8)", name);
     HGR_REQUIRE(dtype == HGR_BF16 || dtype == HGR_F16, "%s: bad dtype %d", name, dtype);
-    if (dtype == HGR_BF16) launch_dt<HGR_BF16>(qkv, out, B, L, heads, causal != 0, (hipStream_t)stream, (float2 *)stats);
-    else launch_dt<HGR_F16>(qkv, out, B, L, heads, causal != 0, (hipStream_t)stream, (float2 *)stats);
+    HGR_REQUIRE(q_rows >= 0 && q_rows <= L, "%s: q_rows=%d must lie in [1, L]", name, q_rows);
+    const int ql = q_rows ? q_rows : L;
+    if (dtype == HGR_BF16) launch_dt<HGR_BF16>(qkv, out, B, L, heads, causal != 0, (hipStream_t)stream, (float2 *)stats, ql);
+    else launch_dt<HGR_F16>(qkv, out, B, L, heads, causal != 0, (hipStream_t)stream, (float2 *)stats, ql);
     HGR_CHECK_LAUNCH(name);
     return HGR_OK;
 }
 
 extern "C" int hgr_mha(const void *qkv, void *out, int B, int L, int heads, int causal, int dtype, void *stream) {
     return mha_entry("hgr_mha", qkv, out, nullptr, B, L, heads, causal, dtype, stream);
+}
+
+extern "C" int hgr_mha_rows(const void *qkv, void *out, int B, int L, int heads, int causal, int q_rows, int dtype, void *stream) {
+    HGR_REQUIRE(q_rows >= 1, "hgr_mha_rows: q_rows=%d must be >= 1", q_rows);
+    return mha_entry("hgr_mha_rows", qkv, out, nullptr, B, L, heads, causal, dtype, stream, q_rows);
 }
 
 extern "C" int hgr_mha_stats(const void *qkv, void *out, float *stats, int B, int L, int heads, int causal, int dtype, void *stream) {

@@ -241,9 +241,15 @@ def layernorm(x: torch.Tensor, gamma, beta, out: torch.Tensor, rows: Optional[in
     return out
 
 
-def mha(qkv: torch.Tensor, out: torch.Tensor, b: int, l: int, heads: int, causal: bool, stats: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``stats`` fp32 [b, heads, l, 2]: also keep every row's softmax statistics (max, 1 / sum) for mha_bwd (training forward)."""
+def mha(qkv: torch.Tensor, out: torch.Tensor, b: int, l: int, heads: int, causal: bool, stats: Optional[torch.Tensor] = None,
+        q_rows: int = 0) -> torch.Tensor:
+    """``stats`` fp32 [b, heads, l, 2]: also keep every row's softmax statistics (max, 1 / sum) for mha_bwd (training forward).
+    ``q_rows`` > 0: only the first q_rows query rows of every sequence are computed and written (hgr_mha_rows)."""
     assert qkv.is_contiguous() and out.is_contiguous() and qkv.shape[1] == 3 * heads * 64 and out.shape[1] == heads * 64
+    if q_rows:
+        assert stats is None
+        _lib.call("hgr_mha_rows", _dev(qkv), _dev(out), b, l, heads, 1 if causal else 0, int(q_rows), DT_OF[qkv.dtype], _stream())
+        return out
     if stats is not None:
         assert stats.dtype == torch.float32 and stats.is_contiguous() and stats.numel() == b * heads * l * 2
         _lib.call("hgr_mha_stats", _dev(qkv), _dev(out), _dev(stats), b, l, heads, 1 if causal else 0, DT_OF[qkv.dtype], _stream())

@@ -154,6 +154,10 @@ int hgr_layernorm(const float *x, const float *gamma, const float *beta, void *y
  * (row = b*L + t); out 16-bit [B*L, W].  causal != 0 masks key > query.  1 <= L <= 288.
  */
 int hgr_mha(const void *qkv, void *out, int B, int L, int heads, int causal, int dtype, void *stream);
+/* The same for the first q_rows query rows of every sequence only (1 <= q_rows <= L): rows q_rows .. L-1 of `out` are left
+ * untouched, the rows that are written carry the bits hgr_mha writes.  A ViT's last block needs the class token's row alone
+ * (clip/model.py:231 reads x[:, 0, :]): its keys / values are still all L tokens. */
+int hgr_mha_rows(const void *qkv, void *out, int B, int L, int heads, int causal, int q_rows, int dtype, void *stream);
 /* The same, and per (batch, head, query) the softmax statistics of the row: stats[((b * heads + h) * L + q) * 2] = max of the
  * scaled scores, [.. + 1] = 1 / sum of exp(score - max) (fp32 [B, heads, L, 2], 8-byte aligned).  The training forward keeps
  * them so that hgr_mha_bwd_stats does not recompute Q K^T for the statistics (what autograd's saved softmax output holds). */
