@@ -200,6 +200,23 @@ def test_mha_vs_oracle(dt, L, causal):
 
 
 @pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("L,q_rows,causal", [(50, 1, False), (50, 20, False), (257, 1, False), (33, 5, True), (16, 16, True)])
+def test_mha_leading_query_rows_only(dt, L, q_rows, causal):
+    """hgr_mha_rows: the first q_rows query rows of every sequence carry the bits hgr_mha writes, the other rows of `out` are not
+    touched (a ViT's last block needs the class token's row alone, clip/model.py:231)."""
+    b, heads = 4, 3
+    w = heads * 64
+    qkv = _rand((b * L, 3 * w), 70 + L, 1.0).to(dt).to(DEV)
+    full = torch.empty(b * L, w, dtype=dt, device=DEV)
+    ops.mha(qkv, full, b, L, heads, causal)
+    part = torch.full((b * L, w), 7.0, dtype=dt, device=DEV)
+    ops.mha(qkv, part, b, L, heads, causal, q_rows=q_rows)
+    f, p_ = full.view(b, L, w), part.view(b, L, w)
+    assert torch.equal(p_[:, :q_rows], f[:, :q_rows])
+    assert bool((p_[:, q_rows:] == 7.0).all())
+
+
+@pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("r,p", [(64, 32), (224, 32), (224, 16), (28, 14)])
 def test_im2col_exact(dt, r, p):
     b = 2
