@@ -83,6 +83,7 @@ SIGNATURES = {
     "hgr_bn_unfold_grad": [_p, _l, _p, _p, _p, _p, _p, _f, _p, _p, _p, _i, _i, _i, _p],
     "hgr_csr_group_aggregate": [_p, _l, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _p, _p, _l, _i, _f, _i, _p],
     "hgr_gemm_nt_res_stats": [_p, _l, _p, _l, _p, _p, _l, _p, _p, _i, _i, _i, _i, _p],
+    "hgr_vit_head": [_p, _p, _l, _l, _p, _p, _f, _p, _p, _i, _i, _i, _i, _p],
     "hgr_gemm_nt_res_stats_guard": [_p, _l, _p, _l, _p, _p, _l, _p, _p, _f, _p, _i, _i, _i, _i, _p],
     "hgr_gemm_nt_ln": [_p, _l, _p, _l, _p, _l, _p, _p, _p, _f, _i, _i, _i, _i, _i, _p],
     "hgr_gemm_nt_bias_gelu_dual": [_p, _l, _p, _l, _p, _l, _p, _l, _p, _i, _i, _i, _i, _p],

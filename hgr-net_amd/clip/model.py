@@ -580,6 +580,9 @@ class CLIP(nn.Module):
                 taps["visual.ln_pre"] = (xh.float() + xl.float()).view(b, l, w)
             _run_blocks(None, p["vblocks"], w // 64, b, l, False, dt, ws, tag, taps, "visual.transformer", (xh, xl), stats, self._ln_flag("v", dev),
                         cls_only_last=taps is None and CLS_LAST)
+            if w <= 1920 and w % 32 == 0 and v.output_dim % 4 == 0:
+                ops.vit_head(xh, xl, l, p["ln_post"][0], p["ln_post"][1], float(v.ln_post.eps), p["proj_t"], out)   # ln_post(class tokens) @ proj
+                return fused
             cls32 = ws.get(tag + ".cls32", (b, w), torch.float32, dev)
             ops.pair_rows_f32(xh, xl, cls32, row_mul=l)                          # the class tokens back in fp32 for ln_post
             ops.layernorm(cls32, p["ln_post"][0], p["ln_post"][1], cls16, rows=b)

@@ -157,6 +157,18 @@ def pair_rows_f32(xh: torch.Tensor, xl: torch.Tensor, out: torch.Tensor, row_mul
     return out
 
 
+def vit_head(xh: torch.Tensor, xl: torch.Tensor, row_mul: int, gamma: torch.Tensor, beta: torch.Tensor, eps: float, proj_t: torch.Tensor,
+             out: torch.Tensor) -> torch.Tensor:
+    """out[b] = LayerNorm(xh[b * row_mul] + xl[b * row_mul]) (16-bit) @ proj_t^T, fp32 [B, D] (hgr_vit_head: ln_post + visual.proj)."""
+    assert xh.dtype == proj_t.dtype and xl.dtype == torch.float16 and xh.stride() == xl.stride() and xh.stride(1) == 1
+    assert out.dtype == torch.float32 and out.is_contiguous() and proj_t.is_contiguous() and proj_t.shape[1] == xh.shape[1] and out.shape[1] == proj_t.shape[0]
+    ev = _prof_begin()
+    _lib.call("hgr_vit_head", _dev(xh), _dev(xl), xh.stride(0), int(row_mul), _dev(gamma), _dev(beta), float(eps), _dev(proj_t), _dev(out),
+              out.shape[0], xh.shape[1], out.shape[1], DT_OF[xh.dtype], _stream())
+    _prof_end(ev, 2.0 * out.shape[0] * out.shape[1] * xh.shape[1], 0, "head")
+    return out
+
+
 def gemm_set_tile(tile: int) -> int:
     """Pin hgr_gemm_nt's tile plan (0 = cost model, 128, 256); returns the previous setting."""
     lib = _lib.load()

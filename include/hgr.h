@@ -487,6 +487,15 @@ int hgr_gemm_nt_res_stats(const void *A, int64_t lda, const void *W, int64_t ldw
 int hgr_gemm_nt_res_stats_guard(const void *A, int64_t lda, const void *W, int64_t ldw, void *xh, void *xl, int64_t ldx,
                                 const float *bias, float *stats, float guard_sumsq, uint32_t *flag,
                                 int M, int N, int K, int dtype, void *stream);
+
+/*
+ * Visual head of a ViT in one launch (clip/model.py:231-233: x = ln_post(x[:, 0, :]); x = x @ proj) on the residual stream kept as
+ * a 16-bit pair: row b of the result = LayerNorm(xh[b * row_mul] + xl[b * row_mul]; gamma, beta, eps) rounded to the MFMA type,
+ * times proj_t^T (proj_t [D, W] 16-bit = visual.proj transposed), fp32 [B, D].  row_mul = tokens per image (the class token is
+ * token 0).  LayerNorm arithmetic = hgr_layernorm's (two-pass statistics in fp32).  W % 32 == 0, W <= 1920, D % 4 == 0.
+ */
+int hgr_vit_head(const void *xh, const void *xl, int64_t ldx, int64_t row_mul, const float *gamma, const float *beta, float eps,
+                 const void *proj_t, float *out, int B, int W, int D, int dtype, void *stream);
 /* C (16-bit) = act( rstd_m (XH Wfold^T - mean_m ln_s) + ln_c ), act: 0 none (ln_1 -> in_proj), 1 QuickGELU (ln_2 -> c_fc -> gelu);
  * K = row width, mean / rstd from `stats` ([M][K/64][2], as written by the producers), eps of the LayerNorm */
 int hgr_gemm_nt_ln(const void *XH, int64_t ldx, const void *Wfold, int64_t ldw, void *C, int64_t ldc,
