@@ -111,7 +111,7 @@ class HgrError(RuntimeError):
 _lib = None
 
 
-ABI_VERSION = 2          # HGR_ABI_VERSION of include/hgr.h this wrapper was written against
+ABI_VERSION = 3          # HGR_ABI_VERSION of include/hgr.h this wrapper was written against
 
 
 def load() -> C.CDLL:

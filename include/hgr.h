@@ -30,7 +30,7 @@ extern "C" {
 
 /* 2: round-2 additions (LayerNorm-folded GEMMs, hgr_logits_eval, RCCL collectives, the training-step fusions); every version-1 entry
  * point is unchanged */
-#define HGR_ABI_VERSION 2
+#define HGR_ABI_VERSION 3
 
 enum { HGR_OK = 0, HGR_EINVAL = -1, HGR_EUNSUPPORTED = -2, HGR_ELAUNCH = -3 };
 

@@ -40,6 +40,15 @@ int main() {
     EXPECT_FAIL(hgr_gemm_tn_splitk(nullptr, 64, h16, 64, f32, 64, 128, 64, 64, 64, HGR_F16, nullptr));
     EXPECT_FAIL(hgr_gemm_nt_res_stats(h16, 128, h16, 128, h16, h16, 100, f32, f32, 4, 100, 128, HGR_F16, nullptr));              // N % 128
     EXPECT_FAIL(hgr_gemm_nt_res_stats(h16, 128, h16, 128, h16, h16, 128, nullptr, f32, 4, 128, 128, HGR_F16, nullptr));          // bias
+    EXPECT_FAIL(hgr_gemm_set_tail(2, -1)); EXPECT_FAIL(hgr_gemm_set_tail(1, -5));
+    EXPECT_OK(hgr_gemm_set_tail(0, -1)); EXPECT_OK(hgr_gemm_set_tail(1, 3)); EXPECT_OK(hgr_gemm_set_tail(1, -1));
+    EXPECT_FAIL(hgr_gemm_nt_res_stats_guard(h16, 128, h16, 128, h16, h16, 128, f32, f32, 0.f, (uint32_t *)i32, 4, 128, 128, HGR_F16, nullptr));   // flag without a guard value
+    EXPECT_FAIL(hgr_gemm_nt_res_stats_guard(h16, 128, h16, 128, h16, h16, 128, f32, f32, 1.f, (uint32_t *)(u8 + 2), 4, 128, 128, HGR_F16, nullptr)); // misaligned flag
+    EXPECT_FAIL(hgr_vit_head(h16, h16, 64, 50, f32, f32, 1e-5f, h16, f32, 4, 100, 64, HGR_F16, nullptr));                        // W % 32
+    EXPECT_FAIL(hgr_vit_head(h16, h16, 64, 50, f32, f32, 1e-5f, h16, f32, 4, 2048, 64, HGR_F16, nullptr));                       // W > 1920
+    EXPECT_FAIL(hgr_vit_head(h16, nullptr, 64, 50, f32, f32, 1e-5f, h16, f32, 4, 64, 64, HGR_F16, nullptr));
+    EXPECT_FAIL(hgr_mha_rows(h16, h16, 1, 50, 12, 0, 0, HGR_F16, nullptr));                                                       // q_rows < 1
+    EXPECT_FAIL(hgr_mha_rows(h16, h16, 1, 50, 12, 0, 51, HGR_F16, nullptr));                                                      // q_rows > L
     EXPECT_FAIL(hgr_pair_rows_f32(h16, nullptr, f32, 4, 64, 1, nullptr, HGR_F16, nullptr));
     EXPECT_FAIL(hgr_gemm_nt_ln(h16, 192, h16, 192, h16, 128, f32, f32, f32, 1e-5f, 4, 128, 192, HGR_F16, 0, nullptr));           // K % 128
     EXPECT_FAIL(hgr_gemm_nt_ln(h16, 128, h16, 128, h16, 128, f32, f32, f32, 1e-5f, 4, 128, 128, HGR_F16, 5, nullptr));           // act
