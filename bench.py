@@ -555,6 +555,14 @@ def main():
                     shapes.setdefault(tag or "untagged", []).append((s_.elapsed_time(e_) * 1e-3, fl))
             roof["by_shape"] = {k: {"launches": len(v), "avg_us": round(sum(t for t, _ in v) / len(v) * 1e6, 1),
                                     "tflops": round(sum(f for _, f in v) / sum(t for t, _ in v) / 1e12, 1)} for k, v in sorted(shapes.items())}
+        if roof:
+            # the launches of the last image block and the visual head, which act on the class-token rows only
+            small = {}
+            for (name, s_, e_, fl, by, tag) in recs:
+                if tag in ("kv", "q_cls", "out_cls", "fc_cls", "proj_cls", "head"):
+                    small.setdefault(tag, []).append(s_.elapsed_time(e_) * 1e3)
+            if small:
+                roof["class_token_tail_us"] = {k: round(sum(v) / len(v), 1) for k, v in sorted(small.items())}
         lg = [(s_.elapsed_time(e_) * 1e-3, fl, by) for (name, s_, e_, fl, by, tag) in recs if tag in ("logits", "logits_eval")]     # tagged, not guessed from sizes
         if lg and roof:
             tl = sum(t for t, _, _ in lg) / len(lg)
@@ -702,6 +710,9 @@ def main():
                 "dtype": a.image_dtype, "data": "synthetic",
                 "config": {"workload": f"{a.arch} zero-shot eval step: encode_image + L2 + [{a.batch}x{cfg['embed_dim']}]x[{cfg['embed_dim']}x{a.nodes}] logits "
                                        f"+ top-20/top-1/level-argmax metrics (main.py:131-191; {'fused into the logits GEMM' if fused_eval else 'hgr_eval_rows on materialised logits'}), N={a.nodes} nodes, batch {a.batch}/GPU",
+                           "tower_notes": ("LayerNorms folded into the GEMMs; the last image block runs out_proj / MLP / its attention row on the class-token rows only - "
+                                           "the rows ln_post reads (clip/model.py:231), same bits; HGR_CLS_LAST=0 carries every token") if cfg["vision_patch_size"] else
+                                          "ModifiedResNet: NHWC 16-bit activations, BatchNorm folded, 1x1 convolutions as GEMMs, 3x3 as implicit GEMMs",
                            "global_batch": a.batch * world, "parallelism": f"dp{world}", "text_dtype": a.text_dtype,
                            "weights": "random-init (hash-seeded), no checkpoint offline"},
                 "roofline": roof, "cpu_baseline": cpu, "parity": parity, "pcie_inclusive": pcie, "metrics_string": summary.strip(),
