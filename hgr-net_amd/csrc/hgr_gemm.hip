@@ -39,6 +39,12 @@ DuoPlan duo_plan(int M, int N, bool allow_tail) {
     const int tiles_m = (M + 255) / 256, tiles_n = (N + 127) / 128, S = 512;
     const int64_t T = (int64_t)tiles_m * tiles_n;
     DuoPlan best{tiles_m, (int)T, 0, (int)T};
+    if (allow_tail && tail_env && pb_env < 0 && T <= S / 4 && M > 128) {
+        // a launch that covers a fraction of the chip (the class-token GEMMs of a ViT's last block: 512 rows) is bound by what ONE
+        // workgroup can pull per K-tile, not by the matrix cores: all half tiles = twice the workgroups, 2/3 of the bytes per K-tile each
+        best.big_panels = 0; best.nbig = 0; best.tiles_m_half = (M + 127) / 128; best.grid = best.tiles_m_half * tiles_n;
+        return best;
+    }
     if (!allow_tail || !tail_env || T <= S || T % S == 0) return best;
     // measured (tools/tail_sweep.py, ViT-B/32 tower launches at batch 512, cold operands): last round 15 - 17 % full (out, proj, patch:
     // 600 / 588 tiles) -13 %, -14.5 %, -11 %; last round 52 % full (qkv, 1800 tiles) +-0; 69 % full (fc, 2400 tiles) +2 %: a

@@ -214,25 +214,32 @@ __global__ __launch_bounds__(256) void vit_head(const void *__restrict__ xh, con
     const int RS = W * 2 + 16;
     const int nv = W >> 2;
     const f32x4 *gv = (const f32x4 *)gamma, *bv = (const f32x4 *)beta;
-    for (int rr = wave * 4; rr < wave * 4 + 4; ++rr) {
-        const int row = min(row0 + rr, B - 1);
+    // wave w normalises rows 4 w .. 4 w + 3; the four rows' loads are requested together (one memory round trip per wave, not four)
+    f32x4 v[4][NV];
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+        const int row = min(row0 + wave * 4 + q4, B - 1);
         const E *ph = (const E *)xh + (int64_t)row * row_mul * ldx;
         const _Float16 *pl = (const _Float16 *)xl + (int64_t)row * row_mul * ldx;
-        f32x4 v[NV];
-        float s = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = i * 64 + lane;
             if (i * 64 < nv) {
-                if (c < nv) {
-                    const vec4 h4 = ((const vec4 *)ph)[c];
-                    const f16x4 l4 = ((const f16x4 *)pl)[c];
+                const int cc = min(c, nv - 1);
+                const vec4 h4 = ((const vec4 *)ph)[cc];
+                const f16x4 l4 = ((const f16x4 *)pl)[cc];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[i][e] = (float)h4[e] + (float)l4[e];
-                } else v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+                for (int e = 0; e < 4; ++e) v[q4][i][e] = c < nv ? (float)h4[e] + (float)l4[e] : 0.f;
             }
         }
+    }
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+        const int rr = wave * 4 + q4;
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (i * 64 < nv) s += v[q4][i][0] + v[q4][i][1] + v[q4][i][2] + v[q4][i][3];
         const float mean = wave_sum(s) / (float)W;
         float q = 0.f;
 #pragma unroll
@@ -240,7 +247,7 @@ __global__ __launch_bounds__(256) void vit_head(const void *__restrict__ xh, con
             const int c = i * 64 + lane;
             if (i * 64 < nv && c < nv) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+                for (int e = 0; e < 4; ++e) { const float d = v[q4][i][e] - mean; q += d * d; }
             }
         }
         const float rstd = rsqrtf(wave_sum(q) / (float)W + eps);
@@ -251,7 +258,7 @@ __global__ __launch_bounds__(256) void vit_head(const void *__restrict__ xh, con
                 const f32x4 ga = gv[c], be = bv[c];
                 f32x4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * ga[e] + be[e];
+                for (int e = 0; e < 4; ++e) o[e] = (v[q4][i][e] - mean) * rstd * ga[e] + be[e];
                 *(vec4 *)(hs + rr * RS + c * 8) = cvt4<DT>(o[0], o[1], o[2], o[3]);
             }
         }
