@@ -528,42 +528,47 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
             const int r8 = lane >> 3, c8 = lane & 7;
             const unsigned ldxB = (unsigned)p.ln_ldx * 2u, ldsB = (unsigned)p.ln_slots * 8u;
             const unsigned xo = r8 * ldxB + c8 * 16, so = r8 * ldsB;
-            u32x4 ohb[2][4], olb[2][4];
+            // 8 (4 for a half tile) passes of 16 rows; the old pair of pass P + 2 is requested while pass P is worked on (a ring of three
+            // 16-register buffers: passes touch disjoint rows, the compiler cannot hoist the loads itself - the pointers alias).  The first
+            // version worked in passes of 32 rows with two 32-register buffers: at the 256-register cap of two workgroups per CU hipcc
+            // then sent 9 - 16 accumulator quads through scratch in every tile.
+            constexpr int NP = MH * 4;
+            u32x4 ohb[3][2], olb[3][2];
             auto pair_load = [&](int buf, int rl) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < 2; ++q) {
                     ohb[buf][q] = *(const u32x4 *)(hw + (xo + (rl + q * 8) * ldxB));
                     olb[buf][q] = *(const u32x4 *)(lw + (xo + (rl + q * 8) * ldxB));
                 }
             };
             pair_load(0, 0);
+            pair_load(1, 16);
+            // the bias of this lane's 8 output columns, added behind the LDS transpose (8 registers; the accumulator layout needs 16)
+            const f32x4 b8lo = *(const f32x4 *)(p.bias + wcol + c8 * 8), b8hi = *(const f32x4 *)(p.bias + wcol + c8 * 8 + 4);
             unsigned gbits = 0u;                              // range guard: largest slot sum of squares seen (as bits: inf / NaN rank highest)
 #pragma unroll
-            for (int a = 0; a < MH; ++a)
-#pragma unroll
-            for (int ih = 0; ih < 2; ++ih) {
-                const int rl = a * 64 + ih * 32;
-                const int pb = ih;                           // pass a * 2 + ih uses buffer ih
-#pragma unroll
-                for (int i2 = 0; i2 < 2; ++i2)
+            for (int ps = 0; ps < NP; ++ps) {
+                const int a = ps >> 2, i = ps & 3;
+                const int rl = a * 64 + i * 16;
+                const int pb = ps % 3;
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    *(f32x4 *)(my + (i2 * 16 + r) * RS + (b * 32 + j * 16 + g * 4) * 4) = acc[a][b][ih * 2 + i2][j] + bq[b][j];
-                if (a * 2 + ih < 2 * MH - 1) pair_load(pb ^ 1, rl + 32);
-                float s1[4], s2[4];
+                    *(f32x4 *)(my + r * RS + (b * 32 + j * 16 + g * 4) * 4) = acc[a][b][i][j];
+                if (ps + 2 < NP) pair_load((ps + 2) % 3, rl + 32);
+                float s1[2], s2[2];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < 2; ++q) {
                     const f32x4 lo4 = *(const f32x4 *)(my + (q * 8 + r8) * RS + c8 * 32);
                     const f32x4 hi4 = *(const f32x4 *)(my + (q * 8 + r8) * RS + c8 * 32 + 16);
                     const vec8 oh = __builtin_bit_cast(vec8, ohb[pb][q]);
                     const f16x8 ol = __builtin_bit_cast(f16x8, olb[pb][q]);
                     float v[8];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = lo4[e] + ((float)oh[e] + (float)ol[e]);
-                        v[e + 4] = hi4[e] + ((float)oh[e + 4] + (float)ol[e + 4]);
+                    for (int e = 0; e < 4; ++e) {              // (acc + bias) + (hi + lo): the order of the 4-column form
+                        v[e] = (lo4[e] + b8lo[e]) + ((float)oh[e] + (float)ol[e]);
+                        v[e + 4] = (hi4[e] + b8hi[e]) + ((float)oh[e + 4] + (float)ol[e + 4]);
                     }
                     vec8 nh;
                     f16x8 nl;
@@ -576,14 +581,14 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
                             (__builtin_fmaf(v[4], v[4], v[5] * v[5]) + __builtin_fmaf(v[6], v[6], v[7] * v[7]));
                 }
                 if (p.dbg & 32) continue;
-#define HGR_DPP_STAGE8(CTRL) _Pragma("unroll") for (int q = 0; q < 4; ++q) { \
+#define HGR_DPP_STAGE8(CTRL) _Pragma("unroll") for (int q = 0; q < 2; ++q) { \
                     s1[q] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1[q]), CTRL, 0xF, 0xF, true)); \
                     s2[q] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s2[q]), CTRL, 0xF, 0xF, true)); }
                 HGR_DPP_STAGE8(0xB1) HGR_DPP_STAGE8(0x4E) HGR_DPP_STAGE8(0x141)
 #undef HGR_DPP_STAGE8
                 if (c8 == 0) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
+                    for (int q = 0; q < 2; ++q) {
                         *(float2 *)(sw + (so + (rl + q * 8) * ldsB)) = make_float2(s1[q], s2[q]);
                         gbits = max(gbits, __float_as_uint(s2[q]));
                     }
