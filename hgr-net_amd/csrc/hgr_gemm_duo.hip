@@ -121,31 +121,6 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
         const float mean = s1 * inv;
         return make_float2(mean, rsqrtf(fmaxf(s2 * inv - mean * mean, 0.f) + p.ln_eps));
     };
-    // LN consumer, full tiles: the 16-byte chunks of row tid's slot statistics are brought into LDS by LDS-DMA during the LAST K-tile
-    // (the A buffers of the other parity are free then: nothing is prefetched any more), so the epilogue starts without a trip
-    // to memory for them.  Chunk c of thread tid lands at slot(c) + tid * 16 (lane-linear per wave): chunks 0-3 in the free A0
-    // buffer, 4-7 in the free A1 buffer.
-    const bool stats_lds = LN == 2 && MH == 2 && (p.ln_slots & 1) == 0 && p.ln_slots <= 16;
-    auto stats_slot = [&](int c, int par) { return (c < 4 ? DUO_A0 : DUO_A1) + par * 16384 + (c & 3) * 4096; };
-    auto issue_stats = [&](int par) {
-        const char *src = (const char *)(p.ln_stats + (int64_t)min(m0 + tid, p.M - 1) * p.ln_slots * 2);
-#pragma unroll
-        for (int c = 0; c < 8; ++c)
-            if (c * 2 < p.ln_slots)
-                __builtin_amdgcn_global_load_lds((const AS1 void *)(src + c * 16), (AS3 void *)(ldsw + stats_slot(c, par)), 16, 0, 0);
-    };
-    auto ln_row_stats_lds = [&](int par) {
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int c = 0; c < 8; ++c)
-            if (c * 2 < p.ln_slots) {
-                const f32x4 t = *(const f32x4 *)(smem + stats_slot(c, par) + tid * 16);
-                s1 += t[0] + t[2]; s2 += t[1] + t[3];
-            }
-        const float inv = 1.0f / (float)p.K;
-        const float mean = s1 * inv;
-        return make_float2(mean, rsqrtf(fmaxf(s2 * inv - mean * mean, 0.f) + p.ln_eps));
-    };
     const int nk = p.K / 64;    // >= 2 (host guarantees)
     const int offA = (wm * 64 + r) * 128;      // + m tile * 2048, within pieces A0 / A1
     const int offW = (wn * 32 + r) * 128;      // + n tile * 2048, within pieces W0 / W1
@@ -177,7 +152,6 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
             }
             if (MODE <= 1) { issueA(oA1, DUO_A1, t + 1, 0); issueA(oA1, DUO_A1, t + 1, 1); }
             if (MODE <= 1) HGR_RWAIT(8); else HGR_RWAIT(0);                 // W1(t) landed
-            if (MODE == 2 && stats_lds) issue_stats((t + 1) & 1);           // last K-tile: the other parity's A buffers are free
             __builtin_amdgcn_s_setprio(1);
     #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
@@ -309,8 +283,7 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
         ktile(nk - 2, std::integral_constant<int, 1>());
         ktile(nk - 1, std::integral_constant<int, 2>());
     }
-    if (stats_lds) HGR_RWAIT(0);        // + my statistic chunks landed
-    else HGR_MBAR();            // every wave's LDS reads are done, no DMA in flight: the staging area is free
+    HGR_MBAR();                 // every wave's LDS reads are done, no DMA in flight: the staging area is free
     // the epilogue is VALU / LDS work next to the partner workgroup's MFMA clusters (priority 1): run it above them, or its
     // instructions only get the issue slots the matrix stream leaves over (HGR_GEMM_DBG bit 16 = off, for A/B runs)
     if (!(p.dbg & 16)) __builtin_amdgcn_s_setprio(3);
@@ -404,11 +377,7 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
             }
         float2 *lnrow = (float2 *)(smem + 4 * 128 * RS);      // 256 x (mean, rstd) behind the four staging slices
         if (LN == 2) {
-            if (stats_lds) {
-                const float2 mine = ln_row_stats_lds(nk & 1);     // staged during K-tile nk - 1 into parity (nk - 1 + 1) & 1
-                __syncthreads();                                  // every thread has read its chunks: the staging slices may be written
-                lnrow[tid] = mine;
-            } else lnrow[tid] = ln_row_stats();
+            lnrow[tid] = ln_row_stats();
             __syncthreads();
         }
 #pragma unroll
