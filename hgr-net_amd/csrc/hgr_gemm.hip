@@ -39,7 +39,9 @@ DuoPlan duo_plan(int M, int N, bool allow_tail) {
     const int tiles_m = (M + 255) / 256, tiles_n = (N + 127) / 128, S = 512;
     const int64_t T = (int64_t)tiles_m * tiles_n;
     DuoPlan best{tiles_m, (int)T, 0, (int)T};
-    if (allow_tail && tail_env && pb_env < 0 && T <= S / 4 && M > 128) {
+    static int smallm_env = -1;              // experiment: launches of at most two row panels that do not fill the slots run as half tiles
+    if (smallm_env < 0) { const char *e = getenv("HGR_DUO_SMALLM"); smallm_env = e ? atoi(e) : 0; }
+    if (allow_tail && tail_env && pb_env < 0 && M > 128 && (T <= S / 4 || (smallm_env && tiles_m <= 2 && T <= S))) {
         // a launch that covers a fraction of the chip (the class-token GEMMs of a ViT's last block: 512 rows) is bound by what ONE
         // workgroup can pull per K-tile, not by the matrix cores: all half tiles = twice the workgroups, 2/3 of the bytes per K-tile each
         best.big_panels = 0; best.nbig = 0; best.tiles_m_half = (M + 127) / 128; best.grid = best.tiles_m_half * tiles_n;
@@ -416,7 +418,7 @@ extern "C" int hgr_logits_eval(const void *feat16, const void *zsl_perm16, int r
     a.ev_m2 = (float *)((char *)workspace + (size_t)rows * S * 40);
     a.ev_tpos = tpos_perm; a.ev_epos = epos_perm; a.ev_slices = S;
     dim3 grid;
-    duo_apply_plan(a, false, grid);                    // the evaluation epilogue owns whole 256-row tiles
+    duo_apply_plan(a, true, grid);
     launch_duo(a, dtype, HGR_EPI_NONE, true, 3, grid, (hipStream_t)stream);
     HGR_CHECK_LAUNCH("hgr_logits_eval (tile stage)");
     return hgr_logits_eval_rows_launch(feat16, zsl_perm16, D, S, a.ev_key, a.ev_tmax, a.ev_p1, a.ev_m2, level_first, n_levels, filler_pos, train_cols, n_train,

@@ -762,7 +762,7 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
         p.K = min(p.kc, p.K - sp * p.kc);
     }
     __shared__ __attribute__((aligned(1024))) char smem[DUO_LDS];
-    const bool half = LN != 3 && (int)blockIdx.x >= p.nbig;
+    const bool half = (int)blockIdx.x >= p.nbig;
     const int nwg = half ? (int)gridDim.x - p.nbig : p.nbig;
     const int orig = half ? (int)blockIdx.x - p.nbig : (int)blockIdx.x;
     const int tiles_m = half ? p.tiles_m_half : p.big_panels;
@@ -779,12 +779,8 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
         const int gs = min(GROUP, tiles_m - first), loc = wg - grp * per;
         tm = first + loc % gs; tn = loc / gs;
     }
-    if constexpr (LN == 3) {
-        duo_tile<DT, EPI, OUT32, LN, 2>(p, smem, tm * 256, tn * 128);
-    } else {
-        if (half) duo_tile<DT, EPI, OUT32, LN, 1>(p, smem, p.big_panels * 256 + tm * 128, tn * 128);
-        else duo_tile<DT, EPI, OUT32, LN, 2>(p, smem, tm * 256, tn * 128);
-    }
+    if (half) duo_tile<DT, EPI, OUT32, LN, 1>(p, smem, p.big_panels * 256 + tm * 128, tn * 128);
+    else duo_tile<DT, EPI, OUT32, LN, 2>(p, smem, tm * 256, tn * 128);
 }
 
 namespace {
