@@ -39,11 +39,11 @@ DuoPlan duo_plan(int M, int N, bool allow_tail) {
     const int tiles_m = (M + 255) / 256, tiles_n = (N + 127) / 128, S = 512;
     const int64_t T = (int64_t)tiles_m * tiles_n;
     DuoPlan best{tiles_m, (int)T, 0, (int)T};
-    static int smallm_env = -1;              // experiment: launches of at most two row panels that do not fill the slots run as half tiles
-    if (smallm_env < 0) { const char *e = getenv("HGR_DUO_SMALLM"); smallm_env = e ? atoi(e) : 0; }
-    if (allow_tail && tail_env && pb_env < 0 && M > 128 && (T <= S / 4 || (smallm_env && tiles_m <= 2 && T <= S))) {
+    if (allow_tail && tail_env && pb_env < 0 && M > 128 && (T <= S / 4 || (tiles_m <= 2 && T <= S))) {
         // a launch that covers a fraction of the chip (the class-token GEMMs of a ViT's last block: 512 rows) is bound by what ONE
-        // workgroup can pull per K-tile, not by the matrix cores: all half tiles = twice the workgroups, 2/3 of the bytes per K-tile each
+        // workgroup can pull per K-tile, not by the matrix cores: all half tiles = twice the workgroups, 2/3 of the bytes per K-tile each.
+        // Likewise at most two row panels on fewer tiles than slots (the class-logits GEMM and hgr_logits_eval at batch 512: 356
+        // full tiles on 256 CUs -> 712 half tiles; measured 48.0 -> 46.2 us fused, 21.6 -> 21.0 us plain, bit-identical)
         best.big_panels = 0; best.nbig = 0; best.tiles_m_half = (M + 127) / 128; best.grid = best.tiles_m_half * tiles_n;
         return best;
     }
