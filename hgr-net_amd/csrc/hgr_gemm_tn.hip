@@ -22,6 +22,8 @@
 #include "hgr_common.h"
 #include <stdlib.h>
 
+#pragma clang diagnostic ignored "-Winline-asm"   // the LDS-DMA assembly below names m0 as clobbered (reserved register: hipcc warns)
+
 namespace {
 
 __device__ __attribute__((aligned(16))) unsigned int tn_zero_page[4] = {0u, 0u, 0u, 0u};
@@ -36,6 +38,15 @@ struct TnArgs {
     int cH, cW, cC;
     unsigned mW, mH, mC;             // ceil(2^32 / W), ceil(2^32 / H), ceil(2^32 / C)
 };
+
+// One LDS-DMA instruction: 64 lanes x 16 bytes from per-lane global addresses to lds_base + 16 * lane (lds_base wave-uniform).  Issued as
+// inline assembly, not __builtin_amdgcn_global_load_lds: behind the builtin hipcc drains s_waitcnt vmcnt(0) in front of the next
+// ds_read_b64_tr_b16 of ANY LDS address (it does not for plain ds_read_b128, see gemm_nt_duo), which made "issue the next stage, then
+// compute this one" load-then-compute in series in the round-1/2 builds of both kernels of this file.  The waits are this file's own.
+__device__ __forceinline__ void glds16(const char *src, char *lds_base) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(AS3 char *)lds_base);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory", "m0");
+}
 
 __device__ __forceinline__ int swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
@@ -90,7 +101,7 @@ __global__ __launch_bounds__(256) void gemm_tn_128(TnArgs p) {
             const int m = ms + kt * 64 + prow[i];
             const bool in = m < me;
             const char *sp = (in && pok[i]) ? p.P + (int64_t)m * p.ldp * 2 + poff[i] : (const char *)tn_zero_page;
-            __builtin_amdgcn_global_load_lds((const AS1 void *)sp, (AS3 void *)(sP + (i * 4 + wave) * 1024), 16, 0, 0);
+            glds16(sp, sP + (i * 4 + wave) * 1024);
             const char *sq;
             if (CONV) {
                 const int t1 = (int)__umulhi((unsigned)m, p.mW), w = m - t1 * p.cW;          // m = (b * H + h) * W + w
@@ -101,7 +112,7 @@ __global__ __launch_bounds__(256) void gemm_tn_128(TnArgs p) {
             } else {
                 sq = (in && qok[i]) ? p.Q + (int64_t)m * p.ldq * 2 + qoff[i] : (const char *)tn_zero_page;
             }
-            __builtin_amdgcn_global_load_lds((const AS1 void *)sq, (AS3 void *)(sQ + (i * 4 + wave) * 1024), 16, 0, 0);
+            glds16(sq, sQ + (i * 4 + wave) * 1024);
         }
     };
 
@@ -187,35 +198,48 @@ __global__ __launch_bounds__(512) void gemm_tn_256(TnArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wa = wave >> 2, wb = wave & 3;
     const int r = lane & 15, g = lane >> 4;
-    const int ta = blockIdx.x / p.tiles_b, tb = blockIdx.x - ta * p.tiles_b;
+    // Workgroup -> (slice, tile), XCD-aware (round 3): the 1-D grid is dealt to the 8 XCDs round-robin (workgroups b, b + 8 share an L2),
+    // so XCD x takes the x-th CONTIGUOUS eighth of the (slice, a-tile, b-tile) order: its ~32 workgroups are two or three rows of b-tiles of
+    // one slice - 2-3 P panels and one set of Q panels for ~64 panel reads - where dealing tiles b, b + 8, ... of every slice to it made
+    // each XCD fetch 7 panels per 12 reads, five slices at once.
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    const int tiles = ((p.Na + 255) >> 8) * p.tiles_b;
+    const int slice = wg / tiles, tile = wg - slice * tiles;
+    const int ta = tile / p.tiles_b, tb = tile - ta * p.tiles_b;
     const int a0 = ta * 256, b0 = tb * 256;
-    const int ms = blockIdx.y * p.kc, me = min(p.M, ms + p.kc);
+    const int ms = slice * p.kc, me = min(p.M, ms + p.kc);
     const int nk = (me - ms + 63) >> 6;
+    const char *zero_page = (const char *)tn_zero_page;
+    asm volatile("" : "+s"(zero_page));                       // keep the address in SGPRs: hipcc re-loaded it from the GOT in every sub-stage
 
-    // LDS-DMA pieces: a stage = 4 halves (P0, P1, Q0, Q1) x 16 pieces of 1 KB; this wave issues pieces i * 8 + wave, i = 0..7
-    // (i < 4: P, half i >> 1; i >= 4: Q, half (i - 4) >> 1; piece ((i & 1) * 8 + wave) of the half)
-    int prow[8];
-    int64_t poff[8];
-    bool pok[8];
+    // Staging (round 3): a RING of four sub-stages of 32 reduction rows (4 x 32 KB = the 128 KB the two 64-row stages used to take), each
+    // = 4 operand halves (P0, P1, Q0, Q1) x [32 rows][128 columns] = 8 pieces of 1 KB per half, one per wave: 4 LDS-DMA instructions per
+    // thread and sub-stage.  Sub-stage j + 3 is issued while j is computed; waits are COUNTED (vmcnt(8): "all but my 8 youngest DMA
+    // instructions have landed" = sub-stage j is in, j + 1 and j + 2 stay in flight) behind one raw s_barrier per sub-stage.  The first
+    // version drained vmcnt(0) + __syncthreads() per 64-row stage with ONE stage in flight: every stage waited out most of a memory round
+    // trip (26 % of the ViT-L/14 training step sat in this kernel).  Same sums in the same order: bit-identical outputs.
+    int64_t poff[4];
+    bool pok[4];
+    const int lrow = wave * 4 + (lane >> 4);                  // this lane's row inside a sub-stage
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int piece = (i & 1) * 8 + wave, half = (i & 3) >> 1;
-        const int row = piece * 4 + (lane >> 4), slot = lane & 15;
-        const int ch = slot ^ swz(row);
-        prow[i] = row;
-        const int col = (i < 4 ? a0 : b0) + half * 128 + ch * 8;
-        pok[i] = col < (i < 4 ? p.Na : p.Nb);
-        poff[i] = (int64_t)col * 2;
+    for (int o = 0; o < 4; ++o) {
+        const int slot = lane & 15;
+        const int ch = slot ^ swz(lrow);
+        const int col = (o < 2 ? a0 : b0) + (o & 1) * 128 + ch * 8;
+        pok[o] = col < (o < 2 ? p.Na : p.Nb);
+        poff[o] = (int64_t)col * 2;
     }
-    auto stage = [&](int buf, int kt) {
-        char *sb = smem + buf * (4 * TILE);
+    auto stage = [&](int j) {                                 // sub-stage j -> ring slot j & 3
+        char *sb = smem + (j & 3) * (2 * TILE);
+        const int m = ms + j * 32 + lrow;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int m = ms + kt * 64 + prow[i];
-            const bool in = m < me && pok[i];
-            const char *src = i < 4 ? p.P + (int64_t)m * p.ldp * 2 : p.Q + (int64_t)m * p.ldq * 2;
-            const char *sp = in ? src + poff[i] : (const char *)tn_zero_page;
-            __builtin_amdgcn_global_load_lds((const AS1 void *)sp, (AS3 void *)(sb + (i >> 1) * TILE + ((i & 1) * 8 + wave) * 1024), 16, 0, 0);
+        for (int o = 0; o < 4; ++o) {
+            const bool in = m < me && pok[o];
+            const char *src = o < 2 ? p.P + (int64_t)m * p.ldp * 2 : p.Q + (int64_t)m * p.ldq * 2;
+            const char *sp = in ? src + poff[o] : zero_page;
+            glds16(sp, sb + o * (TILE / 2) + wave * 1024);
         }
     };
 
@@ -226,52 +250,51 @@ __global__ __launch_bounds__(512) void gemm_tn_256(TnArgs p) {
         for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int l16 = lane & 15, q = l16 >> 2, pp = l16 & 3;
-    int rdoff[2][2], rdx[2];
+    int rdoff[2], rdx[2];
 #pragma unroll
     for (int sec = 0; sec < 2; ++sec) {
         rdx[sec] = (q << 2) | ((2 * g + sec) & 3);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) rdoff[kk][sec] = (kk * 32 + 8 * g + 4 * sec + q) * 256 + 8 * (pp & 1);
+        rdoff[sec] = (8 * g + 4 * sec + q) * 256 + 8 * (pp & 1);
     }
     const int chP = pp >> 1, chQ = (wb & 1) * 8 + (pp >> 1);          // + 2 * fragment index
 
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-        const char *sP = smem + cur * (4 * TILE) + wa * TILE, *sQ = smem + cur * (4 * TILE) + (2 + (wb >> 1)) * TILE;
+    const int ns = 2 * nk;                                            // sub-stages (rows beyond the slice come from the zero page)
+    stage(0);
+    stage(1);
+    if (ns > 2) stage(2);
+#define HGR_TN_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    for (int j = 0; j < ns; ++j) {
+        __builtin_amdgcn_sched_barrier(0);
+        const int ahead = ns - 1 - j;                                 // sub-stages issued behind j: min(2, ahead)
+        if (ahead >= 2) HGR_TN_WAIT(8); else if (ahead == 1) HGR_TN_WAIT(4); else HGR_TN_WAIT(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (j + 3 < ns) stage(j + 3);                                 // slot (j - 1) & 3: every wave's reads of it are behind this barrier
+        const char *sP = smem + (j & 3) * (2 * TILE) + wa * (TILE / 2), *sQ = smem + (j & 3) * (2 * TILE) + (2 + (wb >> 1)) * (TILE / 2);
+        vec8 pf[8], qf[4];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            vec8 pf[8], qf[4];
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const s16x4 p0 = tr_read(sP + rdoff[kk][0] + 16 * ((chP + 2 * t) ^ rdx[0]));
-                const s16x4 p1 = tr_read(sP + rdoff[kk][1] + 16 * ((chP + 2 * t) ^ rdx[1]));
-                pf[t] = __builtin_bit_cast(vec8, (s16x8)__builtin_shufflevector(p0, p1, 0, 1, 2, 3, 4, 5, 6, 7));
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const s16x4 q0 = tr_read(sQ + rdoff[kk][0] + 16 * ((chQ + 2 * t) ^ rdx[0]));
-                const s16x4 q1 = tr_read(sQ + rdoff[kk][1] + 16 * ((chQ + 2 * t) ^ rdx[1]));
-                qf[t] = __builtin_bit_cast(vec8, (s16x8)__builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7));
-            }
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[i][j] = T16<DT>::mfma16(qf[i], pf[j], acc[i][j]);
-            __builtin_amdgcn_s_setprio(0);
+        for (int t = 0; t < 8; ++t) {
+            const s16x4 p0 = tr_read(sP + rdoff[0] + 16 * ((chP + 2 * t) ^ rdx[0]));
+            const s16x4 p1 = tr_read(sP + rdoff[1] + 16 * ((chP + 2 * t) ^ rdx[1]));
+            pf[t] = __builtin_bit_cast(vec8, (s16x8)__builtin_shufflevector(p0, p1, 0, 1, 2, 3, 4, 5, 6, 7));
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        cur ^= 1;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const s16x4 q0 = tr_read(sQ + rdoff[0] + 16 * ((chQ + 2 * t) ^ rdx[0]));
+            const s16x4 q1 = tr_read(sQ + rdoff[1] + 16 * ((chQ + 2 * t) ^ rdx[1]));
+            qf[t] = __builtin_bit_cast(vec8, (s16x8)__builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) acc[i][jj] = T16<DT>::mfma16(qf[i], pf[jj], acc[i][jj]);
+        __builtin_amdgcn_s_setprio(0);
     }
+#undef HGR_TN_WAIT
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
     // lane holds, for tile (i, j): out[a = a0 + wa*128 + j*16 + r][b = b0 + wb*64 + i*16 + 4g .. +3]
-    float *o = p.out + (int64_t)blockIdx.y * p.csplit;
+    float *o = p.out + (int64_t)slice * p.csplit;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int a = a0 + wa * 128 + j * 16 + r;
@@ -318,7 +341,7 @@ int tn_launch(const void *P, int64_t ldp, const void *Q, int64_t ldq, float *par
     hipStream_t s = (hipStream_t)stream;
     if (!conv && tn_tile(Na, Nb) == 256) {
         a.tiles_b = (Nb + 255) / 256;
-        dim3 grid256((unsigned)(((Na + 255) / 256) * a.tiles_b), (unsigned)S);
+        dim3 grid256((unsigned)(((Na + 255) / 256) * a.tiles_b * S));
         if (dtype == HGR_BF16) hipLaunchKernelGGL((gemm_tn_256<HGR_BF16>), grid256, dim3(512), 0, s, a);
         else hipLaunchKernelGGL((gemm_tn_256<HGR_F16>), grid256, dim3(512), 0, s, a);
         HGR_CHECK_LAUNCH(name);
