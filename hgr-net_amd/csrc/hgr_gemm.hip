@@ -77,6 +77,9 @@ DuoPlan duo_plan(int M, int N, bool allow_tail) {
     else
         for (int pb = tiles_m - 1; pb >= 0 && pb >= tiles_m - 96; --pb) {
             const double m = makespan(pb);
+            // (forced panel counts, tools/producer_ab.py with warm clocks and interleaved arms, out_proj K = 768 / c_proj K = 3072 of
+            // ViT-B/32 at batch 512, us: no tail 61.7 / 150.0, 85 full panels - this loop's pick - 55.7 / 132.6, 70: 57.6 / 141.4,
+            // 55: 57.4 / 142.5: more half tiles than the last round needs cost time even on the epilogue-bound K = 768 launch)
             if (m < bm - 1e-9) { bm = m; pick = pb; }
         }
     if (pick == tiles_m) return best;
@@ -88,6 +91,8 @@ DuoPlan duo_plan(int M, int N, bool allow_tail) {
 void duo_apply_plan(GemmArgs &a, bool allow_tail, dim3 &grid) {
     const DuoPlan pl = duo_plan(a.M, a.N, allow_tail);
     a.nbig = pl.nbig; a.big_panels = pl.big_panels; a.tiles_m_half = pl.tiles_m_half;
+    if (duo_dbg() & 64) fprintf(stderr, "[duo_plan] M=%d N=%d K=%d -> %d full panels (%d tiles) + %d half panels, grid %d\n",
+                                     a.M, a.N, a.K, pl.big_panels, pl.nbig, pl.tiles_m_half, pl.grid);
     grid = dim3((unsigned)pl.grid);
 }
 

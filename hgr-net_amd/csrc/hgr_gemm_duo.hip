@@ -92,6 +92,10 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[a][b][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // (LN producer, measured and not kept: touching the tile's lines of the residual pair at tile start - one 4-byte LDS-DMA per 64 bytes
+    // into an LDS region no operand DMA targets before the prologue's counted wait - so that the epilogue's read-modify-write finds them in
+    // L2 / Infinity Cache: out_proj 56.9 -> 66.5 us, c_proj 131 -> 143 us; the prologue waits for them and the epilogue gains nothing.)
+
     // LN consumer: thread t finalises the statistics of tile row t from the producer's per-slot partial sums.  Called in the
     // epilogue, where its loads travel together with the bias / ln_s / ln_c loads (one exposed round trip per tile, covered
     // by the partner workgroup); at kernel entry it would delay the first LDS-DMA by a memory round trip.
@@ -762,6 +766,8 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
         p.K = min(p.kc, p.K - sp * p.kc);
     }
     __shared__ __attribute__((aligned(1024))) char smem[DUO_LDS];
+    // (measured and not kept: dealing 128 / 256 of the half tiles to the second slot of every CU in the first round, so that a CU's two
+    // workgroups are out of phase - producers 62 -> 72-74 us, 131 -> 163 us: half tiles up front only delay the full tiles behind them)
     const bool half = (int)blockIdx.x >= p.nbig;
     const int nwg = half ? (int)gridDim.x - p.nbig : p.nbig;
     const int orig = half ? (int)blockIdx.x - p.nbig : (int)blockIdx.x;

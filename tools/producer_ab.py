@@ -77,12 +77,20 @@ def timeit(fn, iters=12):
 
 
 res = {}
-arms = [("", None)] if not has_tail else [("tail_off", 0), ("tail_on", 1)]
+arms = [("", None, -1)] if not has_tail else [("tail_off", 0, -1), ("tail_on", 1, -1)]
+if has_tail and os.environ.get("AB_PB"):                      # forced full-panel counts, e.g. AB_PB=80,72,64
+    arms += [(f"pb{v}", 1, int(v)) for v in os.environ["AB_PB"].split(",")]
+for _ in range(40):                                           # ~0.2 s of launches first: the first arms otherwise run on ramping clocks
+    timeit(fc)
 for name, fn in (("out", out), ("proj", proj), ("qkv", qk), ("fc", fc)):
-    for tag, en in arms:
-        if en is not None:
-            lib.hgr_gemm_set_tail(en, -1)
-        fn(0)
-        ts = sorted(timeit(fn) for _ in range(5))
-        res[name + ("_" + tag if tag else "")] = [round(ts[0], 1), round(ts[2], 1)]
+    ts = {tag: [] for tag, _, _ in arms}
+    for _ in range(5):                                        # arms interleaved (CDNA guide rule 24)
+        for tag, en, pb in arms:
+            if en is not None:
+                lib.hgr_gemm_set_tail(en, pb)
+            fn(0)
+            ts[tag].append(timeit(fn))
+    for tag, v in ts.items():
+        v.sort()
+        res[name + ("_" + tag if tag else "")] = [round(v[0], 1), round(v[2], 1)]
 print(json.dumps({"lib": os.path.basename(lib_path), "us_min_med": res}))
