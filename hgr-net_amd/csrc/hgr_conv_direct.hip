@@ -14,6 +14,10 @@
 namespace {
 
 __device__ __attribute__((aligned(16))) unsigned int dc_zero_page[4] = {0u, 0u, 0u, 0u};
+// where the stores of lanes outside the image go (never read): every lane of every wave issues the SAME number of store instructions per
+// tile, so the end-of-tile wait can be counted ("all but my youngest N stores" = the next tile's LDS-DMA has landed) instead of
+// draining this tile's stores to memory
+__device__ __attribute__((aligned(16))) unsigned int dc_sink[64 * 4];
 
 constexpr int TP = 18;                         // halo tile edge
 constexpr int IN_CHUNKS = TP * TP * 4;         // 1296 16-byte chunks
@@ -27,37 +31,49 @@ struct DcArgs {
 
 // POOL: the 2 x 2 average pool that follows the stem's conv3 (clip/model.py:108-109) is taken from the staged 16-bit tile
 // (same values and the same fp32 average as hgr_avgpool2_nhwc on the stored tensor), so only the pooled tensor is written.
+// Round 3: PERSISTENT workgroups.  The first version ran one workgroup per tile: every one of the 25 088 tiles of a batch-512 launch
+// re-loaded the weights (19 / 38 KB - more than its 21 KB input tile) and waited out a memory round trip before its ~1 us of MFMAs
+// (437 / 228 us per launch, 11 % of the MFMA time needed, 1.6 TB/s).  Now 2 workgroups per CU keep the weights in LDS and walk over
+// tiles blockIdx.x, + gridDim.x, ...; the halo tile is double-buffered: the next tile's LDS-DMA is issued before the current tile's MFMAs
+// and has the whole compute + epilogue to land.  The epilogue stages through the CURRENT halo buffer (dead after the MFMAs), two
+// output rows per wave at a time (16 KB), so the weights and the buffer being filled are never touched.
 template <int DT, int NOUT, bool POOL = false>  // NOUT = Cout / 16
-__global__ __launch_bounds__(256) void conv3x3_c32(DcArgs p) {
+__global__ __launch_bounds__(256, 2) void conv3x3_c32(DcArgs p) {
     typedef typename T16<DT>::vec8 vec8;
     typedef typename T16<DT>::vec4 vec4;
     constexpr int COUT = NOUT * 16;
-    __shared__ __attribute__((aligned(1024))) char smem[IN_BYTES + COUT * WROW];
-    char *sIn = smem, *sW = smem + IN_BYTES;
+    __shared__ __attribute__((aligned(1024))) char smem[2 * IN_BYTES + COUT * WROW];
+    char *sW = smem + 2 * IN_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
-    int t = blockIdx.x;
-    const int tx = t % p.tiles_x; t /= p.tiles_x;
-    const int ty = t % p.tiles_y; const int b = t / p.tiles_y;
-    const int y0 = ty * 16, x0 = tx * 16;
-    const char *img = p.x + (int64_t)b * p.H * p.W * 64;
+    const int ntiles = p.B * p.tiles_y * p.tiles_x;
 
-    // ---- input halo tile: chunk id -> (pixel, slot); slot s of pixel q holds source chunk s ^ ((q >> 2) & 3)
+    // input halo tile of tile t into buffer buf: chunk id -> (pixel, slot); slot s of pixel q holds source chunk s ^ ((q >> 2) & 3)
+    auto issue_halo = [&](int t, int buf) {
+        const int tx = t % p.tiles_x; t /= p.tiles_x;
+        const int ty = t % p.tiles_y; const int b = t / p.tiles_y;
+        const int y0 = ty * 16, x0 = tx * 16;
+        const char *img = p.x + (int64_t)b * p.H * p.W * 64;
+        char *sIn = smem + buf * IN_BYTES;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const int pc = i * 4 + wave;               // piece (1 KB) index, 21 pieces
-        if (pc < 21) {                              // wave-uniform
-            const int id = pc * 64 + lane;
-            const int q = id >> 2, s = id & 3;
-            const int py = q / TP, px = q - py * TP;
-            const int yy = y0 - 1 + py, xx = x0 - 1 + px;
-            const bool ok = id < IN_CHUNKS && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
-            const char *src = ok ? img + ((int64_t)yy * p.W + xx) * 64 + ((s ^ ((q >> 2) & 3)) * 16) : (const char *)dc_zero_page;
-            __builtin_amdgcn_global_load_lds((const AS1 void *)src, (AS3 void *)(sIn + pc * 1024), 16, 0, 0);
+        for (int i = 0; i < 6; ++i) {
+            const int pc = i * 4 + wave;               // piece (1 KB) index, 21 pieces
+            if (pc < 21) {                              // wave-uniform
+                const int id = pc * 64 + lane;
+                const int q = id >> 2, sl = id & 3;
+                const int py = q / TP, px = q - py * TP;
+                const int yy = y0 - 1 + py, xx = x0 - 1 + px;
+                const bool ok = id < IN_CHUNKS && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+                const char *src = ok ? img + ((int64_t)yy * p.W + xx) * 64 + ((sl ^ ((q >> 2) & 3)) * 16) : (const char *)dc_zero_page;
+                __builtin_amdgcn_global_load_lds((const AS1 void *)src, (AS3 void *)(sIn + pc * 1024), 16, 0, 0);
+            }
         }
-    }
-    // ---- weights: COUT rows of 288 live elements = 36 chunks each
+    };
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    issue_halo(tile, 0);
+    // ---- weights: COUT rows of 288 live elements = 36 chunks each, once per workgroup
     for (int id = tid; id < COUT * 36; id += 256) {
         const int row = id / 36, c = id - row * 36;
         *(u32x4 *)(sW + row * WROW + c * 16) = *(const u32x4 *)(p.w + ((int64_t)row * p.Kp + c * 8) * 2);
@@ -68,76 +84,99 @@ __global__ __launch_bounds__(256) void conv3x3_c32(DcArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    f32x4 acc[4][NOUT];
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int i = 0; i < NOUT; ++i) acc[s][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr int PXB = COUT * 2;                  // bytes per output pixel
+    for (int it = 0; tile < ntiles; ++it, tile += gridDim.x) {
+        const int cur = it & 1;
+        const char *sIn = smem + cur * IN_BYTES;
+        const int nxt = tile + (int)gridDim.x;
+        if (nxt < ntiles) issue_halo(nxt, cur ^ 1);
+        int t = tile;
+        const int tx = t % p.tiles_x; t /= p.tiles_x;
+        const int ty = t % p.tiles_y; const int b = t / p.tiles_y;
+        const int y0 = ty * 16, x0 = tx * 16;
 
-    // output row of subtile s: wave * 4 + s (tile-local); tap (ky, kx) reads halo pixel (row + ky, r + kx)
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-        const int ky = tap / 3, kx = tap % 3;
-        vec8 wf[NOUT], af[4];
-#pragma unroll
-        for (int i = 0; i < NOUT; ++i) wf[i] = *(const vec8 *)(sW + (i * 16 + r) * WROW + (tap * 32 + g * 8) * 2);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int q = (wave * 4 + s + ky) * TP + r + kx;
-            af[s] = *(const vec8 *)(sIn + q * 64 + ((g ^ ((q >> 2) & 3)) * 16));
-        }
+        f32x4 acc[4][NOUT];
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int i = 0; i < NOUT; ++i) acc[s][i] = T16<DT>::mfma16(wf[i], af[s], acc[s][i]);
-    }
-    __syncthreads();                               // every wave is done with the input tile and the weights
+            for (int i = 0; i < NOUT; ++i) acc[s][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // lane holds out[pixel r of row (wave*4 + s)][channels i*16 + 4g .. +3]; stage the wave's 4 rows x 16 px x COUT
-    constexpr int PXB = COUT * 2;                  // bytes per pixel
-    char *my = smem + wave * (4 * 16 * PXB);
+        // output row of subtile s: wave * 4 + s (tile-local); tap (ky, kx) reads halo pixel (row + ky, r + kx)
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3;
+            vec8 wf[NOUT], af[4];
 #pragma unroll
-        for (int i = 0; i < NOUT; ++i) {
-            f32x4 v = acc[s][i] + bq[i];
-            if (p.relu) {
+            for (int i = 0; i < NOUT; ++i) wf[i] = *(const vec8 *)(sW + (i * 16 + r) * WROW + (tap * 32 + g * 8) * 2);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            for (int s = 0; s < 4; ++s) {
+                const int q = (wave * 4 + s + ky) * TP + r + kx;
+                af[s] = *(const vec8 *)(sIn + q * 64 + ((g ^ ((q >> 2) & 3)) * 16));
             }
-            *(vec4 *)(my + (s * 16 + r) * PXB + (i * 16 + g * 4) * 2) = cvt4<DT>(v[0], v[1], v[2], v[3]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < NOUT; ++i) acc[s][i] = T16<DT>::mfma16(wf[i], af[s], acc[s][i]);
         }
-    if (POOL) {
-        // the wave's 4 rows x 16 px -> 2 pooled rows x 8 px; chunk c of a pooled row = (pixel c / CPP, channels 8 (c % CPP) ..)
-        constexpr int CPP = PXB / 16;
-        const int Hp = p.H >> 1, Wp = p.W >> 1;
+        // every wave is done with this tile's input (a raw barrier: __syncthreads() would drain the next tile's LDS-DMA here)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+        // lane holds out[pixel r of row (wave*4 + s)][channels i*16 + 4g .. +3]; the wave stages 2 rows x 16 px x COUT at a time in
+        // its 1/4 of the (dead) current halo buffer: 2 * 16 * PXB <= 4 KB
+        char *my = smem + cur * IN_BYTES + wave * (2 * 16 * PXB);
 #pragma unroll
-        for (int c0 = 0; c0 < 2 * 8 * CPP; c0 += 64) {
-            const int c = c0 + lane;
-            const int pr = c / (8 * CPP), cr = c - pr * (8 * CPP), px = cr / CPP, cc = cr - px * CPP;
-            const char *s00 = my + ((2 * pr) * 16 + 2 * px) * PXB + cc * 16;
-            const vec8 a = *(const vec8 *)s00, b2 = *(const vec8 *)(s00 + PXB);
-            const vec8 c2 = *(const vec8 *)(s00 + 16 * PXB), d = *(const vec8 *)(s00 + 17 * PXB);
-            vec8 o;
+        for (int h = 0; h < 2; ++h) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (typename T16<DT>::elem)(((float)a[e] + (float)b2[e] + (float)c2[e] + (float)d[e]) * 0.25f);
-            const int yp = (y0 >> 1) + wave * 2 + pr, xp = (x0 >> 1) + px;
-            if (yp < Hp && xp < Wp) *(vec8 *)(p.out + (((int64_t)b * Hp + yp) * Wp + xp) * PXB + cc * 16) = o;
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int i = 0; i < NOUT; ++i) {
+                    f32x4 v = acc[2 * h + s2][i] + bq[i];
+                    if (p.relu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    *(vec4 *)(my + (s2 * 16 + r) * PXB + (i * 16 + g * 4) * 2) = cvt4<DT>(v[0], v[1], v[2], v[3]);
+                }
+            if (POOL) {
+                // the wave's 2 rows x 16 px -> 1 pooled row x 8 px; chunk c of the pooled row = (pixel c / CPP, channels 8 (c % CPP) ..)
+                constexpr int CPP = PXB / 16;
+                const int Hp = p.H >> 1, Wp = p.W >> 1;
+#pragma unroll
+                for (int c0 = 0; c0 < 8 * CPP; c0 += 64) {
+                    const int c = min(c0 + lane, 8 * CPP - 1);
+                    const int px = c / CPP, cc = c - px * CPP;
+                    const char *s00 = my + (2 * px) * PXB + cc * 16;
+                    const vec8 a = *(const vec8 *)s00, b2 = *(const vec8 *)(s00 + PXB);
+                    const vec8 c2 = *(const vec8 *)(s00 + 16 * PXB), d = *(const vec8 *)(s00 + 17 * PXB);
+                    vec8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (typename T16<DT>::elem)(((float)a[e] + (float)b2[e] + (float)c2[e] + (float)d[e]) * 0.25f);
+                    const int yp = (y0 >> 1) + wave * 2 + h, xp = (x0 >> 1) + px;
+                    const bool live = c0 + lane < 8 * CPP && yp < Hp && xp < Wp;
+                    char *dst = live ? p.out + (((int64_t)b * Hp + yp) * Wp + xp) * PXB + cc * 16 : (char *)dc_sink + lane * 16;
+                    *(vec8 *)dst = o;
+                }
+            } else {
+                // a row's 16 pixels are 16 * PXB contiguous bytes of the NHWC output: 16-byte chunks, lane-linear
+                constexpr int CPR = 16 * PXB / 16;     // chunks per output row of the tile (64 or 128)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const int y = y0 + wave * 4 + 2 * h + s2;
+#pragma unroll
+                    for (int c0 = 0; c0 < CPR; c0 += 64) {
+                        const int c = c0 + lane;
+                        const int px = c / (PXB / 16);
+                        const bool live = y < p.H && x0 + px < p.W;
+                        char *dst = live ? p.out + (((int64_t)b * p.H + y) * p.W + x0) * PXB + c * 16 : (char *)dc_sink + lane * 16;
+                        *(u32x4 *)dst = *(const u32x4 *)(my + s2 * 16 * PXB + c * 16);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the staging slice is private to the wave; its reads are done before the next half overwrites it
         }
-        return;
-    }
-    // a row's 16 pixels are 16 * PXB contiguous bytes of the NHWC output: 16-byte chunks, lane-linear
-    constexpr int CPR = 16 * PXB / 16;             // chunks per output row of the tile (64 or 128)
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const int y = y0 + wave * 4 + s;
-#pragma unroll
-        for (int c0 = 0; c0 < CPR; c0 += 64) {
-            const int c = c0 + lane;
-            const int px = c / (PXB / 16);
-            if (y < p.H && x0 + px < p.W)
-                *(u32x4 *)(p.out + (((int64_t)b * p.H + y) * p.W + x0) * PXB + c * 16) = *(const u32x4 *)(my + s * 16 * PXB + c * 16);
-        }
+        // the next tile's halo has landed: everything but this tile's stores (the wave's youngest NST vector-memory instructions)
+        constexpr int NST = POOL ? 2 : 4 * (16 * PXB / 16 / 64);
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NST) : "memory");   // ... for every wave; the current buffer is free for the tile after next
     }
 }
 
@@ -241,7 +280,7 @@ int hgr_conv3x3_c32_launch(const void *x, const void *w, const float *bias, void
     a.tiles_x = (W + 15) / 16; a.tiles_y = (H + 15) / 16;
     const int64_t nwg = (int64_t)B * a.tiles_x * a.tiles_y;
     HGR_REQUIRE(nwg < (1ll << 31), "hgr_conv3x3_nhwc: too many tiles");
-    dim3 grid((unsigned)nwg);
+    dim3 grid((unsigned)std::min<int64_t>(nwg, 512));           // persistent: 2 workgroups per CU walk over the tiles
     hipStream_t s = (hipStream_t)stream;
     if (pool) {
         if (Cout == 32) {

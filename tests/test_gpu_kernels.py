@@ -312,6 +312,8 @@ def test_level_argmax_exact(n, levels):
                                                   (1, 9, 9, 320, 320, 1), (1, 6, 6, 640, 640, 1), (2, 24, 24, 24, 48, 1),
                                                   # 32 input channels, stride 1, 32 / 64 outputs: the direct halo-tile kernel (ragged tiles too)
                                                   (2, 16, 16, 32, 32, 1), (1, 33, 17, 32, 64, 1), (3, 40, 48, 32, 32, 1), (2, 5, 70, 32, 64, 1),
+                                                  # ... with more tiles than the 512 persistent workgroups (600 / 1300: every workgroup walks 1 - 3 tiles)
+                                                  (6, 160, 160, 32, 64, 1), (13, 150, 152, 32, 32, 1),
                                                   # 256^2 tiles with a non-power-of-two C (>= 1024 tiles of 256)
                                                   (40, 80, 80, 192, 192, 1)])
 def test_conv3x3_implicit_gemm_vs_conv2d(dt, b, h, w, c, cout, stride):
@@ -333,7 +335,7 @@ def test_conv3x3_implicit_gemm_vs_conv2d(dt, b, h, w, c, cout, stride):
 
 
 @pytest.mark.parametrize("dt", DTS)
-@pytest.mark.parametrize("b,h,w,cout", [(2, 16, 16, 64), (1, 34, 18, 64), (3, 40, 48, 32), (2, 6, 70, 64)])
+@pytest.mark.parametrize("b,h,w,cout", [(2, 16, 16, 64), (1, 34, 18, 64), (3, 40, 48, 32), (2, 6, 70, 64), (5, 176, 160, 64), (6, 160, 162, 32)])
 def test_conv3x3_pool2_equals_conv_then_pool(dt, b, h, w, cout):
     """The fused stem tail must give exactly what the two kernels give (the pool averages the 16-bit conv outputs)."""
     x = _rand((b * h * w, 32), 150).to(dt).to(DEV)
