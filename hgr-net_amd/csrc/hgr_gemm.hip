@@ -250,6 +250,7 @@ static int conv3x3_launch(const void *x, const void *w, const float *bias, void 
     a.m_fastest = 0; a.vec_ok = 1; a.dbg = 0; a.kc = 0; a.csplit = 0;
     a.cH = H; a.cW = W; a.cC = C; a.cStride = stride; a.cHo = Ho; a.cWo = Wo;
     a.cMagic = (unsigned)(((1ull << 32) + (unsigned)C - 1) / (unsigned)C);
+    a.cUni = (C % 64 == 0) ? 1 : 0;
     // big tiles when the output is at least 256 wide-ish and the launch has >= 160 of them (measured at batch 512: 14x14x256
     // 160 -> 142 us with 392 tiles, 7x7x512 160 -> 135 us with 196 tiles; K is 2304 / 4608 there, so one round is long)
     const int64_t t256 = (int64_t)((a.M + 255) / 256) * ((Cout + 255) / 256);
@@ -257,6 +258,21 @@ static int conv3x3_launch(const void *x, const void *w, const float *bias, void 
     // padding - measured 1066 vs 646 us at 56x56x128 and 285 vs 160 us at 28x28x128, batch 512)
     const int waste256 = (Cout + 255) / 256 * 256 - Cout, waste128 = (Cout + 127) / 128 * 128 - Cout;
     const bool big = relu && hgr_gemm_force_tile() != 128 && Kp >= 128 && Cout >= 128 && (t256 >= 160 || hgr_gemm_force_tile() == 256) && waste256 <= waste128;
+    // 256 x 128 tiles, two workgroups per CU (gemm_nt_duo with the implicit-im2col loader): C % 64 == 0, stride 1, outputs that fill
+    // 128-column tiles, operands addressable with 32-bit offsets; HGR_CONV_DUO=0 keeps the kernels above
+    static int conv_duo_env = -1;
+    if (conv_duo_env < 0) { const char *e = getenv("HGR_CONV_DUO"); conv_duo_env = e ? atoi(e) : 1; }
+    const int64_t tduo = (int64_t)((a.M + 255) / 256) * ((Cout + 127) / 128);
+    if (conv_duo_env && relu && a.cUni && stride == 1 && Cout % 128 == 0 && Kp == 9 * C && tduo >= 256 && hgr_aligned(out, 16) &&
+        (int64_t)B * H * W * C * 2 < (1ll << 31) && (int64_t)Cout * Kp * 2 < (1ll << 32) && hgr_gemm_force_tile() == 0) {
+        a.tiles_m = (a.M + 255) / 256; a.tiles_n = Cout / 128; a.group = duo_group();
+        a.ln_stats = nullptr; a.ln_flag = nullptr;
+        dim3 grid;
+        duo_apply_plan(a, true, grid);
+        launch_duo(a, dtype, HGR_EPI_BIAS_RELU, false, 5, grid, (hipStream_t)stream);
+        HGR_CHECK_LAUNCH("hgr_conv3x3_nhwc");
+        return HGR_OK;
+    }
     if (big) {
         a.tiles_m = (a.M + 255) / 256; a.tiles_n = (Cout + 255) / 256;
         launch_256(a, dtype, HGR_EPI_BIAS_RELU, false, true, dim3((unsigned)(a.tiles_m * a.tiles_n)), (hipStream_t)stream);
@@ -298,7 +314,7 @@ extern "C" int hgr_gemm_nt_splitk(const void *A, int64_t lda, const void *W, int
     a.M = M; a.N = N; a.K = K;
     a.tiles_m = (M + BM - 1) / BM; a.tiles_n = (N + BN - 1) / BN;
     a.m_fastest = 0; a.vec_ok = 1; a.dbg = 0; a.kc = kc; a.csplit = (int64_t)M * ldc;
-    a.cH = a.cW = a.cC = a.cStride = a.cHo = a.cWo = 0; a.cMagic = 0;
+    a.cH = a.cW = a.cC = a.cStride = a.cHo = a.cWo = 0; a.cMagic = 0; a.cUni = 0;
     // every slice at least 2 K-tiles deep and an output of at least one 256^2 tile: the deep-pipelined kernel
     const bool big = hgr_gemm_force_tile() != 128 && M >= 256 && N >= 256 && kc >= 128 && (K - (S - 1) * kc) >= 128;
     if (big) {
@@ -326,7 +342,7 @@ void ln_args(GemmArgs &a, const void *A, int64_t lda, const void *W, int64_t ldw
     a.A = (const char *)A; a.lda = lda; a.W = (const char *)W; a.ldw = ldw; a.C = C; a.ldc = ldc; a.bias = nullptr; a.res = nullptr; a.ldr = 0;
     a.M = M; a.N = N; a.K = K; a.tiles_m = (M + 255) / 256; a.tiles_n = N / 128;
     a.m_fastest = ((int64_t)N * K > (int64_t)M * K) ? 1 : 0; a.vec_ok = 1; a.dbg = duo_dbg(); a.kc = 0; a.csplit = 0; a.group = duo_group();
-    a.cH = a.cW = a.cC = a.cStride = a.cHo = a.cWo = 0; a.cMagic = 0;
+    a.cH = a.cW = a.cC = a.cStride = a.cHo = a.cWo = 0; a.cMagic = 0; a.cUni = 0;
     a.ln_stats = nullptr; a.ln_slots = 0; a.ln_eps = 0.f; a.ln_xh = a.ln_xl = nullptr; a.ln_ldx = 0; a.ln_s = a.ln_c = nullptr; a.ln_flag = nullptr; a.ln_guard = 0.f;
 }
 }  // namespace

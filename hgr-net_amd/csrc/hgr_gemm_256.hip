@@ -92,6 +92,7 @@ __global__ __launch_bounds__(NT256) void gemm_nt_256(GemmArgs p) {
                 }
                 vmask[half][j] = vm;
                 src[half ? 3 : 0][j] = p.A + (((int64_t)b * p.cH + hi0) * p.cW + wi0) * p.cC * 2;   // tap (0,0), channel 0
+                if (p.cUni) src[half ? 3 : 0][j] += c * 16;                                         // ... + this lane's chunk (uniform-tap path)
             }
         } else {
             src[0][j] = p.A + ((int64_t)min(m0 + ra0, p.M - 1) * p.lda + c * 8) * 2;
@@ -103,6 +104,20 @@ __global__ __launch_bounds__(NT256) void gemm_nt_256(GemmArgs p) {
         if (!do_ld) return;
         char *dst = smem + (t & 1) * (4 * PIECE) + kind * PIECE + wave * 1024;
         const int64_t koff = (int64_t)t * 128;
+        if (CONV && (kind == 0 || kind == 3) && p.cUni) {
+            // C % 64 == 0: one tap per K-tile - scalar tap / offset, a lane only tests its mask bit (see gemm_nt_128)
+            const int kq0 = t * 64;
+            const int tap = (int)__umulhi((unsigned)kq0, p.cMagic);
+            const int ky = (tap * 11) >> 5, kx = tap - ky * 3;
+            const int64_t soff = ((int64_t)(ky * p.cW + kx) * p.cC + (kq0 - tap * p.cC)) * 2;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const bool ok = tap < 9 && ((vmask[kind == 3][j] >> tap) & 1u);
+                const char *sp = ok ? src[kind][j] + soff : (const char *)hgr_zero_page;
+                __builtin_amdgcn_global_load_lds((const AS1 void *)sp, (AS3 void *)(dst + j * 8192), 16, 0, 0);
+            }
+            return;
+        }
         if (CONV && (kind == 0 || kind == 3)) {
             // implicit im2col (see gemm_nt_128): K index = tap * C + channel, 8 channels per 16-B chunk, OOB taps -> zero page
 #pragma unroll

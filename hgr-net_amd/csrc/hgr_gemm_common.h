@@ -31,6 +31,7 @@ struct GemmArgs {
     // implicit-GEMM 3x3 convolution (CONV kernels only): A is an NHWC image [B, H, W, C], pad 1
     int cH, cW, cC, cStride, cHo, cWo;
     unsigned cMagic;  // ceil(2^32 / cC): __umulhi(k, cMagic) == k / cC for every k < 9 * cC + 64 (k * cC < 2^32)
+    int cUni;         // cC % 64 == 0: a 64-deep K-tile lies inside ONE tap, so tap / kernel offset are wave-uniform per K-tile (scalar ALU)
     // split-K (gemm_nt_128 only): blockIdx.y = split s works on K columns [s * kc, min(K, (s + 1) * kc)) and writes its own
     // fp32 partial C + s * csplit elements; 0 = off
     int kc; int64_t csplit;

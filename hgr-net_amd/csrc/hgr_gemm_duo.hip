@@ -37,7 +37,7 @@ __device__ __forceinline__ void store16_sc1(void *ptr, u32x4 v) {
 // One output tile.  MH = 2: the 256 (M) x 128 (N) tile described above.  MH = 1: a HALF tile, 128 x 128 (m-half 0 only: a wave owns
 // 64 x 64, two phases per K-tile) for the row panels that do not fill a whole round of the chip's 512 workgroup slots - see
 // duo_plan() on the host side and the half-tile schedule below.
-template <int DT, int EPI, bool OUT32, int LN, int MH>
+template <int DT, int EPI, bool OUT32, int LN, int MH, bool CONV = false>
 __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const int m0, const int n0) {
     typedef typename T16<DT>::vec8 vec8;
     typedef typename T16<DT>::elem E;
@@ -52,13 +52,33 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
     // one K-tile: 4 per A piece (32 piece rows each), 2 per W piece.  Piece row pr of A0 = tile row (pr / 64) * 128 + pr % 64,
     // of W0 = tile row (pr / 32) * 64 + pr % 32; A1 / W1 = the same rows + 64 / + 32.  Source chunk ^= row & 7 (rule 21).
     unsigned oA0[4], oA1[4], oW0[2], oW1[2];
+    unsigned vA0[CONV ? 4 : 1], vA1[CONV ? 4 : 1];     // CONV: tap-validity masks of the rows behind oA0 / oA1
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int id = (i * 4 + wave) * 64 + lane;
         const int pr = id >> 3, c = (id & 7) ^ (pr & 7);
         const int ra = MH == 2 ? (pr >> 6) * 128 + (pr & 63) : pr;          // half tile: piece row = tile row
+        if (CONV) {
+            // implicit im2col of a 3 x 3 / pad 1 / stride 1 convolution over NHWC with C % 64 == 0 (a 64-deep K-tile = 64 channels of ONE
+            // tap): the lane keeps the (signed) byte offset of tap (0, 0), channel 8 c of its output pixel and a 9-bit mask of the taps
+            // inside the image; tap and kernel offset of a K-tile are scalar (issueA)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int gm = min(m0 + ra + half * 64, p.M - 1);
+                const int wo = gm % p.cWo, t1 = gm / p.cWo, ho = t1 % p.cHo, b = t1 / p.cHo;
+                unsigned vm = 0;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int hi = ho - 1 + t / 3, wi = wo - 1 + t % 3;
+                    if (hi >= 0 && hi < p.cH && wi >= 0 && wi < p.cW) vm |= 1u << t;
+                }
+                const int64_t o = ((((int64_t)b * p.cH + ho - 1) * p.cW + wo - 1) * p.cC + c * 8) * 2;
+                if (half) { oA1[i] = (unsigned)(int)o; vA1[i] = vm; } else { oA0[i] = (unsigned)(int)o; vA0[i] = vm; }
+            }
+        } else {
         oA0[i] = (unsigned)(((int64_t)min(m0 + ra, p.M - 1) * p.lda + c * 8) * 2);
         oA1[i] = (unsigned)(((int64_t)min(m0 + ra + 64, p.M - 1) * p.lda + c * 8) * 2);
+        }
         if (i < 2) {
             const int rw = (pr >> 5) * 64 + (pr & 31);
             oW0[i] = (unsigned)(((int64_t)min(n0 + rw, p.N - 1) * p.ldw + c * 8) * 2);
@@ -67,9 +87,27 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
     }
     char *const ldsw = smem + wave * 1024;
     // halves of an A piece: instructions [2h, 2h + 2)
-    auto issueA = [&](const unsigned (&off)[4], int slot_base, int t, int h) {
-        const char *base = p.A + (int64_t)t * 128;
+    // CONV: base of K-tile t = A + kernel offset of its tap + its first channel (scalar); a lane whose tap is outside the image reads zeros
+    auto conv_base = [&](int t, int &tap) {
+        const int kq0 = t * 64;
+        tap = (int)__umulhi((unsigned)kq0, p.cMagic);
+        const int ky = (tap * 11) >> 5, kx = tap - ky * 3;
+        return p.A + ((int64_t)(ky * p.cW + kx) * p.cC + (kq0 - tap * p.cC)) * 2;
+    };
+    auto issueA = [&](const unsigned (&off)[4], const unsigned (&vm)[CONV ? 4 : 1], int slot_base, int t, int h) {
         char *dst = ldsw + slot_base + (t & 1) * 16384;
+        if (CONV) {
+            int tap;
+            const char *base = conv_base(t, tap);
+#pragma unroll
+            for (int i = 2 * h; i < 2 * h + 2; ++i) {
+                const bool ok = (vm[CONV ? i : 0] >> tap) & 1u;
+                const char *sp = ok ? base + (int64_t)(int)off[i] : (const char *)hgr_zero_page;
+                __builtin_amdgcn_global_load_lds((const AS1 void *)sp, (AS3 void *)(dst + i * 4096), 16, 0, 0);
+            }
+            return;
+        }
+        const char *base = p.A + (int64_t)t * 128;
 #pragma unroll
         for (int i = 2 * h; i < 2 * h + 2; ++i)
             __builtin_amdgcn_global_load_lds((const AS1 void *)(base + off[i]), (AS3 void *)(dst + i * 4096), 16, 0, 0);
@@ -132,10 +170,10 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
     vec8 af[4][2], wf0[2][2], wf1[2][2];
     if constexpr (MH == 2) {
         // prologue in steady-state order: A0(0), A1(0), W0(0), W1(0), A0(1)
-        issueA(oA0, DUO_A0, 0, 0); issueA(oA0, DUO_A0, 0, 1);
-        issueA(oA1, DUO_A1, 0, 0); issueA(oA1, DUO_A1, 0, 1);
+        issueA(oA0, vA0, DUO_A0, 0, 0); issueA(oA0, vA0, DUO_A0, 0, 1);
+        issueA(oA1, vA1, DUO_A1, 0, 0); issueA(oA1, vA1, DUO_A1, 0, 1);
         issueW(oW0, DUO_W0, 0); issueW(oW1, DUO_W1, 0);
-        issueA(oA0, DUO_A0, 1, 0); issueA(oA0, DUO_A0, 1, 1);
+        issueA(oA0, vA0, DUO_A0, 1, 0); issueA(oA0, vA0, DUO_A0, 1, 1);
         HGR_RWAIT(6);               // A0(0), W0(0) landed
 
 
@@ -154,7 +192,7 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
                 af[i][0] = *(const vec8 *)(bufA0 + offA + i * 2048 + sw0);
                 af[i][1] = *(const vec8 *)(bufA0 + offA + i * 2048 + sw1);
             }
-            if (MODE <= 1) { issueA(oA1, DUO_A1, t + 1, 0); issueA(oA1, DUO_A1, t + 1, 1); }
+            if (MODE <= 1) { issueA(oA1, vA1, DUO_A1, t + 1, 0); issueA(oA1, vA1, DUO_A1, t + 1, 1); }
             if (MODE <= 1) HGR_RWAIT(8); else HGR_RWAIT(0);                 // W1(t) landed
             __builtin_amdgcn_s_setprio(1);
     #pragma unroll
@@ -187,7 +225,7 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
                 af[i][1] = *(const vec8 *)(bufA1 + offA + i * 2048 + sw1);
             }
             if (MODE <= 1) issueW(oW1, DUO_W1, t + 1);
-            if (MODE == 0) issueA(oA0, DUO_A0, t + 2, 0);
+            if (MODE == 0) issueA(oA0, vA0, DUO_A0, t + 2, 0);
             __builtin_amdgcn_sched_barrier(0);                              // no barrier here: nothing is refilled before ph4's barrier that ph3 reads
             __builtin_amdgcn_s_setprio(1);
     #pragma unroll
@@ -198,7 +236,7 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
                     for (int j = 0; j < 2; ++j) acc[1][1][i][j] = T16<DT>::mfma16(wf1[j][kk], af[i][kk], acc[1][1][i][j]);
             __builtin_amdgcn_s_setprio(0);
             // ---- ph4: Q(1,0) ----
-            if (MODE == 0) issueA(oA0, DUO_A0, t + 2, 1);
+            if (MODE == 0) issueA(oA0, vA0, DUO_A0, t + 2, 1);
             if (MODE == 0) HGR_RWAIT(6); else if (MODE == 1) HGR_RWAIT(2);  // W0(t+1), A0(t+1) landed
             __builtin_amdgcn_s_setprio(1);
     #pragma unroll
@@ -222,8 +260,19 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
         // issue order ... W1(t), A(t+1) | W0(t+1) | W1(t+1), A(t+2) | W0(t+2) ...: a count = "my N youngest may still be in flight".
         constexpr int HW0 = 49152, HW1 = 65536;
         auto issueAh = [&](int t, int buf) {
-            const char *base = p.A + (int64_t)t * 128;
             char *dst = ldsw + buf * 16384;
+            if (CONV) {
+                int tap;
+                const char *base = conv_base(t, tap);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool ok = (vA0[CONV ? i : 0] >> tap) & 1u;
+                    const char *sp = ok ? base + (int64_t)(int)oA0[i] : (const char *)hgr_zero_page;
+                    __builtin_amdgcn_global_load_lds((const AS1 void *)sp, (AS3 void *)(dst + i * 4096), 16, 0, 0);
+                }
+                return;
+            }
+            const char *base = p.A + (int64_t)t * 128;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 __builtin_amdgcn_global_load_lds((const AS1 void *)(base + oA0[i]), (AS3 void *)(dst + i * 4096), 16, 0, 0);
@@ -757,7 +806,7 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
 // Block -> tile.  Blocks [0, p.nbig) are full tiles on the first p.big_panels row panels of 256; blocks [p.nbig, gridDim.x) are
 // half tiles on the remaining rows (128-row panels): dispatched last, they fill the slots the last, partly empty round of full
 // tiles would leave idle with work of half the size.  Each region has its own XCD-aware grouped raster.
-template <int DT, int EPI, bool OUT32, int LN = 0>
+template <int DT, int EPI, bool OUT32, int LN = 0, bool CONV = false>
 __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
     if (p.kc) {                                   // split-K (see gemm_nt_128)
         const int sp = blockIdx.y;
@@ -785,8 +834,8 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
         const int gs = min(GROUP, tiles_m - first), loc = wg - grp * per;
         tm = first + loc % gs; tn = loc / gs;
     }
-    if (half) duo_tile<DT, EPI, OUT32, LN, 1>(p, smem, p.big_panels * 256 + tm * 128, tn * 128);
-    else duo_tile<DT, EPI, OUT32, LN, 2>(p, smem, tm * 256, tn * 128);
+    if (half) duo_tile<DT, EPI, OUT32, LN, 1, CONV>(p, smem, p.big_panels * 256 + tm * 128, tn * 128);
+    else duo_tile<DT, EPI, OUT32, LN, 2, CONV>(p, smem, tm * 256, tn * 128);
 }
 
 namespace {
@@ -800,6 +849,7 @@ void launch_duo_dt(const GemmArgs &a, int epi, bool out32, int ln, dim3 grid, hi
             return;
         case 3: hipLaunchKernelGGL((gemm_nt_duo<DT, HGR_EPI_NONE, true, 3>), grid, dim3(NTD), 0, s, a); return;
         case 4: hipLaunchKernelGGL((gemm_nt_duo<DT, HGR_EPI_BIAS, false, 4>), grid, dim3(NTD), 0, s, a); return;
+        case 5: hipLaunchKernelGGL((gemm_nt_duo<DT, HGR_EPI_BIAS_RELU, false, 0, true>), grid, dim3(NTD), 0, s, a); return;   // 3 x 3 convolution (implicit im2col loader)
         default: break;
     }
 #define HGR_DUO(E) do { if (out32) hipLaunchKernelGGL((gemm_nt_duo<DT, E, true>), grid, dim3(NTD), 0, s, a); \

@@ -314,6 +314,9 @@ def test_level_argmax_exact(n, levels):
                                                   (2, 16, 16, 32, 32, 1), (1, 33, 17, 32, 64, 1), (3, 40, 48, 32, 32, 1), (2, 5, 70, 32, 64, 1),
                                                   # ... with more tiles than the 512 persistent workgroups (600 / 1300: every workgroup walks 1 - 3 tiles)
                                                   (6, 160, 160, 32, 64, 1), (13, 150, 152, 32, 32, 1),
+                                                  # C % 64 == 0, stride 1, Cout % 128 == 0 and >= 256 tiles of 256 x 128: gemm_nt_duo with the implicit-im2col
+                                                  # loader - full tiles only (282), tail plan with half tiles (633 tiles), ragged last row panel + 4 column tiles
+                                                  (20, 60, 60, 128, 128, 1), (45, 60, 60, 128, 128, 1), (24, 30, 31, 256, 512, 1),
                                                   # 256^2 tiles with a non-power-of-two C (>= 1024 tiles of 256)
                                                   (40, 80, 80, 192, 192, 1)])
 def test_conv3x3_implicit_gemm_vs_conv2d(dt, b, h, w, c, cout, stride):
