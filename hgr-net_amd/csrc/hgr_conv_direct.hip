@@ -20,9 +20,20 @@ __device__ __attribute__((aligned(16))) unsigned int dc_zero_page[4] = {0u, 0u, 
 __device__ __attribute__((aligned(16))) unsigned int dc_sink[64 * 4];
 
 constexpr int TP = 18;                         // halo tile edge
-constexpr int IN_CHUNKS = TP * TP * 4;         // 1296 16-byte chunks
-constexpr int IN_BYTES = 21 * 1024;            // 21 wave-instructions of LDS-DMA (1344 chunks), the tail is scratch
-constexpr int WROW = 592;                      // weight row stride in LDS: 288 x 2 B + 16 B pad -> conflict-free b128 reads
+// per input-channel count CIN (32: the stem; 64: the three 3x3 convolutions of layer1, round 3): 16-byte chunks per pixel, chunks and
+// LDS-DMA pieces (1 KB) of a halo tile, bytes of one halo buffer, weight row stride in LDS (9 CIN x 2 B + 32 B pad: the four
+// ds_read_b128 lane groups of a 16-row x 4-chunk fragment read hit 64 distinct banks; the first build's + 16 B was 2-way)
+template <int CIN> struct DcGeom {
+    static constexpr int CHP = CIN / 8;                            // 4 / 8
+    static constexpr int IN_CHUNKS = TP * TP * CHP;                // 1296 / 2592
+    static constexpr int PIECES = (IN_CHUNKS + 63) / 64;           // 21 / 41
+    static constexpr int IN_BYTES = PIECES * 1024;
+    static constexpr int WROW = 9 * CIN * 2 + 32;                  // 608 / 1184
+    // workgroup shape: CIN = 32: 4 waves x 4 output rows, two workgroups per CU; CIN = 64 (halo 41 KB x 2 + weights 74 KB = 156 KB):
+    // 8 waves x 2 output rows, ONE workgroup per CU (two waves per SIMD all the same)
+    static constexpr int NW = CIN == 32 ? 4 : 8;
+    static constexpr int RPW = 16 / NW;
+};
 
 struct DcArgs {
     const char *x; const char *w; const float *bias; char *out;
@@ -37,35 +48,39 @@ struct DcArgs {
 // tiles blockIdx.x, + gridDim.x, ...; the halo tile is double-buffered: the next tile's LDS-DMA is issued before the current tile's MFMAs
 // and has the whole compute + epilogue to land.  The epilogue stages through the CURRENT halo buffer (dead after the MFMAs), two
 // output rows per wave at a time (16 KB), so the weights and the buffer being filled are never touched.
-template <int DT, int NOUT, bool POOL = false>  // NOUT = Cout / 16
-__global__ __launch_bounds__(256, 2) void conv3x3_c32(DcArgs p) {
+template <int DT, int NOUT, bool POOL = false, int CIN = 32>  // NOUT = Cout / 16
+__global__ __launch_bounds__(DcGeom<CIN>::NW * 64, CIN == 32 ? 2 : 1) void conv3x3_c32(DcArgs p) {
     typedef typename T16<DT>::vec8 vec8;
     typedef typename T16<DT>::vec4 vec4;
-    constexpr int COUT = NOUT * 16;
+    typedef DcGeom<CIN> G;
+    constexpr int COUT = NOUT * 16, NW = G::NW, RPW = G::RPW, NT = NW * 64, CHP = G::CHP, PB = CIN * 2;
+    constexpr int IN_BYTES = G::IN_BYTES, WROW = G::WROW;
     __shared__ __attribute__((aligned(1024))) char smem[2 * IN_BYTES + COUT * WROW];
     char *sW = smem + 2 * IN_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
     const int ntiles = p.B * p.tiles_y * p.tiles_x;
+    // slot s of pixel q holds source chunk s ^ swz(q): CIN = 32 (64-byte pixels) (q >> 2) & 3, CIN = 64 (128-byte pixels) q & 7
+    auto swz = [](int q) { return CIN == 32 ? (q >> 2) & 3 : q & 7; };
 
-    // input halo tile of tile t into buffer buf: chunk id -> (pixel, slot); slot s of pixel q holds source chunk s ^ ((q >> 2) & 3)
+    // input halo tile of tile t into buffer buf
     auto issue_halo = [&](int t, int buf) {
         const int tx = t % p.tiles_x; t /= p.tiles_x;
         const int ty = t % p.tiles_y; const int b = t / p.tiles_y;
         const int y0 = ty * 16, x0 = tx * 16;
-        const char *img = p.x + (int64_t)b * p.H * p.W * 64;
+        const char *img = p.x + (int64_t)b * p.H * p.W * PB;
         char *sIn = smem + buf * IN_BYTES;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int pc = i * 4 + wave;               // piece (1 KB) index, 21 pieces
-            if (pc < 21) {                              // wave-uniform
+        for (int i = 0; i < (G::PIECES + NW - 1) / NW; ++i) {
+            const int pc = i * NW + wave;              // piece (1 KB) index
+            if (pc < G::PIECES) {                       // wave-uniform
                 const int id = pc * 64 + lane;
-                const int q = id >> 2, sl = id & 3;
+                const int q = id / CHP, sl = id - q * CHP;
                 const int py = q / TP, px = q - py * TP;
                 const int yy = y0 - 1 + py, xx = x0 - 1 + px;
-                const bool ok = id < IN_CHUNKS && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
-                const char *src = ok ? img + ((int64_t)yy * p.W + xx) * 64 + ((sl ^ ((q >> 2) & 3)) * 16) : (const char *)dc_zero_page;
+                const bool ok = id < G::IN_CHUNKS && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+                const char *src = ok ? img + ((int64_t)yy * p.W + xx) * PB + ((sl ^ swz(q)) * 16) : (const char *)dc_zero_page;
                 __builtin_amdgcn_global_load_lds((const AS1 void *)src, (AS3 void *)(sIn + pc * 1024), 16, 0, 0);
             }
         }
@@ -73,9 +88,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32(DcArgs p) {
     int tile = blockIdx.x;
     if (tile >= ntiles) return;
     issue_halo(tile, 0);
-    // ---- weights: COUT rows of 288 live elements = 36 chunks each, once per workgroup
-    for (int id = tid; id < COUT * 36; id += 256) {
-        const int row = id / 36, c = id - row * 36;
+    // ---- weights: COUT rows of 9 CIN live elements, once per workgroup
+    constexpr int WCH = 9 * CIN / 8;                   // chunks per weight row (36 / 72)
+    for (int id = tid; id < COUT * WCH; id += NT) {
+        const int row = id / WCH, c = id - row * WCH;
         *(u32x4 *)(sW + row * WROW + c * 16) = *(const u32x4 *)(p.w + ((int64_t)row * p.Kp + c * 8) * 2);
     }
     f32x4 bq[NOUT];
@@ -95,37 +111,40 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32(DcArgs p) {
         const int ty = t % p.tiles_y; const int b = t / p.tiles_y;
         const int y0 = ty * 16, x0 = tx * 16;
 
-        f32x4 acc[4][NOUT];
+        f32x4 acc[RPW][NOUT];
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int s = 0; s < RPW; ++s)
 #pragma unroll
             for (int i = 0; i < NOUT; ++i) acc[s][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-        // output row of subtile s: wave * 4 + s (tile-local); tap (ky, kx) reads halo pixel (row + ky, r + kx)
+        // output row of subtile s: wave * RPW + s (tile-local); tap (ky, kx), channel block kc reads halo pixel (row + ky, r + kx)
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap % 3;
-            vec8 wf[NOUT], af[4];
 #pragma unroll
-            for (int i = 0; i < NOUT; ++i) wf[i] = *(const vec8 *)(sW + (i * 16 + r) * WROW + (tap * 32 + g * 8) * 2);
+            for (int kc = 0; kc < CIN / 32; ++kc) {
+                vec8 wf[NOUT], af[RPW];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int q = (wave * 4 + s + ky) * TP + r + kx;
-                af[s] = *(const vec8 *)(sIn + q * 64 + ((g ^ ((q >> 2) & 3)) * 16));
+                for (int i = 0; i < NOUT; ++i) wf[i] = *(const vec8 *)(sW + (i * 16 + r) * WROW + (tap * CIN + kc * 32 + g * 8) * 2);
+#pragma unroll
+                for (int s = 0; s < RPW; ++s) {
+                    const int q = (wave * RPW + s + ky) * TP + r + kx;
+                    af[s] = *(const vec8 *)(sIn + q * PB + (((kc * 4 + g) ^ swz(q)) * 16));
+                }
+#pragma unroll
+                for (int s = 0; s < RPW; ++s)
+#pragma unroll
+                    for (int i = 0; i < NOUT; ++i) acc[s][i] = T16<DT>::mfma16(wf[i], af[s], acc[s][i]);
             }
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int i = 0; i < NOUT; ++i) acc[s][i] = T16<DT>::mfma16(wf[i], af[s], acc[s][i]);
         }
         // every wave is done with this tile's input (a raw barrier: __syncthreads() would drain the next tile's LDS-DMA here)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
-        // lane holds out[pixel r of row (wave*4 + s)][channels i*16 + 4g .. +3]; the wave stages 2 rows x 16 px x COUT at a time in
-        // its 1/4 of the (dead) current halo buffer: 2 * 16 * PXB <= 4 KB
+        // lane holds out[pixel r of row (wave*RPW + s)][channels i*16 + 4g .. +3]; the wave stages 2 rows x 16 px x COUT at a time in
+        // its share of the (dead) current halo buffer: NW * 2 * 16 * PXB <= IN_BYTES
         char *my = smem + cur * IN_BYTES + wave * (2 * 16 * PXB);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < RPW / 2; ++h) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -151,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32(DcArgs p) {
                     vec8 o;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] = (typename T16<DT>::elem)(((float)a[e] + (float)b2[e] + (float)c2[e] + (float)d[e]) * 0.25f);
-                    const int yp = (y0 >> 1) + wave * 2 + h, xp = (x0 >> 1) + px;
+                    const int yp = (y0 >> 1) + wave * (RPW / 2) + h, xp = (x0 >> 1) + px;
                     const bool live = c0 + lane < 8 * CPP && yp < Hp && xp < Wp;
                     char *dst = live ? p.out + (((int64_t)b * Hp + yp) * Wp + xp) * PXB + cc * 16 : (char *)dc_sink + lane * 16;
                     *(vec8 *)dst = o;
@@ -161,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32(DcArgs p) {
                 constexpr int CPR = 16 * PXB / 16;     // chunks per output row of the tile (64 or 128)
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
-                    const int y = y0 + wave * 4 + 2 * h + s2;
+                    const int y = y0 + wave * RPW + 2 * h + s2;
 #pragma unroll
                     for (int c0 = 0; c0 < CPR; c0 += 64) {
                         const int c = c0 + lane;
@@ -175,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32(DcArgs p) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the staging slice is private to the wave; its reads are done before the next half overwrites it
         }
         // the next tile's halo has landed: everything but this tile's stores (the wave's youngest NST vector-memory instructions)
-        constexpr int NST = POOL ? 2 : 4 * (16 * PXB / 16 / 64);
+        constexpr int NST = (RPW / 2) * (POOL ? 1 : 2 * (16 * PXB / 16 / 64));
         asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NST) : "memory");   // ... for every wave; the current buffer is free for the tile after next
     }
 }
@@ -273,15 +292,21 @@ __global__ __launch_bounds__(256) void stem_conv1(StemArgs p) {
 
 // Called by hgr_conv3x3_nhwc / hgr_conv3x3_nhwc_plain (hgr_gemm.hip) for C = 32, stride 1, Cout in {32, 64}.
 int hgr_conv3x3_c32_launch(const void *x, const void *w, const float *bias, void *out, int B, int H, int W, int Cout, int Kp,
-                           int dtype, int relu, void *stream, int pool) {
+                           int dtype, int relu, void *stream, int pool, int C) {
     DcArgs a;
     a.x = (const char *)x; a.w = (const char *)w; a.bias = bias; a.out = (char *)out;
     a.B = B; a.H = H; a.W = W; a.Kp = Kp; a.relu = relu;
     a.tiles_x = (W + 15) / 16; a.tiles_y = (H + 15) / 16;
     const int64_t nwg = (int64_t)B * a.tiles_x * a.tiles_y;
     HGR_REQUIRE(nwg < (1ll << 31), "hgr_conv3x3_nhwc: too many tiles");
-    dim3 grid((unsigned)std::min<int64_t>(nwg, 512));           // persistent: 2 workgroups per CU walk over the tiles
+    dim3 grid((unsigned)std::min<int64_t>(nwg, C == 64 ? 256 : 512));           // persistent: 2 (C = 64: 1) workgroups per CU walk over the tiles
     hipStream_t s = (hipStream_t)stream;
+    if (C == 64) {                                  // 64 -> 64 channels (ModifiedResNet layer1): 8 waves, one workgroup per CU
+        if (dtype == HGR_BF16) hipLaunchKernelGGL((conv3x3_c32<HGR_BF16, 4, false, 64>), grid, dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((conv3x3_c32<HGR_F16, 4, false, 64>), grid, dim3(512), 0, s, a);
+        HGR_CHECK_LAUNCH("hgr_conv3x3_nhwc");
+        return HGR_OK;
+    }
     if (pool) {
         if (Cout == 32) {
             if (dtype == HGR_BF16) hipLaunchKernelGGL((conv3x3_c32<HGR_BF16, 2, true>), grid, dim3(256), 0, s, a);
@@ -339,5 +364,5 @@ extern "C" int hgr_conv3x3_pool2_nhwc(const void *x, const void *w, const float 
     HGR_REQUIRE(C == 32 && (Cout == 32 || Cout == 64) && Kp >= 288 && Kp % 8 == 0, "hgr_conv3x3_pool2_nhwc: built for C = 32, Cout in {32, 64} (got C=%d Cout=%d Kp=%d)", C, Cout, Kp);
     HGR_REQUIRE(hgr_aligned(x, 16) && hgr_aligned(w, 16) && hgr_aligned(out, 16) && hgr_aligned(bias, 16), "hgr_conv3x3_pool2_nhwc: misaligned operand");
     HGR_REQUIRE(dtype == HGR_BF16 || dtype == HGR_F16, "hgr_conv3x3_pool2_nhwc: bad dtype %d", dtype);
-    return hgr_conv3x3_c32_launch(x, w, bias, out, B, H, W, Cout, Kp, dtype, 1, stream, 1);
+    return hgr_conv3x3_c32_launch(x, w, bias, out, B, H, W, Cout, Kp, dtype, 1, stream, 1, 32);
 }

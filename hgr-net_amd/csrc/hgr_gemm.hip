@@ -4,7 +4,7 @@
 using namespace hgr_gemm;
 
 int hgr_conv3x3_c32_launch(const void *x, const void *w, const float *bias, void *out, int B, int H, int W, int Cout, int Kp,
-                           int dtype, int relu, void *stream, int pool);      // hgr_conv_direct.hip
+                           int dtype, int relu, void *stream, int pool, int C);      // hgr_conv_direct.hip
 
 namespace {
 constexpr int BM = 128, BN = 128;
@@ -238,7 +238,11 @@ static int conv3x3_launch(const void *x, const void *w, const float *bias, void 
     static int direct_env = -1;
     if (direct_env < 0) { const char *e = getenv("HGR_CONV_DIRECT"); direct_env = e ? atoi(e) : 1; }
     if (direct_env && C == 32 && stride == 1 && (Cout == 32 || Cout == 64) && Kp >= 288 && hgr_aligned(out, 16))
-        return hgr_conv3x3_c32_launch(x, w, bias, out, B, H, W, Cout, Kp, dtype, relu ? 1 : 0, stream, 0);
+        return hgr_conv3x3_c32_launch(x, w, bias, out, B, H, W, Cout, Kp, dtype, relu ? 1 : 0, stream, 0, 32);
+    // 64 -> 64 channels (layer1 of the ModifiedResNets): the implicit GEMM pulls every input byte nine times through LDS-DMA at
+    // ~28 GB/s per CU (258 us at 56 x 56, batch 512); the halo-tile kernel reads it 1.27 times
+    if (direct_env && C == 64 && Cout == 64 && stride == 1 && Kp >= 576 && hgr_aligned(out, 16) && (int64_t)B * H * W >= 4096)
+        return hgr_conv3x3_c32_launch(x, w, bias, out, B, H, W, Cout, Kp, dtype, relu ? 1 : 0, stream, 0, 64);
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     const int64_t M64 = (int64_t)B * Ho * Wo;
     HGR_REQUIRE(M64 < (1ll << 31), "hgr_conv3x3_nhwc: too many output pixels");

@@ -314,6 +314,8 @@ def test_level_argmax_exact(n, levels):
                                                   (2, 16, 16, 32, 32, 1), (1, 33, 17, 32, 64, 1), (3, 40, 48, 32, 32, 1), (2, 5, 70, 32, 64, 1),
                                                   # ... with more tiles than the 512 persistent workgroups (600 / 1300: every workgroup walks 1 - 3 tiles)
                                                   (6, 160, 160, 32, 64, 1), (13, 150, 152, 32, 32, 1),
+                                                  # 64 -> 64 channels with >= 4096 pixels: the halo-tile kernel's 8-wave form (54 tiles; 400 tiles on 256 workgroups)
+                                                  (6, 40, 42, 64, 64, 1), (20, 70, 60, 64, 64, 1),
                                                   # C % 64 == 0, stride 1, Cout % 128 == 0 and >= 256 tiles of 256 x 128: gemm_nt_duo with the implicit-im2col
                                                   # loader - full tiles only (282), tail plan with half tiles (633 tiles), ragged last row panel + 4 column tiles
                                                   (20, 60, 60, 128, 128, 1), (45, 60, 60, 128, 128, 1), (24, 30, 31, 256, 512, 1),
