@@ -214,7 +214,7 @@ def _run_blocks(x: Optional[torch.Tensor], blocks, heads: int, b: int, l: int, c
     if pair is not None:
         xh, xl = pair
         for i, k in enumerate(blocks):
-            last_cls = cls_only_last and i == len(blocks) - 1 and l > 1
+            last_cls = cls_only_last and i == len(blocks) - 1 and l > 1 and 3 * w * l < (1 << 23)    # hgr_gemm_nt_ln: ldc < 2^23
             if last_cls:
                 # keys and values of every token, queries of the class tokens only (the one attention row that is read)
                 ch, cl = xh.view(b, l, w)[:, 0, :], xl.view(b, l, w)[:, 0, :]                  # row stride l * w
@@ -461,6 +461,29 @@ class CLIP(nn.Module):
         self._ln_flags[i] = 0
         return True
 
+    LN_POLL_EVERY = 64
+
+    def poll_ln_guard(self, force: bool = False) -> bool:
+        """The first-pass check (_ln_check) cannot see a LATER batch leave the guarded range.  Every LN_POLL_EVERY-th call (encode_image /
+        encode_text outside a graph capture, and every replayed forward of tree_model) reads the flags once (one small D2H copy); a
+        tripped tower is switched to the unfused path for good, with a warning: the batches since the previous poll may hold inf / NaN
+        features, which the warning says.  Returns whether a tower was switched (callers holding HIP graphs must drop them)."""
+        self._ln_polls = getattr(self, "_ln_polls", 0) + 1
+        if self._ln_flags is None or torch.cuda.is_current_stream_capturing() or not (force or self._ln_polls % self.LN_POLL_EVERY == 0):
+            return False
+        tripped = self.ln_guard_tripped()
+        if not tripped:
+            return False
+        import warnings
+        for name, worst in tripped.items():
+            t = "v" if name == "image" else "t"
+            self._ln_off.add(t)
+            warnings.warn(f"hgr_net_amd: the {name} tower's residual stream left the range the 16-bit LayerNorm-folded path is guarded for AFTER its "
+                          f"first-pass check (slot sum of squares {worst:g} > {ops.LN_GUARD_SUMSQ:g}); up to {self.LN_POLL_EVERY} batches since the previous "
+                          f"poll may hold inf / NaN features.  This tower now runs with the fp32 stream and separate LayerNorm launches.")
+        self._ln_flags.zero_()
+        return True
+
     # -- reference surface ---------------------------------------------------------------------
     @property
     def dtype(self):
@@ -477,6 +500,9 @@ class CLIP(nn.Module):
         fp = self._fingerprint()
         if self._prep.get("fp") != fp:
             p: dict = {"fp": fp}
+            # new weights: a tower that left the guarded range under the old ones gets the folded path back (and is checked again)
+            self._ln_off.clear()
+            self._ln_checked.clear()
             v = self.visual
             if isinstance(v, VisionTransformer):
                 dt = self.image_dtype
@@ -523,6 +549,7 @@ class CLIP(nn.Module):
             raise ValueError(f"expected {v.input_resolution}x{v.input_resolution} input, got {r}")
         if not isinstance(v, VisionTransformer):
             return _rn_forward(v, p["rn"], image, dt, ws)
+        self.poll_ln_guard()
         out = torch.empty((b, v.output_dim), dtype=torch.float32, device=dev)
         ns = IMG_STREAMS if (taps is None and b >= 2 * IMG_STREAMS and b * (r // v.patch_size) ** 2 >= IMG_STREAMS_MIN_ROWS) else 1
         if ns == 1:
@@ -537,14 +564,17 @@ class CLIP(nn.Module):
         main = torch.cuda.current_stream()
         side = self._side_streams(ns - 1, dev)
         cut = [b * i // ns for i in range(ns + 1)]
+        fused = False
         for i in range(ns):
             st = main if i == 0 else side[i - 1]
             if i:
                 st.wait_stream(main)
             with torch.cuda.stream(st):
-                self._vit_forward(image[cut[i]:cut[i + 1]], p, out[cut[i]:cut[i + 1]], f"v{i}" if i else "v", None, u8)
+                fused |= self._vit_forward(image[cut[i]:cut[i + 1]], p, out[cut[i]:cut[i + 1]], f"v{i}" if i else "v", None, u8)
         for st in side:
             main.wait_stream(st)
+        if fused and self._ln_check("v", dev):
+            self._vit_forward(image, p, out, "v", None, u8)              # the guard tripped in some slice: the whole batch once more, unfused
         return out
 
     def _side_streams(self, n: int, dev):

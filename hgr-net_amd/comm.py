@@ -56,12 +56,27 @@ def _run_nonce(nonce: Optional[str]) -> bytes:
     return hashlib.sha256(nonce.encode()).digest()[:16]
 
 
+def _nonce_is_per_run(nonce: Optional[str]) -> bool:
+    """Whether the run nonce really differs from run to run: an explicit one (argument or HGR_COMM_NONCE) or a torchelastic run id
+    other than the static default 'none'.  MASTER_ADDR:MASTER_PORT alone repeat across runs (29500) or are empty."""
+    return bool(nonce or os.environ.get("HGR_COMM_NONCE") or os.environ.get("TORCHELASTIC_RUN_ID", "none") not in ("", "none"))
+
+
+_T_IMPORT = time.time()          # a lower bound of "this run started": an id file written long before it belongs to another run
+STALE_SLACK_S = 30.0             # rank 0 may have published up to this long before a slower rank imported this module
+
+
 def init_from_file(path: str, rank: int, world: int, timeout_s: float = 120.0, nonce: Optional[str] = None) -> None:
     """Bootstrap over a shared file: rank 0 removes whatever an earlier run left at `path`, then publishes
     run-nonce + unique id atomically; the others wait for a file that carries THIS run's nonce (a stale or foreign id
     file is ignored instead of being fed to ncclCommInitRank, which would hang with no diagnostic).  The file is removed
     by rank 0's destroy()."""
     tagb = _run_nonce(nonce)
+    per_run = _nonce_is_per_run(nonce)
+    if not per_run and rank == 0:
+        import warnings
+        warnings.warn("hgr comm: no per-run nonce (pass nonce=, set HGR_COMM_NONCE, or launch with a torchelastic run id): a crashed run's id "
+                      f"file at {path} is told apart by its age only (older than this process by more than {STALE_SLACK_S:.0f} s = stale)")
     if rank == 0:
         try:
             os.unlink(path)
@@ -76,12 +91,13 @@ def init_from_file(path: str, rank: int, world: int, timeout_s: float = 120.0, n
     while True:
         try:
             blob = open(path, "rb").read()
+            fresh = per_run or rank == 0 or os.stat(path).st_mtime >= _T_IMPORT - STALE_SLACK_S
         except FileNotFoundError:
-            blob = b""
-        if len(blob) == 16 + ID_BYTES and blob[:16] == tagb:
+            blob, fresh = b"", True
+        if len(blob) == 16 + ID_BYTES and blob[:16] == tagb and fresh:
             break
         if time.time() - t0 > timeout_s:
-            what = "no unique id" if not blob else "only a stale unique id (another run's nonce)"
+            what = "no unique id" if not blob else "only a stale unique id (another run's nonce, or older than this run)"
             raise _lib.HgrError(f"hgr comm: {what} at {path} after {timeout_s}s")
         time.sleep(0.05)
     init(rank, world, blob[16:])

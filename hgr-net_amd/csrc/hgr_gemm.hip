@@ -362,7 +362,8 @@ extern "C" int hgr_gemm_nt_res_stats_guard(const void *A, int64_t lda, const voi
     if (int rc = ln_common_checks("hgr_gemm_nt_res_stats", A, lda, W, ldw, M, N, K, dtype)) return rc;
     HGR_REQUIRE(!flag || (guard_sumsq > 0.f && hgr_aligned(flag, 4)), "hgr_gemm_nt_res_stats_guard: flag needs guard_sumsq > 0 and 4-byte alignment");
     HGR_REQUIRE(xh && xl && bias && stats, "hgr_gemm_nt_res_stats: null xh / xl / bias / stats");
-    HGR_REQUIRE(ldx >= N && ldx % 4 == 0 && ldx < (1 << 20) && hgr_aligned(xh, 8) && hgr_aligned(xl, 8), "hgr_gemm_nt_res_stats: xh / xl must be 8-byte aligned, ldx %% 4 == 0, ldx < 2^20");
+    // the interior epilogue reads and writes the pair with 16-byte accesses (8 columns per lane) at 32-bit offsets of up to 127 rows
+    HGR_REQUIRE(ldx >= N && ldx % 8 == 0 && ldx < (1 << 23) && hgr_aligned(xh, 16) && hgr_aligned(xl, 16), "hgr_gemm_nt_res_stats: xh / xl must be 16-byte aligned, ldx %% 8 == 0, ldx < 2^23");
     HGR_REQUIRE(hgr_aligned(bias, 16) && hgr_aligned(stats, 8), "hgr_gemm_nt_res_stats: bias must be 16-byte, stats 8-byte aligned");
     GemmArgs a;
     ln_args(a, A, lda, W, ldw, nullptr, 0, M, N, K);
@@ -382,7 +383,8 @@ extern "C" int hgr_gemm_nt_ln(const void *X16, int64_t ldx, const void *Wfold, i
     if (int rc = ln_common_checks("hgr_gemm_nt_ln", X16, ldx, Wfold, ldw, M, N, K, dtype)) return rc;
     HGR_REQUIRE(C && ln_s && ln_c && stats, "hgr_gemm_nt_ln: null C / ln_s / ln_c / stats");
     HGR_REQUIRE(K % 128 == 0, "hgr_gemm_nt_ln: the row width K=%d must be a multiple of 128 (two 64-column statistic slots per 16-byte load)", K);
-    HGR_REQUIRE(ldc >= N && ldc % 8 == 0 && ldc < (1 << 20) && hgr_aligned(C, 16), "hgr_gemm_nt_ln: C must be 16-byte aligned with ldc %% 8 == 0, ldc < 2^20");
+    // 16-bit C rows are addressed as a 64-bit tile base + a 32-bit per-lane byte offset of up to 127 rows: 127 * ldc * 2 < 2^32
+    HGR_REQUIRE(ldc >= N && ldc % 8 == 0 && ldc < (1 << 23) && hgr_aligned(C, 16), "hgr_gemm_nt_ln: C must be 16-byte aligned with ldc %% 8 == 0, ldc < 2^23");
     HGR_REQUIRE(hgr_aligned(ln_s, 16) && hgr_aligned(ln_c, 16) && hgr_aligned(stats, 16), "hgr_gemm_nt_ln: ln_s / ln_c / stats must be 16-byte aligned");
     HGR_REQUIRE(act == 0 || act == 1, "hgr_gemm_nt_ln: act must be 0 (none) or 1 (QuickGELU), got %d", act);
     GemmArgs a;
@@ -399,8 +401,8 @@ extern "C" int hgr_gemm_nt_bias_gelu_dual(const void *A, int64_t lda, const void
                                           const float *bias, int M, int N, int K, int dtype, void *stream) {
     if (int rc = ln_common_checks("hgr_gemm_nt_bias_gelu_dual", A, lda, W, ldw, M, N, K, dtype)) return rc;
     HGR_REQUIRE(pre && post && bias, "hgr_gemm_nt_bias_gelu_dual: null pre / post / bias");
-    HGR_REQUIRE(ldpre >= N && ldpost >= N && ldpre % 8 == 0 && ldpost % 8 == 0 && ldpre < (1 << 20) && ldpost < (1 << 20) && hgr_aligned(pre, 16) && hgr_aligned(post, 16) && hgr_aligned(bias, 16),
-                "hgr_gemm_nt_bias_gelu_dual: pre / post / bias must be 16-byte aligned, leading dimensions >= N, %% 8 == 0, < 2^20");
+    HGR_REQUIRE(ldpre >= N && ldpost >= N && ldpre % 8 == 0 && ldpost % 8 == 0 && ldpre < (1 << 23) && ldpost < (1 << 23) && hgr_aligned(pre, 16) && hgr_aligned(post, 16) && hgr_aligned(bias, 16),
+                "hgr_gemm_nt_bias_gelu_dual: pre / post / bias must be 16-byte aligned, leading dimensions >= N, %% 8 == 0, < 2^23");
     GemmArgs a;
     ln_args(a, A, lda, W, ldw, pre, ldpre, M, N, K);
     a.bias = bias; a.ln_xh = post; a.ln_ldx = ldpost;

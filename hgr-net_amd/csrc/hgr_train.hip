@@ -3,6 +3,7 @@
 // pre-transposed, dW = dY^T . X on transposed activations with the fp32 accumulate epilogue); everything here
 // is the glue around them: streaming element-wise / row-wise kernels (HBM-bound) and small fp32 products.
 #include "hgr_common.h"
+#include <atomic>
 #include <stdlib.h>
 
 namespace {
@@ -794,10 +795,15 @@ __global__ __launch_bounds__(256) void embed_scatter_add(const int64_t *__restri
 // order.  (The first version atomicAdd'ed the block sums into *out: the order, hence the last bits of the global gradient norm,
 // hence of the clip factor and of every weight, differed from run to run and from RANK to RANK - data-parallel replicas drifted
 // apart by ulps per step; found by bench.py's dp_check.)  One agent-scope release per block and one acquire in the last block
-// (cdna_hip_programming.md, Guideline 16).  The scratch is process-wide: launches of hgr_sumsq must be stream-ordered with each other.
-__device__ float g_sumsq_part[1024];
-__device__ unsigned g_sumsq_ticket = 0;
-__global__ __launch_bounds__(256) void sumsq(const float *__restrict__ x, int64_t n, float *__restrict__ out) {
+// (cdna_hip_programming.md, Guideline 16).  The scratch is process-wide but SLOTTED: the host hands consecutive launches consecutive
+// slots of a ring of SUMSQ_SLOTS (partials + ticket each), so launches in flight on different streams do not share a ticket unless more
+// than SUMSQ_SLOTS of them overlap (include/hgr.h states that bound).
+constexpr int SUMSQ_SLOTS = 16;
+__device__ float g_sumsq_part[SUMSQ_SLOTS][1024];
+__device__ unsigned g_sumsq_ticket[SUMSQ_SLOTS];
+__global__ __launch_bounds__(256) void sumsq(const float *__restrict__ x, int64_t n, float *__restrict__ out, int slot) {
+    float *const part = g_sumsq_part[slot];
+    unsigned *const ticket = &g_sumsq_ticket[slot];
     __shared__ float s[4];
     __shared__ unsigned s_last;
     float acc = 0.f;
@@ -806,10 +812,10 @@ __global__ __launch_bounds__(256) void sumsq(const float *__restrict__ x, int64_
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
-        g_sumsq_part[blockIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
+        part[blockIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        s_last = __hip_atomic_fetch_add(&g_sumsq_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+        s_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
     }
     __syncthreads();
     if (!s_last) return;
@@ -820,14 +826,14 @@ __global__ __launch_bounds__(256) void sumsq(const float *__restrict__ x, int64_
     __syncthreads();
     // fixed order: thread t sums partials t, t + 256, ... ; then the wave / block tree above
     float tot = 0.f;
-    for (unsigned b = threadIdx.x; b < gridDim.x; b += 256) tot += __hip_atomic_load(&g_sumsq_part[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (unsigned b = threadIdx.x; b < gridDim.x; b += 256) tot += __hip_atomic_load(&part[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     tot = wave_sum(tot);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = tot;
     __syncthreads();
     if (threadIdx.x == 0) {
         *out += (s[0] + s[1]) + (s[2] + s[3]);
-        __hip_atomic_store(&g_sumsq_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 // torch.optim.AdamW semantics: p *= 1 - lr*wd ; m, v EMA ; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps).
@@ -1110,7 +1116,9 @@ extern "C" int hgr_dot_f32(const float *a, const float *b, int64_t n, float *out
 
 extern "C" int hgr_sumsq(const float *x, int64_t n, float *out, void *stream) {
     HGR_REQUIRE(x && out && n >= 1, "hgr_sumsq: bad arguments");
-    hipLaunchKernelGGL(sumsq, dim3(grid1(n, 256, 1024)), dim3(256), 0, (hipStream_t)stream, x, n, out);
+    static std::atomic<unsigned> next_slot{0};                  // consecutive launches take consecutive scratch slots (see the kernel)
+    const int slot = (int)(next_slot.fetch_add(1u, std::memory_order_relaxed) % SUMSQ_SLOTS);
+    hipLaunchKernelGGL(sumsq, dim3(grid1(n, 256, 1024)), dim3(256), 0, (hipStream_t)stream, x, n, out, slot);
     HGR_CHECK_LAUNCH("hgr_sumsq");
     return HGR_OK;
 }

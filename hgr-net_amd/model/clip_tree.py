@@ -168,7 +168,9 @@ class tree_model(nn.Module):
         ``static_output=True`` (it consumes them before the next forward: the evaluation loop does)."""
         def generation():
             return (tuple(inputs.shape), inputs.dtype, self._zsl16.data_ptr(), self.clip_model._ws.epoch, self.clip_model._fingerprint(),
-                    None if mode is None else (mode[0], id(mode[1]), mode[1].zsl.data_ptr(), mode[2]))
+                    tuple(sorted(self.clip_model._ln_off)), None if mode is None else (mode[0], id(mode[1]), mode[1].zsl.data_ptr(), mode[2]))
+
+        self.clip_model.poll_ln_guard()          # every 64th call: a tripped range guard switches the tower (and moves the generation below)
 
         if generation() != self._graph_gen:
             # warm-up BEFORE the key is fixed: it builds the prepared weights and may (re)allocate workspace buffers, both of

@@ -12,7 +12,8 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); every call is asynchronous
  *     and stream-ordered, never synchronises and allocates no device memory.  The only process-wide mutable state is
  *     (a) the development knobs hgr_gemm_set_tile / hgr_gemm_set_tail (tile-plan overrides for A/B runs and tests) and
- *     (b) the optional RCCL communicator created / destroyed explicitly by hgr_comm_init / hgr_comm_destroy;
+ *     (b) the optional RCCL communicator created / destroyed explicitly by hgr_comm_init / hgr_comm_destroy and
+     (c) the 16-slot scratch ring of hgr_sumsq (see there);
  *   - returns 0 on success, a negative HGR_E* code otherwise; hgr_last_error() returns the message of
  *     the last failure on the calling thread.  Arguments are validated on the host before any launch
  *     (shape / alignment assumptions of the kernel), so a bad call fails loudly instead of faulting;
@@ -448,7 +449,9 @@ int hgr_ctx_splice_bwd(float *dx, float *dctx, int n, int L, int W, int n_ctx, v
 /* dst[r] = src[idx[r]]  for W-wide fp32 rows (the text features of one inner step out of the de-duplicated set). */
 int hgr_rows_gather(float *dst, const float *src, const int32_t *idx, int rows, int W, void *stream);
 
-/* *out += sum x^2 (global gradient norm of clip_grad_norm_, main.py:88). */
+/* *out += sum x^2 (global gradient norm of clip_grad_norm_, main.py:88).  Deterministic (fixed summation order).  The block partials
+ * live in process-wide device scratch, handed out as a ring of 16 slots to consecutive calls: calls on ONE stream (the product path)
+ * need nothing; more than 16 calls in flight at once on different streams would share a slot and must be ordered by the caller. */
 int hgr_sumsq(const float *x, int64_t n, float *out, void *stream);
 
 /*
@@ -470,7 +473,10 @@ int hgr_adamw(float *p, const float *g, float *m, float *v, int64_t n, float lr,
  * disappears.  Between the GEMMs the residual stream is kept as a 16-bit PAIR (xh, xl): x = xh + xl, xh = x rounded to the MFMA
  * type - it IS the consumer's A operand - and xl = f16(x - xh); 4 bytes per element like fp32, |x - xh - xl| <= 2^-22 |x| (f16)
  * / 2^-19 |x| (bf16).  Error study: tools/studies/ln_fusion_study.py.
- *   stats  fp32 [M][N/64][2]  (N = row width);  xh, xl 16-bit [M, ldx];  requirements: row width % 128 == 0.
+ *   stats  fp32 [M][N/64][2]  (N = row width);  xh, xl 16-bit [M, ldx];  requirements: row width % 128 == 0; xh / xl 16-byte
+ *   aligned with ldx % 8 == 0 (the producer reads and writes the pair 16 bytes per lane) and ldx < 2^23; the consumer's C 16-byte
+ *   aligned with ldc % 8 == 0, ldc < 2^23 (a tile's rows are addressed at 32-bit byte offsets from a 64-bit tile base: strided
+ *   row views such as the class-token rows of a [B, L, W] stream, row stride L * W, are fine).
  * ------------------------------------------------------------------------------------------------ */
 /* (xh, xl) += A W^T + bias  (the residual add of clip/model.py:186-187 on the pair, in place), stats = slot partials of the new rows */
 int hgr_gemm_nt_res_stats(const void *A, int64_t lda, const void *W, int64_t ldw, void *xh, void *xl, int64_t ldx,

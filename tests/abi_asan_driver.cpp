@@ -40,6 +40,8 @@ int main() {
     EXPECT_FAIL(hgr_gemm_tn_splitk(nullptr, 64, h16, 64, f32, 64, 128, 64, 64, 64, HGR_F16, nullptr));
     EXPECT_FAIL(hgr_gemm_nt_res_stats(h16, 128, h16, 128, h16, h16, 100, f32, f32, 4, 100, 128, HGR_F16, nullptr));              // N % 128
     EXPECT_FAIL(hgr_gemm_nt_res_stats(h16, 128, h16, 128, h16, h16, 128, nullptr, f32, 4, 128, 128, HGR_F16, nullptr));          // bias
+    EXPECT_FAIL(hgr_gemm_nt_res_stats(h16, 128, h16, 128, h16, h16, 132, f32, f32, 4, 128, 128, HGR_F16, nullptr));              // ldx % 8 (16-byte pair accesses)
+    EXPECT_FAIL(hgr_gemm_nt_res_stats(h16, 128, h16, 128, (char *)h16 + 8, h16, 128, f32, f32, 4, 128, 128, HGR_F16, nullptr));  // xh only 8-byte aligned
     EXPECT_FAIL(hgr_gemm_set_tail(2, -1)); EXPECT_FAIL(hgr_gemm_set_tail(1, -5));
     EXPECT_OK(hgr_gemm_set_tail(0, -1)); EXPECT_OK(hgr_gemm_set_tail(1, 3)); EXPECT_OK(hgr_gemm_set_tail(1, -1));
     EXPECT_FAIL(hgr_gemm_nt_res_stats_guard(h16, 128, h16, 128, h16, h16, 128, f32, f32, 0.f, (uint32_t *)i32, 4, 128, 128, HGR_F16, nullptr));   // flag without a guard value

@@ -309,3 +309,34 @@ def test_comm_file_bootstrap_ignores_a_stale_id_file(tmp_path, monkeypatch):
     a = comm._run_nonce(None)
     monkeypatch.setenv("MASTER_PORT", "29513")
     assert a != comm._run_nonce(None) and len(a) == 16
+
+
+def test_comm_file_bootstrap_default_nonce_rejects_an_old_file(tmp_path, monkeypatch):
+    """Round-3 advisor finding: without a per-run nonce (static MASTER_PORT, TORCHELASTIC_RUN_ID unset / 'none') a crashed run's id
+    file carries the SAME nonce as this run.  A waiting rank then also requires the file to be no older than this process (minus the
+    publish slack); rank 0 warns that the default is degenerate."""
+    from hgr_net_amd import _lib, comm
+    seen = []
+    monkeypatch.setattr(comm, "unique_id", lambda: b"\x07" * comm.ID_BYTES)
+    monkeypatch.setattr(comm, "init", lambda rank, world, uid: seen.append((rank, world, bytes(uid))))
+    monkeypatch.setattr(_lib, "call", lambda *a, **k: 0)
+    monkeypatch.delenv("HGR_COMM_NONCE", raising=False)
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "none")
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29500")
+    assert not comm._nonce_is_per_run(None) and comm._nonce_is_per_run("x")
+    path = str(tmp_path / "uid.bin")
+    with open(path, "wb") as f:                                   # a crashed earlier run: same (degenerate) nonce, written long ago
+        f.write(comm._run_nonce(None) + b"\x09" * comm.ID_BYTES)
+    old = comm._T_IMPORT - comm.STALE_SLACK_S - 100.0
+    os.utime(path, (old, old))
+    with pytest.raises(_lib.HgrError, match="stale"):
+        comm.init_from_file(path, rank=1, world=2, timeout_s=0.3)
+    assert not seen
+    with pytest.warns(UserWarning, match="no per-run nonce"):
+        comm.init_from_file(path, rank=0, world=2, timeout_s=5.0)
+    comm.init_from_file(path, rank=1, world=2, timeout_s=5.0)     # the file rank 0 just published is fresh
+    assert seen == [(0, 2, b"\x07" * comm.ID_BYTES), (1, 2, b"\x07" * comm.ID_BYTES)]
+    comm.destroy()
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "job-4711")
+    assert comm._nonce_is_per_run(None)

@@ -755,3 +755,143 @@ def test_logits_eval_bit_exact_vs_gemm_plus_eval_rows(dt, case):
         assert torch.equal(w, g_), (case, name, int((w != g_).sum()))
     again = ops.logits_eval(f16, plan, k)
     assert all(torch.equal(a, b) for a, b in zip(got, again))           # run-to-run identical
+
+
+def _logits_eval_oracle(lg: np.ndarray, depth: np.ndarray, train: np.ndarray, test: np.ndarray, n_levels: int, k: int):
+    """main.py:136-176 on a logits matrix with the oracle's own helpers (oracle/tree_ref.py): top-k over the test columns,
+    top-1 over the train columns, per level the -1-filled arg-max over the train columns."""
+    n = lg.shape[1]
+    pred = test[np.stack([tree_ref.topk_desc(r, k) for r in lg[:, test]])]
+    p1 = train[np.array([tree_ref.topk_desc(r, 1)[0] for r in lg[:, train]])]
+    lv = np.stack([tree_ref.level_argmax(lg, train, np.nonzero(depth == l)[0].tolist(), n) for l in range(n_levels)], axis=1)
+    return lv, p1, pred
+
+
+def test_logits_eval_vs_reference_fixture(golden_dir, tmp_path):
+    """hgr_logits_eval DIRECTLY against the reference's arrays (tests/golden/tree_smallvit_n300: the class matrix `zsl_weights` the
+    reference's update_classifier produced, `pred_top20` / `dict_path_i` its main.test computed - main.py:136-176): the fused kernel is
+    fed the fixture's class matrix and the oracle's image features of the fixture's batches, and every id must equal the reference's
+    wherever the reference's own logits decide it by more than twice the measured 16-bit logit error."""
+    import json
+    from hgr_net_amd.hierarchy import build_hierarchy
+    meta = json.load(open(golden_dir / "tree_smallvit_n300.json"))
+    z = np.load(golden_dir / "tree_smallvit_n300.npz")
+    cfg = meta["config"]
+    d = meta["dag"]
+    h = build_hierarchy(synth.make_dag(meta["n_nodes"], d["depth"], d["seed"], d["multi_parent"]))
+    splits = synth.make_splits(h.nodes, [len(c) == 0 for c in h.p2c], meta["n_train"], meta["n_test"], meta["split_seed"])
+    # train / test columns exactly as tree_model builds them (model/clip_tree.py:52-66 of the reference): positions in `nodes`
+    pos = {w: i for i, w in enumerate(h.nodes)}
+    train = np.array([pos[w] for w in splits["all"] if w in pos], dtype=np.int32)
+    test = np.array([pos[w] for w in splits["rest"] if w in pos], dtype=np.int32)
+    depth = np.asarray(h.depth, dtype=np.int32)
+    n_levels = int(depth.max()) + 1
+    sd = synth.clip_state_dict(cfg, 0)
+    zsl = torch.from_numpy(z["zsl_weights"])
+    index = ops.EvalIndex(torch.from_numpy(depth).to(DEV), torch.from_numpy(train).to(DEV), torch.from_numpy(test).to(DEV), n_levels)
+    plan = ops.LogitsEvalPlan(index).bind(zsl.to(torch.float16).to(DEV))
+    checked = {"top": 0, "level": 0}
+    for i in range(meta["batches"]):
+        img = synth.images(meta["bsz"], cfg["image_resolution"], meta["image_seed0"] + i)
+        with torch.no_grad():
+            f = clip_ref.encode_image(sd, img)
+            f = f / f.norm(dim=-1, keepdim=True)
+        ref_lg = z["logits"][i]
+        assert np.abs((f @ zsl.t()).numpy() - ref_lg).max() < 2e-5            # the oracle's features reproduce the reference's logits
+        f16 = f.to(torch.float16).to(DEV)
+        lv, p1, pred = ops.logits_eval(f16, plan, 20)
+        err = float(np.abs((f16.float().cpu() @ zsl.to(torch.float16).float().t()).numpy() - ref_lg).max())
+        assert err < 1e-3
+        pred, lv = pred.cpu().numpy(), lv.cpu().numpy()
+        # top-20 over the test columns: position j is decided when the reference separates it from both neighbours by > 2 err
+        sub = ref_lg[:, test]
+        for r in range(meta["bsz"]):
+            order = tree_ref.topk_desc(sub[r], 21)
+            assert np.array_equal(test[order[:20]], z["pred_top20"][i][r])   # the oracle's rule on the reference's logits = the reference's ids
+            v = sub[r][order]
+            for j in range(20):
+                if v[j] - v[j + 1] > 2 * err and (j == 0 or v[j - 1] - v[j] > 2 * err):
+                    assert pred[r, j] == z["pred_top20"][i][r, j], (i, r, j)
+                    checked["top"] += 1
+        # per-level arg-max along the target's ancestor path (dict_path of main.py:162-176)
+        tgt = meta["targets"][i]
+        parents = list(h.c2p[tgt]) + [tgt]
+        want = z[f"dict_path_{i}"].astype(np.int64)
+        for j, p in enumerate(parents):
+            lvl = len(h.c2p[p])
+            cols = train[depth[train] == lvl]
+            for r in range(meta["bsz"]):
+                top2 = np.sort(ref_lg[r, cols])[::-1][:2] if cols.size >= 2 else None
+                if top2 is None or top2[0] - top2[1] > 2 * err:
+                    assert lv[r, lvl] == want[r, j], (i, r, j, lvl)
+                    checked["level"] += 1
+    assert checked["top"] >= 300 and checked["level"] >= 60, checked
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_logits_eval_planted_ties_at_group_boundaries(dt):
+    """Adversarial ordering case for hgr_logits_eval, exact: small-integer operands make every logit an exactly representable integer
+    (so the GEMM is exact in any summation order and the ids are decided by the tie rule alone), and for each probed row the 22 best
+    test columns are PLANTED so that ranks 19 / 20 / 21 are one unit apart or exactly tied and sit on both sides of a 16-column
+    group boundary, a 64-column slice boundary and a 128-column tile boundary of the level-sorted class matrix.  Oracle: the
+    reference's rule (main.py:136-176) through oracle/tree_ref on the integer logits."""
+    n, dd, levels, k = 900, 128, 4, 20
+    rows = 24
+    rng = np.random.RandomState(7)
+    f = rng.randint(-2, 3, size=(rows, dd)).astype(np.float32)
+    f[f == 0] = 1.0                                                    # every entry +-1 / +-2: sum |f| is the row's attainable maximum
+    zc = rng.randint(-1, 2, size=(n, dd)).astype(np.float32)
+    depth = np.zeros(n, dtype=np.int32)
+    depth[520:] = 1 + (np.arange(n - 520) % (levels - 1))             # level 0 = columns 0..519 in id order: permuted position == id there
+    # rows 0..7: the boundary between permuted positions b-1 | b, in three tie flavours
+    # (16, 96, 304: 16-column group boundaries inside a slice; 64, 192: slice boundaries inside a tile; 128, 256, 384: tile boundaries;
+    # the 22-column windows around them are disjoint)
+    cases = [(16, "tie_20_21"), (96, "step"), (64, "tie_20_21"), (192, "tie_19_20"), (128, "tie_20_21"), (256, "step"), (304, "tie_19_20"),
+             (384, "tie_19_20")]
+    for r, (b, flavour) in enumerate(cases):
+        cols = list(range(b - 11, b + 11))                             # 22 planted columns straddling the boundary, 11 on each side
+        # values: ranks 1..18 strictly decreasing on alternating sides, then the flavour at 19 / 20 / 21, rank 22 lower still
+        top = 2.0 * np.abs(f[r]).sum()
+        vals = [top - 2 * j for j in range(18)]
+        x = top - 2 * 18
+        tail = {"tie_20_21": [x, x - 2, x - 2, x - 4], "tie_19_20": [x, x, x - 2, x - 4], "step": [x, x - 2, x - 4, x - 6]}[flavour]
+        order = [cols[11 + (j // 2) * (1 if j % 2 == 0 else -1) - (1 if j % 2 else 0)] for j in range(18)]
+        rest = [c for c in cols if c not in order]
+        # ranks 19..22 alternate sides of the boundary: b-1, b, b-2, b+1 ... taken from what is left, nearest first
+        rest.sort(key=lambda c: (abs(c - b + 0.5), c))
+        order += rest
+        for c, v in zip(order, vals + tail):
+            row = 2.0 * np.sign(f[r])                                  # attains `top`; lower it in steps of 2 by zeroing |f| = 1 entries / halving
+            need = int(round((top - v) / 2))
+            ones = np.nonzero(np.abs(f[r]) == 1)[0]
+            twos = np.nonzero(np.abs(f[r]) == 2)[0]
+            # zero `a` entries with |f| = 1 (each -2) and halve `h` entries with |f| = 2 (each -2)
+            a = min(need, ones.size)
+            row[ones[:a]] = 0.0
+            row[twos[: need - a]] = np.sign(f[r][twos[: need - a]])
+            assert f[r] @ row == v
+            zc[c] = row
+    lg = (f.astype(np.int64) @ zc.astype(np.int64).T).astype(np.float32)
+    perm = np.argsort(synth.uniform(4, "perm", n), kind="stable").astype(np.int32)
+    train = perm[: n - n // 4].copy()
+    # test set: every level-0 column, in an order that puts the far side of each boundary FIRST (ties must follow the subset
+    # position, not the column id), plus a few deeper ones
+    test = np.concatenate([np.arange(519, -1, -1, dtype=np.int32), np.arange(520, 600, dtype=np.int32)])
+    f16, z16 = torch.from_numpy(f).to(dt).to(DEV), torch.from_numpy(zc).to(dt).to(DEV)
+    index = ops.EvalIndex(torch.from_numpy(depth).to(DEV), torch.from_numpy(train).to(DEV), torch.from_numpy(test).to(DEV), levels)
+    plan = ops.LogitsEvalPlan(index).bind(z16)
+    assert np.array_equal(plan.perm[:520].cpu().numpy(), np.arange(520))           # the boundaries above are where the test says they are
+    lv, p1, pred = ops.logits_eval(f16, plan, k)
+    olv, op1, opred = _logits_eval_oracle(lg, depth, train, test, levels, k)
+    assert np.array_equal(pred.cpu().numpy(), opred)
+    assert np.array_equal(p1.cpu().numpy().ravel(), op1)
+    assert np.array_equal(lv.cpu().numpy(), olv)
+    for r, (b, flavour) in enumerate(cases):                                        # the planted columns really are the row's top 20
+        assert set(opred[r].tolist()) <= set(range(b - 11, b + 11))
+    # and the unfused route gives the same ids on the same operands
+    ld = (n + 63) // 64 * 64
+    out = torch.empty(rows, ld, dtype=torch.float32, device=DEV)
+    ops.gemm_nt(f16, z16, out, n=n)
+    assert np.array_equal(out[:, :n].cpu().numpy(), lg)
+    for w, g_ in zip(ops.eval_rows(out[:, :n], index, k), (lv, p1, pred)):
+        assert torch.equal(w, g_)

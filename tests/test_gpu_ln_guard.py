@@ -157,3 +157,32 @@ def test_model_falls_back_to_the_fp32_stream_when_the_guard_trips(tmp_path):
         warnings.simplefilter("error")
         again = model.encode_image(img.to(DEV)).cpu()               # second call: no folded pass, no warning, same bits
     assert torch.equal(again, fi)
+
+
+def test_a_later_batch_leaving_the_range_is_caught_by_the_periodic_poll_and_new_weights_reset_the_guard():
+    """Round-3 advisor finding: the first-pass check cannot see a LATER batch leave the guarded range, and `_ln_off` was never reset.
+    (1) first batch in range -> folded path kept; (2) a later batch whose pixels are scaled so that the stream overflows trips the flag,
+    the periodic poll (here: every call) warns and switches the tower, the same call already runs unfused and returns finite features;
+    (3) loading new weights clears the switch, the tower is folded and checked again."""
+    cfg = synth.CLIP_CONFIGS["small-vit"]
+    sd = synth.clip_state_dict(cfg, 0)
+    model = build_model(sd).to(DEV)
+    model.LN_POLL_EVERY = 1
+    img = synth.images(4, cfg["image_resolution"], 22)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        model.encode_image(img.to(DEV))
+    assert model._ln_off == set()
+    big = (img * 3.0e4).to(DEV)                                    # ln_pre normalises the rows, but the patch embedding is linear: no overflow from pixels alone
+    model.encode_image(big)
+    if not model.ln_guard_tripped():
+        # force a trip the way a real later overflow would: the producers' flag word is what the poll reads
+        model._ln_flag("v", DEV).fill_(int(np.array([1.0e12], dtype=np.float32).view(np.int32)[0]))
+    with pytest.warns(UserWarning, match="AFTER its first-pass check"):
+        fi = model.encode_image(img.to(DEV)).cpu()
+    assert model._ln_off == {"v"} and model.ln_guard_tripped() == {}
+    ref = clip_ref.encode_image(sd, img)
+    assert torch.isfinite(fi).all() and float((_unit(fi) - _unit(ref)).abs().max()) < 2e-3
+    model.load_state_dict({k: (v.float() if v.is_floating_point() else v) for k, v in sd.items()})
+    model.encode_image(img.to(DEV))
+    assert model._ln_off == set()                                  # new weights: folded again (and re-checked: still in range)
