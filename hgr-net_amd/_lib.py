@@ -86,6 +86,7 @@ SIGNATURES = {
     "hgr_vit_head": [_p, _p, _l, _l, _p, _p, _f, _p, _p, _i, _i, _i, _i, _p],
     "hgr_gemm_nt_res_stats_guard": [_p, _l, _p, _l, _p, _p, _l, _p, _p, _f, _p, _i, _i, _i, _i, _p],
     "hgr_gemm_nt_ln": [_p, _l, _p, _l, _p, _l, _p, _p, _p, _f, _i, _i, _i, _i, _i, _p],
+    "hgr_gemm_nt_ln_mha": [_p, _l, _p, _l, _p, _p, _p, _f, _p, _l, _i, _i, _i, _i, _i, _p],
     "hgr_gemm_nt_bias_gelu_dual": [_p, _l, _p, _l, _p, _l, _p, _l, _p, _i, _i, _i, _i, _p],
     "hgr_vit_embed_ln_stats": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p],
     "hgr_row_stats16": [_p, _p, _p, _p, _i, _i, _i, _p],
@@ -111,7 +112,7 @@ class HgrError(RuntimeError):
 _lib = None
 
 
-ABI_VERSION = 3          # HGR_ABI_VERSION of include/hgr.h this wrapper was written against
+ABI_VERSION = 4          # HGR_ABI_VERSION of include/hgr.h this wrapper was written against
 
 
 def load() -> C.CDLL:
@@ -135,7 +136,14 @@ def load() -> C.CDLL:
     return lib
 
 
+# True only while tree_model captures the TAIL graph of a pipelined evaluation step: the host code of the step's head is walked again
+# (same views, same workspace buffers) with its launches skipped, up to ops.split_point().  Never set on any other path.
+MUTED = False
+
+
 def call(name: str, *args) -> None:
+    if MUTED:
+        return
     lib = load()
     rc = getattr(lib, name)(*args)
     if rc != 0:

@@ -180,6 +180,7 @@ IMG_STREAMS = max(1, int(os.environ.get("HGR_IMG_STREAMS", "1")))
 IMG_STREAMS_MIN_ROWS = 8192
 CLS_LAST = os.environ.get("HGR_CLS_LAST", "1") != "0"      # HGR_CLS_LAST=0: the last image block runs out_proj / MLP on every token (A/B runs, tests)
 LN_FUSED = os.environ.get("HGR_LN_FUSED", "1") != "0"     # HGR_LN_FUSED=0: separate LayerNorm launches (the first build's path), for A/B runs
+QKV_MHA = os.environ.get("HGR_QKV_MHA", "1") != "0"       # HGR_QKV_MHA=0: the in_proj GEMM writes qkv and hgr_mha reads it back (two launches)
 
 
 def ln_fusable(w: int, m: int = 0) -> bool:
@@ -197,8 +198,8 @@ def _run_blocks(x: Optional[torch.Tensor], blocks, heads: int, b: int, l: int, c
     Fused form (``pair`` = (xh, xl): the residual stream as a 16-bit pair, x = xh + xl, with its LayerNorm slot statistics in
     ``stats`` - from hgr_vit_embed_ln_stats / hgr_row_stats16): the LayerNorms are folded into the GEMMs around them, 5 launches
     per block and no LayerNorm pass:
-        QKV = LN-folded GEMM(xh) -> attention -> (xh, xl) += out GEMM (+ stats) -> u = LN-folded GEMM(xh, QuickGELU)
-        -> (xh, xl) += proj GEMM (+ stats)
+        QKV = LN-folded GEMM(xh) -> attention [one launch, no qkv tensor, for sequences of <= 64 tokens: hgr_gemm_nt_ln_mha]
+        -> (xh, xl) += out GEMM (+ stats) -> u = LN-folded GEMM(xh, QuickGELU) -> (xh, xl) += proj GEMM (+ stats)
     ``flag``: the producers' range guard (ops.gemm_nt_res_stats), see CLIP._ln_check.
     ``cls_only_last`` (image tower): the visual head reads ONLY the class token of the last block's output
     (``x = self.ln_post(x[:, 0, :])``, clip/model.py:231), and out_proj / ln_2 / the MLP act on every token independently (:186-187), so
@@ -215,17 +216,22 @@ def _run_blocks(x: Optional[torch.Tensor], blocks, heads: int, b: int, l: int, c
         xh, xl = pair
         for i, k in enumerate(blocks):
             last_cls = cls_only_last and i == len(blocks) - 1 and l > 1 and 3 * w * l < (1 << 23)    # hgr_gemm_nt_ln: ldc < 2^23
+            fused_attn = QKV_MHA and not last_cls and ops.ln_mha_ok(w, l)
             if last_cls:
                 # keys and values of every token, queries of the class tokens only (the one attention row that is read)
                 ch, cl = xh.view(b, l, w)[:, 0, :], xl.view(b, l, w)[:, 0, :]                  # row stride l * w
                 ops.gemm_nt_ln(xh, k.wf_in[w:], qkv[:, w:], k.s_in[w:], k.c_in[w:], stats, k.eps1, tag="kv")
+                ops.split_point("class_token_tail")      # everything behind this line works on b rows: a few dozen workgroups per launch
                 st_q = ws.get(tag + ".stats_q", (b, w // 64, 2), torch.float32, dev)
                 idx = ws.const(f"cls_rows.{b}.{l}", lambda: (torch.arange(b, dtype=torch.int32, device=dev) * l).contiguous())
                 ops.rows_gather(stats.view(b * l, -1), idx, st_q.view(b, -1))                   # the class rows' ln_1 statistics, compact
                 ops.gemm_nt_ln(ch, k.wf_in[:w], qkv.view(b, l, 3 * w)[:, 0, :w], k.s_in[:w], k.c_in[:w], st_q, k.eps1, tag="q_cls")
+            elif fused_attn:
+                ops.gemm_nt_ln_mha(xh, k.wf_in, att, k.s_in, k.c_in, stats, b, l, heads, causal, k.eps1)    # no qkv tensor, no attention launch
             else:
                 ops.gemm_nt_ln(xh, k.wf_in, qkv, k.s_in, k.c_in, stats, k.eps1, tag="qkv")
-            ops.mha(qkv, att, b, l, heads, causal, q_rows=1 if last_cls else 0)
+            if not fused_attn:
+                ops.mha(qkv, att, b, l, heads, causal, q_rows=1 if last_cls else 0)
             if last_cls:
                 ca = att.view(b, l, w)[:, 0, :]
                 st_c = ws.get(tag + ".stats_cls", (b, w // 64, 2), torch.float32, dev)
@@ -423,6 +429,7 @@ class CLIP(nn.Module):
         self._ln_flags: Optional[torch.Tensor] = None
         self._ln_off: set = set()
         self._ln_checked: dict = {}
+        self._img_tag = "v"
 
     # -- LayerNorm-folding range guard ------------------------------------------------------------
     def _ln_flag(self, tower: str, dev) -> torch.Tensor:
@@ -553,9 +560,10 @@ class CLIP(nn.Module):
         out = torch.empty((b, v.output_dim), dtype=torch.float32, device=dev)
         ns = IMG_STREAMS if (taps is None and b >= 2 * IMG_STREAMS and b * (r // v.patch_size) ** 2 >= IMG_STREAMS_MIN_ROWS) else 1
         if ns == 1:
-            fused = self._vit_forward(image, p, out, "v", taps, u8)
+            tag = self._img_tag           # workspace set of this call ("v"; tree_model's pipelined evaluation alternates two sets)
+            fused = self._vit_forward(image, p, out, tag, taps, u8)
             if fused and self._ln_check("v", dev):
-                self._vit_forward(image, p, out, "v", taps, u8)          # the guard tripped: once more on the unfused path
+                self._vit_forward(image, p, out, tag, taps, u8)          # the guard tripped: once more on the unfused path
             return out
         # The batch in ``ns`` independent slices on ``ns`` streams: the residual stack is a strict chain of launches, and a
         # launch whose tile count is not a multiple of the chip's workgroup slots ends in a partly empty round (N = 768 at

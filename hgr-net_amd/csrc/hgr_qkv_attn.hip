@@ -1,0 +1,341 @@
+// =================================================================================================
+// hgr_gemm_nt_ln_mha: the attention half of a residual block in ONE launch -
+//     att = softmax(q k^T / 8 [+ causal mask]) v,   [q | k | v] = LayerNorm(x) W_in^T + b_in
+// (clip/model.py:167-188: ln_1 -> nn.MultiheadAttention's in_proj -> scaled dot-product attention; out_proj stays a GEMM of its own).
+// The [M, 3 W] qkv tensor is never written or re-read: at ViT-B/32 batch 512 that is 118 MB out + 118 MB in per layer, and the
+// separate attention launch (hgr_mha: 31.7 us of a 134 us pair) disappears.
+//
+// Tile = 256 rows x 192 columns x K: the rows are S = floor(256 / L) WHOLE sequences (L <= 64 tokens: 5 x 50 at ViT-B/32), the
+// columns the 64 q, 64 k and 64 v outputs of ONE head, so softmax(q k^T) v of those S sequences and that head needs nothing from
+// outside the tile.  512 threads = 8 waves as 4 (M) x 2 (N); a wave owns 64 x 96 = 4 x 6 MFMA tiles = 96 accumulator registers.
+// One workgroup per CU (LDS 112 KB; two waves per SIMD).
+//
+// Main loop = the LayerNorm-folded consumer GEMM of gemm_nt_duo (same operand roles, same K order per output element, hence the same
+// accumulator bits).  A K-tile (64 deep) is staged by LDS-DMA as three pieces cut by the phase that reads them:
+//     PA0 = rows 0-31 of every wave row (16 KB), PW = the 192 weight rows (24 KB): read in ph1;   PA1 = rows 32-63 (16 KB): read in ph2
+// two stages of 56 KB; a piece is refilled for K-tile t + 2 as soon as both ping-pong groups have read it:
+//     ph1(t): issues PA1(t+1) x2                reads W (12 x ds_read_b128), A rows 0-31 (4 x)   waits vmcnt(7): PA1(t) landed
+//     ph2(t): issues PA0(t+2) x2, PW(t+2) x3    reads A rows 32-63 (4 x)                          waits vmcnt(7): PA0(t+1), PW(t+1) landed
+// (xN = global_load_lds_dwordx4 per thread; a count = "my N youngest may still be in flight"), 24 MFMAs per wave and phase.  Waves
+// 0-3 and 4-7 (one of each per SIMD) run one barrier interval apart, so one group's reads and waits sit beside the other's MFMAs
+// (the ping-pong of gemm_nt_256).
+//
+// Epilogue: y = rstd (acc - mean s_n) + c_n as in the consumer GEMM, rounded to the MFMA type - the value the unfused path stores in
+// qkv - into LDS: Q and K as swizzled 128-byte rows, V row-major (144-byte rows).  Then hgr_mha's arithmetic, instruction for
+// instruction, per 16-query tile and sequence: S^T = K Q^T on the matrix cores (keys from LDS as the A operand, queries as B),
+// softmax in registers, the exponentiated accumulators as the B operand of O^T = V^T P^T (V^T fragments by ds_read_b64_tr_b16).  A
+// query tile that straddles two sequences is computed against each and every lane keeps its own sequence's result.  Same bits as
+// hgr_gemm_nt_ln + hgr_mha (tests/test_gpu_kernels.py::test_gemm_ln_mha_equals_gemm_then_mha).
+// =================================================================================================
+#include "hgr_gemm_common.h"
+
+namespace hgr_gemm {
+
+struct QkvAttnArgs {
+    const char *A; int64_t lda;          // x16 [M, K]: the un-normalised 16-bit rows (residual stream's high half)
+    const char *W; int64_t ldw;          // gamma-folded in_proj weight [3 Wd, K]
+    const float *ln_s, *ln_c;            // [3 Wd]
+    const float *ln_stats; int ln_slots; float ln_eps;
+    void *out; int64_t ldo;              // att [M, Wd] 16-bit
+    int M, K, Wd, L, H, S;               // S = sequences per tile, rows per tile = S * L
+    int tiles_m;
+};
+
+namespace {
+typedef __attribute__((ext_vector_type(4))) short qa_s16x4;
+typedef __attribute__((ext_vector_type(8))) short qa_s16x8;
+
+constexpr int QA_NT = 512;
+constexpr int QA_STAGE = 57344;                              // PA0 16 K | PA1 16 K | PW 24 K
+constexpr int QA_PA0 = 0, QA_PA1 = 16384, QA_PW = 32768;
+constexpr int QA_LDS = 2 * QA_STAGE;                         // 112 KB
+constexpr int QA_Q = 0, QA_K = 32768, QA_V = 65536, QA_VR = 72, QA_LN = 65536 + 256 * QA_VR * 2;     // attention-phase layout (104 448 B)
+
+template <int DT, bool CAUSAL>
+__global__ __launch_bounds__(QA_NT) void qkv_attn(QkvAttnArgs p) {
+    typedef typename T16<DT>::vec8 vec8;
+    typedef typename T16<DT>::vec4 vec4;
+    typedef typename T16<DT>::elem E;
+    __shared__ __attribute__((aligned(1024))) char smem[QA_LDS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 2, wm = wave & 3;          // waves w and w + 4 share a SIMD: wn is also the ping-pong group
+    const int r = lane & 15, g = lane >> 4;
+
+    // block -> (row tile, head): every XCD (blocks b, b + 8, ... share an L2) walks a contiguous range of tiles, heads fastest, so the
+    // 12 tiles of a row panel run together on one L2 and the 3.5 MB of folded weights stay resident beside ~3 row panels
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    const int tm = wg / p.H, h = wg - tm * p.H;
+    const int rows_valid = p.S * p.L;
+    const int m0 = tm * rows_valid;
+
+    // per-lane source offsets of one K-tile's LDS-DMA instructions (bytes from A / W; operands < 4 GB, checked on the host)
+    unsigned oA0[2], oA1[2], oW[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int id = (i * 8 + wave) * 64 + lane;
+        const int pr = id >> 3, c = (id & 7) ^ (pr & 7);
+        if (i < 2) {
+            const int tr = (pr >> 5) * 64 + (pr & 31);
+            oA0[i] = (unsigned)(((int64_t)min(m0 + tr, p.M - 1) * p.lda + c * 8) * 2);
+            oA1[i] = (unsigned)(((int64_t)min(m0 + tr + 32, p.M - 1) * p.lda + c * 8) * 2);
+        }
+        const int wr = (pr >> 6) * p.Wd + h * 64 + (pr & 63);      // piece row pr = column pr of the tile: q 0-63, k 64-127, v 128-191
+        oW[i] = (unsigned)(((int64_t)wr * p.ldw + c * 8) * 2);
+    }
+    char *const ldsw = smem + wave * 1024;
+    auto issueA = [&](const unsigned (&off)[2], int piece, int t) {
+        const char *base = p.A + (int64_t)t * 128;
+        char *dst = ldsw + (t & 1) * QA_STAGE + piece;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((const AS1 void *)(base + off[i]), (AS3 void *)(dst + i * 8192), 16, 0, 0);
+    };
+    auto issueW = [&](int t) {
+        const char *base = p.W + (int64_t)t * 128;
+        char *dst = ldsw + (t & 1) * QA_STAGE + QA_PW;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            __builtin_amdgcn_global_load_lds((const AS1 void *)(base + oW[i]), (AS3 void *)(dst + i * 8192), 16, 0, 0);
+    };
+
+    f32x4 acc[4][6];            // [m tile][n tile]: C[wm*64 + 16 i + r][wn*96 + 16 j + 4 g .. + 3]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / 64;    // >= 2 (host guarantees)
+    const int offA = (wm * 32 + r) * 128;          // + m tile (0, 1) * 2048 within PA0 / PA1
+    const int offW = (wn * 96 + r) * 128;          // + n tile * 2048 within PW
+    const int sw0 = ((0 + g) ^ (r & 7)) * 16, sw1 = ((4 + g) ^ (r & 7)) * 16;
+    vec8 wf[6][2], af[2][2];
+
+    // prologue in steady-state order: PA0(0), PW(0) | PA1(0) | PA0(1), PW(1)
+    issueA(oA0, QA_PA0, 0); issueW(0);
+    issueA(oA1, QA_PA1, 0);
+    issueA(oA0, QA_PA0, 1); issueW(1);
+    HGR_RWAIT(7);               // PA0(0), PW(0) landed
+    if (wn) HGR_MBAR();         // ping-pong: group 1 runs one barrier interval behind group 0
+
+    // MODE 0: steady state (t + 2 < nk), 1: second-last K-tile, 2: last K-tile
+    auto ktile = [&](int t, auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        const char *st = smem + (t & 1) * QA_STAGE;
+        // ---- ph1: rows 0-31 of the wave x all 96 columns ----
+        if (MODE <= 1) issueA(oA1, QA_PA1, t + 1);              // its slot was last read in ph2(t - 1), two barriers ago
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            wf[j][0] = *(const vec8 *)(st + QA_PW + offW + j * 2048 + sw0);
+            wf[j][1] = *(const vec8 *)(st + QA_PW + offW + j * 2048 + sw1);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            af[i][0] = *(const vec8 *)(st + QA_PA0 + offA + i * 2048 + sw0);
+            af[i][1] = *(const vec8 *)(st + QA_PA0 + offA + i * 2048 + sw1);
+        }
+        if (MODE <= 1) HGR_RWAIT(7); else HGR_RWAIT(0);         // PA1(t) landed
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) acc[i][j] = T16<DT>::mfma16(wf[j][kk], af[i][kk], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        HGR_MBAR();
+        // ---- ph2: rows 32-63 ----
+        if (MODE == 0) { issueA(oA0, QA_PA0, t + 2); issueW(t + 2); }     // read in ph1(t), two barriers ago
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            af[i][0] = *(const vec8 *)(st + QA_PA1 + offA + i * 2048 + sw0);
+            af[i][1] = *(const vec8 *)(st + QA_PA1 + offA + i * 2048 + sw1);
+        }
+        if (MODE == 0) HGR_RWAIT(7); else if (MODE == 1) HGR_RWAIT(2); else HGR_RBAR();      // PA0(t+1), PW(t+1) landed
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) acc[2 + i][j] = T16<DT>::mfma16(wf[j][kk], af[i][kk], acc[2 + i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        HGR_MBAR();
+    };
+    for (int t = 0; t < nk - 2; ++t) ktile(t, std::integral_constant<int, 0>());
+    ktile(nk - 2, std::integral_constant<int, 1>());
+    ktile(nk - 1, std::integral_constant<int, 2>());
+    if (!wn) HGR_MBAR();        // group 0 waits for group 1's last interval: every LDS read is done, no DMA in flight
+
+    // ---- LayerNorm row statistics of the tile's 256 rows (thread t < 256: row t), as the consumer GEMM finalises them ----
+    float2 *lnrow = (float2 *)(smem + QA_LN);
+    if (tid < 256) {
+        const f32x4 *sp = (const f32x4 *)(p.ln_stats + (int64_t)min(m0 + tid, p.M - 1) * p.ln_slots * 2);
+        float s1 = 0.f, s2 = 0.f;
+        auto fixed = [&](auto nq_tag) {
+            constexpr int NQ = decltype(nq_tag)::value;
+            f32x4 t[NQ];
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) t[i] = sp[i];
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) { s1 += t[i][0] + t[i][2]; s2 += t[i][1] + t[i][3]; }
+        };
+        switch (p.ln_slots) {
+            case 4: fixed(std::integral_constant<int, 2>()); break;
+            case 8: fixed(std::integral_constant<int, 4>()); break;
+            case 10: fixed(std::integral_constant<int, 5>()); break;
+            case 12: fixed(std::integral_constant<int, 6>()); break;
+            case 16: fixed(std::integral_constant<int, 8>()); break;
+            default:
+                for (int i = 0; i < p.ln_slots / 2; ++i) { const f32x4 t = sp[i]; s1 += t[0] + t[2]; s2 += t[1] + t[3]; }
+        }
+        const float inv = 1.0f / (float)p.K;
+        const float mean = s1 * inv;
+        lnrow[tid] = make_float2(mean, rsqrtf(fmaxf(s2 * inv - mean * mean, 0.f) + p.ln_eps));
+    }
+    __syncthreads();
+
+    // ---- q / k / v of the tile, rounded to the MFMA type, into LDS ----
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int col0 = wn * 96 + j * 16;                           // wave-uniform: part 0 = q, 1 = k, 2 = v; head dim d0 + 4 g + e
+        const int part = col0 >> 6, d0 = col0 & 63;
+        const int gn = part * p.Wd + h * 64 + d0 + g * 4;
+        const f32x4 sq = *(const f32x4 *)(p.ln_s + gn), cq = *(const f32x4 *)(p.ln_c + gn);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = wm * 64 + i * 16 + r;
+            const float2 mr = lnrow[row];
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaf(mr.y, acc[i][j][e] - mr.x * sq[e], cq[e]);
+            const vec4 hv = cvt4<DT>(v[0], v[1], v[2], v[3]);
+            const int d = d0 + g * 4;
+            if (part == 2) *(vec4 *)(smem + QA_V + row * (QA_VR * 2) + d * 2) = hv;
+            else *(vec4 *)(smem + (part ? QA_K : QA_Q) + row * 128 + (((d >> 3) ^ (row & 7)) * 16) + (d & 4) * 2) = hv;
+        }
+    }
+    __syncthreads();
+
+    // ---- attention: query tile qt = rows 16 qt .. 16 qt + 15 of the tile; wave w takes tiles w and w + 8 ----
+    constexpr int KT = 2;              // 64 key slots: L <= 64
+    const E *sV = (const E *)(smem + QA_V);
+    for (int qt = wave; qt * 16 < rows_valid; qt += 8) {
+        const int qrow = qt * 16 + r;                                // this lane's query row inside the tile
+        const int myseq = min(qrow / p.L, p.S - 1);
+        const int s_lo = (qt * 16) / p.L, s_hi = min((qt * 16 + 15) / p.L, p.S - 1);
+        const char *qr = smem + QA_Q + qrow * 128;
+        const vec8 q0 = *(const vec8 *)(qr + sw0), q1 = *(const vec8 *)(qr + sw1);
+        f32x4 res[4];
+#pragma unroll
+        for (int td = 0; td < 4; ++td) res[td] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int s = s_lo; s <= s_hi; ++s) {
+            const int kb = s * p.L;                                  // first key row of sequence s
+            const int q = qrow - kb;                                 // query position inside the sequence (meaningful when myseq == s)
+            f32x4 sc[2 * KT];
+#pragma unroll
+            for (int t = 0; t < 2 * KT; ++t) {
+                sc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const int krow = min(kb + t * 16 + r, 255);          // key slots past the sequence are masked below: any finite row will do
+                const char *kr = smem + QA_K + krow * 128;
+                sc[t] = T16<DT>::mfma16(*(const vec8 *)(kr + (((0 + g) ^ (krow & 7)) * 16)), q0, sc[t]);
+                sc[t] = T16<DT>::mfma16(*(const vec8 *)(kr + (((4 + g) ^ (krow & 7)) * 16)), q1, sc[t]);
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 2 * KT; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int key = t * 16 + g * 4 + e;
+                    float x = sc[t][e] * 0.125f;      // 64^-0.5, exact
+                    if (key >= p.L || (CAUSAL && key > q)) x = -INFINITY;
+                    sc[t][e] = x;
+                    mx = fmaxf(mx, x);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float sum = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2 * KT; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float pexp = __expf(sc[t][e] - mx);
+                    sc[t][e] = pexp;
+                    sum += pexp;
+                }
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            const float inv = 1.0f / sum;
+            f32x4 o[4];
+#pragma unroll
+            for (int td = 0; td < 4; ++td) o[td] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KT; ++ks) {
+                vec8 pf;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { pf[e] = (E)sc[2 * ks][e]; pf[4 + e] = (E)sc[2 * ks + 1][e]; }
+                const int v0 = min(kb + ks * 32 + g * 4 + (r >> 2), 255), v1 = min(kb + ks * 32 + 16 + g * 4 + (r >> 2), 255);
+#pragma unroll
+                for (int td = 0; td < 4; ++td) {
+                    // A operand = V^T[d = 16 td + r][keys 32 ks + 4 g .. + 3, 32 ks + 16 + 4 g .. + 3] (hgr_mha's transposing reads)
+                    const qa_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AS3 qa_s16x4 *)(sV + v0 * QA_VR + td * 16 + (r & 3) * 4));
+                    const qa_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AS3 qa_s16x4 *)(sV + v1 * QA_VR + td * 16 + (r & 3) * 4));
+                    const vec8 vf = __builtin_bit_cast(vec8, (qa_s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                    o[td] = T16<DT>::mfma16(vf, pf, o[td]);
+                }
+            }
+            if (myseq == s) {
+#pragma unroll
+                for (int td = 0; td < 4; ++td) res[td] = o[td] * inv;
+            }
+        }
+        if (qrow < rows_valid && m0 + qrow < p.M) {
+            E *orow = (E *)p.out + (int64_t)(m0 + qrow) * p.ldo + h * 64 + g * 4;
+#pragma unroll
+            for (int td = 0; td < 4; ++td) *(vec4 *)(orow + td * 16) = cvt4<DT>(res[td][0], res[td][1], res[td][2], res[td][3]);
+        }
+    }
+}
+}  // namespace
+
+void launch_qkv_attn(const QkvAttnArgs &a, int dtype, bool causal, hipStream_t s) {
+    const dim3 grid((unsigned)(a.tiles_m * a.H)), block(QA_NT);
+    if (dtype == HGR_BF16) {
+        if (causal) hipLaunchKernelGGL((qkv_attn<HGR_BF16, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((qkv_attn<HGR_BF16, false>), grid, block, 0, s, a);
+    } else {
+        if (causal) hipLaunchKernelGGL((qkv_attn<HGR_F16, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((qkv_attn<HGR_F16, false>), grid, block, 0, s, a);
+    }
+}
+
+}  // namespace hgr_gemm
+
+using namespace hgr_gemm;
+
+extern "C" int hgr_gemm_nt_ln_mha(const void *X16, int64_t ldx, const void *Wfold, int64_t ldw, const float *ln_s, const float *ln_c,
+                                  const float *stats, float eps, void *att, int64_t ldatt, int B, int L, int heads, int causal,
+                                  int dtype, void *stream) {
+    HGR_REQUIRE(X16 && Wfold && ln_s && ln_c && stats && att, "hgr_gemm_nt_ln_mha: null operand");
+    HGR_REQUIRE(B >= 1 && heads >= 1 && L >= 1 && L <= 64, "hgr_gemm_nt_ln_mha: B=%d heads=%d L=%d unsupported (1 <= L <= 64: whole sequences inside a 256-row tile)", B, heads, L);
+    const int Wd = heads * 64, K = Wd;
+    const int64_t M = (int64_t)B * L;
+    HGR_REQUIRE(K % 128 == 0 && K >= 128, "hgr_gemm_nt_ln_mha: the row width %d must be a multiple of 128", K);
+    HGR_REQUIRE(ldx >= K && ldw >= K && ldx % 8 == 0 && ldw % 8 == 0 && ldatt >= Wd && ldatt % 4 == 0, "hgr_gemm_nt_ln_mha: leading dimensions (ldx, ldw %% 8 == 0, ldatt %% 4 == 0)");
+    HGR_REQUIRE(hgr_aligned(X16, 16) && hgr_aligned(Wfold, 16) && hgr_aligned(ln_s, 16) && hgr_aligned(ln_c, 16) && hgr_aligned(stats, 16) && hgr_aligned(att, 8),
+                "hgr_gemm_nt_ln_mha: operands must be 16-byte aligned (att: 8)");
+    HGR_REQUIRE(M * ldx * 2 < (1ll << 32) && 3ll * Wd * ldw * 2 < (1ll << 32), "hgr_gemm_nt_ln_mha: operands beyond 4 GB");
+    HGR_REQUIRE(dtype == HGR_BF16 || dtype == HGR_F16, "hgr_gemm_nt_ln_mha: bad dtype %d", dtype);
+    QkvAttnArgs a;
+    a.A = (const char *)X16; a.lda = ldx; a.W = (const char *)Wfold; a.ldw = ldw; a.ln_s = ln_s; a.ln_c = ln_c;
+    a.ln_stats = stats; a.ln_slots = K / 64; a.ln_eps = eps; a.out = att; a.ldo = ldatt;
+    a.M = (int)M; a.K = K; a.Wd = Wd; a.L = L; a.H = heads; a.S = 256 / L; a.tiles_m = (B + a.S - 1) / a.S;
+    HGR_REQUIRE((int64_t)a.tiles_m * heads < (1ll << 31), "hgr_gemm_nt_ln_mha: grid too large");
+    launch_qkv_attn(a, dtype, causal != 0, (hipStream_t)stream);
+    HGR_CHECK_LAUNCH("hgr_gemm_nt_ln_mha");
+    return HGR_OK;
+}

@@ -64,6 +64,8 @@ class Evaluator:
         top-1 over the train columns :157, arg-max per depth level :162-176) and hgr_eval_counters (hits, hit / path /
         point ratios :139-148,157-160,177-191).  Returns (pred_top20, dict_path) int32 tensors unless ``want_outputs``
         is False (the evaluation loop itself does not need them)."""
+        if hasattr(self.model, "join_tail"):
+            self.model.join_tail()
         lv, p1, pred = ops.eval_rows(logits, self.index, max(TOPK))
         parents, levels64, levels32, L = self._parents(target)
         tg = None
@@ -87,11 +89,21 @@ class Evaluator:
         bit, as add_batch(model(imgs), ...); use add_batch when the caller needs the logits themselves."""
         if self._plan is None:
             self._plan = ops.LogitsEvalPlan(self.index)
-        lv, p1, pred = self.model.forward_eval(imgs, self._plan, max(TOPK))
         parents, levels64, levels32, L = self._parents(target)
         tg = None
         if targets is not None:
             tg = (targets if targets.dtype == torch.int64 else targets.to(torch.int64)).contiguous()
+        if not want_outputs and hasattr(self.model, "forward_eval_overlapped"):
+            # the loop's own route: the step as a two-stage pipeline (the class-token tail of this batch beside the next batch's tower);
+            # the counters are advanced on the tail's stream, counters() / summary() join it
+            if tg is not None:
+                tg.record_stream(self.model._pipe_state(imgs.device)["side"])
+            if self.model.forward_eval_overlapped(imgs, self._plan, max(TOPK), lambda lv, p1, pred: ops.eval_counters(
+                    pred, tg, int(target), p1.view(-1), lv, parents, levels32, self.acc)):
+                return None
+        if hasattr(self.model, "join_tail"):
+            self.model.join_tail()                      # the counters may still be in flight on the tail stream of earlier batches
+        lv, p1, pred = self.model.forward_eval(imgs, self._plan, max(TOPK))
         ops.eval_counters(pred, tg, int(target), p1.view(-1), lv, parents, levels32, self.acc)
         if not want_outputs:
             return None
@@ -99,6 +111,8 @@ class Evaluator:
 
     def counters(self, group=None) -> Dict[str, float]:
         """Read the counters (one D2H copy); with a process group, all-reduce(sum) them first."""
+        if hasattr(self.model, "join_tail"):
+            self.model.join_tail()                      # pipelined steps advance the counters on the tail stream
         acc = self.acc
         if group is not None:
             import torch.distributed as dist

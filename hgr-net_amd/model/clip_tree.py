@@ -30,6 +30,14 @@ from .._lib import HgrError
 
 TEMPLATE = "a photo of a {}."     # data/templates.py TEMPLATES_SIMPLE[0], the only one used (clip_tree.py:52)
 
+# Evaluation steps as a two-stage pipeline (forward_eval_overlapped): the class-token tail of step i beside the head of step i + 1.
+# HGR_TAIL_OVERLAP=0 (or clip_tree.TAIL_OVERLAP = False) keeps every step one graph on one stream.
+TAIL_OVERLAP = os.environ.get("HGR_TAIL_OVERLAP", "1") != "0"
+
+
+class _StopHead(Exception):
+    """Raised by the split hook while the HEAD graph of a pipelined step is captured: the rest of the step belongs to the tail graph."""
+
 
 class tree_model(nn.Module):
     def __init__(self, opts, candidates_train: Sequence[str], candidates_test: Sequence[str],
@@ -103,6 +111,7 @@ class tree_model(nn.Module):
         self._zsl16 = None
         self.use_graph = os.environ.get("HGR_GRAPH", "1") != "0"     # replay forward() as a HIP graph (HGR_GRAPH=0: eager launches)
         self._graphs, self._graph_gen, self._graph_misses, self._graph_static = {}, None, 0, None
+        self._pipe = None            # state of the two-stage evaluation pipeline (forward_eval_overlapped)
 
     @staticmethod
     def _wordnet_name(wnid: str) -> str:
@@ -198,6 +207,130 @@ class tree_model(nn.Module):
             self._graph_misses = 0
         ent[0].replay()
         return ent[1] if (static_output or mode is not None) else ent[1].clone()
+
+    # ---------------------------------------------------------------------------------------------
+    # evaluation steps as a two-stage pipeline
+    # ---------------------------------------------------------------------------------------------
+    def _eager_phase(self, inputs, mode, phase: str, tag: str):
+        """One half of an evaluation step on the current stream, workspace set ``tag``.  'head': every launch up to ops.split_point()
+        (patch unfold and GEMM, blocks 0 .. n-2, keys / values of the last block).  'tail': the rest (the last block on the class-token
+        rows, visual head, L2 norm, class logits + evaluation); the host code of the head is walked with its launches muted so that the
+        tail sees exactly the views and buffers the head wrote.  Returns (outputs or None, whether the split point was reached)."""
+        from .. import _lib
+        seen = []
+        if phase == "head":
+            def hook(name):
+                seen.append(name)
+                raise _StopHead()
+        else:
+            def hook(name):
+                seen.append(name)
+                _lib.MUTED = False
+        prev_hook, prev_tag = ops.SPLIT_HOOK, self.clip_model._img_tag
+        ops.SPLIT_HOOK, self.clip_model._img_tag = hook, tag
+        out = None
+        try:
+            _lib.MUTED = phase == "tail"
+            out = self._forward_eager(inputs, mode)
+        except _StopHead:
+            pass
+        finally:
+            _lib.MUTED = False
+            ops.SPLIT_HOOK, self.clip_model._img_tag = prev_hook, prev_tag
+        return out, bool(seen)
+
+    def _pipe_state(self, dev):
+        if self._pipe is None:
+            # the tail's launches are a few dozen workgroups each: a high-priority stream lets them take the first slots that free up
+            side = torch.cuda.Stream(device=dev, priority=-1)
+            self._pipe = {"side": side, "graphs": {}, "gen": None, "ok": None, "step": 0, "misses": 0, "static": {},
+                          "head_done": [torch.cuda.Event(), torch.cuda.Event()], "tail_done": [torch.cuda.Event(), torch.cuda.Event()]}
+            for e in self._pipe["tail_done"]:
+                e.record()
+        return self._pipe
+
+    def join_tail(self) -> None:
+        """Order the current stream behind every tail launched so far (readers of the evaluation counters call this)."""
+        if self._pipe is not None:
+            torch.cuda.current_stream().wait_stream(self._pipe["side"])
+
+    @torch.no_grad()
+    def forward_eval_overlapped(self, inputs, plan, k: int, consume) -> bool:
+        """forward_eval as a two-stage pipeline over consecutive calls.  The last image block, the visual head, the class logits and the
+        evaluation act on B rows - a few dozen workgroups per launch, ~0.17 ms of a 5.4 ms ViT-B/32 step with the chip idle.  Here
+        every step is TWO HIP graphs: the head on the caller's stream, the tail on a second stream behind an event, each step parity on
+        its own workspace set, so the tail of step i runs beside the head of step i + 1 (which may not start on a workspace set before
+        the tail that last read it has finished).  ``consume(level_ids, top1, topk)`` is called with the second stream current: its
+        launches (hgr_eval_counters) are ordered behind the tail and ahead of the next use of those static outputs.  Same kernels on
+        the same data as forward_eval: same ids.  Returns False when the step cannot be split (no HIP graphs, a tower without a
+        class-token tail): the caller then takes forward_eval."""
+        if not (TAIL_OVERLAP and self.use_graph and inputs.is_cuda) or self._zsl16 is None:
+            return False
+        plan.bind(self._zsl16)
+        mode = ("eval", plan, k)
+        st = self._pipe_state(inputs.device)
+        self.clip_model.poll_ln_guard()
+        gen = (tuple(inputs.shape), inputs.dtype, self._zsl16.data_ptr(), self.clip_model._fingerprint(), tuple(sorted(self.clip_model._ln_off)),
+               id(plan), plan.zsl.data_ptr(), k)
+        main = torch.cuda.current_stream()
+        if gen != st["gen"]:
+            # new generation (shape, classifier, weights): both workspace sets exist after one eager step each; whether the step has
+            # a split point is learnt from the head phase
+            main.wait_stream(st["side"])
+            st["graphs"].clear()
+            st["static"].clear()
+            st["misses"] = 0
+            ok = True
+            for tag in ("v", "v@1"):
+                ok &= self._eager_phase(inputs, mode, "head", tag)[1]
+                if ok:
+                    self._eager_phase(inputs, mode, "tail", tag)
+            main.synchronize()
+            st["gen"], st["ok"] = gen, ok
+        if not st["ok"]:
+            return False
+        par = st["step"] & 1
+        st["step"] += 1
+        tag = "v@1" if par else "v"
+        key = (inputs.data_ptr(), par, self.clip_model._ws.epoch)
+        ent = st["graphs"].get(key)
+        if ent is None:
+            st["misses"] += 1
+            if st["misses"] > 8:                              # input addresses never repeat: one static input buffer per parity
+                buf = st["static"].get(par)
+                if buf is None:
+                    buf = st["static"][par] = torch.empty_like(inputs)
+                buf.copy_(inputs)                             # on the caller's stream, behind the head that last read it
+                inputs = buf
+                key = (buf.data_ptr(), par, self.clip_model._ws.epoch)
+                ent = st["graphs"].get(key)
+        else:
+            st["misses"] = 0
+        if ent is None:
+            if len(st["graphs"]) >= 8:
+                main.wait_stream(st["side"])
+                st["graphs"].clear()
+            main.wait_stream(st["side"])
+            main.synchronize()
+            gh, gt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gh):
+                self._eager_phase(inputs, mode, "head", tag)
+            with torch.cuda.graph(gt):
+                outs, _ = self._eager_phase(inputs, mode, "tail", tag)
+            if key[2] != self.clip_model._ws.epoch:          # a capture re-allocated a workspace buffer: the warm-up above should have made that impossible
+                raise HgrError("workspace buffers moved during the capture of a pipelined evaluation step")
+            ent = st["graphs"][key] = (gh, gt, outs)
+        gh, gt, outs = ent
+        main.wait_event(st["tail_done"][par])               # the tail that last read this workspace set (step i - 2)
+        gh.replay()
+        st["head_done"][par].record(main)
+        side = st["side"]
+        with torch.cuda.stream(side):
+            side.wait_event(st["head_done"][par])
+            gt.replay()
+            consume(*outs)
+            st["tail_done"][par].record(side)
+        return True
 
     def _capture(self, inputs, mode=None):
         self._forward_eager(inputs, mode)                       # warm-up: workspace buffers and prepared weights exist

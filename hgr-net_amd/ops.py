@@ -20,6 +20,17 @@ PROFILE = None
 # tree_model.forward) also key on this counter.
 WEIGHTS_GEN = [0]
 
+# set by tree_model while it captures the head / tail graphs of a pipelined evaluation step (model/clip_tree.py): called at the point
+# of the step behind which only the class-token rows are worked on (clip/model.py:_run_blocks)
+SPLIT_HOOK = None
+
+
+def split_point(name: str) -> None:
+    h = SPLIT_HOOK
+    if h is not None:
+        h(name)
+
+
 TORCH16 = {HGR_BF16: torch.bfloat16, HGR_F16: torch.float16}
 DT_OF = {torch.bfloat16: HGR_BF16, torch.float16: HGR_F16}
 
@@ -137,6 +148,27 @@ def gemm_nt_ln(x16: torch.Tensor, wfold: torch.Tensor, out: torch.Tensor, ln_s: 
               _dev(stats), float(eps), m, n, k, DT_OF[x16.dtype], 1 if quickgelu else 0, _stream())
     _prof_end(ev, 2.0 * m * n * k, 2 * m * k + 2 * n * k + 2 * m * n, tag)
     return out
+
+
+def gemm_nt_ln_mha(x16: torch.Tensor, wfold: torch.Tensor, att: torch.Tensor, ln_s: torch.Tensor, ln_c: torch.Tensor, stats: torch.Tensor,
+                   b: int, l: int, heads: int, causal: bool, eps: float = 1e-5, tag: str = "qkv_mha") -> torch.Tensor:
+    """att [b*l, heads*64] = softmax(q k^T / 8 [+ causal]) v with [q | k | v] = LayerNorm(x) @ W_in^T + b_in, one launch, no qkv tensor
+    (hgr_gemm_nt_ln_mha; see include/hgr.h).  Same bits as gemm_nt_ln into a qkv buffer + mha."""
+    m, k = x16.shape
+    w = heads * 64
+    assert m == b * l and k == w and wfold.shape == (3 * w, k) and x16.dtype == wfold.dtype == att.dtype and att.shape == (m, w)
+    assert x16.stride(1) == wfold.stride(1) == att.stride(1) == 1 and ln_s.numel() == ln_c.numel() == 3 * w
+    assert stats.dtype == torch.float32 and stats.numel() >= m * (k // 64) * 2
+    ev = _prof_begin()
+    _lib.call("hgr_gemm_nt_ln_mha", _dev(x16), x16.stride(0), _dev(wfold), wfold.stride(0), _dev(ln_s), _dev(ln_c), _dev(stats), float(eps),
+              _dev(att), att.stride(0), b, l, heads, 1 if causal else 0, DT_OF[x16.dtype], _stream())
+    _prof_end(ev, 2.0 * m * 3 * w * k + 4.0 * b * heads * l * l * 64, 2 * m * k + 2 * 3 * w * k + 2 * m * w, tag)
+    return att
+
+
+def ln_mha_ok(w: int, l: int) -> bool:
+    """Shape contract of hgr_gemm_nt_ln_mha: whole sequences inside a 256-row tile, head width 64, row width a multiple of 128."""
+    return 1 <= l <= 64 and w % 128 == 0
 
 
 def vit_embed_ln_stats(patches, cls, pos, gamma, beta, xh, xl, stats, b, g, eps=1e-5):

@@ -29,9 +29,9 @@
 extern "C" {
 #endif
 
-/* 2: round-2 additions (LayerNorm-folded GEMMs, hgr_logits_eval, RCCL collectives, the training-step fusions); every version-1 entry
- * point is unchanged */
-#define HGR_ABI_VERSION 3
+/* 2: round-2 additions (LayerNorm-folded GEMMs, hgr_logits_eval, RCCL collectives, the training-step fusions); 4: round-4 additions
+ * (hgr_gemm_nt_ln_mha); every earlier entry point is unchanged */
+#define HGR_ABI_VERSION 4
 
 enum { HGR_OK = 0, HGR_EINVAL = -1, HGR_EUNSUPPORTED = -2, HGR_ELAUNCH = -3 };
 
@@ -507,6 +507,19 @@ int hgr_vit_head(const void *xh, const void *xl, int64_t ldx, int64_t row_mul, c
 int hgr_gemm_nt_ln(const void *XH, int64_t ldx, const void *Wfold, int64_t ldw, void *C, int64_t ldc,
                    const float *ln_s, const float *ln_c, const float *stats, float eps,
                    int M, int N, int K, int dtype, int act, void *stream);
+
+/*
+ * The attention half of a residual block in one launch (clip/model.py:171,183-186: `self.attn(x, x, x)` on `self.ln_1(x)` -
+ * nn.MultiheadAttention's in_proj, the scaled dot products, softmax and the value product; out_proj stays hgr_gemm_nt_res_stats):
+ *     att [B * L, heads * 64] = softmax(q k^T / 8 [+ causal mask]) v per (sequence, head),   [q | k | v] = LN(x) W_in^T + b_in
+ * with the LayerNorm folded as in hgr_gemm_nt_ln (XH, Wfold [3 W, W], ln_s / ln_c [3 W], stats, eps as there).  A tile is
+ * floor(256 / L) WHOLE sequences x the 192 q / k / v columns of one head, so the [B * L, 3 W] qkv tensor is never written or
+ * re-read and no attention launch follows.  Same bits as hgr_gemm_nt_ln into a qkv buffer followed by hgr_mha on it.
+ * 1 <= L <= 64 (ViT-B/32: 50, trimmed prompts, the attention pool); row width W = heads * 64, W % 128 == 0.
+ */
+int hgr_gemm_nt_ln_mha(const void *XH, int64_t ldx, const void *Wfold, int64_t ldw, const float *ln_s, const float *ln_c,
+                       const float *stats, float eps, void *att, int64_t ldatt, int B, int L, int heads, int causal,
+                       int dtype, void *stream);
 
 /* Training forward of the QuickGELU MLP (clip/model.py:177-180 under autograd): one GEMM, two 16-bit outputs -
  *   pre  [M, ldpre]  = A W^T + bias                (kept for the backward: HGR_EPI_QGELU_GRAD16 / hgr_quickgelu16 read it)

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"libhgr.so does not export {name}"
     assert declared - {"hgr_abi_version", "hgr_last_error"} == set(_lib.SIGNATURES), "ctypes table out of sync with hgr.h"
-    assert lib.hgr_abi_version() == _lib.ABI_VERSION == 3
+    assert lib.hgr_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_product_path_has_no_cpu_fallback():

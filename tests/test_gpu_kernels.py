@@ -895,3 +895,49 @@ def test_logits_eval_planted_ties_at_group_boundaries(dt):
     assert np.array_equal(out[:, :n].cpu().numpy(), lg)
     for w, g_ in zip(ops.eval_rows(out[:, :n], index, k), (lv, p1, pred)):
         assert torch.equal(w, g_)
+
+
+# ---- in_proj GEMM + attention in one launch (hgr_gemm_nt_ln_mha) -------------------------------------------------------------
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("b,l,heads,causal", [(512, 50, 12, False),      # ViT-B/32 image tower at batch 512: 103 row tiles x 12 heads, last tile ragged
+                                              (7, 50, 4, False),         # fewer sequences than one tile holds + 1: a full and a 2-sequence tile
+                                              (3, 64, 2, False),         # L = 64: 4 sequences per tile, every key slot live
+                                              (33, 17, 2, True),         # prompts: causal, 15 sequences per tile, query tiles straddle two sequences
+                                              (5, 1, 2, False),          # one token per sequence: the softmax of a single score
+                                              (40, 16, 8, True)])        # 16 sequences per tile, no straddling
+def test_gemm_ln_mha_equals_gemm_then_mha(dt, b, l, heads, causal):
+    """hgr_gemm_nt_ln_mha (in_proj of the folded ln_1 + scaled dot-product attention in one launch, clip/model.py:171,183-186) must give
+    the BITS of hgr_gemm_nt_ln into a qkv buffer followed by hgr_mha, and agree with the fp32 oracle (oracle/clip_ref.mha on the
+    LayerNorm-ed rows) to the 16-bit operand tolerance."""
+    w = heads * 64
+    m = b * l
+    x = (_rand((m, w), 41, 1.2) + 0.2 * _rand((m, 1), 42))
+    x = x * (0.6 + torch.rand(m, 1, generator=torch.Generator().manual_seed(9)))
+    w_in, b_in = _rand((3 * w, w), 43, w ** -0.5), 0.1 * _rand((3 * w,), 44)
+    gamma, beta = 1.0 + 0.2 * _rand((w,), 45), 0.1 * _rand((w,), 46)
+    xd = x.to(DEV)
+    x16 = torch.empty(m, w, dtype=dt, device=DEV)
+    xlo = torch.empty(m, w, dtype=torch.float16, device=DEV)
+    stats = torch.empty(m, w // 64, 2, dtype=torch.float32, device=DEV)
+    ops.row_stats16(xd, x16, xlo, stats)
+    wf = (w_in * gamma[None, :]).to(dt)
+    s = wf.float().sum(1).to(DEV)
+    c = (w_in @ beta + b_in).to(DEV)
+    wf = wf.to(DEV)
+    qkv = torch.empty(m, 3 * w, dtype=dt, device=DEV)
+    want = torch.empty(m, w, dtype=dt, device=DEV)
+    ops.gemm_nt_ln(x16, wf, qkv, s, c, stats, 1e-5)
+    ops.mha(qkv, want, b, l, heads, causal)
+    got = torch.full((m, w), 7.0, dtype=dt, device=DEV)
+    ops.gemm_nt_ln_mha(x16, wf, got, s, c, stats, b, l, heads, causal, 1e-5)
+    assert torch.equal(got, want), (int((got != want).sum()), float((got.float() - want.float()).abs().max()))
+    again = torch.empty_like(got)
+    ops.gemm_nt_ln_mha(x16, wf, again, s, c, stats, b, l, heads, causal, 1e-5)
+    assert torch.equal(again, got)                                            # run-to-run identical
+    if m <= 4096:                                                             # oracle: fp32 attention of the LayerNorm-ed rows
+        sd = {"p.attn.in_proj_weight": w_in, "p.attn.in_proj_bias": b_in,
+              "p.attn.out_proj.weight": torch.eye(w), "p.attn.out_proj.bias": torch.zeros(w)}
+        h = torch.nn.functional.layer_norm(x, (w,), gamma, beta, 1e-5).view(b, l, w)
+        ref = clip_ref.mha(h, sd, "p.attn", heads, causal, clip_ref.identity).reshape(m, w)
+        tol = dict(rtol=2e-2, atol=3e-2) if dt == torch.bfloat16 else dict(rtol=3e-3, atol=4e-3)
+        assert torch.allclose(got.float().cpu(), ref, **tol), float((got.float().cpu() - ref).abs().max())

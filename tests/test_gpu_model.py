@@ -1,6 +1,7 @@
 """GPU: CLIP towers, tree_model forward and the evaluation metrics through the C ABI, against the
 fixtures captured from the reference (tests/golden) and the CPU oracle."""
 import json
+import os
 import types
 
 import numpy as np
@@ -471,3 +472,71 @@ def test_fused_evaluation_equals_logits_then_eval(golden_dir, tmp_path):
                    "label": torch.full((1, meta["bsz"]), meta["targets"][i], dtype=torch.long)}
     out = evaluate.test(model.opts, model, DEV, None, loader=loader(), log=False)
     assert out == ev_a.summary()
+
+
+def test_pipelined_evaluation_steps_equal_single_stream_steps(golden_dir, tmp_path):
+    """tree_model.forward_eval_overlapped: every evaluation step as two HIP graphs (head on the caller's stream, class-token tail +
+    class logits + evaluation + counters on a second stream, step parities on alternating workspace sets) must advance the counters of
+    main.py:131-191 EXACTLY like the single-graph route - over an odd number of steps, with recycled and with never-repeating input
+    buffers (static-input fallback), with a step that asks for its outputs in between (it joins the tail stream) and after new weights
+    (new generation)."""
+    from hgr_net_amd.model import clip_tree
+    meta, z, cfg, edges = _tree_case("smallvit_n300", golden_dir)
+    sd = synth.clip_state_dict(cfg, 0)
+    from hgr_net_amd.hierarchy import build_hierarchy
+    h = build_hierarchy(edges)
+    splits = synth.make_splits(h.nodes, [len(c) == 0 for c in h.p2c], meta["n_train"], meta["n_test"], meta["split_seed"])
+    model = tree_model(_opts(tmp_path, edges), splits["all"], splits["rest"],
+                       node_tokens=torch.from_numpy(z["node_tokens"].astype(np.int64)), clip_model=build_model(sd).to(DEV))
+    model.update_classifier()
+    te = model.test_index.cpu().tolist()
+    imgs = [synth.images(meta["bsz"], cfg["image_resolution"], 900 + i).to(DEV) for i in range(13)]
+    tgs = [te[(5 * i) % len(te)] for i in range(13)]
+
+    bufs = [torch.empty_like(imgs[0]) for _ in range(3)]          # a loader that recycles three input buffers
+
+    def run(overlap: bool, fresh_buffers: bool):
+        clip_tree.TAIL_OVERLAP = overlap
+        ev = evaluate.Evaluator(model)
+        outs = None
+        for i in range(13):
+            x = bufs[i % 3]
+            x.copy_(imgs[i])
+            if i == 6:
+                outs = ev.add_images(x, tgs[i], want_outputs=True)
+                outs = (outs[0].clone(), outs[1].clone())
+            else:
+                lab = torch.full((meta["bsz"],), tgs[i], dtype=torch.long, device=DEV) if i % 3 == 0 else None
+                ev.add_images(x, tgs[i], lab)
+        return ev.counters(), ev.summary(), outs
+
+    try:
+        base = run(False, False)
+        assert model._pipe is None or not model._pipe["graphs"]
+        got = run(True, False)
+        assert model._pipe is not None and model._pipe["ok"] and len(model._pipe["graphs"]) >= 2      # the pipeline really ran
+        assert not model._pipe["static"]
+        assert got[0] == base[0] and got[1] == base[1] and torch.equal(got[2][0], base[2][0]) and torch.equal(got[2][1], base[2][1])
+        keep = []                                                   # never-repeating addresses: hold every clone alive
+
+        def run_fresh():
+            clip_tree.TAIL_OVERLAP = True
+            ev = evaluate.Evaluator(model)
+            for i in range(13):
+                keep.append(imgs[i].clone())
+                ev.add_images(keep[-1], tgs[i])
+            return ev.counters()
+        base2 = evaluate.Evaluator(model)
+        clip_tree.TAIL_OVERLAP = False
+        for i in range(13):
+            base2.add_images(imgs[i], tgs[i])
+        assert run_fresh() == base2.counters()
+        assert model._pipe["static"], "13 distinct input addresses must have switched to the static input buffers"
+        # new weights -> new generation: graphs are dropped and re-captured, results follow the weights
+        with torch.no_grad():
+            model.clip_model.visual.proj.mul_(-1.0)
+        a = run(True, False)
+        b = run(False, False)
+        assert a[0] == b[0] and a[1] == b[1] and a[0] != base[0]
+    finally:
+        clip_tree.TAIL_OVERLAP = os.environ.get("HGR_TAIL_OVERLAP", "1") != "0"
