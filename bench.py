@@ -309,6 +309,8 @@ def train_mode(a, model, cfg, h, rank, world, group, ranks_seen, dev, real_stdou
     tg = torch.full((a.batch,), target, dtype=torch.long, device=dev)
     random.seed(0)                                                                     # identical negatives on every rank
 
+    model._dp_group = group            # data-parallel: the step's distinct prompts are sharded over the ranks (training.OMTrainer)
+
     def step():
         opt.zero_grad()
         tr = getattr(model, "_trainer", None)

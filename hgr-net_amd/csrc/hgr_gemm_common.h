@@ -78,6 +78,20 @@ __device__ __forceinline__ float quick_gelu_grad(float x) {
     const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * x));
     return s * (1.0f + 1.702f * x * (1.0f - s));
 }
+// The folded LayerNorm's arithmetic, written with explicit fused multiply-adds: every kernel that finalises row statistics or applies
+// them (the consumer epilogues of gemm_nt_duo, hgr_gemm_nt_ln_mha) must round identically, and left to -ffp-contract the compiler is
+// free to contract `s2 * inv - mean * mean` and `acc - mean * s` differently from one kernel to the next (the in_proj + attention kernel
+// differed from gemm_nt_ln + hgr_mha in 578 of 19.7 M f16 outputs by one ulp before this).
+__device__ __forceinline__ float2 ln_finalize(float s1, float s2, float inv_k, float eps) {
+    const float mean = s1 * inv_k;
+    const float msq = mean * mean;
+    return make_float2(mean, rsqrtf(fmaxf(__builtin_fmaf(s2, inv_k, -msq), 0.f) + eps));
+}
+// rstd * (acc - mean * s_n) + c_n
+__device__ __forceinline__ float ln_apply(float2 mr, float acc, float s_n, float c_n) {
+    return __builtin_fmaf(mr.y, __builtin_fmaf(-mr.x, s_n, acc), c_n);
+}
+
 __host__ __device__ constexpr bool epi_has_bias(int epi) { return epi != HGR_EPI_NONE && epi != HGR_EPI_ACCUM && epi != HGR_EPI_QGELU_GRAD16; }
 __host__ __device__ constexpr bool epi_has_idn16(int epi) { return epi == HGR_EPI_BIAS_ADD16_RELU || epi == HGR_EPI_QGELU_GRAD16; }
 

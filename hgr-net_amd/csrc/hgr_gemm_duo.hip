@@ -159,9 +159,7 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
             default:
                 for (int i = 0; i < p.ln_slots / 2; ++i) { const f32x4 t = sp[i]; s1 += t[0] + t[2]; s2 += t[1] + t[3]; }
         }
-        const float inv = 1.0f / (float)p.K;
-        const float mean = s1 * inv;
-        return make_float2(mean, rsqrtf(fmaxf(s2 * inv - mean * mean, 0.f) + p.ln_eps));
+        return ln_finalize(s1, s2, 1.0f / (float)p.K, p.ln_eps);
     };
     const int nk = p.K / 64;    // >= 2 (host guarantees)
     const int offA = (wm * 64 + r) * 128;      // + m tile * 2048, within pieces A0 / A1
@@ -446,7 +444,7 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
             f32x4 v;
             if (LN == 2) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaf(mr.y, acc[a][b][i][j][e] - mr.x * lsq[b][j][e], bq[b][j][e]);
+                for (int e = 0; e < 4; ++e) v[e] = ln_apply(mr, acc[a][b][i][j][e], lsq[b][j][e], bq[b][j][e]);
             } else v = acc[a][b][i][j] + bq[b][j];
             if (EPI == HGR_EPI_BIAS_QUICKGELU) {
 #pragma unroll
@@ -710,7 +708,7 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    v[e] = fmaf(mr.y, acc[a][b][i][j][e] - mr.x * sq[e], cq4[e]);
+                    v[e] = ln_apply(mr, acc[a][b][i][j][e], sq[e], cq4[e]);
                     if (EPI == HGR_EPI_BIAS_QUICKGELU) v[e] = quick_gelu(v[e]);
                 }
                 store_quad<DT, HGR_EPI_NONE, OUT32>(p, v, m, n);

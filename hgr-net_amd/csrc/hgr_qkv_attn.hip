@@ -171,6 +171,16 @@ __global__ __launch_bounds__(QA_NT) void qkv_attn(QkvAttnArgs p) {
     ktile(nk - 1, std::integral_constant<int, 2>());
     if (!wn) HGR_MBAR();        // group 0 waits for group 1's last interval: every LDS read is done, no DMA in flight
 
+    // the folded-LayerNorm vectors of this lane's columns: requested now, they travel beside the statistics loads below (loaded inside
+    // the store loop every n tile waited for its own L2 round trip: six in a row per tile)
+    f32x4 sq[6], cq[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int col0 = wn * 96 + j * 16;                           // wave-uniform: part 0 = q, 1 = k, 2 = v; head dim d0 + 4 g + e
+        const int gn = (col0 >> 6) * p.Wd + h * 64 + (col0 & 63) + g * 4;
+        sq[j] = *(const f32x4 *)(p.ln_s + gn);
+        cq[j] = *(const f32x4 *)(p.ln_c + gn);
+    }
     // ---- LayerNorm row statistics of the tile's 256 rows (thread t < 256: row t), as the consumer GEMM finalises them ----
     float2 *lnrow = (float2 *)(smem + QA_LN);
     if (tid < 256) {
@@ -193,30 +203,26 @@ __global__ __launch_bounds__(QA_NT) void qkv_attn(QkvAttnArgs p) {
             default:
                 for (int i = 0; i < p.ln_slots / 2; ++i) { const f32x4 t = sp[i]; s1 += t[0] + t[2]; s2 += t[1] + t[3]; }
         }
-        const float inv = 1.0f / (float)p.K;
-        const float mean = s1 * inv;
-        lnrow[tid] = make_float2(mean, rsqrtf(fmaxf(s2 * inv - mean * mean, 0.f) + p.ln_eps));
+        lnrow[tid] = ln_finalize(s1, s2, 1.0f / (float)p.K, p.ln_eps);
     }
     __syncthreads();
 
     // ---- q / k / v of the tile, rounded to the MFMA type, into LDS ----
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        const int col0 = wn * 96 + j * 16;                           // wave-uniform: part 0 = q, 1 = k, 2 = v; head dim d0 + 4 g + e
-        const int part = col0 >> 6, d0 = col0 & 63;
-        const int gn = part * p.Wd + h * 64 + d0 + g * 4;
-        const f32x4 sq = *(const f32x4 *)(p.ln_s + gn), cq = *(const f32x4 *)(p.ln_c + gn);
+    for (int i = 0; i < 4; ++i) {
+        const int row = wm * 64 + i * 16 + r;
+        const float2 mr = lnrow[row];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = wm * 64 + i * 16 + r;
-            const float2 mr = lnrow[row];
+        for (int j = 0; j < 6; ++j) {
+            const int col0 = wn * 96 + j * 16;
+            const int part = col0 >> 6, d = (col0 & 63) + g * 4;
             f32x4 v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaf(mr.y, acc[i][j][e] - mr.x * sq[e], cq[e]);
-            const vec4 hv = cvt4<DT>(v[0], v[1], v[2], v[3]);
-            const int d = d0 + g * 4;
-            if (part == 2) *(vec4 *)(smem + QA_V + row * (QA_VR * 2) + d * 2) = hv;
-            else *(vec4 *)(smem + (part ? QA_K : QA_Q) + row * 128 + (((d >> 3) ^ (row & 7)) * 16) + (d & 4) * 2) = hv;
+            for (int e = 0; e < 4; ++e) v[e] = ln_apply(mr, acc[i][j][e], sq[j][e], cq[j][e]);
+            // branch-free destination: V rows are 144 bytes, row-major; Q / K rows 128 bytes with the chunk swizzle of the fragment reads
+            const int base = part == 2 ? QA_V : part ? QA_K : QA_Q;
+            const int at = part == 2 ? row * (QA_VR * 2) + d * 2 : row * 128 + (((d >> 3) ^ (row & 7)) * 16) + (d & 4) * 2;
+            *(vec4 *)(smem + base + at) = cvt4<DT>(v[0], v[1], v[2], v[3]);
         }
     }
     __syncthreads();

@@ -101,6 +101,7 @@ def train(opts, epoch, model, train_loader, num_batches, optimizer, optimizer2, 
     """One epoch of main.train (main.py:72-101): scheduler, train_batch, clip + AdamW (fused kernels), logging."""
     torch.cuda.empty_cache()
     gc.collect()
+    model._dp_group = group           # data-parallel: the distinct prompts of every step are sharded over the ranks (training.OMTrainer)
     for i, data in enumerate(train_loader):
         scheduler(i + epoch * num_batches)
         imgs, targets = data["img"][0].to(device), data["label"][0].to(device)

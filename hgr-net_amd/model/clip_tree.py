@@ -242,7 +242,7 @@ class tree_model(nn.Module):
     def _pipe_state(self, dev):
         if self._pipe is None:
             # the tail's launches are a few dozen workgroups each: a high-priority stream lets them take the first slots that free up
-            side = torch.cuda.Stream(device=dev, priority=-1)
+            side = torch.cuda.Stream(device=dev, priority=int(os.environ.get("HGR_TAIL_PRIO", "-1")))
             self._pipe = {"side": side, "graphs": {}, "gen": None, "ok": None, "step": 0, "misses": 0, "static": {},
                           "head_done": [torch.cuda.Event(), torch.cuda.Event()], "tail_done": [torch.cuda.Event(), torch.cuda.Event()]}
             for e in self._pipe["tail_done"]:

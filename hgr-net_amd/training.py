@@ -330,6 +330,10 @@ class OMTrainer:
         # data-parallel hook: called with "early" once every gradient except the image tower's is final (right before the
         # image tower's backward, model/clip_tree.py:280) and with "late" at the end of the step
         self.grad_ready_hook: Optional[Callable[[str], None]] = None
+        # data-parallel process group (None = single process): with a group the step's distinct prompts are SHARDED over the ranks -
+        # every rank text-encodes and back-propagates 1 / world of them (see _text_features_dp) instead of all of them
+        self.dp_group = None
+        self.last_text_rows = 0          # prompts this rank encoded in the last step (tests / accounting)
 
     def _head(self, img_n, dimg_n, tfeat, label_pos: int, weight, loss_acc, ce_out=None):
         """logits = img_n tn^T * exp(logit_scale); CE (all rows share the label); gradients of the three inputs."""
@@ -357,6 +361,62 @@ class OMTrainer:
         dtfeat = torch.empty_like(tfeat)
         ops.l2norm_bwd(tfeat, dtn, dtfeat)
         return dtfeat
+
+    # -- prompt-parallel text tower (data-parallel training) ---------------------------------------------------------------
+    def _text_shard(self, n_u: int):
+        """Contiguous shard [lo, hi) of the step's n_u distinct prompts for this rank, shard size ns = ceil(n_u / world) (the last
+        shards may be short or empty); every rank encodes exactly ns rows so that the all-gather is regular - missing rows are
+        filled with the step's first prompt and never receive a gradient."""
+        import torch.distributed as dist
+        world, rank = dist.get_world_size(self.dp_group), dist.get_rank(self.dp_group)
+        ns = -(-n_u // world)
+        lo = min(n_u, rank * ns)
+        return world, rank, ns, lo, min(n_u, lo + ns)
+
+    def _text_features_dp(self, uniq: list, ctx):
+        """The reference text-encodes the <= 257 prompts of every inner step on the device that owns the batch
+        (model/clip_tree.py:256-262).  Data-parallel, every rank used to encode - and back-propagate - ALL distinct prompts of the
+        step: at ViT-L/14 + CoOp that is ~25 % of a rank's FLOPs, replicated world times.  Here rank r encodes the prompts
+        uniq[lo:hi) only and the [n_u, D] features are all-gathered (fp32, a few MB); see _text_backward_dp for the way back."""
+        import torch.distributed as dist
+        tree, e = self.tree, self.engine
+        world, rank, ns, lo, hi = self._text_shard(len(uniq))
+        # the sharding is only meaningful when every rank works on the SAME prompt list (same single-class batch, same sampling seed:
+        # SURVEY H7, dataset/imagenet_group.py shard="within"); a rank that drew other negatives would gather garbage or hang in a
+        # mis-sized collective, so the list's hash is compared first (one 16-byte max-reduce; the step synchronises with the host
+        # for logit_scale and the EOT length anyway)
+        import hashlib
+        hsh = int.from_bytes(hashlib.sha256(repr(uniq).encode()).digest()[:7], "little")
+        chk = torch.tensor([hsh, -hsh], dtype=torch.int64, device=e.dev)
+        dist.all_reduce(chk, op=dist.ReduceOp.MAX, group=self.dp_group)
+        chk = chk.tolist()
+        if chk[0] != -chk[1]:
+            raise HgrError("data-parallel OM step: the ranks drew different negative classes (seed `random` identically on every rank and "
+                           "hand every rank its rows of the SAME single-class batch); prompt-parallel text encoding needs one prompt list")
+        mine = uniq[lo:hi] + [uniq[0]] * (ns - (hi - lo))
+        feat_l, tsave = e.text_fwd(tree.node_tokens[torch.tensor(mine, device=e.dev)], ctx)
+        self.last_text_rows = ns
+        full = torch.empty(world, ns, feat_l.shape[1], dtype=torch.float32, device=e.dev)
+        dist.all_gather(list(full.unbind(0)), feat_l.contiguous(), group=self.dp_group)
+        # rank r's block starts at row r * ns = the index of its first prompt, and padding rows exist at the tail only: the first
+        # n_u rows of the gathered buffer ARE the features in `uniq` order
+        return full.view(world * ns, -1)[: len(uniq)], tsave
+
+    def _text_backward_dp(self, dtfeat_u: torch.Tensor, tsave: dict, n_u: int):
+        """dL/d(text features) is a sum over the images of the WHOLE batch: all-reduce it (sum; [n_u, D] fp32) BEFORE the text
+        tower's backward, then every rank back-propagates its own prompts' rows only.  The parameter gradients a rank gets are the
+        full-batch gradients of its prompts; the bucketed gradient all-reduce that follows sums them over the prompt shards, exactly
+        as it sums the image tower's over the image shards.  Compared with back-propagating each rank's PARTIAL feature gradient
+        through the 16-bit backward chain (round 3: 1.8e-2 relative L2 against the one-rank step) the text-tower gradients now
+        differ from the one-rank step's by fp32 summation order only."""
+        import torch.distributed as dist
+        e = self.engine
+        world, rank, ns, lo, hi = self._text_shard(n_u)
+        dist.all_reduce(dtfeat_u, op=dist.ReduceOp.SUM, group=self.dp_group)
+        mine = torch.zeros(ns, dtfeat_u.shape[1], dtype=torch.float32, device=e.dev)
+        if hi > lo:
+            mine[: hi - lo] = dtfeat_u[lo:hi]
+        e.text_bwd(mine, tsave)
 
     @torch.no_grad()
     def train_batch(self, inputs, targets, training_method: str = "OM", sample_strategy: Optional[str] = None) -> float:
@@ -399,7 +459,13 @@ class OMTrainer:
         self.last_contra = [(ids, pos) for ids, pos, _, _ in picks]
         uniq = sorted({i for ids, _, _, _ in picks for i in ids})
         where = {nid: j for j, nid in enumerate(uniq)}
-        tfeat_u, tsave = e.text_fwd(tree.node_tokens[torch.tensor(uniq, device=e.dev)], getattr(tree, "ctx", None))
+        dp = self.dp_group if self.dp_group is not None else getattr(tree, "_dp_group", None)
+        self.dp_group = dp
+        if dp is not None:
+            tfeat_u, tsave = self._text_features_dp(uniq, getattr(tree, "ctx", None))
+        else:
+            tfeat_u, tsave = e.text_fwd(tree.node_tokens[torch.tensor(uniq, device=e.dev)], getattr(tree, "ctx", None))
+            self.last_text_rows = len(uniq)
         dtfeat_u = torch.zeros_like(tfeat_u)
         adaptive = tree.opts.weights == "adaptive"
         ces = torch.zeros(len(picks), 1, dtype=torch.float32, device=e.dev) if adaptive else None
@@ -409,7 +475,10 @@ class OMTrainer:
             ops.rows_gather(tfeat_u, loc, tfeat)
             dtfeat = self._head(img_n, dimg_n, tfeat, pos, wgt, loss_acc, ces[j: j + 1] if adaptive else None)
             ops.rows_axpy(dtfeat_u, dtfeat, dst_mul=0, dst_idx=loc)
-        e.text_bwd(dtfeat_u, tsave)
+        if dp is not None:
+            self._text_backward_dp(dtfeat_u, tsave, len(uniq))
+        else:
+            e.text_bwd(dtfeat_u, tsave)
         if adaptive:
             # loss = sum_j CE_j * w_j(layer_weight): the <= 13-element softmax(100 ** layer_weight) of get_weights is host-level
             # glue in the reference too (clip_tree.py:209); its gradient comes from autograd over those tiny tensors

@@ -103,9 +103,10 @@ def test_two_rank_om_step_equals_one_rank(tmp_path):
     """SURVEY H7 (model/clip_tree.py:222-281): ONE single-class batch sharded over 2 ranks with identical sampling seeds,
     mean CE over equal shards, gradient all-reduce(sum) x 1/world == the 1-rank full-batch step.
     Image tower: every row's backward is bit-identical up to the exact factor 2 of the shard's 1/b, so the averaged
-    gradient differs from the full-batch one by fp32 summation order only (<= 1e-4 relative L2).  Text tower: each rank
-    back-propagates ITS partial feature gradient and the backward chain rounds activations' gradients to bf16 (nonlinear),
-    so the bound there is bf16 rounding (2^-9 per element, random; measured 1.8e-2 worst): <= 4e-2 relative L2, cosine >= 0.999."""
+    gradient differs from the full-batch one by fp32 summation order only (<= 1e-4 relative L2).  Text tower (round 4): the step's
+    distinct prompts are sharded over the ranks, dL/d(text features) is all-reduced BEFORE the text backward and every rank
+    back-propagates the full-batch gradient of its own prompts - the same bound now holds there (round 3 back-propagated each
+    rank's partial gradient through the bf16 chain: 1.8e-2).  And every rank encodes 1 / world of the prompts."""
     import torch
     one = _dp("train", 1, tmp_path / "t1.pt")
     two = _dp("train", 2, tmp_path / "t2.pt")
@@ -126,9 +127,48 @@ def test_two_rank_om_step_equals_one_rank(tmp_path):
             assert abs(float(g1) - float(g2)) <= 1e-4 * (1.0 + abs(float(g1))), (float(g1), float(g2))
         else:
             worst_txt = max(worst_txt, rel)
-            cos = float(torch.dot(g1.flatten(), g2.flatten()) / (g1.norm() * g2.norm()))
-            assert rel <= 4e-2 and cos >= 0.999, (k, rel, cos)
+            assert rel <= 1e-4, (k, rel)
     print(f"\n[2-rank vs 1-rank OM step] worst relative L2 difference: image tower {worst_img:.2e}, text tower {worst_txt:.2e}")
+    # prompt-parallel: rank 0 of the 2-rank run encoded half of the distinct prompts (ceil), and launched about half of the step's
+    # GEMM FLOPs (half of the images, half of the prompts; the [B, <= 257] loss heads are fp32 matmuls outside these records)
+    assert one["uniq"] == two["uniq"] and one["text_rows"] == one["uniq"] and two["text_rows"] == -(-two["uniq"] // 2), (one["text_rows"], two["text_rows"], one["uniq"])
+    assert 0.45 * one["gemm_flops"] <= two["gemm_flops"] <= 0.56 * one["gemm_flops"], (one["gemm_flops"], two["gemm_flops"])
+
+
+def test_two_rank_coop_context_gradient_is_identical_on_both_ranks_and_equals_one_rank(tmp_path):
+    """BASELINE configs[4] (CoOp learnable context, model/CoOp.py:58-113) under the prompt-parallel text tower: d loss / d ctx sums
+    over ALL prompts of the step, each rank back-propagates its own half, the bucketed all-reduce adds the halves - after it both
+    ranks hold the same bits, equal to the one-rank full-batch gradient up to fp32 summation order."""
+    import torch
+    one = _dp("trainctx", 1, tmp_path / "c1.pt")
+    two = _dp("trainctx", 2, tmp_path / "c2.pt")
+    assert one["contra"] == two["contra"]
+    a, b = two["ctx_grad_per_rank"]
+    assert torch.equal(a, b)
+    ref = one["ctx_grad_per_rank"][0]
+    assert float(ref.norm()) > 0
+    rel = float((a - ref).norm() / ref.norm())
+    assert rel <= 1e-4, rel
+    for k, g1 in one["grads"].items():
+        if not k.startswith("visual.") and k != "logit_scale" and float(g1.norm()) > 1e-9:
+            assert float((g1 - two["grads"][k]).norm() / g1.norm()) <= 1e-4, k
+
+
+def test_many_rank_bench_control_flow_on_one_gpu():
+    """`bench.py --gpus 8` (evaluation) with eight ranks sharing the test box's one GPU (gloo; toy size; N % 8 != 0): the 8-way control
+    flow - shard bounds of the prompt shards with a short last shard, batches dealt to 8 ranks, counter all-reduce, dp_check, exactly
+    one JSON line - runs before the driver's real 8-GPU node ever does.  The test boxes allow at most 6 processes on the card at once
+    (this pytest process is one of them), so the default is 5 ranks, an odd count that divides neither the prompt list nor the
+    class count; HGR_TEST_MAX_RANKS=8 runs the full eight where nothing limits it."""
+    n = int(os.environ.get("HGR_TEST_MAX_RANKS", "5"))
+    d = _bench(n, ["--steps", "3", "--warmup", "1", "--nodes", "1003", "--batch", "8", "--arch", "small-vit", "--no-cpu-baseline", "--no-pcie"])
+    c = d["dp_check"]
+    assert d["n_gpus"] == n and d["ranks_seen"] == n and d["config"]["parallelism"] == f"dp{n}" and d["config"]["global_batch"] == 8 * n
+    assert c["ok"] and c["ranks_seen"] == n and c["zsl_checksum_equal"] and c["counters_allreduce_equals_sum_of_ranks"], c
+    assert len(c["num_sample_per_rank"]) == n and sum(c["num_sample_per_rank"]) == n * (3 + 1) * 8, c
+    # and one sharded training step per rank count: the prompt shards of `n` ranks over a prompt list that does not divide evenly
+    t = _bench(n, ["--mode", "train", "--arch", "small-vit", "--nodes", "1003", "--batch", "2", "--steps", "1", "--warmup", "1"])
+    assert t["dp_check"]["ok"] and t["dp_check"]["negatives_equal"] and t["n_gpus"] == n, t["dp_check"]
 
 
 def test_two_rank_adaptive_layer_weights_stay_identical(tmp_path):

@@ -85,13 +85,14 @@ n = 301                                                   # odd: uneven text sha
 edges = synth.make_dag(n, depth=8, seed=7, multi_parent=0.05)
 h = build_hierarchy(edges)
 splits = synth.make_splits(h.nodes, [len(c) == 0 for c in h.p2c], 100, 150, 13)
-tokens = synth.make_tokens(n, 11, cfg["vocab_size"])
+n_ctx = 4 if mode == "trainctx" else 0                     # CoOp learnable context (BASELINE configs[4]): its gradient sums over ALL prompts
+tokens = synth.make_tokens(n, 11, cfg["vocab_size"], n_ctx=n_ctx)
 tmp = tempfile.mkdtemp(prefix="hgr_dp_")
 gp = os.path.join(tmp, "g.json")
 json.dump(edges, open(gp, "w"))
 opts = types.SimpleNamespace(device=dev, folder=tmp, exp_name="HGR", weights="adaptive" if mode == "adaptive" else "equal", out_ratio=0.5, in_ratio=0.5, from_epoch=-1,
                              graph_path=gp, arch="synthetic", fetch=False, load=False, load_path="none", scale=1.0, num_compare=12, k=1,
-                             sample_strategy="topk", weighting="both", train_dtype="bf16")
+                             sample_strategy="topk", weighting="both", train_dtype="bf16", n_ctx=n_ctx)
 model = tree_model(opts, splits["all"], splits["rest"], node_tokens=tokens, clip_model=build_model(sd).to(dev))
 res = cfg["image_resolution"]
 
@@ -152,10 +153,15 @@ else:
         # before the image tower's backward, the image tower's buckets after it
         from hgr_net_amd.training import OMTrainer
         model._trainer = OMTrainer(model, opts.train_dtype)
+        model._dp_group = group                                  # prompt-parallel text tower (what hgr_net_amd.main.train and bench.py set)
         opt.set_late_params(model.clip_model.visual.parameters())
         model._trainer.grad_ready_hook = lambda part: opt.allreduce_part(part, group)
     random.seed(5)
+    from hgr_net_amd import ops as _ops
+    _ops.PROFILE = []                                            # algorithmic FLOPs of every GEMM this rank launches in the step
     loss = model.train_batch(img[lo:hi].to(dev), torch.full((hi - lo,), target, dtype=torch.long, device=dev), "OM", "topk")
+    recs, _ops.PROFILE = _ops.PROFILE, None
+    gemm_flops = float(sum(r[3] for r in recs))
     loss_t = torch.tensor([loss], dtype=torch.float64, device=dev)
     if group is not None:
         import torch.distributed as dist
@@ -164,7 +170,18 @@ else:
     torch.cuda.synchronize()
     if rank == 0:
         grads = {nm: (p.grad.detach() * opt.grad_scale).cpu() for nm, p in zip(names, params)}
-        torch.save({"loss": float(loss_t.item()), "grads": grads, "contra": model._trainer.last_contra}, out_path)
+    ctx_all = None
+    if model.ctx is not None:                                    # the context gradient as every rank holds it after the all-reduce
+        cg = (model.ctx.grad.detach() * opt.grad_scale).contiguous()
+        ctx_all = [cg.cpu()]
+        if group is not None:
+            box = [torch.empty_like(cg) for _ in range(world)]
+            dist.all_gather(box, cg)
+            ctx_all = [b.cpu() for b in box]
+    if rank == 0:
+        uniq = len({i for ids, _ in model._trainer.last_contra for i in ids})
+        torch.save({"loss": float(loss_t.item()), "grads": grads, "contra": model._trainer.last_contra, "gemm_flops": gemm_flops,
+                    "text_rows": model._trainer.last_text_rows, "uniq": uniq, "ctx_grad_per_rank": ctx_all}, out_path)
 if group is not None:
     import torch.distributed as dist
     dist.barrier()
