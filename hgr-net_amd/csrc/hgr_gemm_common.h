@@ -173,6 +173,21 @@ __device__ __forceinline__ void store_quad_full(const GemmArgs &p, f32x4 v, f32x
 }
 
 
+// LDS-DMA in its BUFFER form (buffer_load_dwordx4 ... offen lds): the per-lane source is a 32-bit byte offset into a buffer resource
+// (128-bit descriptor in SGPRs: base, no stride, 4 GB of records, raw dword format) and the K-tile advance rides in the scalar offset
+// operand - one address VGPR per instruction and no VALU, where the global form (global_load_lds_dwordx4) needs a 64-bit per-lane
+// pointer, i.e. a 64-bit add (two VALU) and two address VGPRs per instruction.  -DHGR_DMA_GLOBAL=1 builds the global form (A/B runs).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t dma_rsrc(const void *base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)0xFFFFFFFFu, 0x00020000);
+}
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, const char *base, unsigned voff, int soff, char *lds_dst) {
+#if defined(HGR_DMA_GLOBAL) && HGR_DMA_GLOBAL
+    __builtin_amdgcn_global_load_lds((const AS1 void *)(base + soff + voff), (AS3 void *)lds_dst, 16, 0, 0);
+#else
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (AS3 void *)lds_dst, 16, (int)voff, soff, 0, 0);
+#endif
+}
+
 // R interval end: my share of the piece the NEXT read interval needs has landed (counted vmcnt), my own
 // ds_reads are complete (so the slot they read may be refilled), then the barrier.  M interval end: barrier.
 #define HGR_RWAIT(N) do { __builtin_amdgcn_sched_barrier(0); \

@@ -86,6 +86,7 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
         }
     }
     char *const ldsw = smem + wave * 1024;
+    const __amdgpu_buffer_rsrc_t rA = dma_rsrc(p.A), rW = dma_rsrc(p.W);
     // halves of an A piece: instructions [2h, 2h + 2)
     // CONV: base of K-tile t = A + kernel offset of its tap + its first channel (scalar); a lane whose tap is outside the image reads zeros
     auto conv_base = [&](int t, int &tap) {
@@ -107,17 +108,13 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
             }
             return;
         }
-        const char *base = p.A + (int64_t)t * 128;
 #pragma unroll
-        for (int i = 2 * h; i < 2 * h + 2; ++i)
-            __builtin_amdgcn_global_load_lds((const AS1 void *)(base + off[i]), (AS3 void *)(dst + i * 4096), 16, 0, 0);
+        for (int i = 2 * h; i < 2 * h + 2; ++i) dma16(rA, p.A, off[i], t * 128, dst + i * 4096);
     };
     auto issueW = [&](const unsigned (&off)[2], int slot_base, int t) {
-        const char *base = p.W + (int64_t)t * 128;
         char *dst = ldsw + slot_base;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((const AS1 void *)(base + off[i]), (AS3 void *)(dst + i * 4096), 16, 0, 0);
+        for (int i = 0; i < 2; ++i) dma16(rW, p.W, off[i], t * 128, dst + i * 4096);
     };
 
     f32x4 acc[MH][2][4][2];     // [m-half][n-half][m tile][n tile]
@@ -270,17 +267,13 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
                 }
                 return;
             }
-            const char *base = p.A + (int64_t)t * 128;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                __builtin_amdgcn_global_load_lds((const AS1 void *)(base + oA0[i]), (AS3 void *)(dst + i * 4096), 16, 0, 0);
+            for (int i = 0; i < 4; ++i) dma16(rA, p.A, oA0[i], t * 128, dst + i * 4096);
         };
         auto issueWh = [&](const unsigned (&off)[2], int slot_base, int t) {
-            const char *base = p.W + (int64_t)t * 128;
             char *dst = ldsw + slot_base + (t & 1) * 8192;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-                __builtin_amdgcn_global_load_lds((const AS1 void *)(base + off[i]), (AS3 void *)(dst + i * 4096), 16, 0, 0);
+            for (int i = 0; i < 2; ++i) dma16(rW, p.W, off[i], t * 128, dst + i * 4096);
         };
         // prologue in steady-state order: A(0), W0(0), W1(0), A(1), W0(1)
         issueAh(0, 0); issueWh(oW0, HW0, 0); issueWh(oW1, HW1, 0); issueAh(1, 1); issueWh(oW0, HW0, 1);

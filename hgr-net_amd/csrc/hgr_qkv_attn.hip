@@ -48,8 +48,10 @@ typedef __attribute__((ext_vector_type(8))) short qa_s16x8;
 constexpr int QA_NT = 512;
 constexpr int QA_STAGE = 57344;                              // PA0 16 K | PA1 16 K | PW 24 K
 constexpr int QA_PA0 = 0, QA_PA1 = 16384, QA_PW = 32768;
-constexpr int QA_LDS = 2 * QA_STAGE;                         // 112 KB
-constexpr int QA_Q = 0, QA_K = 32768, QA_V = 65536, QA_VR = 72, QA_LN = 65536 + 256 * QA_VR * 2;     // attention-phase layout (104 448 B)
+// attention-phase layout (104 448 B) ABOVE stage 0: a persistent workgroup lets the next tile's first K-tile land in stage 0 meanwhile
+constexpr int QA_VR = 72;
+constexpr int QA_Q = QA_STAGE, QA_K = QA_Q + 32768, QA_V = QA_K + 32768, QA_LN = QA_V + 256 * QA_VR * 2;
+constexpr int QA_LDS = QA_LN + 2048;                         // 161 792 B of the CU's 163 840
 
 template <int DT, bool CAUSAL>
 __global__ __launch_bounds__(QA_NT) void qkv_attn(QkvAttnArgs p) {
@@ -64,50 +66,52 @@ __global__ __launch_bounds__(QA_NT) void qkv_attn(QkvAttnArgs p) {
     const int wn = wave >> 2, wm = wave & 3;          // waves w and w + 4 share a SIMD: wn is also the ping-pong group
     const int r = lane & 15, g = lane >> 4;
 
-    // block -> (row tile, head): every XCD (blocks b, b + 8, ... share an L2) walks a contiguous range of tiles, heads fastest, so the
-    // 12 tiles of a row panel run together on one L2 and the 3.5 MB of folded weights stay resident beside ~3 row panels
-    const int nwg = gridDim.x, orig = blockIdx.x;
-    const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
-    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-    const int tm = wg / p.H, h = wg - tm * p.H;
+    // tiles -> workgroups.  Tile id = row tile * H + head (heads fastest).  Every XCD (blocks b, b + 8, ... share an L2) owns a
+    // contiguous range of tile ids and its workgroups walk it with a stride of the XCD's workgroup count: the tiles in flight on an L2
+    // are a contiguous window - the 12 heads of ~3 row panels beside the 3.5 MB of folded weights.  grid = tiles: one tile per
+    // workgroup.  grid = CUs (the default): PERSISTENT workgroups; the next tile's first K-tile is requested before this tile's
+    // attention phase, so its prologue latency (and a workgroup launch) is off the critical path.
+    const int ntiles = p.tiles_m * p.H, orig = blockIdx.x, G = gridDim.x;
+    const int xcd = orig & 7, q8 = ntiles >> 3, r8 = ntiles & 7;
+    const int xbase = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8, xcnt = q8 + (xcd < r8 ? 1 : 0);
+    const int xwgs = (G >> 3) + (xcd < (G & 7) ? 1 : 0);
+    int cur = orig >> 3;                                     // index of this workgroup's tile inside the XCD's range
+    if (cur >= xcnt) return;
     const int rows_valid = p.S * p.L;
-    const int m0 = tm * rows_valid;
 
     // per-lane source offsets of one K-tile's LDS-DMA instructions (bytes from A / W; operands < 4 GB, checked on the host)
     unsigned oA0[2], oA1[2], oW[3];
+    int m0, h;
+    auto set_tile = [&](int tile) {
+        const int tm = tile / p.H;
+        h = tile - tm * p.H;
+        m0 = tm * rows_valid;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int id = (i * 8 + wave) * 64 + lane;
-        const int pr = id >> 3, c = (id & 7) ^ (pr & 7);
-        if (i < 2) {
-            const int tr = (pr >> 5) * 64 + (pr & 31);
-            oA0[i] = (unsigned)(((int64_t)min(m0 + tr, p.M - 1) * p.lda + c * 8) * 2);
-            oA1[i] = (unsigned)(((int64_t)min(m0 + tr + 32, p.M - 1) * p.lda + c * 8) * 2);
+        for (int i = 0; i < 3; ++i) {
+            const int id = (i * 8 + wave) * 64 + lane;
+            const int pr = id >> 3, c = (id & 7) ^ (pr & 7);
+            if (i < 2) {
+                const int tr = (pr >> 5) * 64 + (pr & 31);
+                oA0[i] = (unsigned)(((int64_t)min(m0 + tr, p.M - 1) * p.lda + c * 8) * 2);
+                oA1[i] = (unsigned)(((int64_t)min(m0 + tr + 32, p.M - 1) * p.lda + c * 8) * 2);
+            }
+            const int wr = (pr >> 6) * p.Wd + h * 64 + (pr & 63);      // piece row pr = column pr of the tile: q 0-63, k 64-127, v 128-191
+            oW[i] = (unsigned)(((int64_t)wr * p.ldw + c * 8) * 2);
         }
-        const int wr = (pr >> 6) * p.Wd + h * 64 + (pr & 63);      // piece row pr = column pr of the tile: q 0-63, k 64-127, v 128-191
-        oW[i] = (unsigned)(((int64_t)wr * p.ldw + c * 8) * 2);
-    }
+    };
+    set_tile(xbase + cur);
     char *const ldsw = smem + wave * 1024;
+    const __amdgpu_buffer_rsrc_t rA = dma_rsrc(p.A), rW = dma_rsrc(p.W);
     auto issueA = [&](const unsigned (&off)[2], int piece, int t) {
-        const char *base = p.A + (int64_t)t * 128;
         char *dst = ldsw + (t & 1) * QA_STAGE + piece;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((const AS1 void *)(base + off[i]), (AS3 void *)(dst + i * 8192), 16, 0, 0);
+        for (int i = 0; i < 2; ++i) dma16(rA, p.A, off[i], t * 128, dst + i * 8192);
     };
     auto issueW = [&](int t) {
-        const char *base = p.W + (int64_t)t * 128;
         char *dst = ldsw + (t & 1) * QA_STAGE + QA_PW;
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
-            __builtin_amdgcn_global_load_lds((const AS1 void *)(base + oW[i]), (AS3 void *)(dst + i * 8192), 16, 0, 0);
+        for (int i = 0; i < 3; ++i) dma16(rW, p.W, oW[i], t * 128, dst + i * 8192);
     };
-
-    f32x4 acc[4][6];            // [m tile][n tile]: C[wm*64 + 16 i + r][wn*96 + 16 j + 4 g .. + 3]
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 6; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nk = p.K / 64;    // >= 2 (host guarantees)
     const int offA = (wm * 32 + r) * 128;          // + m tile (0, 1) * 2048 within PA0 / PA1
@@ -119,7 +123,15 @@ __global__ __launch_bounds__(QA_NT) void qkv_attn(QkvAttnArgs p) {
     issueA(oA0, QA_PA0, 0); issueW(0);
     issueA(oA1, QA_PA1, 0);
     issueA(oA0, QA_PA0, 1); issueW(1);
-    HGR_RWAIT(7);               // PA0(0), PW(0) landed
+  for (;;) {
+    f32x4 acc[4][6];            // [m tile][n tile]: C[wm*64 + 16 i + r][wn*96 + 16 j + 4 g .. + 3]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // PA0(0), PW(0) landed: my 7 youngest operations are PA1(0) x2 + PA0(1), PW(1) x5 (first tile), or - across a tile seam, where the
+    // previous tile's output stores sit between PA1(0) and PA0(1) in issue order - PA0(1), PW(1) x5 and two of those stores
+    HGR_RWAIT(7);
     if (wn) HGR_MBAR();         // ping-pong: group 1 runs one barrier interval behind group 0
 
     // MODE 0: steady state (t + 2 < nk), 1: second-last K-tile, 2: last K-tile
@@ -170,6 +182,16 @@ __global__ __launch_bounds__(QA_NT) void qkv_attn(QkvAttnArgs p) {
     ktile(nk - 2, std::integral_constant<int, 1>());
     ktile(nk - 1, std::integral_constant<int, 2>());
     if (!wn) HGR_MBAR();        // group 0 waits for group 1's last interval: every LDS read is done, no DMA in flight
+    // this tile's coordinates for the epilogue; then (persistent) the next tile's first K-tile is requested into stage 0, which the
+    // attention phase below does not touch
+    const int m0c = m0, hc = h;
+    const int nxt = cur + xwgs;
+    const bool has_next = nxt < xcnt;
+    if (has_next) {
+        set_tile(xbase + nxt);
+        issueA(oA0, QA_PA0, 0); issueW(0);
+        issueA(oA1, QA_PA1, 0);
+    }
 
     // the folded-LayerNorm vectors of this lane's columns: requested now, they travel beside the statistics loads below (loaded inside
     // the store loop every n tile waited for its own L2 round trip: six in a row per tile)
@@ -177,14 +199,14 @@ __global__ __launch_bounds__(QA_NT) void qkv_attn(QkvAttnArgs p) {
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
         const int col0 = wn * 96 + j * 16;                           // wave-uniform: part 0 = q, 1 = k, 2 = v; head dim d0 + 4 g + e
-        const int gn = (col0 >> 6) * p.Wd + h * 64 + (col0 & 63) + g * 4;
+        const int gn = (col0 >> 6) * p.Wd + hc * 64 + (col0 & 63) + g * 4;
         sq[j] = *(const f32x4 *)(p.ln_s + gn);
         cq[j] = *(const f32x4 *)(p.ln_c + gn);
     }
     // ---- LayerNorm row statistics of the tile's 256 rows (thread t < 256: row t), as the consumer GEMM finalises them ----
     float2 *lnrow = (float2 *)(smem + QA_LN);
     if (tid < 256) {
-        const f32x4 *sp = (const f32x4 *)(p.ln_stats + (int64_t)min(m0 + tid, p.M - 1) * p.ln_slots * 2);
+        const f32x4 *sp = (const f32x4 *)(p.ln_stats + (int64_t)min(m0c + tid, p.M - 1) * p.ln_slots * 2);
         float s1 = 0.f, s2 = 0.f;
         auto fixed = [&](auto nq_tag) {
             constexpr int NQ = decltype(nq_tag)::value;
@@ -299,17 +321,40 @@ __global__ __launch_bounds__(QA_NT) void qkv_attn(QkvAttnArgs p) {
                 for (int td = 0; td < 4; ++td) res[td] = o[td] * inv;
             }
         }
-        if (qrow < rows_valid && m0 + qrow < p.M) {
-            E *orow = (E *)p.out + (int64_t)(m0 + qrow) * p.ldo + h * 64 + g * 4;
+        if (qrow < rows_valid && m0c + qrow < p.M) {
+            E *orow = (E *)p.out + (int64_t)(m0c + qrow) * p.ldo + hc * 64 + g * 4;
 #pragma unroll
             for (int td = 0; td < 4; ++td) *(vec4 *)(orow + td * 16) = cvt4<DT>(res[td][0], res[td][1], res[td][2], res[td][3]);
         }
     }
+    if (!has_next) break;
+    __syncthreads();            // every wave's attention reads are done: stage 1 (under Q / K) may be refilled
+    issueA(oA0, QA_PA0, 1); issueW(1);
+    cur = nxt;
+  }
 }
 }  // namespace
 
+// HGR_QA_PERSIST=0: one tile per workgroup (grid = tiles); default: one persistent workgroup per CU
+static int qa_persist() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("HGR_QA_PERSIST"); v = e ? atoi(e) : 1; }
+    return v;
+}
+static int qa_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) n = pr.multiProcessorCount;
+        else n = 256;
+    }
+    return n;
+}
+
 void launch_qkv_attn(const QkvAttnArgs &a, int dtype, bool causal, hipStream_t s) {
-    const dim3 grid((unsigned)(a.tiles_m * a.H)), block(QA_NT);
+    const int tiles = a.tiles_m * a.H;
+    const dim3 grid((unsigned)(qa_persist() ? (tiles < qa_cus() ? tiles : qa_cus()) : tiles)), block(QA_NT);
     if (dtype == HGR_BF16) {
         if (causal) hipLaunchKernelGGL((qkv_attn<HGR_BF16, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((qkv_attn<HGR_BF16, false>), grid, block, 0, s, a);

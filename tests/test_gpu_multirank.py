@@ -113,6 +113,8 @@ def test_two_rank_om_step_equals_one_rank(tmp_path):
     assert one["contra"] == two["contra"]                      # same negatives on every rank
     assert abs(one["loss"] - two["loss"]) <= 1e-5 * abs(one["loss"]), (one["loss"], two["loss"])
     worst_img, worst_txt = 0.0, 0.0
+    report = {k: float((g1 - two["grads"][k]).norm() / max(float(g1.norm()), 1e-30)) for k, g1 in one["grads"].items() if float(g1.norm()) >= 1e-9}
+    print("\n[2-rank vs 1-rank OM step] relative L2 per parameter (worst 12): " + ", ".join(f"{k} {v:.1e}" for k, v in sorted(report.items(), key=lambda kv: -kv[1])[:12]))
     for k, g1 in one["grads"].items():
         g2 = two["grads"][k]
         n1 = float(g1.norm())
