@@ -259,6 +259,7 @@ __global__ __launch_bounds__(QA_NT) void qkv_attn(QkvAttnArgs p) {
         const char *qr = smem + QA_Q + qrow * 128;
         const vec8 q0 = *(const vec8 *)(qr + sw0), q1 = *(const vec8 *)(qr + sw1);
         f32x4 res[4];
+        float rinv = 0.f;
 #pragma unroll
         for (int td = 0; td < 4; ++td) res[td] = (f32x4){0.f, 0.f, 0.f, 0.f};
         for (int s = s_lo; s <= s_hi; ++s) {
@@ -317,14 +318,18 @@ __global__ __launch_bounds__(QA_NT) void qkv_attn(QkvAttnArgs p) {
                 }
             }
             if (myseq == s) {
+                rinv = inv;
 #pragma unroll
-                for (int td = 0; td < 4; ++td) res[td] = o[td] * inv;
+                for (int td = 0; td < 4; ++td) res[td] = o[td];
             }
         }
         if (qrow < rows_valid && m0c + qrow < p.M) {
             E *orow = (E *)p.out + (int64_t)(m0c + qrow) * p.ldo + hc * 64 + g * 4;
 #pragma unroll
-            for (int td = 0; td < 4; ++td) *(vec4 *)(orow + td * 16) = cvt4<DT>(res[td][0], res[td][1], res[td][2], res[td][3]);
+            // product and 16-bit conversion in one expression, as in hgr_mha: for f16 hipcc fuses them into v_fma_mixlo_f16 (ONE rounding);
+            // a product kept in fp32 and converted later rounds twice and differs by one f16 ulp in ~3e-5 of the elements
+            for (int td = 0; td < 4; ++td)
+                *(vec4 *)(orow + td * 16) = cvt4<DT>(res[td][0] * rinv, res[td][1] * rinv, res[td][2] * rinv, res[td][3] * rinv);
         }
     }
     if (!has_next) break;

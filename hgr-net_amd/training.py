@@ -334,30 +334,43 @@ class OMTrainer:
         # every rank text-encodes and back-propagates 1 / world of them (see _text_features_dp) instead of all of them
         self.dp_group = None
         self.last_text_rows = 0          # prompts this rank encoded in the last step (tests / accounting)
+        # Data-parallel loss head.  False (default): every rank runs the [b_local, <= 257] head of its own image rows and the feature
+        # gradient dL/d(text features) is all-reduced - scalable, but its fp32 sum is associated differently from a one-rank run, and a
+        # 16-bit backward chain amplifies ANY input difference to its own rounding noise (measured 3 - 4e-3 relative L2 on the text
+        # tower's gradients against the one-rank step; round 3's partial-gradient scheme: 1.8e-2).  True (HGR_DP_EXACT_HEAD=1): the
+        # normalised image features are all-gathered and every rank runs the head over the WHOLE batch - the same kernels on the same
+        # operands in the same order as one rank, so the text tower's backward starts from the same bits (x world, exact) and its
+        # gradients equal the one-rank step's up to the fp32 order of the cross-rank sums (<= 1e-4).  The head's FLOPs are then
+        # replicated on every rank (B_total x <= 257 x D per inner step, fp32): reproducibility across world sizes, not speed.
+        self.dp_exact_head = os.environ.get("HGR_DP_EXACT_HEAD", "0") == "1"
 
-    def _head(self, img_n, dimg_n, tfeat, label_pos: int, weight, loss_acc, ce_out=None):
-        """logits = img_n tn^T * exp(logit_scale); CE (all rows share the label); gradients of the three inputs."""
+    def _head(self, img_n, dimg_n, tfeat, label_pos: int, weight, loss_acc, ce_out=None, replicas: int = 1):
+        """logits = img_n tn^T * exp(logit_scale); CE (all rows share the label); gradients of the three inputs.  ``replicas`` > 1
+        (exact data-parallel head): img_n holds the rows of ALL ranks and every rank runs this same call, so the per-row weight stays
+        that of a rank's own shard (rows / replicas) and the terms every rank would add to a summed gradient carry 1 / replicas."""
         e, m, dev = self.engine, self.engine.m, self.engine.dev
         b, d = img_n.shape
+        b = b // replicas                                      # the shard size the 1/b of the mean refers to (gradients are summed over ranks, then x 1/world)
         n = tfeat.shape[0]
         tn = torch.empty_like(tfeat)
         ops.l2norm_rows(tfeat, y32=tn)
         scale = self._scale
-        logits = torch.empty(b, n, dtype=torch.float32, device=dev)
+        rows = img_n.shape[0]
+        logits = torch.empty(rows, n, dtype=torch.float32, device=dev)
         ops.matmul_f32(img_n, tn.t(), logits, alpha=scale)
-        labels = torch.full((b,), label_pos, dtype=torch.int32, device=dev)
-        loss_rows = torch.empty(b, dtype=torch.float32, device=dev)
+        labels = torch.full((rows,), label_pos, dtype=torch.int32, device=dev)
+        loss_rows = torch.empty(rows, dtype=torch.float32, device=dev)
         dlog = torch.empty_like(logits)
         wv = float(weight)
         ops.ce_rows(logits, labels, loss_rows, dlog, gscale=wv / b)
-        ops.matmul_f32(loss_rows.view(1, b), torch.ones(b, 1, device=dev), loss_acc, alpha=wv / b, accumulate=True)   # loss_j = mean * w
+        ops.matmul_f32(loss_rows.view(1, rows), torch.ones(rows, 1, device=dev), loss_acc, alpha=wv / rows, accumulate=True)   # loss_j = mean * w
         if ce_out is not None:
-            ops.matmul_f32(loss_rows.view(1, b), torch.ones(b, 1, device=dev), ce_out, alpha=1.0 / b)
+            ops.matmul_f32(loss_rows.view(1, rows), torch.ones(rows, 1, device=dev), ce_out, alpha=1.0 / rows)
         ops.matmul_f32(dlog, tn, dimg_n, alpha=scale, accumulate=True)                     # d img_n += s * dlog @ tn
         dtn = torch.empty_like(tn)
         ops.matmul_f32(dlog.t(), img_n, dtn, alpha=scale)                                  # d tn = s * dlog^T @ img_n
         # d logit_scale += sum(dlog * logits)   (logits = cos * exp(ls) => d logits / d ls = logits)
-        ops.dot_f32(dlog, logits, _grad(m.logit_scale).view(1), accumulate=True)
+        ops.dot_f32(dlog, logits, _grad(m.logit_scale).view(1), alpha=1.0 / replicas, accumulate=True)
         dtfeat = torch.empty_like(tfeat)
         ops.l2norm_bwd(tfeat, dtn, dtfeat)
         return dtfeat
@@ -402,7 +415,7 @@ class OMTrainer:
         # n_u rows of the gathered buffer ARE the features in `uniq` order
         return full.view(world * ns, -1)[: len(uniq)], tsave
 
-    def _text_backward_dp(self, dtfeat_u: torch.Tensor, tsave: dict, n_u: int):
+    def _text_backward_dp(self, dtfeat_u: torch.Tensor, tsave: dict, n_u: int, reduce: bool = True):
         """dL/d(text features) is a sum over the images of the WHOLE batch: all-reduce it (sum; [n_u, D] fp32) BEFORE the text
         tower's backward, then every rank back-propagates its own prompts' rows only.  The parameter gradients a rank gets are the
         full-batch gradients of its prompts; the bucketed gradient all-reduce that follows sums them over the prompt shards, exactly
@@ -412,7 +425,8 @@ class OMTrainer:
         import torch.distributed as dist
         e = self.engine
         world, rank, ns, lo, hi = self._text_shard(n_u)
-        dist.all_reduce(dtfeat_u, op=dist.ReduceOp.SUM, group=self.dp_group)
+        if reduce:                     # (exact head: every rank already holds the whole batch's feature gradient)
+            dist.all_reduce(dtfeat_u, op=dist.ReduceOp.SUM, group=self.dp_group)
         mine = torch.zeros(ns, dtfeat_u.shape[1], dtype=torch.float32, device=e.dev)
         if hi > lo:
             mine[: hi - lo] = dtfeat_u[lo:hi]
@@ -467,16 +481,28 @@ class OMTrainer:
             tfeat_u, tsave = e.text_fwd(tree.node_tokens[torch.tensor(uniq, device=e.dev)], getattr(tree, "ctx", None))
             self.last_text_rows = len(uniq)
         dtfeat_u = torch.zeros_like(tfeat_u)
+        exact = dp is not None and self.dp_exact_head
+        img_h, dimg_h, replicas = img_n, dimg_n, 1
+        if exact:
+            # every rank runs the head over the rows of ALL ranks (rank-major: the one-rank run's row order)
+            import torch.distributed as dist
+            replicas, rnk = dist.get_world_size(dp), dist.get_rank(dp)
+            img_h = torch.empty(replicas, img_n.shape[0], img_n.shape[1], dtype=torch.float32, device=e.dev)
+            dist.all_gather(list(img_h.unbind(0)), img_n.contiguous(), group=dp)
+            img_h = img_h.view(replicas * img_n.shape[0], -1)
+            dimg_h = torch.zeros_like(img_h)
         adaptive = tree.opts.weights == "adaptive"
         ces = torch.zeros(len(picks), 1, dtype=torch.float32, device=e.dev) if adaptive else None
         for j, (ids, pos, wgt, _) in enumerate(picks):
             loc = torch.tensor([where[i] for i in ids], dtype=torch.int32, device=e.dev)
             tfeat = torch.empty(len(ids), tfeat_u.shape[1], dtype=torch.float32, device=e.dev)
             ops.rows_gather(tfeat_u, loc, tfeat)
-            dtfeat = self._head(img_n, dimg_n, tfeat, pos, wgt, loss_acc, ces[j: j + 1] if adaptive else None)
+            dtfeat = self._head(img_h, dimg_h, tfeat, pos, wgt, loss_acc, ces[j: j + 1] if adaptive else None, replicas)
             ops.rows_axpy(dtfeat_u, dtfeat, dst_mul=0, dst_idx=loc)
+        if exact:
+            dimg_n.copy_(dimg_h.view(replicas, -1, dimg_h.shape[1])[rnk])          # this rank's rows of the whole-batch image-side gradient
         if dp is not None:
-            self._text_backward_dp(dtfeat_u, tsave, len(uniq))
+            self._text_backward_dp(dtfeat_u, tsave, len(uniq), reduce=not exact)
         else:
             e.text_bwd(dtfeat_u, tsave)
         if adaptive:
