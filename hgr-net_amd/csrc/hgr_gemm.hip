@@ -420,8 +420,8 @@ int hgr_logits_eval_rows_launch(const void *feat, const void *zslp, int D, int S
                                 int32_t *out_topk, int rows, int dtype, void *stream);      // hgr_select.hip
 
 extern "C" int64_t hgr_logits_eval_workspace_bytes(int rows, int n_perm) {
-    if (rows < 1 || n_perm < 128 || n_perm % 128) return -1;
-    return (int64_t)rows * (n_perm / 64) * 56;           // per (row, slice): 8-byte train key + per 16-column group (max, position, second) = 4 x 12 bytes
+    if (rows < 1 || n_perm < 96 || n_perm % 96) return -1;
+    return (int64_t)rows * (n_perm / 32) * 32;           // per (row, 32-column slice): 8-byte train key + per 16-column group (max, position, second) = 2 x 12 bytes
 }
 
 extern "C" int hgr_logits_eval(const void *feat16, const void *zsl_perm16, int rows, int D, int n_perm,
@@ -431,22 +431,21 @@ extern "C" int hgr_logits_eval(const void *feat16, const void *zsl_perm16, int r
                                int32_t *out_level, int32_t *out_top1, int32_t *out_topk, void *workspace, int dtype, void *stream) {
     HGR_REQUIRE(feat16 && zsl_perm16 && tpos_perm && epos_perm && level_first && filler_pos && train_cols && out_level && workspace, "hgr_logits_eval: null operand");
     HGR_REQUIRE(rows >= 1 && D >= 128 && D % 128 == 0 && D <= 1024, "hgr_logits_eval: rows=%d D=%d unsupported (D %% 128 == 0, D <= 1024)", rows, D);
-    HGR_REQUIRE(n_perm >= 128 && n_perm % 128 == 0 && n_perm / 64 <= 1024, "hgr_logits_eval: n_perm=%d must be a multiple of 128 and <= 65536 (level-aligned, padded columns)", n_perm);
+    HGR_REQUIRE(n_perm >= 96 && n_perm % 96 == 0 && n_perm / 32 <= 1024, "hgr_logits_eval: n_perm=%d must be a multiple of 96 and <= 32768 (32-column level-aligned slices, 96-column slabs)", n_perm);
     HGR_REQUIRE(n_levels >= 1 && n_levels <= 32 && n_train >= 1, "hgr_logits_eval: bad sizes (n_levels <= 32)");
     HGR_REQUIRE(k == 0 || (out_topk && test_cols && k >= 1 && k <= 32 && n_test >= k), "hgr_logits_eval: bad top-k arguments");
     HGR_REQUIRE(hgr_aligned(feat16, 16) && hgr_aligned(zsl_perm16, 16) && hgr_aligned(tpos_perm, 16) && hgr_aligned(epos_perm, 16) && hgr_aligned(workspace, 16), "hgr_logits_eval: operands must be 16-byte aligned");
     HGR_REQUIRE(dtype == HGR_BF16 || dtype == HGR_F16, "hgr_logits_eval: bad dtype %d", dtype);
-    const int S = n_perm / 64;
-    GemmArgs a;
-    ln_args(a, feat16, D, zsl_perm16, D, nullptr, 0, rows, n_perm, D);
+    HGR_REQUIRE((int64_t)rows * D * 2 < (1ll << 32) && (int64_t)n_perm * D * 2 < (1ll << 32), "hgr_logits_eval: operands beyond 4 GB");
+    const int S = n_perm / 32;
+    SlabArgs a;
+    a.A = (const char *)feat16; a.lda = D; a.W = (const char *)zsl_perm16; a.ldw = D; a.M = rows; a.K = D; a.Np = n_perm;
+    a.tpos = tpos_perm; a.epos = epos_perm; a.S = S;
     a.ev_key = (unsigned long long *)workspace;
     a.ev_tmax = (float *)((char *)workspace + (size_t)rows * S * 8);
-    a.ev_p1 = (int *)((char *)workspace + (size_t)rows * S * 24);
-    a.ev_m2 = (float *)((char *)workspace + (size_t)rows * S * 40);
-    a.ev_tpos = tpos_perm; a.ev_epos = epos_perm; a.ev_slices = S;
-    dim3 grid;
-    duo_apply_plan(a, true, grid);
-    launch_duo(a, dtype, HGR_EPI_NONE, true, 3, grid, (hipStream_t)stream);
+    a.ev_p1 = (int *)((char *)workspace + (size_t)rows * S * 16);
+    a.ev_m2 = (float *)((char *)workspace + (size_t)rows * S * 24);
+    launch_logits_slab(a, dtype, (hipStream_t)stream);
     HGR_CHECK_LAUNCH("hgr_logits_eval (tile stage)");
     return hgr_logits_eval_rows_launch(feat16, zsl_perm16, D, S, a.ev_key, a.ev_tmax, a.ev_p1, a.ev_m2, level_first, n_levels, filler_pos, train_cols, n_train,
                                        epos_perm, test_cols, n_test, k, out_level, out_top1, out_topk, rows, dtype, stream);

@@ -51,10 +51,6 @@ struct GemmArgs {
     // gemm_nt_duo tail plan (duo_plan): blocks [0, nbig) = full 256 x 128 tiles on row panels [0, big_panels), the remaining blocks =
     // 128 x 128 half tiles on the rows behind them (tiles_m_half panels of 128 rows).  No tail: nbig = grid, big_panels = tiles_m.
     int nbig, big_panels, tiles_m_half;
-    // fused evaluation (LN = 3, hgr_logits_eval): W = level-sorted, level-aligned class matrix, so every 64-column slice (one
-    // wave's share of a tile) lies inside ONE hierarchy level.  Nothing of C is written; per (row, slice) the epilogue emits
-    // the best train column as an orderable key and the largest value over the test columns.
-    unsigned long long *ev_key; float *ev_tmax, *ev_m2; int *ev_p1; const int *ev_tpos, *ev_epos; int ev_slices;
 };
 
 
@@ -205,8 +201,20 @@ enum { V128_PLAIN = 0, V128_TALL = 1, V128_CONV = 2, V128_CONV_TALL = 3 };
 void launch_128(const GemmArgs &a, int dtype, int epi, bool out32, int variant, dim3 grid, hipStream_t s);
 // gemm_nt_256: plain (any epi) or the implicit-GEMM convolution (BIAS_RELU, 16-bit out)
 void launch_256(const GemmArgs &a, int dtype, int epi, bool out32, bool conv, dim3 grid, hipStream_t s);
-// gemm_nt_duo: ln = 0 plain (any epi), 1 LayerNorm producer, 2 LayerNorm consumer (epi BIAS / BIAS_QUICKGELU), 3 evaluation
-// consumers (hgr_logits_eval), 4 dual output (pre-activation + QuickGELU)
+// gemm_nt_duo: ln = 0 plain (any epi), 1 LayerNorm producer, 2 LayerNorm consumer (epi BIAS / BIAS_QUICKGELU), 4 dual output
+// (pre-activation + QuickGELU), 5 the 3 x 3 convolution
 void launch_duo(const GemmArgs &a, int dtype, int epi, bool out32, int ln, dim3 grid, hipStream_t s);
+
+// first stage of hgr_logits_eval (hgr_logits_slab.hip): 512-row x 96-column tiles, one per CU, evaluation consumers in the epilogue
+struct SlabArgs {
+    const char *A; int64_t lda;          // features [M, K] 16-bit
+    const char *W; int64_t ldw;          // level-sorted class matrix [Np, K] 16-bit, Np % 96 == 0
+    int M, K, Np;
+    const int *tpos, *epos;              // [Np] train / test position of every permuted column (-1 = not in the subset / padding)
+    unsigned long long *ev_key;          // [M][S]      S = Np / 32
+    float *ev_tmax, *ev_m2; int *ev_p1;  // [M][S][2]
+    int S;
+};
+void launch_logits_slab(const SlabArgs &a, int dtype, hipStream_t s);
 
 }  // namespace hgr_gemm

@@ -333,75 +333,6 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
     if (!(p.dbg & 16)) __builtin_amdgcn_s_setprio(3);
 
     // tile (a, b, i, j) of this lane holds C[m][n .. n+3],  m = m0 + wm*128 + a*64 + i*16 + r,  n = n0 + wn*64 + b*32 + j*16 + g*4
-    if (LN == 3) {
-        // Evaluation consumers in place of the C store (main.py:136-176 consuming model/clip_tree.py:331).  This wave's 128 rows x
-        // 64 columns are slice s = n0 / 64 + wn of every row; a lane holds, per row, 16 of the 64 columns (4 quads), the other
-        // 48 sit in the lanes r + 16, r + 32, r + 48.  key = (orderable(value) << 32) | (0x7fffffff - train position): unsigned
-        // max = "larger value, then smaller position" (the tie rule of logits[:, train_index].topk); 0 = no train column.
-        const int sl = (n0 >> 6) + wn;
-        int tp[2][2][4], ep[2][2][4];
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + wn * 64 + b * 32 + j * 16 + g * 4;
-            const int4 t4 = *(const int4 *)(p.ev_tpos + n), e4 = *(const int4 *)(p.ev_epos + n);
-            tp[b][j][0] = t4.x; tp[b][j][1] = t4.y; tp[b][j][2] = t4.z; tp[b][j][3] = t4.w;
-            ep[b][j][0] = e4.x; ep[b][j][1] = e4.y; ep[b][j][2] = e4.z; ep[b][j][3] = e4.w;
-        }
-#pragma unroll
-        for (int a = 0; a < MH; ++a)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            unsigned long long key = 0ull;
-            // per 16-column group (b, j) of the slice: largest test value, the test position of one element attaining it, and
-            // the second largest value (multiplicity counted: m2 == m1 when the maximum is attained twice)
-            f32x4 m1, m2;
-            int p1[4];
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                float x[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float v = acc[a][b][i][j][e] + 0.0f;             // -0 -> +0, as the row sweep of hgr_eval_rows does
-                    const unsigned u = __float_as_uint(v);
-                    const unsigned long long k2 = ((unsigned long long)(u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u)) << 32) | (unsigned)(0x7fffffff - tp[b][j][e]);
-                    if (tp[b][j][e] >= 0 && k2 > key) key = k2;
-                    x[e] = ep[b][j][e] >= 0 ? v : -INFINITY;
-                }
-                const float hi01 = fmaxf(x[0], x[1]), lo01 = fminf(x[0], x[1]), hi23 = fmaxf(x[2], x[3]), lo23 = fminf(x[2], x[3]);
-                const float top = fmaxf(hi01, hi23);
-                m1[b * 2 + j] = top;
-                m2[b * 2 + j] = fmaxf(fminf(hi01, hi23), fmaxf(lo01, lo23));
-                p1[b * 2 + j] = x[0] == top ? ep[b][j][0] : x[1] == top ? ep[b][j][1] : x[2] == top ? ep[b][j][2] : ep[b][j][3];
-            }
-#pragma unroll
-            for (int o = 16; o <= 32; o <<= 1) {
-                const unsigned hi = __shfl_xor((unsigned)(key >> 32), o), lo = __shfl_xor((unsigned)key, o);
-                const unsigned long long x = ((unsigned long long)hi << 32) | lo;
-                key = x > key ? x : key;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float o1 = __shfl_xor(m1[q], o), o2 = __shfl_xor(m2[q], o);
-                    const int op = __shfl_xor(p1[q], o);
-                    m2[q] = fmaxf(fminf(m1[q], o1), fmaxf(m2[q], o2));
-                    p1[q] = o1 > m1[q] ? op : p1[q];
-                    m1[q] = fmaxf(m1[q], o1);
-                }
-            }
-            const int m = m0 + wm * WR + a * 64 + i * 16 + r;
-            if (g == 0 && m < p.M) {
-                const int64_t at = (int64_t)m * p.ev_slices + sl;
-                p.ev_key[at] = key;
-                *(f32x4 *)(p.ev_tmax + at * 4) = m1;
-                *(int4 *)(p.ev_p1 + at * 4) = make_int4(p1[0], p1[1], p1[2], p1[3]);
-                *(f32x4 *)(p.ev_m2 + at * 4) = m2;
-            }
-        }
-        return;
-    }
     constexpr bool HAS_BIAS = epi_has_bias(EPI);
     constexpr bool HAS_ADD = EPI == HGR_EPI_BIAS_RESIDUAL || EPI == HGR_EPI_ACCUM;
     const bool full = p.vec_ok && m0 + 2 * WR <= p.M && n0 + 128 <= p.N;
@@ -838,7 +769,6 @@ void launch_duo_dt(const GemmArgs &a, int epi, bool out32, int ln, dim3 grid, hi
             if (epi == HGR_EPI_BIAS_QUICKGELU) hipLaunchKernelGGL((gemm_nt_duo<DT, HGR_EPI_BIAS_QUICKGELU, false, 2>), grid, dim3(NTD), 0, s, a);
             else hipLaunchKernelGGL((gemm_nt_duo<DT, HGR_EPI_BIAS, false, 2>), grid, dim3(NTD), 0, s, a);
             return;
-        case 3: hipLaunchKernelGGL((gemm_nt_duo<DT, HGR_EPI_NONE, true, 3>), grid, dim3(NTD), 0, s, a); return;
         case 4: hipLaunchKernelGGL((gemm_nt_duo<DT, HGR_EPI_BIAS, false, 4>), grid, dim3(NTD), 0, s, a); return;
         case 5: hipLaunchKernelGGL((gemm_nt_duo<DT, HGR_EPI_BIAS_RELU, false, 0, true>), grid, dim3(NTD), 0, s, a); return;   // 3 x 3 convolution (implicit im2col loader)
         default: break;

@@ -1,0 +1,210 @@
+// =================================================================================================
+// First stage of hgr_logits_eval: logits = feat . zsl_perm^T (model/clip_tree.py:331) with the evaluation consumers of main.test
+// (main.py:136-176) in the epilogue - nothing [B, N] is written.
+//
+// north_star asks >= 40 % of the MFMA peak of this product ([512 x 512] . [512 x 21 841]: 11.45 GFLOP = 11.5 us).  Rounds 2 / 3 ran
+// it on gemm_nt_duo's 128 x 128 half tiles: 712 workgroups on 512 slots, every one a prologue + 8 K-tiles + an epilogue with nothing
+// to overlap - 29.9 us.  This kernel gives every CU ONE tile of the whole batch:
+//
+//   tile = 512 rows (the batch) x 96 columns x K;  grid = N' / 96 slabs (230 at N = 21 841: one round on 256 CUs, every CU the same
+//   work) x ceil(rows / 512);  512 threads = 8 waves, wave w owns rows 64 w .. 64 w + 63 x all 96 columns = 4 x 6 MFMA tiles.
+//
+// The class matrix streams through each CU exactly once (96 rows x 2 D bytes per CU, 22 MB chip-wide from HBM); the 512 x D feature
+// matrix (written microseconds earlier by l2norm_rows) is re-read by every CU out of its XCD's L2.  Staging and main loop are those
+// of hgr_gemm_nt_ln_mha (hgr_qkv_attn.hip): LDS-DMA pieces cut by the phase that reads them - PA0 (rows 0-31 of every wave, 32 KB),
+// PW (the 96 class rows, padded to 16 KB), PA1 (rows 32-63, 32 KB) - two stages of 80 KB = the CU's whole LDS, counted vmcnt(10)
+// waits, one barrier per interval, waves 0-3 / 4-7 one interval apart (ping-pong):
+//     ph1(t): issues PA1(t+1) x4               reads W (12 x ds_read_b128), A rows 0-31 (4 x)    24 MFMAs
+//     ph2(t): issues PA0(t+2) x4, PW(t+2) x2   reads A rows 32-63 (4 x)                           24 MFMAs
+//
+// Epilogue: the class matrix is LEVEL-SORTED and level-aligned to 32 columns (ops.LogitsEvalPlan), so every 32-column slice - two of
+// a lane's n tiles - lies inside one hierarchy level.  Per (row, slice): the best train column as an orderable 64-bit key
+// (value, then smaller train position - the tie rule of logits[:, train_index].topk); per 16-column group the largest test value, the
+// test position of an element attaining it and the second largest value.  32 bytes per (row, slice), written as ONE 8-byte store per
+// lane (lane group g = 0 .. 3 writes key / maxima / positions / second values).  hgr_logits_eval's row stage (hgr_select.hip) turns
+// them into the level arg-max, the top-1 and the top-k.
+// =================================================================================================
+#include "hgr_gemm_common.h"
+
+namespace hgr_gemm {
+
+namespace {
+constexpr int LS_NT = 512;
+constexpr int LS_PA0 = 0, LS_PA1 = 32768, LS_PW = 65536, LS_STAGE = 81920, LS_LDS = 2 * LS_STAGE;     // 163 840 B: all of the CU's LDS
+
+template <int DT>
+__global__ __launch_bounds__(LS_NT) void logits_slab(SlabArgs p) {
+    typedef typename T16<DT>::vec8 vec8;
+    __shared__ __attribute__((aligned(1024))) char smem[LS_LDS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pg = wave >> 2;                      // waves w and w + 4 share a SIMD: the ping-pong group
+    const int r = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * 96, m0 = blockIdx.y * 512;
+
+    // per-lane source offsets of one K-tile's LDS-DMA instructions (bytes from A / W; operands < 4 GB, checked on the host)
+    unsigned oA0[4], oA1[4], oW[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int id = (i * 8 + wave) * 64 + lane;
+        const int pr = id >> 3, c = (id & 7) ^ (pr & 7);
+        const int tr = (pr >> 5) * 64 + (pr & 31);              // PA0 piece row pr = rows 0-31 of wave pr / 32
+        oA0[i] = (unsigned)(((int64_t)min(m0 + tr, p.M - 1) * p.lda + c * 8) * 2);
+        oA1[i] = (unsigned)(((int64_t)min(m0 + tr + 32, p.M - 1) * p.lda + c * 8) * 2);
+        if (i < 2) oW[i] = (unsigned)(((int64_t)(n0 + min(pr, 95)) * p.ldw + c * 8) * 2);      // piece rows 96-127: padding (row 95 again)
+    }
+    char *const ldsw = smem + wave * 1024;
+    const __amdgpu_buffer_rsrc_t rA = dma_rsrc(p.A), rW = dma_rsrc(p.W);
+    auto issueA = [&](const unsigned (&off)[4], int piece, int t) {
+        char *dst = ldsw + (t & 1) * LS_STAGE + piece;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma16(rA, p.A, off[i], t * 128, dst + i * 8192);
+    };
+    auto issueW = [&](int t) {
+        char *dst = ldsw + (t & 1) * LS_STAGE + LS_PW;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) dma16(rW, p.W, oW[i], t * 128, dst + i * 8192);
+    };
+
+    f32x4 acc[4][6];            // [m tile][n tile]: logits[m0 + 64 wave + 16 i + r][n0 + 16 j + 4 g .. + 3]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / 64;    // >= 2 (host guarantees)
+    const int offA = (wave * 32 + r) * 128;        // + m tile (0, 1) * 2048 within PA0 / PA1
+    const int offW = r * 128;                      // + n tile * 2048 within PW
+    const int sw0 = ((0 + g) ^ (r & 7)) * 16, sw1 = ((4 + g) ^ (r & 7)) * 16;
+    vec8 wf[6][2], af[2][2];
+
+    // prologue in steady-state order: PA0(0), PW(0) | PA1(0) | PA0(1), PW(1)
+    issueA(oA0, LS_PA0, 0); issueW(0);
+    issueA(oA1, LS_PA1, 0);
+    issueA(oA0, LS_PA0, 1); issueW(1);
+    HGR_RWAIT(10);              // PA0(0), PW(0) landed
+    if (pg) HGR_MBAR();         // ping-pong: group 1 runs one barrier interval behind group 0
+
+    // MODE 0: steady state (t + 2 < nk), 1: second-last K-tile, 2: last K-tile
+    auto ktile = [&](int t, auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        const char *st = smem + (t & 1) * LS_STAGE;
+        // ---- ph1: rows 0-31 of the wave x all 96 columns ----
+        if (MODE <= 1) issueA(oA1, LS_PA1, t + 1);              // its slot was last read in ph2(t - 1), two barriers ago
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            wf[j][0] = *(const vec8 *)(st + LS_PW + offW + j * 2048 + sw0);
+            wf[j][1] = *(const vec8 *)(st + LS_PW + offW + j * 2048 + sw1);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            af[i][0] = *(const vec8 *)(st + LS_PA0 + offA + i * 2048 + sw0);
+            af[i][1] = *(const vec8 *)(st + LS_PA0 + offA + i * 2048 + sw1);
+        }
+        if (MODE <= 1) HGR_RWAIT(10); else HGR_RWAIT(0);        // PA1(t) landed
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) acc[i][j] = T16<DT>::mfma16(wf[j][kk], af[i][kk], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        HGR_MBAR();
+        // ---- ph2: rows 32-63 ----
+        if (MODE == 0) { issueA(oA0, LS_PA0, t + 2); issueW(t + 2); }     // read in ph1(t), two barriers ago
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            af[i][0] = *(const vec8 *)(st + LS_PA1 + offA + i * 2048 + sw0);
+            af[i][1] = *(const vec8 *)(st + LS_PA1 + offA + i * 2048 + sw1);
+        }
+        if (MODE == 0) HGR_RWAIT(10); else if (MODE == 1) HGR_RWAIT(4); else HGR_RBAR();     // PA0(t+1), PW(t+1) landed
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) acc[2 + i][j] = T16<DT>::mfma16(wf[j][kk], af[i][kk], acc[2 + i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        HGR_MBAR();
+    };
+    for (int t = 0; t < nk - 2; ++t) ktile(t, std::integral_constant<int, 0>());
+    ktile(nk - 2, std::integral_constant<int, 1>());
+    ktile(nk - 1, std::integral_constant<int, 2>());
+    if (!pg) HGR_MBAR();        // (barrier counts of the two groups balanced; nothing below touches LDS)
+
+    // ---- evaluation consumers.  Lane (r, g) holds, of row m = m0 + 64 wave + 16 i + r, the columns n0 + 16 j + 4 g + e (e = 0..3)
+    // of n tile j; a 32-column slice = n tiles 2 s, 2 s + 1, the other 3/4 of its columns sit in the lanes r + 16, r + 32, r + 48 ----
+    int tp[6][4], ep[6][4];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int n = n0 + j * 16 + g * 4;
+        const int4 t4 = *(const int4 *)(p.tpos + n), e4 = *(const int4 *)(p.epos + n);
+        tp[j][0] = t4.x; tp[j][1] = t4.y; tp[j][2] = t4.z; tp[j][3] = t4.w;
+        ep[j][0] = e4.x; ep[j][1] = e4.y; ep[j][2] = e4.z; ep[j][3] = e4.w;
+    }
+    // lane group g writes one of the four 8-byte records of a (row, slice): 0 = key, 1 = (m1, m1'), 2 = (p1, p1'), 3 = (m2, m2')
+    char *const rec = g == 0 ? (char *)p.ev_key : g == 1 ? (char *)p.ev_tmax : g == 2 ? (char *)p.ev_p1 : (char *)p.ev_m2;
+    const int sl0 = blockIdx.x * 3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wave * 64 + i * 16 + r;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            unsigned long long key = 0ull;
+            float m1[2], m2[2];
+            int p1[2];
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = 2 * s + jj;
+                float x[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = acc[i][j][e] + 0.0f;               // -0 -> +0, as the row sweep of hgr_eval_rows does
+                    const unsigned u = __float_as_uint(v);
+                    const unsigned long long k2 = ((unsigned long long)(u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u)) << 32) | (unsigned)(0x7fffffff - tp[j][e]);
+                    if (tp[j][e] >= 0 && k2 > key) key = k2;
+                    x[e] = ep[j][e] >= 0 ? v : -INFINITY;
+                }
+                const float hi01 = fmaxf(x[0], x[1]), lo01 = fminf(x[0], x[1]), hi23 = fmaxf(x[2], x[3]), lo23 = fminf(x[2], x[3]);
+                const float top = fmaxf(hi01, hi23);
+                m1[jj] = top;
+                m2[jj] = fmaxf(fminf(hi01, hi23), fmaxf(lo01, lo23));
+                p1[jj] = x[0] == top ? ep[j][0] : x[1] == top ? ep[j][1] : x[2] == top ? ep[j][2] : ep[j][3];
+            }
+#pragma unroll
+            for (int o = 16; o <= 32; o <<= 1) {
+                const unsigned hi = __shfl_xor((unsigned)(key >> 32), o), lo = __shfl_xor((unsigned)key, o);
+                const unsigned long long x = ((unsigned long long)hi << 32) | lo;
+                key = x > key ? x : key;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const float o1 = __shfl_xor(m1[q], o), o2 = __shfl_xor(m2[q], o);
+                    const int op = __shfl_xor(p1[q], o);
+                    m2[q] = fmaxf(fminf(m1[q], o1), fmaxf(m2[q], o2));
+                    p1[q] = o1 > m1[q] ? op : p1[q];
+                    m1[q] = fmaxf(m1[q], o1);
+                }
+            }
+            if (m < p.M) {
+                const unsigned long long v8 = g == 0 ? key
+                    : g == 1 ? ((unsigned long long)__float_as_uint(m1[1]) << 32) | __float_as_uint(m1[0])
+                    : g == 2 ? ((unsigned long long)(unsigned)p1[1] << 32) | (unsigned)p1[0]
+                             : ((unsigned long long)__float_as_uint(m2[1]) << 32) | __float_as_uint(m2[0]);
+                *(unsigned long long *)(rec + ((int64_t)m * p.S + sl0 + s) * 8) = v8;
+            }
+        }
+    }
+}
+}  // namespace
+
+void launch_logits_slab(const SlabArgs &a, int dtype, hipStream_t s) {
+    const dim3 grid((unsigned)(a.Np / 96), (unsigned)((a.M + 511) / 512)), block(LS_NT);
+    if (dtype == HGR_BF16) hipLaunchKernelGGL((logits_slab<HGR_BF16>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((logits_slab<HGR_F16>), grid, block, 0, s, a);
+}
+
+}  // namespace hgr_gemm

@@ -515,18 +515,18 @@ __global__ __launch_bounds__(EL_NT) void eval_rows_lds(const float *__restrict__
 }
 
 
-// ---- second stage of hgr_logits_eval (first stage: gemm_nt_duo<.., LN = 3> in hgr_gemm.hip) ------------------------------------
-// One workgroup per image row.  Input: per 64-column slice of the level-sorted class matrix the best train key of this row and the
-// largest test value of each of the slice's four 16-column groups.  (1) level arg-max = max of the keys of the level's slices,
+// ---- second stage of hgr_logits_eval (first stage: logits_slab in hgr_logits_slab.hip) ------------------------------------------
+// One workgroup per image row.  Input: per 32-column slice of the level-sorted class matrix the best train key of this row and the
+// largest test value of each of the slice's two 16-column groups (LE_GPS groups per slice).  (1) level arg-max = max of the keys of the level's slices,
 // with the reference's -1 filler rule; unmasked top-1 = best of the level bests; (2) threshold t = k-th largest SLICE maximum over
 // the test columns (k distinct elements >= t exist; fewer than k non-empty slices: t = -inf); (3) only a 16-column group whose
 // maximum reaches t can hold one of the k best (typically k .. k + 5 groups of ~1 400): its 16 logits are recomputed on the matrix
 // cores with the first stage's operand roles and K order (bit-identical values), elements >= t are ranked by (value, test
 // position).  The [B, N] logits never exist in memory.
-constexpr int LE_NT = 512, LE_NW = LE_NT / 64, LE_MAXS = 1024, LE_CAP = 2048;
+constexpr int LE_NT = 512, LE_NW = LE_NT / 64, LE_MAXS = 1024, LE_CAP = 2048, LE_GPS = 2;
 
 template <int DT>
-__global__ __launch_bounds__(LE_NT) void logits_eval_rows(const void *__restrict__ feat, const void *__restrict__ zslp, int D, int S,
+__global__ __launch_bounds__(LE_NT, 4) void logits_eval_rows(const void *__restrict__ feat, const void *__restrict__ zslp, int D, int S,
                                                         const unsigned long long *__restrict__ keys, const float *__restrict__ gmax,
                                                         const int *__restrict__ gp1, const float *__restrict__ gm2,
                                                         const int32_t *__restrict__ level_first, int n_levels, const int32_t *__restrict__ filler_pos,
@@ -535,11 +535,14 @@ __global__ __launch_bounds__(LE_NT) void logits_eval_rows(const void *__restrict
                                                         int32_t *__restrict__ out_level, int32_t *__restrict__ out_top1, int32_t *__restrict__ out_topk, int dbg) {
     typedef typename T16<DT>::vec8 vec8;
     typedef typename T16<DT>::elem E;
+    // 58 KB of LDS: two rows per CU, so the 512 rows of a batch are one round on 256 CUs
     __shared__ unsigned long long s_lkey[32];
     __shared__ unsigned long long s_keys[LE_MAXS];
-    __shared__ __attribute__((aligned(16))) float s_gm[LE_MAXS * 4];
+    __shared__ __attribute__((aligned(16))) float s_gm[LE_MAXS * LE_GPS];
+    __shared__ __attribute__((aligned(16))) float s_m2[LE_MAXS * LE_GPS];
+    __shared__ __attribute__((aligned(16))) int s_p1[LE_MAXS * LE_GPS];
     __shared__ float s_tm[LE_MAXS];
-    __shared__ short s_cand[LE_MAXS * 4];
+    __shared__ short s_cand[LE_MAXS * LE_GPS];
     __shared__ __attribute__((aligned(16))) E s_feat[1024];
     __shared__ float s_cv[LE_CAP];
     __shared__ int s_cp[LE_CAP];
@@ -551,38 +554,95 @@ __global__ __launch_bounds__(LE_NT) void logits_eval_rows(const void *__restrict
     const int row = blockIdx.x;
     if (tid < 32) s_lkey[tid] = 0ull;
     if (tid == 0) { s_ncand = 0; s_cnt = 0; s_nonempty = 0; s_t = -INFINITY; }
-    for (int c = tid; c < (D >> 3); c += LE_NT) ((u32x4 *)s_feat)[c] = ((const u32x4 *)((const E *)feat + (int64_t)row * D))[c];
-    __syncthreads();
+    // ONE round trip to memory for everything the row needs: the first stage's four records of every slice (S <= 1024: at most two
+    // slices per thread, all eight loads requested before the first use) and the image's feature row (the recompute's B operand).
+    // Round 3 took five dependent trips (feature row | keys + maxima | ... | second values and positions of the groups above the
+    // threshold | class rows of the recomputed groups): 18.5 us for 7 MB.
     {
-        int mine = 0;                                       // non-empty slices seen by this thread (one LDS atomic per WAVE: same-address
-        for (int s = tid; s < S; s += LE_NT) {              // LDS atomics serialise, 355 of them cost more than the rest of the kernel)
-            const f32x4 g4 = *(const f32x4 *)(gmax + ((int64_t)row * S + s) * 4);
-            s_keys[s] = keys[(int64_t)row * S + s];
-            *(f32x4 *)(s_gm + s * 4) = g4;
-            const float t = fmaxf(fmaxf(g4[0], g4[1]), fmaxf(g4[2], g4[3]));
-            s_tm[s] = t;
+        const int s0 = tid, s1 = tid + LE_NT;
+        const int64_t r0 = (int64_t)row * S + min(s0, S - 1), r1 = (int64_t)row * S + min(s1, S - 1);
+        const unsigned long long k0 = keys[r0], k1 = keys[r1];
+        const float2 a0 = *(const float2 *)(gmax + r0 * LE_GPS), a1 = *(const float2 *)(gmax + r1 * LE_GPS);
+        const float2 b0 = *(const float2 *)(gm2 + r0 * LE_GPS), b1 = *(const float2 *)(gm2 + r1 * LE_GPS);
+        const int2 c0 = *(const int2 *)(gp1 + r0 * LE_GPS), c1 = *(const int2 *)(gp1 + r1 * LE_GPS);
+        u32x4 fv = (u32x4){0u, 0u, 0u, 0u};
+        if (tid < (D >> 3)) fv = ((const u32x4 *)((const E *)feat + (int64_t)row * D))[tid];
+        int mine = 0;
+        if (s0 < S) {
+            s_keys[s0] = k0; *(float2 *)(s_gm + s0 * LE_GPS) = a0; *(float2 *)(s_m2 + s0 * LE_GPS) = b0; *(int2 *)(s_p1 + s0 * LE_GPS) = c0;
+            const float t = fmaxf(a0.x, a0.y);
+            s_tm[s0] = t;
             mine += t > -INFINITY ? 1 : 0;
         }
+        if (s1 < S) {
+            s_keys[s1] = k1; *(float2 *)(s_gm + s1 * LE_GPS) = a1; *(float2 *)(s_m2 + s1 * LE_GPS) = b1; *(int2 *)(s_p1 + s1 * LE_GPS) = c1;
+            const float t = fmaxf(a1.x, a1.y);
+            s_tm[s1] = t;
+            mine += t > -INFINITY ? 1 : 0;
+        }
+        if (tid < (D >> 3)) ((u32x4 *)s_feat)[tid] = fv;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
-        if (lane == 0 && mine) atomicAdd(&s_nonempty, mine);
+        if (lane == 0 && mine) atomicAdd(&s_nonempty, mine);     // one LDS atomic per WAVE (same-address LDS atomics serialise)
     }
     __syncthreads();
-    // level bests: the slices of level l are the contiguous range [level_first[l], level_first[l + 1]); wave w reduces levels
-    // w, w + 8, ... from the staged keys (same-address LDS atomics would serialise: ~30 per level)
-    for (int l = wave; l < n_levels; l += LE_NW) {
-        unsigned long long m = 0ull;
-        for (int s = level_first[l] + lane; s < level_first[l + 1]; s += 64) { const unsigned long long x = s_keys[s]; m = x > m ? x : m; }
+    const bool want_k = k > 0 && dbg != 1;
+    if (wave == 0 && want_k && s_nonempty >= k) {
+        // threshold t: any value such that at least k DISTINCT test elements are >= t will do (a smaller t only lengthens the
+        // candidate list).  Lane l holds the maxima of slices l, l + 64, ...; m = the largest of them.  The k-th largest of the 64
+        // lane maxima is such a value (k lanes reach it, each with an element of its own) and costs one rank count per lane; round 3
+        // ran a 32-step bisection over all slice maxima here (ballot + popcount per register and step: ~3.7 us of one wave).  With
+        // fewer than k non-empty lanes (a tiny, clustered test set) the exact k-th largest slice maximum is bisected as before.
+        unsigned kv[LE_MAXS / 64];
+        const int nreg = (S + 63) >> 6;                     // registers that hold real slices (11 at N = 21 841): wave-uniform
+        unsigned best = 0;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const unsigned hi = __shfl_xor((unsigned)(m >> 32), o), lo = __shfl_xor((unsigned)m, o);
-            const unsigned long long x = ((unsigned long long)hi << 32) | lo;
-            m = x > m ? x : m;
+        for (int i = 0; i < LE_MAXS / 64; ++i) {
+            const int s = i * 64 + lane;
+            const unsigned u = __float_as_uint(s < S ? s_tm[s] : -INFINITY);
+            kv[i] = u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+            best = max(best, kv[i]);
         }
-        if (lane == 0) s_lkey[l] = m;
+        const unsigned ninf = 0x007FFFFFu;                  // orderable key of -inf
+        const int lanes_live = __popcll(__ballot(best > ninf));
+        unsigned x = 0;
+        if (lanes_live >= k) {
+            int rk = 0;                                     // number of lanes whose maximum beats mine (ties: lower lane first)
+            for (int j = 0; j < 64; ++j) {
+                const unsigned o = (unsigned)__builtin_amdgcn_readlane((int)best, j);
+                rk += (o > best || (o == best && j < lane)) ? 1 : 0;
+            }
+            const unsigned long long pick = __ballot(rk == k - 1);
+            x = (unsigned)__builtin_amdgcn_readlane((int)best, (int)__builtin_ctzll(pick));
+        } else {
+            for (int bit = 31; bit >= 0; --bit) {
+                const unsigned c = x | (1u << bit);
+                int cntc = 0;
+#pragma unroll
+                for (int i = 0; i < LE_MAXS / 64; ++i)
+                    if (i < nreg) cntc += __popcll(__ballot(kv[i] >= c));
+                if (cntc >= k) x = c;
+            }
+        }
+        if (lane == 0) s_t = __uint_as_float(x ^ ((x >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+    } else if (wave > 0 || !want_k || s_nonempty < k) {
+        // level bests: the slices of level l are the contiguous range [level_first[l], level_first[l + 1]); waves 1 .. 7 (all eight when
+        // no threshold is wanted) reduce the levels from the staged keys while wave 0 finds the threshold
+        const int w0 = (want_k && s_nonempty >= k) ? 1 : 0, nw = LE_NW - w0;
+        for (int l = wave - w0; l < n_levels; l += nw) {
+            unsigned long long m = 0ull;
+            for (int s = level_first[l] + lane; s < level_first[l + 1]; s += 64) { const unsigned long long x = s_keys[s]; m = x > m ? x : m; }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned hi = __shfl_xor((unsigned)(m >> 32), o), lo = __shfl_xor((unsigned)m, o);
+                const unsigned long long x = ((unsigned long long)hi << 32) | lo;
+                m = x > m ? x : m;
+            }
+            if (lane == 0) s_lkey[l] = m;
+        }
     }
     __syncthreads();
-    if (wave == 0) {                                        // lane l < n_levels finishes level l (hgr_eval_rows' rule, main.py:162-176)
+    if (wave == LE_NW - 1) {                                // lane l < n_levels finishes level l (hgr_eval_rows' rule, main.py:162-176)
         const int l = lane;
         Best b = {-INFINITY, 0x7fffffff};
         if (l < n_levels) {
@@ -602,42 +662,18 @@ __global__ __launch_bounds__(LE_NT) void logits_eval_rows(const void *__restrict
         const Best top = wave_best(b);
         if (lane == 0 && out_top1) out_top1[row] = top.p < n_train ? train_cols[top.p] : -1;
     }
-    if (k <= 0 || dbg == 1) return;
-    // threshold: the k-th largest slice maximum, found by wave 0 alone: the <= 1024 maxima as orderable keys in registers, a
-    // 32-step search for the largest x with #(key >= x) >= k (ballot + popcount: no LDS traffic, no barrier inside)
-    if (wave == 0 && s_nonempty >= k) {
-        unsigned kv[LE_MAXS / 64];
-        const int nreg = (S + 63) >> 6;                     // registers that hold real slices (6 at N = 21 841): wave-uniform
-#pragma unroll
-        for (int i = 0; i < LE_MAXS / 64; ++i) {
-            const int s = i * 64 + lane;
-            const unsigned u = __float_as_uint(s < S ? s_tm[s] : -INFINITY);
-            kv[i] = u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
-        }
-        unsigned x = 0;
-        for (int bit = 31; bit >= 0; --bit) {
-            const unsigned c = x | (1u << bit);
-            int cntc = 0;
-#pragma unroll
-            for (int i = 0; i < LE_MAXS / 64; ++i)
-                if (i < nreg) cntc += __popcll(__ballot(kv[i] >= c));
-            if (cntc >= k) x = c;
-        }
-        if (lane == 0) s_t = __uint_as_float(x ^ ((x >> 31) ? 0x80000000u : 0xFFFFFFFFu));
-    }
-    __syncthreads();
+    if (!want_k) return;
     if (dbg == 2) return;
     const float t = s_t;
     // a group whose maximum reaches t holds a candidate: its (value, position) are already known from the tile stage; only when its
     // SECOND largest value reaches t too (two of the best k in one 16-column group, or a tie at the maximum) the group is recomputed
-    for (int q = tid; q < S * 4; q += LE_NT) {
+    for (int q = tid; q < S * LE_GPS; q += LE_NT) {
         const float m1 = s_gm[q];
         if (m1 > -INFINITY && m1 >= t) {
-            const int64_t at = (int64_t)row * S * 4 + q;
-            if (gm2[at] >= t) s_cand[atomicAdd(&s_ncand, 1)] = (short)q;
+            if (s_m2[q] >= t) s_cand[atomicAdd(&s_ncand, 1)] = (short)q;
             else {
                 const int slot = atomicAdd(&s_cnt, 1);
-                if (slot < LE_CAP) { s_cv[slot] = m1; s_cp[slot] = gp1[at]; }
+                if (slot < LE_CAP) { s_cv[slot] = m1; s_cp[slot] = s_p1[q]; }
             }
         }
     }
@@ -709,7 +745,7 @@ __global__ __launch_bounds__(LE_NT) void logits_eval_rows(const void *__restrict
     __syncthreads();
     if (tid == 0) s_ncand = 0;
     __syncthreads();
-    for (int q = tid; q < S * 4; q += LE_NT)
+    for (int q = tid; q < S * LE_GPS; q += LE_NT)
         if (s_gm[q] > -INFINITY && s_gm[q] >= t) s_cand[atomicAdd(&s_ncand, 1)] = (short)q;
     __syncthreads();
     ncand = s_ncand;

@@ -400,9 +400,10 @@ def eval_rows(logits: torch.Tensor, index: EvalIndex, k: int):
 
 class LogitsEvalPlan:
     """Level-sorted view of the class matrix for hgr_logits_eval (include/hgr.h): the column permutation (levels contiguous, each
-    padded to a multiple of 64 columns, total to a multiple of 128), the per-column train / test positions in permuted order and
-    the level of every 64-column slice.  Built once per model from an EvalIndex; `bind(zsl16)` gathers the permuted 16-bit class
-    matrix (once per update_classifier)."""
+    padded to a multiple of 32 columns, total to a multiple of 96 = one CU's slab), the per-column train / test positions in permuted
+    order and the first 32-column slice of every level.  Built once per model from an EvalIndex; `bind(zsl16)` gathers the permuted
+    16-bit class matrix (once per update_classifier)."""
+    SLICE, SLAB = 32, 96
 
     def __init__(self, index: EvalIndex):
         import numpy as np
@@ -412,13 +413,14 @@ class LogitsEvalPlan:
         cols, level_first = [], [0]
         for l in range(index.n_levels):
             c = np.nonzero(lvl == l)[0]
-            pad = (-c.size) % 64
+            pad = (-c.size) % self.SLICE
             cols.append(np.concatenate([c, np.full(pad, -1, dtype=np.int64)]))
-            level_first.append(level_first[-1] + (c.size + pad) // 64)
+            level_first.append(level_first[-1] + (c.size + pad) // self.SLICE)
         assert int((lvl >= index.n_levels).sum()) == 0, "a node lies deeper than n_levels"
         perm = np.concatenate(cols)
-        if (perm.size // 64) % 2:                                    # whole 128-column tiles; the last slice belongs to no level
-            perm = np.concatenate([perm, np.full(64, -1, dtype=np.int64)])
+        tail = (-perm.size) % self.SLAB                              # whole 96-column slabs; the slices behind the last level belong to no level
+        if tail or perm.size == 0:
+            perm = np.concatenate([perm, np.full(tail or self.SLAB, -1, dtype=np.int64)])
         dev = index.lvl8.device
         valid = perm >= 0
         safe = np.where(valid, perm, 0)

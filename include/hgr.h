@@ -542,16 +542,18 @@ int hgr_pair_rows_f32(const void *xh, const void *xl, float *out, int rows, int 
  * (main.py:136-176: top-20 over the test columns, top-1 over the train columns, arg-max per depth level) in its epilogue, so the
  * [rows, N] logits are never written or re-read.  Same outputs, bit for bit, as hgr_gemm_nt (fp32 logits) followed by
  * hgr_eval_rows.  The caller prepares, once per classifier, a LEVEL-SORTED class matrix: columns ordered by depth level, every
- * level padded with zero rows to a multiple of 64 columns (and the total to a multiple of 128), so that each 64-column slice lies
- * inside one level:
+ * level padded with zero rows to a multiple of 32 columns (and the total to a multiple of 96 = one CU's slab), so that each 32-column
+ * slice lies inside one level:
  *   zsl_perm16 16-bit [n_perm, D] (D = row stride);  tpos_perm / epos_perm int32 [n_perm]: position of the column in
- *   train_index / test_index or -1 (padding: both -1);  level_first int32 [n_levels + 1]: level l owns the 64-column slices
+ *   train_index / test_index or -1 (padding: both -1);  level_first int32 [n_levels + 1]: level l owns the 32-column slices
  *   [level_first[l], level_first[l + 1]) (an empty level: an empty range; trailing padding slices belong to no level);
  *   filler_pos / train_cols / test_cols exactly as for hgr_eval_rows;  feat16: L2-normalised image features, 16-bit [rows, D].
- * Stage 1 (gemm_nt_duo tiles): per (row, slice) the best train column as an orderable key and the largest test value -> workspace.
- * Stage 2 (one workgroup per row): level arg-max / top-1 from the keys; top-k threshold = k-th largest slice maximum; the few slices
- * that reach it are recomputed on the matrix cores (same operand roles and K order: identical bits) and their elements ranked.
- * workspace: hgr_logits_eval_workspace_bytes(rows, n_perm) bytes, 16-byte aligned.  D % 128 == 0, D <= 1024, n_levels <= 32.
+ * Stage 1 (round 4: one 512-row x 96-column tile per CU, the class matrix streams through every CU once): per (row, slice) the
+ * best train column as an orderable key and, per 16-column group, the largest test value, its position and the runner-up -> workspace.
+ * Stage 2 (one workgroup per row): level arg-max / top-1 from the keys; top-k threshold = k-th largest slice maximum; the few groups
+ * that hold two candidates are recomputed on the matrix cores (same operand roles and K order: identical bits) and ranked.
+ * workspace: hgr_logits_eval_workspace_bytes(rows, n_perm) bytes, 16-byte aligned.  D % 128 == 0, D <= 1024, n_levels <= 32,
+ * n_perm % 96 == 0, n_perm <= 32768.
  * ------------------------------------------------------------------------------------------------ */
 int64_t hgr_logits_eval_workspace_bytes(int rows, int n_perm);
 int hgr_logits_eval(const void *feat16, const void *zsl_perm16, int rows, int D, int n_perm,

@@ -57,9 +57,9 @@ int main() {
     EXPECT_FAIL(hgr_row_stats16(f32, h16, h16, f32, 4, 100, HGR_F16, nullptr));
     EXPECT_FAIL(hgr_vit_embed_ln_stats(f32, f32, f32, f32, f32, h16, nullptr, f32, 1, 4, 64, 1e-5f, HGR_F16, nullptr));
     EXPECT_FAIL(hgr_logits_eval(h16, h16, 4, 100, 128, i32, i32, i32, 4, i32, i32, 8, i32, 32, 20, i32, i32, i32, f32, HGR_F16, nullptr));       // D % 128
-    EXPECT_FAIL(hgr_logits_eval(h16, h16, 4, 128, 192, i32, i32, i32, 4, i32, i32, 8, i32, 32, 20, i32, i32, i32, f32, HGR_F16, nullptr));       // n_perm % 128
-    EXPECT_FAIL(hgr_logits_eval(h16, h16, 4, 128, 256, i32, i32, i32, 4, i32, i32, 8, i32, 8, 20, i32, i32, i32, f32, HGR_F16, nullptr));        // n_test < k
-    EXPECT_OK(hgr_logits_eval_workspace_bytes(512, 22784) == 512ll * 356 * 56 ? 0 : -1);
+    EXPECT_FAIL(hgr_logits_eval(h16, h16, 4, 128, 128, i32, i32, i32, 4, i32, i32, 8, i32, 32, 20, i32, i32, i32, f32, HGR_F16, nullptr));       // n_perm % 96
+    EXPECT_FAIL(hgr_logits_eval(h16, h16, 4, 128, 288, i32, i32, i32, 4, i32, i32, 8, i32, 8, 20, i32, i32, i32, f32, HGR_F16, nullptr));        // n_test < k
+    EXPECT_OK(hgr_logits_eval_workspace_bytes(512, 22080) == 512ll * 690 * 32 ? 0 : -1);
     // streaming / normalisation kernels
     EXPECT_FAIL(hgr_layernorm(f32, f32, f32, h16, 4, 6, 1, nullptr, 1e-5f, HGR_F16, 0, nullptr));                                // W % 4
     EXPECT_FAIL(hgr_layernorm(f32, f32, f32, h16, 0, 64, 1, nullptr, 1e-5f, HGR_F16, 0, nullptr));

@@ -749,7 +749,7 @@ def test_logits_eval_bit_exact_vs_gemm_plus_eval_rows(dt, case):
     ops.gemm_nt(f16, z16, lg, n=n)
     want = ops.eval_rows(lg[:, :n], index, k)
     plan = ops.LogitsEvalPlan(index).bind(z16)
-    assert plan.n_perm % 128 == 0 and int(plan.valid.sum()) == n
+    assert plan.n_perm % 96 == 0 and int(plan.valid.sum()) == n
     got = ops.logits_eval(f16, plan, k)
     for w, g_, name in zip(want, got, ("level arg-max", "top-1", "top-k")):
         assert torch.equal(w, g_), (case, name, int((w != g_).sum()))
@@ -833,7 +833,7 @@ def test_logits_eval_planted_ties_at_group_boundaries(dt):
     """Adversarial ordering case for hgr_logits_eval, exact: small-integer operands make every logit an exactly representable integer
     (so the GEMM is exact in any summation order and the ids are decided by the tie rule alone), and for each probed row the 22 best
     test columns are PLANTED so that ranks 19 / 20 / 21 are one unit apart or exactly tied and sit on both sides of a 16-column
-    group boundary, a 64-column slice boundary and a 128-column tile boundary of the level-sorted class matrix.  Oracle: the
+    group boundary, a 32-column slice boundary and a 96-column slab boundary of the level-sorted class matrix.  Oracle: the
     reference's rule (main.py:136-176) through oracle/tree_ref on the integer logits."""
     n, dd, levels, k = 900, 128, 4, 20
     rows = 24
@@ -844,8 +844,8 @@ def test_logits_eval_planted_ties_at_group_boundaries(dt):
     depth = np.zeros(n, dtype=np.int32)
     depth[520:] = 1 + (np.arange(n - 520) % (levels - 1))             # level 0 = columns 0..519 in id order: permuted position == id there
     # rows 0..7: the boundary between permuted positions b-1 | b, in three tie flavours
-    # (16, 96, 304: 16-column group boundaries inside a slice; 64, 192: slice boundaries inside a tile; 128, 256, 384: tile boundaries;
-    # the 22-column windows around them are disjoint)
+    # (16, 304: 16-column group boundaries inside a 32-column slice; 64, 128, 256: slice boundaries inside a 96-column slab; 96, 192, 384:
+    # slab boundaries - another CU's tile; the 22-column windows around them are disjoint)
     cases = [(16, "tie_20_21"), (96, "step"), (64, "tie_20_21"), (192, "tie_19_20"), (128, "tie_20_21"), (256, "step"), (304, "tie_19_20"),
              (384, "tie_19_20")]
     for r, (b, flavour) in enumerate(cases):

@@ -152,6 +152,7 @@ def test_two_rank_coop_context_gradient_is_identical_on_both_ranks_and_equals_on
     one = _dp("trainctx", 1, tmp_path / "c1.pt", HGR_DP_EXACT_HEAD="1")
     two = _dp("trainctx", 2, tmp_path / "c2.pt", HGR_DP_EXACT_HEAD="1")
     assert one["contra"] == two["contra"]
+    assert abs(one["loss"] - two["loss"]) <= 1e-5 * abs(one["loss"]), (one["loss"], two["loss"])
     a, b = two["ctx_grad_per_rank"]
     assert torch.equal(a, b)
     ref = one["ctx_grad_per_rank"][0]

@@ -94,6 +94,10 @@ opts = types.SimpleNamespace(device=dev, folder=tmp, exp_name="HGR", weights="ad
                              graph_path=gp, arch="synthetic", fetch=False, load=False, load_path="none", scale=1.0, num_compare=12, k=1,
                              sample_strategy="topk", weighting="both", train_dtype="bf16", n_ctx=n_ctx)
 model = tree_model(opts, splits["all"], splits["rest"], node_tokens=tokens, clip_model=build_model(sd).to(dev))
+if model.ctx is not None:                                  # the reference draws the context from torch's generator (model/CoOp.py:66-68): pin it
+    import numpy as np
+    c0 = torch.from_numpy(synth.normal(21, "ctx", n_ctx * cfg["transformer_width"]).astype(np.float32).reshape(n_ctx, -1)) * 0.02
+    model.ctx.data.copy_(c0.to(dev))
 res = cfg["image_resolution"]
 
 if mode == "eval":
