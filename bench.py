@@ -621,7 +621,7 @@ def main():
                         traffic = d["tower_gemm"]["hbm_bytes_per_launch"]
                         traffic_src = f"HBM bytes per launch (rocprofv3 PMC, profiles/{pmc.name}, kernel sources {now})"
                         break
-            roof = {"kernel": "gemm_nt_duo (image-tower GEMMs: qkv, out, fc, proj, patch)" if a.arch.startswith("ViT") else "gemm_nt_256 / gemm_nt_128 (image-tower 1x1 GEMMs and implicit-GEMM 3x3 convolutions)", "bound": "mfma",
+            roof = {"kernel": "gemm_nt_duo + qkv_attn (image-tower GEMMs: in_proj fused with its attention [tag qkv_mha: GEMM + attention FLOPs], out, fc, proj, patch)" if a.arch.startswith("ViT") else "gemm_nt_256 / gemm_nt_128 (image-tower 1x1 GEMMs and implicit-GEMM 3x3 convolutions)", "bound": "mfma",
                     "achieved": round(ach, 1), "peak": PEAK_TFLOPS_BF16, "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS_BF16, 4),
                     "traffic": traffic, "traffic_unit": traffic_src,
                     "algorithmic_bytes_per_launch": round(sum(b for _, _, b in tower) / len(tower)),
@@ -648,6 +648,24 @@ def main():
                                    "gbps": round(lg[0][2] / tl / 1e9, 1), "frac_hbm": round(lg[0][2] / tl / 8e12, 4),
                                    "what": ("hgr_logits_eval: logits GEMM + top-20 / top-1 / level arg-max in its epilogue, both stages, no logits written "
                                             "(target of north_star: >= 0.40 of the MFMA peak)") if fused_eval else "hgr_gemm_nt writing fp32 logits (hgr_eval_rows runs behind it)"}
+            if fused_eval:
+                # the two stages on their own (hgr_logits_eval_tile_stage / _row_stage: the same launches, timed one at a time, eager, after
+                # a tower pass so that the operands are as cold as in the step): the tile stage IS the logits GEMM north_star prices
+                ops.PROFILE = []
+                f16 = torch.empty((a.batch, cfg["embed_dim"]), dtype=model._zsl16.dtype, device=dev)
+                for _ in range(5):
+                    ops.l2norm_rows(model.clip_model.encode_image(batches[0]), y16=f16)
+                    ops.logits_eval(f16, ev._plan, 20, stage="tile")
+                    ops.logits_eval(f16, ev._plan, 20, stage="row")
+                torch.cuda.synchronize()
+                st, ops.PROFILE = ops.PROFILE, None
+                for nm in ("tile", "row"):
+                    ts = sorted(s_.elapsed_time(e_) * 1e3 for (name, s_, e_, fl, by, tag) in st if tag == "logits_eval_" + nm)
+                    if ts:
+                        roof["logits_gemm"][nm + "_stage_us"] = round(ts[len(ts) // 2], 1)
+                tile = roof["logits_gemm"].get("tile_stage_us")
+                if tile:
+                    roof["logits_gemm"]["tile_stage_frac_mfma"] = round(lg[0][1] / (tile * 1e-6) / 1e12 / PEAK_TFLOPS_BF16, 4)
 
     # PCIe-inclusive rate (never `value`): the same step fed from pinned HOST memory with uint8 NHWC crops (what a
     # JPEG decoder hands over), H2D on a copy stream double-buffered against compute, normalisation fused into the

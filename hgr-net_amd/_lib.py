@@ -93,6 +93,8 @@ SIGNATURES = {
     "hgr_pair_rows_f32": [_p, _p, _p, _i, _i, _l, _p, _i, _p],
     "hgr_logits_eval_workspace_bytes": [_i, _i],
     "hgr_logits_eval": [_p, _p, _i, _i, _i, _p, _p, _p, _i, _p, _p, _i, _p, _i, _i, _p, _p, _p, _p, _i, _p],
+    "hgr_logits_eval_tile_stage": [_p, _p, _i, _i, _i, _p, _p, _p, _i, _p, _p, _i, _p, _i, _i, _p, _p, _p, _p, _i, _p],
+    "hgr_logits_eval_row_stage": [_p, _p, _i, _i, _i, _p, _p, _p, _i, _p, _p, _i, _p, _i, _i, _p, _p, _p, _p, _i, _p],
     "hgr_comm_unique_id": [_p],
     "hgr_comm_init": [_i, _i, _p],
     "hgr_comm_destroy": [],

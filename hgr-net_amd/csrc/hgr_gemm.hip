@@ -414,6 +414,18 @@ extern "C" int hgr_gemm_nt_bias_gelu_dual(const void *A, int64_t lda, const void
 }
 
 // ---- logits GEMM with the evaluation consumers in its epilogue ------------------------------------------------------------
+#define HGR_LE_PARAMS const void *feat16, const void *zsl_perm16, int rows, int D, int n_perm, const int32_t *tpos_perm, const int32_t *epos_perm, \
+    const int32_t *level_first, int n_levels, const int32_t *filler_pos, const int32_t *train_cols, int n_train, const int32_t *test_cols, int n_test, int k, \
+    int32_t *out_level, int32_t *out_top1, int32_t *out_topk, void *workspace, int dtype, void *stream
+#define HGR_LE_ARGS feat16, zsl_perm16, rows, D, n_perm, tpos_perm, epos_perm, level_first, n_levels, filler_pos, train_cols, n_train, test_cols, n_test, k, \
+    out_level, out_top1, out_topk, workspace, dtype, stream
+static int logits_eval_stages(int stages, HGR_LE_PARAMS);
+extern "C" int hgr_logits_eval(HGR_LE_PARAMS) { return logits_eval_stages(3, HGR_LE_ARGS); }
+// the two stages on their own (same arguments; the row stage reads the workspace the tile stage of the same call sequence wrote):
+// bench.py times them separately, hgr_logits_eval is the pair
+extern "C" int hgr_logits_eval_tile_stage(HGR_LE_PARAMS) { return logits_eval_stages(1, HGR_LE_ARGS); }
+extern "C" int hgr_logits_eval_row_stage(HGR_LE_PARAMS) { return logits_eval_stages(2, HGR_LE_ARGS); }
+
 int hgr_logits_eval_rows_launch(const void *feat, const void *zslp, int D, int S, const unsigned long long *keys, const float *tmax,
                                 const int *gp1, const float *gm2, const int32_t *level_first, int n_levels, const int32_t *filler_pos, const int32_t *train_cols, int n_train,
                                 const int32_t *epos, const int32_t *test_cols, int n_test, int k, int32_t *out_level, int32_t *out_top1,
@@ -424,7 +436,7 @@ extern "C" int64_t hgr_logits_eval_workspace_bytes(int rows, int n_perm) {
     return (int64_t)rows * (n_perm / 32) * 32;           // per (row, 32-column slice): 8-byte train key + per 16-column group (max, position, second) = 2 x 12 bytes
 }
 
-extern "C" int hgr_logits_eval(const void *feat16, const void *zsl_perm16, int rows, int D, int n_perm,
+static int logits_eval_stages(int stages, const void *feat16, const void *zsl_perm16, int rows, int D, int n_perm,
                                const int32_t *tpos_perm, const int32_t *epos_perm, const int32_t *level_first,
                                int n_levels, const int32_t *filler_pos, const int32_t *train_cols, int n_train,
                                const int32_t *test_cols, int n_test, int k,
@@ -445,8 +457,9 @@ extern "C" int hgr_logits_eval(const void *feat16, const void *zsl_perm16, int r
     a.ev_tmax = (float *)((char *)workspace + (size_t)rows * S * 8);
     a.ev_p1 = (int *)((char *)workspace + (size_t)rows * S * 16);
     a.ev_m2 = (float *)((char *)workspace + (size_t)rows * S * 24);
-    launch_logits_slab(a, dtype, (hipStream_t)stream);
+    if (stages & 1) launch_logits_slab(a, dtype, (hipStream_t)stream);
     HGR_CHECK_LAUNCH("hgr_logits_eval (tile stage)");
+    if (!(stages & 2)) return HGR_OK;
     return hgr_logits_eval_rows_launch(feat16, zsl_perm16, D, S, a.ev_key, a.ev_tmax, a.ev_p1, a.ev_m2, level_first, n_levels, filler_pos, train_cols, n_train,
                                        epos_perm, test_cols, n_test, k, out_level, out_top1, out_topk, rows, dtype, stream);
 }

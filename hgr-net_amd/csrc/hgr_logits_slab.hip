@@ -20,8 +20,8 @@
 // Epilogue: the class matrix is LEVEL-SORTED and level-aligned to 32 columns (ops.LogitsEvalPlan), so every 32-column slice - two of
 // a lane's n tiles - lies inside one hierarchy level.  Per (row, slice): the best train column as an orderable 64-bit key
 // (value, then smaller train position - the tie rule of logits[:, train_index].topk); per 16-column group the largest test value, the
-// test position of an element attaining it and the second largest value.  32 bytes per (row, slice), written as ONE 8-byte store per
-// lane (lane group g = 0 .. 3 writes key / maxima / positions / second values).  hgr_logits_eval's row stage (hgr_select.hip) turns
+// test position of an element attaining it and the second largest value.  96 bytes per (row, slab), written as ONE 8-byte store per
+// lane and slice (lane group g = 0 .. 3 writes key / maxima / positions / second values) into the slab's own contiguous block.  hgr_logits_eval's row stage (hgr_select.hip) turns
 // them into the level arg-max, the top-1 and the top-k.
 // =================================================================================================
 #include "hgr_gemm_common.h"
@@ -54,6 +54,26 @@ __global__ __launch_bounds__(LS_NT) void logits_slab(SlabArgs p) {
         oA0[i] = (unsigned)(((int64_t)min(m0 + tr, p.M - 1) * p.lda + c * 8) * 2);
         oA1[i] = (unsigned)(((int64_t)min(m0 + tr + 32, p.M - 1) * p.lda + c * 8) * 2);
         if (i < 2) oW[i] = (unsigned)(((int64_t)(n0 + min(pr, 95)) * p.ldw + c * 8) * 2);      // piece rows 96-127: padding (row 95 again)
+    }
+    // The class rows of this slab come from HBM, 12 KB per K-tile, and the pipeline below requests a piece ~1.5 K-tiles (~1 us) before it
+    // is read - less than a loaded HBM round trip, so every K-tile would wait for memory (first version: 26 us per launch, slower than
+    // the tiled GEMM it replaces).  The whole slab is only 96 x 2 K bytes: touch every 64-byte sector of it ONCE, up front, with plain
+    // loads whose values are never looked at before the kernel's last instruction - one HBM latency for the slab, after which every
+    // LDS-DMA of it is an L2 hit.  Likewise this workgroup's share of the feature matrix (every XCD's L2 fetches it once from the
+    // Infinity Cache; the 29 - 32 workgroups of an XCD - blocks b, b + 8, ... - touch a 1 / 32 share each).
+    // (unconditional loads into separate registers, ids clamped: a load under a branch or feeding a running sum is waited for at once)
+    unsigned tw[6], ta;
+    {
+        const int spr = p.K >> 5;                               // 64-byte sectors per row (K <= 1024: at most 6 touches of W per thread)
+        const int nw = 96 * spr;
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int id = min(tid + u * LS_NT, nw - 1);
+            tw[u] = *(const unsigned *)(p.W + ((int64_t)(n0 + id / spr) * p.ldw) * 2 + (id % spr) * 64);
+        }
+        const int rows_here = min(512, p.M - m0), na = rows_here * spr;
+        const int id = min((int)(blockIdx.x >> 3) * LS_NT + tid, na - 1);
+        ta = *(const unsigned *)(p.A + ((int64_t)(m0 + id / spr) * p.lda) * 2 + (id % spr) * 64);
     }
     char *const ldsw = smem + wave * 1024;
     const __amdgpu_buffer_rsrc_t rA = dma_rsrc(p.A), rW = dma_rsrc(p.W);
@@ -146,9 +166,10 @@ __global__ __launch_bounds__(LS_NT) void logits_slab(SlabArgs p) {
         tp[j][0] = t4.x; tp[j][1] = t4.y; tp[j][2] = t4.z; tp[j][3] = t4.w;
         ep[j][0] = e4.x; ep[j][1] = e4.y; ep[j][2] = e4.z; ep[j][3] = e4.w;
     }
-    // lane group g writes one of the four 8-byte records of a (row, slice): 0 = key, 1 = (m1, m1'), 2 = (p1, p1'), 3 = (m2, m2')
-    char *const rec = g == 0 ? (char *)p.ev_key : g == 1 ? (char *)p.ev_tmax : g == 2 ? (char *)p.ev_p1 : (char *)p.ev_m2;
-    const int sl0 = blockIdx.x * 3;
+    // records of this slab: [row][96 bytes] = keys of the 3 slices | (m1, m1') x 3 | (p1, p1') x 3 | (m2, m2') x 3, contiguous per
+    // workgroup (48 KB: whole lines from one CU; the first version wrote [row][slice] arrays, i.e. 8-byte pieces of lines shared by
+    // CUs of different XCDs).  Lane group g writes the g-th 24-byte part.
+    char *const rec = (char *)p.ev_key + (int64_t)blockIdx.x * p.M * 96 + g * 24;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + wave * 64 + i * 16 + r;
@@ -189,12 +210,13 @@ __global__ __launch_bounds__(LS_NT) void logits_slab(SlabArgs p) {
                     m1[q] = fmaxf(m1[q], o1);
                 }
             }
-            if (m < p.M) {
+            // (the warm-up loads' values are consumed here, at the very end; the extra condition never holds)
+            if (m < p.M || ((tw[0] ^ tw[1] ^ tw[2]) + (tw[3] ^ tw[4] ^ tw[5]) + ta == 0x9E3779B9u && m == 0x7fffffff)) {
                 const unsigned long long v8 = g == 0 ? key
                     : g == 1 ? ((unsigned long long)__float_as_uint(m1[1]) << 32) | __float_as_uint(m1[0])
                     : g == 2 ? ((unsigned long long)(unsigned)p1[1] << 32) | (unsigned)p1[0]
                              : ((unsigned long long)__float_as_uint(m2[1]) << 32) | __float_as_uint(m2[0]);
-                *(unsigned long long *)(rec + ((int64_t)m * p.S + sl0 + s) * 8) = v8;
+                *(unsigned long long *)(rec + (int64_t)m * 96 + s * 8) = v8;
             }
         }
     }

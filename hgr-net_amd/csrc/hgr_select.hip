@@ -532,7 +532,7 @@ __global__ __launch_bounds__(LE_NT, 4) void logits_eval_rows(const void *__restr
                                                         const int32_t *__restrict__ level_first, int n_levels, const int32_t *__restrict__ filler_pos,
                                                         const int32_t *__restrict__ train_cols, int n_train, const int32_t *__restrict__ epos,
                                                         const int32_t *__restrict__ test_cols, int n_test, int k,
-                                                        int32_t *__restrict__ out_level, int32_t *__restrict__ out_top1, int32_t *__restrict__ out_topk, int dbg) {
+                                                        int32_t *__restrict__ out_level, int32_t *__restrict__ out_top1, int32_t *__restrict__ out_topk, int dbg, int rows) {
     typedef typename T16<DT>::vec8 vec8;
     typedef typename T16<DT>::elem E;
     // 58 KB of LDS: two rows per CU, so the 512 rows of a batch are one round on 256 CUs
@@ -559,12 +559,15 @@ __global__ __launch_bounds__(LE_NT, 4) void logits_eval_rows(const void *__restr
     // Round 3 took five dependent trips (feature row | keys + maxima | ... | second values and positions of the groups above the
     // threshold | class rows of the recomputed groups): 18.5 us for 7 MB.
     {
+        // record layout of the first stage: [slab = slice / 3][row][96 bytes: keys x 3 | (m1, m1') x 3 | (p1, p1') x 3 | (m2, m2') x 3]
         const int s0 = tid, s1 = tid + LE_NT;
-        const int64_t r0 = (int64_t)row * S + min(s0, S - 1), r1 = (int64_t)row * S + min(s1, S - 1);
-        const unsigned long long k0 = keys[r0], k1 = keys[r1];
-        const float2 a0 = *(const float2 *)(gmax + r0 * LE_GPS), a1 = *(const float2 *)(gmax + r1 * LE_GPS);
-        const float2 b0 = *(const float2 *)(gm2 + r0 * LE_GPS), b1 = *(const float2 *)(gm2 + r1 * LE_GPS);
-        const int2 c0 = *(const int2 *)(gp1 + r0 * LE_GPS), c1 = *(const int2 *)(gp1 + r1 * LE_GPS);
+        const int c0s = min(s0, S - 1), c1s = min(s1, S - 1);
+        const char *r0 = (const char *)keys + ((int64_t)(c0s / 3) * rows + row) * 96 + (c0s % 3) * 8;
+        const char *r1 = (const char *)keys + ((int64_t)(c1s / 3) * rows + row) * 96 + (c1s % 3) * 8;
+        const unsigned long long k0 = *(const unsigned long long *)r0, k1 = *(const unsigned long long *)r1;
+        const float2 a0 = *(const float2 *)(r0 + 24), a1 = *(const float2 *)(r1 + 24);
+        const int2 c0 = *(const int2 *)(r0 + 48), c1 = *(const int2 *)(r1 + 48);
+        const float2 b0 = *(const float2 *)(r0 + 72), b1 = *(const float2 *)(r1 + 72);
         u32x4 fv = (u32x4){0u, 0u, 0u, 0u};
         if (tid < (D >> 3)) fv = ((const u32x4 *)((const E *)feat + (int64_t)row * D))[tid];
         int mine = 0;
@@ -773,9 +776,9 @@ int hgr_logits_eval_rows_launch(const void *feat, const void *zslp, int D, int S
     static int dbg = -1;                              // HGR_LE_DBG = 1..4: leave the row stage after level / threshold / candidate list / scan (timing experiments only)
     if (dbg < 0) { const char *e = getenv("HGR_LE_DBG"); dbg = e ? atoi(e) : 0; }
     if (dtype == HGR_BF16) hipLaunchKernelGGL((logits_eval_rows<HGR_BF16>), dim3(rows), dim3(LE_NT), 0, (hipStream_t)stream, feat, zslp, D, S, keys, tmax, gp1, gm2, level_first,
-                                              n_levels, filler_pos, train_cols, n_train, epos, test_cols, n_test, k, out_level, out_top1, out_topk, dbg);
+                                              n_levels, filler_pos, train_cols, n_train, epos, test_cols, n_test, k, out_level, out_top1, out_topk, dbg, rows);
     else hipLaunchKernelGGL((logits_eval_rows<HGR_F16>), dim3(rows), dim3(LE_NT), 0, (hipStream_t)stream, feat, zslp, D, S, keys, tmax, gp1, gm2, level_first,
-                            n_levels, filler_pos, train_cols, n_train, epos, test_cols, n_test, k, out_level, out_top1, out_topk, dbg);
+                            n_levels, filler_pos, train_cols, n_train, epos, test_cols, n_test, k, out_level, out_top1, out_topk, dbg, rows);
     HGR_CHECK_LAUNCH("hgr_logits_eval (row stage)");
     return HGR_OK;
 }

@@ -450,9 +450,10 @@ class LogitsEvalPlan:
         return self._ws
 
 
-def logits_eval(feat16: torch.Tensor, plan: LogitsEvalPlan, k: int):
+def logits_eval(feat16: torch.Tensor, plan: LogitsEvalPlan, k: int, stage: str = ""):
     """(level arg-max [rows, n_levels], top-1 [rows, 1], top-k [rows, k]) int32 node ids straight from the L2-normalised 16-bit
-    image features: the logits GEMM with the evaluation in its epilogue (hgr_logits_eval) - no [rows, N] logits in memory."""
+    image features: the logits GEMM with the evaluation in its epilogue (hgr_logits_eval) - no [rows, N] logits in memory.
+    ``stage`` = "tile" / "row": that stage alone (measurement; the row stage reads the workspace the last tile stage wrote)."""
     ix = plan.index
     assert plan.zsl is not None, "LogitsEvalPlan.bind(zsl16) first"
     assert feat16.is_contiguous() and feat16.dtype == plan.zsl.dtype and feat16.shape[1] == plan.zsl.shape[1]
@@ -463,10 +464,11 @@ def logits_eval(feat16: torch.Tensor, plan: LogitsEvalPlan, k: int):
     topk = torch.empty((rows, max(k, 1)), dtype=torch.int32, device=dev)
     prof = PROFILE
     ev = _prof_begin()
-    _lib.call("hgr_logits_eval", _dev(feat16), _dev(plan.zsl), rows, d, plan.n_perm, _dev(plan.tpos), _dev(plan.epos), _dev(plan.level_first),
+    _lib.call({"": "hgr_logits_eval", "tile": "hgr_logits_eval_tile_stage", "row": "hgr_logits_eval_row_stage"}[stage],
+              _dev(feat16), _dev(plan.zsl), rows, d, plan.n_perm, _dev(plan.tpos), _dev(plan.epos), _dev(plan.level_first),
               ix.n_levels, _dev(ix.filler), _dev(ix.train_cols), ix.n_train, _dev(ix.test_cols), ix.n_test, k,
               _dev(lvl), _dev(top1), _dev(topk), _dev(plan.workspace(rows, dev)), DT_OF[feat16.dtype], _stream())
-    _prof_end(ev, 2.0 * rows * ix.n_nodes * d, 2 * rows * d + 2 * ix.n_nodes * d, "logits_eval")
+    _prof_end(ev, 2.0 * rows * ix.n_nodes * d, 2 * rows * d + 2 * ix.n_nodes * d, "logits_eval" + ("_" + stage if stage else ""))
     return lvl, top1, topk
 
 

@@ -561,6 +561,18 @@ int hgr_logits_eval(const void *feat16, const void *zsl_perm16, int rows, int D,
                     int n_levels, const int32_t *filler_pos, const int32_t *train_cols, int n_train,
                     const int32_t *test_cols, int n_test, int k,
                     int32_t *out_level, int32_t *out_top1, int32_t *out_topk, void *workspace, int dtype, void *stream);
+/* The two stages of hgr_logits_eval on their own (same arguments): measurement only - hgr_logits_eval is exactly the pair, and the row
+ * stage reads the workspace a tile stage with the same arguments wrote. */
+int hgr_logits_eval_tile_stage(const void *feat16, const void *zsl_perm16, int rows, int D, int n_perm,
+                    const int32_t *tpos_perm, const int32_t *epos_perm, const int32_t *level_first,
+                    int n_levels, const int32_t *filler_pos, const int32_t *train_cols, int n_train,
+                    const int32_t *test_cols, int n_test, int k,
+                    int32_t *out_level, int32_t *out_top1, int32_t *out_topk, void *workspace, int dtype, void *stream);
+int hgr_logits_eval_row_stage(const void *feat16, const void *zsl_perm16, int rows, int D, int n_perm,
+                    const int32_t *tpos_perm, const int32_t *epos_perm, const int32_t *level_first,
+                    int n_levels, const int32_t *filler_pos, const int32_t *train_cols, int n_train,
+                    const int32_t *test_cols, int n_test, int k,
+                    int32_t *out_level, int32_t *out_top1, int32_t *out_topk, void *workspace, int dtype, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Data-parallel collectives over RCCL / xGMI (one process per GPU).  The reference has no distributed code (its only

@@ -46,7 +46,8 @@ def main():
         k = short(r["Name"])
         k = k.replace("hgr_gemm::", "")
         if not k.startswith(("gemm_nt", "gemm_tn", "layernorm", "mha_", "im2col", "topk", "level_argmax", "eval_rows", "logits_eval", "vit_embed", "l2norm", "text_embed",
-                             "conv3x3", "stem_", "avgpool", "attnpool", "transpose", "colsum", "quickgelu", "adamw", "sumsq")):
+                             "conv3x3", "stem_", "avgpool", "attnpool", "transpose", "colsum", "quickgelu", "adamw", "sumsq", "qkv_attn", "logits_slab", "vit_head",
+                             "eval_counters", "rows_gather")):
             continue
         fv, wv = f.get(k, []), w.get(k, [])
         fetch_b = 2 * 1024 * sum(fv) / len(fv) if fv else None
@@ -54,7 +55,8 @@ def main():
         rows.append(dict(kernel=k, calls=int(r["Calls"]), avg_us=round(float(r["AverageNs"]) / 1e3, 1), pct=float(r["Percentage"]),
                          hbm_read_bytes_per_launch=round(fetch_b) if fetch_b else None,
                          hbm_write_bytes_per_launch=round(write_b) if write_b else None))
-    gem = [r for r in rows if r["kernel"].startswith(("gemm_nt", "gemm_tn")) and r["avg_us"] > 60 and r["hbm_read_bytes_per_launch"] and r["hbm_write_bytes_per_launch"] is not None]
+    # the tower GEMM family: gemm_nt_* / gemm_tn_* and (round 4) the in_proj GEMM fused with its attention, qkv_attn
+    gem = [r for r in rows if r["kernel"].startswith(("gemm_nt", "gemm_tn", "qkv_attn")) and r["avg_us"] > 60 and r["hbm_read_bytes_per_launch"] and r["hbm_write_bytes_per_launch"] is not None]
     tot_calls = sum(r["calls"] for r in gem)
     out = dict(tag=tag, config=config or "vitb32", kernel_source_hash=kernel_source_hash(), note="FETCH_SIZE doubled (gfx950 correction), WRITE_SIZE as is; KiB -> bytes; averages per launch",
                kernels=rows,
