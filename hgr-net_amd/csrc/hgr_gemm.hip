@@ -453,6 +453,7 @@ static int logits_eval_stages(int stages, const void *feat16, const void *zsl_pe
     SlabArgs a;
     a.A = (const char *)feat16; a.lda = D; a.W = (const char *)zsl_perm16; a.ldw = D; a.M = rows; a.K = D; a.Np = n_perm;
     a.tpos = tpos_perm; a.epos = epos_perm; a.S = S;
+    { static int d = -1; if (d < 0) { const char *e = getenv("HGR_LS_DBG"); d = e ? atoi(e) : 0; } a.dbg = d; }
     a.ev_key = (unsigned long long *)workspace;
     a.ev_tmax = (float *)((char *)workspace + (size_t)rows * S * 8);
     a.ev_p1 = (int *)((char *)workspace + (size_t)rows * S * 16);

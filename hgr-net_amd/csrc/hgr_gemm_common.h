@@ -214,6 +214,7 @@ struct SlabArgs {
     unsigned long long *ev_key;          // [M][S]      S = Np / 32
     float *ev_tmax, *ev_m2; int *ev_p1;  // [M][S][2]
     int S;
+    int dbg;                             // HGR_LS_DBG (timing experiments only, wrong results): 1 skip the MFMAs, 2 skip the feature DMAs, 4 skip the class-row DMAs, 8 skip the epilogue, 16 skip the warm-up touches
 };
 void launch_logits_slab(const SlabArgs &a, int dtype, hipStream_t s);
 

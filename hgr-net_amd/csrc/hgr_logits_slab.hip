@@ -69,7 +69,7 @@ __global__ __launch_bounds__(LS_NT) void logits_slab(SlabArgs p) {
 #pragma unroll
         for (int u = 0; u < 6; ++u) {
             const int id = min(tid + u * LS_NT, nw - 1);
-            tw[u] = *(const unsigned *)(p.W + ((int64_t)(n0 + id / spr) * p.ldw) * 2 + (id % spr) * 64);
+            tw[u] = (p.dbg & 16) ? 0u : *(const unsigned *)(p.W + ((int64_t)(n0 + id / spr) * p.ldw) * 2 + (id % spr) * 64);
         }
         const int rows_here = min(512, p.M - m0), na = rows_here * spr;
         const int id = min((int)(blockIdx.x >> 3) * LS_NT + tid, na - 1);
@@ -78,11 +78,13 @@ __global__ __launch_bounds__(LS_NT) void logits_slab(SlabArgs p) {
     char *const ldsw = smem + wave * 1024;
     const __amdgpu_buffer_rsrc_t rA = dma_rsrc(p.A), rW = dma_rsrc(p.W);
     auto issueA = [&](const unsigned (&off)[4], int piece, int t) {
+        if (p.dbg & 2) return;
         char *dst = ldsw + (t & 1) * LS_STAGE + piece;
 #pragma unroll
         for (int i = 0; i < 4; ++i) dma16(rA, p.A, off[i], t * 128, dst + i * 8192);
     };
     auto issueW = [&](int t) {
+        if (p.dbg & 4) return;
         char *dst = ldsw + (t & 1) * LS_STAGE + LS_PW;
 #pragma unroll
         for (int i = 0; i < 2; ++i) dma16(rW, p.W, oW[i], t * 128, dst + i * 8192);
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(LS_NT) void logits_slab(SlabArgs p) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 6; ++j) acc[i][j] = T16<DT>::mfma16(wf[j][kk], af[i][kk], acc[i][j]);
+                for (int j = 0; j < 6; ++j) if (!(p.dbg & 1)) acc[i][j] = T16<DT>::mfma16(wf[j][kk], af[i][kk], acc[i][j]);
         __builtin_amdgcn_s_setprio(0);
         HGR_MBAR();
         // ---- ph2: rows 32-63 ----
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(LS_NT) void logits_slab(SlabArgs p) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 6; ++j) acc[2 + i][j] = T16<DT>::mfma16(wf[j][kk], af[i][kk], acc[2 + i][j]);
+                for (int j = 0; j < 6; ++j) if (!(p.dbg & 1)) acc[2 + i][j] = T16<DT>::mfma16(wf[j][kk], af[i][kk], acc[2 + i][j]);
         __builtin_amdgcn_s_setprio(0);
         HGR_MBAR();
     };
@@ -156,6 +158,7 @@ __global__ __launch_bounds__(LS_NT) void logits_slab(SlabArgs p) {
     ktile(nk - 1, std::integral_constant<int, 2>());
     if (!pg) HGR_MBAR();        // (barrier counts of the two groups balanced; nothing below touches LDS)
 
+    if (p.dbg & 8) { if (acc[0][0][0] == 123.456f && acc[3][5][3] == 1.f) p.ev_key[0] = 1ull; return; }
     // ---- evaluation consumers.  Lane (r, g) holds, of row m = m0 + 64 wave + 16 i + r, the columns n0 + 16 j + 4 g + e (e = 0..3)
     // of n tile j; a 32-column slice = n tiles 2 s, 2 s + 1, the other 3/4 of its columns sit in the lanes r + 16, r + 32, r + 48 ----
     int tp[6][4], ep[6][4];
@@ -170,45 +173,78 @@ __global__ __launch_bounds__(LS_NT) void logits_slab(SlabArgs p) {
     // workgroup (48 KB: whole lines from one CU; the first version wrote [row][slice] arrays, i.e. 8-byte pieces of lines shared by
     // CUs of different XCDs).  Lane group g writes the g-th 24-byte part.
     char *const rec = (char *)p.ev_key + (int64_t)blockIdx.x * p.M * 96 + g * 24;
+    // Cross-lane steps: the four lane groups g = lane >> 4 of a row meet through v_permlane16_swap / v_permlane32_swap (gfx950: VALU, no
+    // LDS crossbar).  swap(x, x) returns (a, b) = for the lane pair (L, L ^ 16) [resp. ^ 32] the even row's and the odd row's value, the
+    // SAME pair in both lanes, so max(a, b) etc. leave both lanes with the same result.  (First version: 64-bit keys per element and 16
+    // __shfl_xor = ds_bpermute per (row, slice): the epilogue took 13 of the launch's 26 us.)
+#define LS_SWAP16(x) __builtin_amdgcn_permlane16_swap((unsigned)(x), (unsigned)(x), false, false)
+#define LS_SWAP32(x) __builtin_amdgcn_permlane32_swap((unsigned)(x), (unsigned)(x), false, false)
+    auto xmaxf = [&](float v) {
+        auto a = LS_SWAP16(__float_as_uint(v));
+        v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+        auto b = LS_SWAP32(__float_as_uint(v));
+        return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+    };
+    auto xmini = [&](int v) {
+        auto a = LS_SWAP16(v);
+        v = min((int)a[0], (int)a[1]);
+        auto b = LS_SWAP32(v);
+        return min((int)b[0], (int)b[1]);
+    };
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + wave * 64 + i * 16 + r;
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
-            unsigned long long key = 0ull;
             float m1[2], m2[2];
             int p1[2];
+            // ---- train columns of the slice: value first, position second (ties in the value: the smaller train position) ----
+            float tv[2][4];
+            float V = -INFINITY;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    tv[jj][e] = tp[2 * s + jj][e] >= 0 ? acc[i][2 * s + jj][e] + 0.0f : -INFINITY;    // -0 -> +0, as the row sweep of hgr_eval_rows does
+                    V = fmaxf(V, tv[jj][e]);
+                }
+            V = xmaxf(V);
+            int P = 0x7fffffff;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) P = min(P, (tp[2 * s + jj][e] >= 0 && tv[jj][e] == V) ? tp[2 * s + jj][e] : 0x7fffffff);
+            P = xmini(P);
+            const unsigned vu = __float_as_uint(V);
+            // (no train column in the slice: P stays INT_MAX -> key 0, which loses against every real key)
+            const unsigned long long key = P == 0x7fffffff ? 0ull
+                : ((unsigned long long)(vu ^ ((vu >> 31) ? 0xFFFFFFFFu : 0x80000000u)) << 32) | (unsigned)(0x7fffffff - P);
+            // ---- test columns: per 16-column group the largest value, the position of an element attaining it, the runner-up ----
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
                 const int j = 2 * s + jj;
                 float x[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float v = acc[i][j][e] + 0.0f;               // -0 -> +0, as the row sweep of hgr_eval_rows does
-                    const unsigned u = __float_as_uint(v);
-                    const unsigned long long k2 = ((unsigned long long)(u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u)) << 32) | (unsigned)(0x7fffffff - tp[j][e]);
-                    if (tp[j][e] >= 0 && k2 > key) key = k2;
-                    x[e] = ep[j][e] >= 0 ? v : -INFINITY;
-                }
+                for (int e = 0; e < 4; ++e) x[e] = ep[j][e] >= 0 ? acc[i][j][e] + 0.0f : -INFINITY;
                 const float hi01 = fmaxf(x[0], x[1]), lo01 = fminf(x[0], x[1]), hi23 = fmaxf(x[2], x[3]), lo23 = fminf(x[2], x[3]);
-                const float top = fmaxf(hi01, hi23);
-                m1[jj] = top;
-                m2[jj] = fmaxf(fminf(hi01, hi23), fmaxf(lo01, lo23));
-                p1[jj] = x[0] == top ? ep[j][0] : x[1] == top ? ep[j][1] : x[2] == top ? ep[j][2] : ep[j][3];
-            }
-#pragma unroll
-            for (int o = 16; o <= 32; o <<= 1) {
-                const unsigned hi = __shfl_xor((unsigned)(key >> 32), o), lo = __shfl_xor((unsigned)key, o);
-                const unsigned long long x = ((unsigned long long)hi << 32) | lo;
-                key = x > key ? x : key;
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const float o1 = __shfl_xor(m1[q], o), o2 = __shfl_xor(m2[q], o);
-                    const int op = __shfl_xor(p1[q], o);
-                    m2[q] = fmaxf(fminf(m1[q], o1), fmaxf(m2[q], o2));
-                    p1[q] = o1 > m1[q] ? op : p1[q];
-                    m1[q] = fmaxf(m1[q], o1);
+                float t1 = fmaxf(hi01, hi23);
+                float t2 = fmaxf(fminf(hi01, hi23), fmaxf(lo01, lo23));
+                int q1 = x[0] == t1 ? ep[j][0] : x[1] == t1 ? ep[j][1] : x[2] == t1 ? ep[j][2] : ep[j][3];
+                {
+                    auto a1 = LS_SWAP16(__float_as_uint(t1)); auto a2 = LS_SWAP16(__float_as_uint(t2)); auto ap = LS_SWAP16(q1);
+                    const float e1 = __uint_as_float(a1[0]), o1 = __uint_as_float(a1[1]);
+                    t2 = fmaxf(fminf(e1, o1), fmaxf(__uint_as_float(a2[0]), __uint_as_float(a2[1])));
+                    q1 = o1 > e1 ? (int)ap[1] : (int)ap[0];
+                    t1 = fmaxf(e1, o1);
                 }
+                {
+                    auto a1 = LS_SWAP32(__float_as_uint(t1)); auto a2 = LS_SWAP32(__float_as_uint(t2)); auto ap = LS_SWAP32(q1);
+                    const float e1 = __uint_as_float(a1[0]), o1 = __uint_as_float(a1[1]);
+                    t2 = fmaxf(fminf(e1, o1), fmaxf(__uint_as_float(a2[0]), __uint_as_float(a2[1])));
+                    q1 = o1 > e1 ? (int)ap[1] : (int)ap[0];
+                    t1 = fmaxf(e1, o1);
+                }
+                m1[jj] = t1; m2[jj] = t2; p1[jj] = q1;
             }
             // (the warm-up loads' values are consumed here, at the very end; the extra condition never holds)
             if (m < p.M || ((tw[0] ^ tw[1] ^ tw[2]) + (tw[3] ^ tw[4] ^ tw[5]) + ta == 0x9E3779B9u && m == 0x7fffffff)) {
@@ -220,6 +256,8 @@ __global__ __launch_bounds__(LS_NT) void logits_slab(SlabArgs p) {
             }
         }
     }
+#undef LS_SWAP16
+#undef LS_SWAP32
 }
 }  // namespace
 

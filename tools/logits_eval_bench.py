@@ -38,5 +38,7 @@ def timeit(fn, iters=30):
 
 
 print(json.dumps({"fused_us": round(timeit(lambda: ops.logits_eval(f, plan, k)), 1),
+                  "tile_us": round(timeit(lambda: ops.logits_eval(f, plan, k, stage="tile")), 1),
+                  "row_us": round(timeit(lambda: ops.logits_eval(f, plan, k, stage="row")), 1),
                   "gemm_us": round(timeit(lambda: ops.gemm_nt(f, z, lg, n=n)), 1),
                   "gemm_plus_eval_rows_us": round(timeit(lambda: (ops.gemm_nt(f, z, lg, n=n), ops.eval_rows(lg[:, :n], index, k))), 1)}))
