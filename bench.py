@@ -633,7 +633,7 @@ def main():
             roof["by_shape"] = {k: {"launches": len(v), "avg_us": round(sum(t for t, _ in v) / len(v) * 1e6, 1),
                                     "tflops": round(sum(f for _, f in v) / sum(t for t, _ in v) / 1e12, 1)} for k, v in sorted(shapes.items())}
         if roof:
-            # the launches of the last image block and the visual head, which act on the class-token rows only
+            # the launches of the last image block and the visual head, which act on the class-token rows only ("the last image block")
             small = {}
             for (name, s_, e_, fl, by, tag) in recs:
                 if tag in ("kv", "q_cls", "out_cls", "fc_cls", "proj_cls", "head"):

@@ -6,7 +6,7 @@
 // Why: at one workgroup per CU nothing overlaps a tile's prologue (first operand pieces) and epilogue (bias / fp32
 // residual loads, stores): ~14 us of a ~35 us tile at K = 768, and a whole round of 256 tiles stores (and, for the
 // residual epilogue, re-reads) its 33 - 67 MB in one burst.  A wave's stores and its LDS-DMA loads share one in-order
-// vmcnt, so a single persistent workgroup cannot hide them either (finding 3).  Two independent
+// vmcnt, so a single persistent workgroup cannot hide them either (profiles/NOTES.md 4.1, finding 3).  Two independent
 // workgroups per CU can: while one is in its epilogue or waits for operands, the other one's waves own the matrix
 // pipes of the same SIMDs.  No ping-pong groups inside a workgroup, so ONE barrier per phase (4 per K-tile).
 //

@@ -82,7 +82,7 @@ int hgr_gemm_set_tile(int tile);
 /*
  * Tail plan of the 256 x 128 tile kernel (hgr_gemm_nt and the LayerNorm-folded forms below): a launch whose tile count is not a
  * whole number of rounds of the chip's 512 workgroup slots gives its LAST row panels to 128 x 128 half tiles, dispatched after
- * the full tiles, so that the last round is not left to a few workgroups.  enabled = 1 (default; HGR_DUO_TAIL)
+ * the full tiles, so that the last round is not left to a few workgroups ("tail plan").  enabled = 1 (default; HGR_DUO_TAIL)
  * / 0; full_panels = -1 lets the host's list-scheduling model choose how many 256-row panels stay on full tiles, n >= 0 forces
  * it (measurement sweeps; HGR_DUO_PB).  Every output element sums K in the same order on either tile: results are bit-identical.
  * Process-wide development knob like hgr_gemm_set_tile.  Returns the previous `enabled`.

@@ -603,7 +603,7 @@ def test_gemm_nt_res_stats(dt, m, n, k):
 @pytest.mark.parametrize("m,n,k,panels", [(25600, 768, 768, -1), (25600, 768, 3072, -1), (25600, 2304, 768, 86), (25523, 768, 128, -1),
                                            (25600, 768, 192, 0), (25600, 768, 256, 1), (25600, 768, 256, 99), (26000, 1536, 256, -1)])
 def test_gemm_tail_plan_is_bit_identical(dt, m, n, k, panels):
-    """The tail plan of the 256 x 128 tile kernel (half tiles on the last row panels, hgr_gemm_set_tail) against the
+    """The tail plan of the 256 x 128 tile kernel (half tiles on the last row panels, hgr_gemm_set_tail; DESIGN.md 4.1, "tail plan") against the
     all-full-tile launch of the same call: every output element sums K in the same order on either tile, so every entry point that
     rides the kernel - plain 16-bit / fp32 epilogues, the LayerNorm producer (pair + slot statistics) and consumer, the dual-output
     forward - must give the same BITS on random data.  ViT-B/32 tower shapes at batch 512 (600 / 1800 tiles on 512 slots), a ragged

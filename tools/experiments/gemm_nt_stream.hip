@@ -1,4 +1,4 @@
-// EXPERIMENT - NOT part of libhgr.so (kept for the next round; results in tools/experiments/README.md and DESIGN.md 4.1b).
+// EXPERIMENT - NOT part of libhgr.so (kept for the next round; results in tools/experiments/README.md and profiles/NOTES.md 4.1b).
 // Two persistent kernels for the class-logits product that were built, validated bit-exact / exact on MI355X, measured,
 // and NOT adopted: in the evaluation step (operands cold in HBM) the tiled kernels of hgr_gemm.hip are faster.
 //   gemm_nt_stream  LDS ring fed by loader waves, MFMA waves never wait on memory      22.0 us warm / 32.6 us in the step
@@ -15,7 +15,7 @@
 // tile's life in its prologue / epilogue and fetch one K-tile ahead (23-29 us, 16-20 % of the MFMA peak, 2.3-2.9 TB/s).
 // Here a workgroup is PERSISTENT and the three jobs of a GEMM are given to different waves, so that none of them ever
 // waits for another one's memory traffic (vmcnt retires in issue order inside a wave: a wave that both stores C and waits
-// for operand loads waits for its stores too - DESIGN.md section 4.1, finding 3):
+// for operand loads waits for its stores too - profiles/NOTES.md section 4.1, finding 3):
 //   * waves 4-5 ("loaders") only issue LDS-DMA (global_load_lds_dwordx4): a ring of 3 stages of 40 KB, each stage one
 //     64-deep K-tile of the workgroup's 64 A rows (8 KB) and 256 W rows (32 KB); two stages (80 KB per CU) are always in
 //     flight, across K-tiles AND across output tiles - the stream of class embeddings never stops at a tile boundary;

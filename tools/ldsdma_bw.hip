@@ -3,7 +3,7 @@
 //   mode 1: register path  global_load_dwordx4 -> VGPR -> ds_write_b128
 //   mode 2: register path without the LDS write (global_load_dwordx4 only)
 // NOTE: the mode-1 numbers are not trustworthy for the large region (hipcc hoists the pass-invariant loads out of the pass
-// loop there: 'bandwidths' of hundreds of GB/s per CU); modes 0 and 2 are the ones quoted in DESIGN.md section 4.1b.
+// loop there: 'bandwidths' of hundreds of GB/s per CU); modes 0 and 2 are the ones quoted in profiles/NOTES.md section 4.1b.
 // Each wave keeps DEPTH loads of 1 KB in flight (counted vmcnt) and walks its workgroup's private, L2-hot region
 // (`region` bytes, re-read `passes` times).  pattern 0: an instruction reads 1 KB contiguous; pattern 1: 8 rows of
 // 128 B, 1 KB apart (one K-tile slice of 8 operand rows with K = 512 - the GEMM loaders' pattern).
