@@ -244,7 +244,7 @@ def _run_blocks(x: Optional[torch.Tensor], blocks, heads: int, b: int, l: int, c
             ops.gemm_nt_ln(xh, k.wf_fc, u16, k.s_fc, k.c_fc, stats, k.eps2, quickgelu=True, tag="fc")
             ops.gemm_nt_res_stats(u16, k.w_proj, xh, xl, k.b_proj, stats, tag="proj", flag=flag)
             if taps is not None:
-                taps[f"{tap_prefix}.resblocks.{i}"] = (xh.float() + xl.float()).view(b, l, w)
+                taps[f"{tap_prefix}.resblocks.{i}"] = ops.pair_value(xh, xl).view(b, l, w)
         return None
     h16 = ws.get(tag + ".h16", (m, w), dt, dev)
     for i, k in enumerate(blocks):
@@ -611,11 +611,11 @@ class CLIP(nn.Module):
         fused = ln_fusable(w, b * l) and "v" not in self._ln_off
         if fused:
             xh = ws.get(tag + ".xh", (b * l, w), dt, dev)
-            xl = ws.get(tag + ".xl", (b * l, w), torch.float16, dev)
+            xl = ws.get(tag + ".xl", (b * l, w), ops.PAIR_LO, dev)
             stats = ws.get(tag + ".stats", (b * l, w // 64, 2), torch.float32, dev)
             ops.vit_embed_ln_stats(pe, p["cls"], p["pos"], p["ln_pre"][0], p["ln_pre"][1], xh, xl, stats, b, gg)
             if taps is not None:
-                taps["visual.ln_pre"] = (xh.float() + xl.float()).view(b, l, w)
+                taps["visual.ln_pre"] = ops.pair_value(xh, xl).view(b, l, w)
             _run_blocks(None, p["vblocks"], w // 64, b, l, False, dt, ws, tag, taps, "visual.transformer", (xh, xl), stats, self._ln_flag("v", dev),
                         cls_only_last=taps is None and CLS_LAST)
             if w <= 1920 and w % 32 == 0 and v.output_dim % 4 == 0:
@@ -663,7 +663,7 @@ class CLIP(nn.Module):
             fused = ln_fusable(w, c * l) and "t" not in self._ln_off
             if fused:
                 xh = ws.get("t.xh", (c * l, w), dt, dev)
-                xl = ws.get("t.xl", (c * l, w), torch.float16, dev)
+                xl = ws.get("t.xl", (c * l, w), ops.PAIR_LO, dev)
                 stats = ws.get("t.stats", (c * l, w // 64, 2), torch.float32, dev)
                 ops.row_stats16(x, xh, xl, stats)
                 _run_blocks(None, p["tblocks"], w // 64, c, l, True, dt, ws, "t", pair=(xh, xl), stats=stats, flag=self._ln_flag("t", dev))

@@ -54,6 +54,35 @@ template <int DT> __device__ __forceinline__ typename T16<DT>::vec4 cvt4(float a
     return r;
 }
 
+// ---- the residual stream's 16-bit-plus-8-bit PAIR (round 4) ----------------------------------------------------------------------
+// x (fp32) is kept as hi - x in the MFMA type (f16 / bf16: it IS the next GEMM's A operand) - and ONE byte q, both cut out of x's own
+// bit pattern.  With S = 13 (f16) / 16 (bf16) mantissa bits dropped by hi:
+//     t  = bits(x) + 2^(S-1)          (round the magnitude half up at hi's last place; float bit patterns are monotonic integers)
+//     hi = t with its low S bits cleared  (exactly representable in the MFMA type)      q = bits S-1 .. S-8 of t
+//     decode:  bits(x') = bits(hi) + ((q - 128) << (S - 8))  =  bits(x) with its low S - 8 bits cleared
+// i.e. x to 8 more mantissa bits than hi alone (19 / 16 significant bits; |x - x'| < ulp(hi) / 256, towards zero) in 3 bytes, for ~2
+// integer operations per element each way - rounds 2 - 3 kept lo = f16(x - hi): 22 bits in 4 bytes.  The residual producers are
+// bound by this stream's read-modify-write; a byte less each way is 39 MB per launch at ViT-B/32 batch 512.  (A first round-4 form -
+// q = rint((x - hi) 254 / ulp(hi)) through v_ldexp / fma, ~13 floating-point operations per element - saved the bytes and lost the
+// same time to VALU: 5.01 vs 5.01 ms per step.)  hi differs from round-to-nearest-EVEN on exact ties only (half away from zero).
+// Values below the f16 normal range (|x| < 2^-14) keep an absolute error <= 2^-25 instead of a relative one; inf / NaN are the range
+// guard's business.  Every kernel that touches the pair uses these two functions.
+template <int DT> __device__ __forceinline__ void pair_split(float x, typename T16<DT>::elem &hi, unsigned &q) {
+    constexpr int S = DT == HGR_F16 ? 13 : 16;
+    const unsigned t = __float_as_uint(x) + (1u << (S - 1));
+    q = (t >> (S - 8)) & 255u;
+    if (DT == HGR_F16) {
+        // below the f16 normal range the conversion is not a bit copy (it rounds into subnormals, or to zero): no extra bits there -
+        // q = 128 decodes to hi itself (|x - hi| <= 2^-25); a stale q < 128 on hi = 0 would decode to a NaN pattern
+        if ((t & 0x7FFFFFFFu) < 0x38800000u) q = 128u;
+        hi = (typename T16<DT>::elem)__uint_as_float(t & ~((1u << S) - 1u));
+    } else hi = __builtin_bit_cast(typename T16<DT>::elem, (unsigned short)(t >> 16));
+}
+template <int DT> __device__ __forceinline__ float pair_dec(typename T16<DT>::elem hi, unsigned q) {
+    constexpr int S = DT == HGR_F16 ? 13 : 16;
+    return __uint_as_float(__float_as_uint((float)hi) + (unsigned)(((int)q - 128) * (1 << (S - 8))));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

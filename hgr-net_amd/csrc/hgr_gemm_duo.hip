@@ -487,10 +487,10 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
         // every global address below = wave-uniform 64-bit base + 32-bit per-lane byte offset (see the 16-bit epilogue)
         const int64_t wrow = m0 + wm * WR, wcol = n0 + wn * 64;
         if (LN == 1) {
-            // Producer of a folded LayerNorm.  The residual stream lives in memory as a 16-bit pair: x = hi + lo, hi = x rounded to
-            // the MFMA type (= the A operand of the next GEMM, no second copy of the stream), lo = f16(x - hi): |x - hi - lo| <=
-            // 2^-11 |x - hi| (2^-22 |x| with f16 hi, 2^-19 |x| with bf16 hi), far below the 16-bit rounding of every GEMM input.
-            // Same bytes as an fp32 read-modify-write.  Plus this wave's 64-column share of the rows' LayerNorm statistics; the
+            // Producer of a folded LayerNorm.  The residual stream lives in memory as a pair: hi = x rounded to the MFMA type (= the A
+            // operand of the next GEMM, no second copy of the stream) and one byte q = the next 8 mantissa bits of x (hgr_common.h:
+            // pair_split / pair_dec; 2^-19 |x| with f16 hi, 2^-16 |x| with bf16 hi), far below the 16-bit rounding of every GEMM input.
+            // 3 bytes per element each way (rounds 2 - 3: lo = f16(x - hi), 4 bytes).  Plus this wave's 64-column share of the rows' LayerNorm statistics; the
             // 16 reduction chains of a pass (8 row groups x {sum, sum of squares}) advance stage by stage (DPP latencies overlap).
             // 16-byte accesses on the pair (T21 of the CDNA guide: a row-per-lane epilogue is store-ISSUE bound): a lane owns 8
             // consecutive columns of a row (8 lanes per row, 8 rows per instruction), i.e. ONE 16-byte load / store per half of the
@@ -498,22 +498,27 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
             // tile.  The slot sums pair the same values as the 4-column form stage by stage (a lane's 8 columns = the first
             // exchange of two 4-column lanes), so the statistics keep their bits.  Measured against the 8-byte form, same box, interleaved: out 69.1 -> 64.6 us, proj 146 -> 140 us, image tower 6.04 -> 5.89 ms.
             char *hw = (char *)p.ln_xh + (wrow * p.ln_ldx + wcol) * 2;
-            char *lw = (char *)p.ln_xl + (wrow * p.ln_ldx + wcol) * 2;
+            char *lw = (char *)p.ln_xl + (wrow * p.ln_ldx + wcol);            // the low byte of the pair: one byte per element
             char *sw = (char *)(p.ln_stats + (wrow * p.ln_slots + (n0 >> 6) + wn) * 2);
             const int r8 = lane >> 3, c8 = lane & 7;
             const unsigned ldxB = (unsigned)p.ln_ldx * 2u, ldsB = (unsigned)p.ln_slots * 8u;
             const unsigned xo = r8 * ldxB + c8 * 16, so = r8 * ldsB;
+            const unsigned ldlB = (unsigned)p.ln_ldx, lo8 = r8 * ldlB + c8 * 8;            // byte offsets into the low half (8 columns = 8 bytes per lane)
             // 8 (4 for a half tile) passes of 16 rows; the old pair of pass P + 2 is requested while pass P is worked on (a ring of three
             // 16-register buffers: passes touch disjoint rows, the compiler cannot hoist the loads itself - the pointers alias).  The first
             // version worked in passes of 32 rows with two 32-register buffers: at the 256-register cap of two workgroups per CU hipcc
             // then sent 9 - 16 accumulator quads through scratch in every tile.
             constexpr int NP = MH * 4;
-            u32x4 ohb[3][2], olb[3][2];
+            u32x4 ohb[3][2];
+            u32x2 olb[3][2];
             auto pair_load = [&](int buf, int rl) {
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     ohb[buf][q] = *(const u32x4 *)(hw + (xo + (rl + q * 8) * ldxB));
-                    olb[buf][q] = *(const u32x4 *)(lw + (xo + (rl + q * 8) * ldxB));
+                    // (HGR_GEMM_DBG bit 64, measurement only: the pair's low half is neither read nor written - the bound of what any
+                    // narrower encoding of it can save: 5.12 -> 4.88 ms per step with the 16-bit low half of round 3)
+                    if (!(p.dbg & 64)) olb[buf][q] = *(const u32x2 *)(lw + (lo8 + (rl + q * 8) * ldlB));
+                    else olb[buf][q] = (u32x2){0x80808080u, 0x80808080u};
                 }
             };
             pair_load(0, 0);
@@ -538,19 +543,27 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
                     const f32x4 lo4 = *(const f32x4 *)(my + (q * 8 + r8) * RS + c8 * 32);
                     const f32x4 hi4 = *(const f32x4 *)(my + (q * 8 + r8) * RS + c8 * 32 + 16);
                     const vec8 oh = __builtin_bit_cast(vec8, ohb[pb][q]);
-                    const f16x8 ol = __builtin_bit_cast(f16x8, olb[pb][q]);
+                    const u32x2 ol = olb[pb][q];
                     float v[8];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {              // (acc + bias) + (hi + lo): the order of the 4-column form
-                        v[e] = (lo4[e] + b8lo[e]) + ((float)oh[e] + (float)ol[e]);
-                        v[e + 4] = (hi4[e] + b8hi[e]) + ((float)oh[e + 4] + (float)ol[e + 4]);
+                    for (int e = 0; e < 4; ++e) {              // (acc + bias) + old x (pair_dec: hi's bits + the low byte's 8 mantissa bits)
+                        v[e] = (lo4[e] + b8lo[e]) + pair_dec<DT>(oh[e], (ol[0] >> (8 * e)) & 255u);
+                        v[e + 4] = (hi4[e] + b8hi[e]) + pair_dec<DT>(oh[e + 4], (ol[1] >> (8 * e)) & 255u);
                     }
                     vec8 nh;
-                    f16x8 nl;
+                    u32x2 nl = (u32x2){0u, 0u};
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { nh[e] = (E)v[e]; nl[e] = (_Float16)(v[e] - (float)nh[e]); }
+                    for (int e = 0; e < 4; ++e) {
+                        unsigned q0, q1;
+                        E h0, h1;
+                        pair_split<DT>(v[e], h0, q0);
+                        pair_split<DT>(v[e + 4], h1, q1);
+                        nh[e] = h0; nh[e + 4] = h1;
+                        nl[0] |= q0 << (8 * e);
+                        nl[1] |= q1 << (8 * e);
+                    }
                     *(u32x4 *)(hw + (xo + (rl + q * 8) * ldxB)) = __builtin_bit_cast(u32x4, nh);
-                    *(u32x4 *)(lw + (xo + (rl + q * 8) * ldxB)) = __builtin_bit_cast(u32x4, nl);
+                    if (!(p.dbg & 64)) *(u32x2 *)(lw + (lo8 + (rl + q * 8) * ldlB)) = nl;
                     s1[q] = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
                     s2[q] = (__builtin_fmaf(v[0], v[0], v[1] * v[1]) + __builtin_fmaf(v[2], v[2], v[3] * v[3])) +
                             (__builtin_fmaf(v[4], v[4], v[5] * v[5]) + __builtin_fmaf(v[6], v[6], v[7] * v[7]));
@@ -667,19 +680,19 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
                 const int64_t at = row * p.ln_ldx + n0 + wn * 64 + cq * 4;
                 if (ok) {
                     const hvec4 oh = *(const hvec4 *)((const E *)p.ln_xh + at);
-                    const f16x4 ol = *(const f16x4 *)((const _Float16 *)p.ln_xl + at);
+                    const unsigned ol = *(const unsigned *)((const unsigned char *)p.ln_xl + at);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += (float)oh[e] + (float)ol[e];
+                    for (int e = 0; e < 4; ++e) v[e] += pair_dec<DT>(oh[e], (ol >> (8 * e)) & 255u);
                 }
                 const float s1 = row16_sum((v[0] + v[1]) + (v[2] + v[3]));
                 const float s2 = row16_sum(__builtin_fmaf(v[0], v[0], v[1] * v[1]) + __builtin_fmaf(v[2], v[2], v[3] * v[3]));
                 if (ok) {
-                    const hvec4 nh = cvt4<DT>(v[0], v[1], v[2], v[3]);
-                    f16x4 nl;
+                    hvec4 nh;
+                    unsigned nl = 0u;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) nl[e] = (_Float16)(v[e] - (float)nh[e]);
+                    for (int e = 0; e < 4; ++e) { unsigned q; E h; pair_split<DT>(v[e], h, q); nh[e] = h; nl |= q << (8 * e); }
                     *(hvec4 *)((E *)p.ln_xh + at) = nh;
-                    *(f16x4 *)((_Float16 *)p.ln_xl + at) = nl;
+                    *(unsigned *)((unsigned char *)p.ln_xl + at) = nl;
                     if (cq == 0) *(float2 *)(p.ln_stats + (row * p.ln_slots + (n0 >> 6) + wn) * 2) = make_float2(s1, s2);
                     if (cq == 0 && p.ln_flag && __float_as_uint(s2) > __float_as_uint(p.ln_guard)) atomicMax(p.ln_flag, __float_as_uint(s2));
                 }

@@ -108,12 +108,12 @@ __global__ __launch_bounds__(256) void vit_embed_ln(const float *__restrict__ pa
                 // the first block's LayerNorm is folded into its QKV GEMM (hgr_gemm_nt_ln): the row leaves as the 16-bit pair
                 // (hi, lo), x = hi + lo, the form the residual stream keeps between the GEMMs, + the (sum, sum of squares)
                 // of every 64-column slot = one DPP row of 16 lanes per slot (W % 64 == 0)
-                const typename T16<DT>::vec4 nh = cvt4<DT>(o[0], o[1], o[2], o[3]);
-                f16x4 nl;
+                typename T16<DT>::vec4 nh;
+                unsigned nl = 0u;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) nl[e] = (_Float16)(o[e] - (float)nh[e]);
+                for (int e = 0; e < 4; ++e) { unsigned q; typename T16<DT>::elem h; pair_split<DT>(o[e], h, q); nh[e] = h; nl |= q << (8 * e); }
                 ((typename T16<DT>::vec4 *)((typename T16<DT>::elem *)xh + (int64_t)row * W))[c] = nh;
-                ((f16x4 *)((_Float16 *)xl + (int64_t)row * W))[c] = nl;
+                ((unsigned *)((unsigned char *)xl + (int64_t)row * W))[c] = nl;
                 const float s1 = row16_sum((o[0] + o[1]) + (o[2] + o[3]));
                 const float s2 = row16_sum((o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]));
                 if ((lane & 15) == 0) *(float2 *)(stats + ((int64_t)row * (W >> 6) + (c >> 4)) * 2) = make_float2(s1, s2);
@@ -138,12 +138,12 @@ __global__ __launch_bounds__(256) void row_stats16(const float *__restrict__ x, 
         const float s1 = row16_sum((v[0] + v[1]) + (v[2] + v[3]));
         const float s2 = row16_sum((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]));
         if (ok) {
-            const typename T16<DT>::vec4 nh = cvt4<DT>(v[0], v[1], v[2], v[3]);
-            f16x4 nl;
+            typename T16<DT>::vec4 nh;
+            unsigned nl = 0u;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) nl[e] = (_Float16)(v[e] - (float)nh[e]);
+            for (int e = 0; e < 4; ++e) { unsigned q; typename T16<DT>::elem h; pair_split<DT>(v[e], h, q); nh[e] = h; nl |= q << (8 * e); }
             ((typename T16<DT>::vec4 *)((typename T16<DT>::elem *)xh + (int64_t)row * W))[c] = nh;
-            ((f16x4 *)((_Float16 *)xl + (int64_t)row * W))[c] = nl;
+            ((unsigned *)((unsigned char *)xl + (int64_t)row * W))[c] = nl;
             if ((lane & 15) == 0) *(float2 *)(stats + ((int64_t)row * (W >> 6) + (c >> 4)) * 2) = make_float2(s1, s2);
         }
     }
@@ -160,8 +160,8 @@ __global__ __launch_bounds__(256) void pair_rows_f32(const void *__restrict__ xh
     const int64_t src = (int64_t)row * row_mul + (row_idx ? row_idx[row] : 0);
     for (int c = lane; c < (W >> 2); c += 64) {
         const typename T16<DT>::vec4 h = ((const typename T16<DT>::vec4 *)((const typename T16<DT>::elem *)xh + src * W))[c];
-        const f16x4 l = ((const f16x4 *)((const _Float16 *)xl + src * W))[c];
-        ((f32x4 *)(out + (int64_t)row * W))[c] = (f32x4){(float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2], (float)h[3] + (float)l[3]};
+        const unsigned l = ((const unsigned *)((const unsigned char *)xl + src * W))[c];
+        ((f32x4 *)(out + (int64_t)row * W))[c] = (f32x4){pair_dec<DT>(h[0], l & 255u), pair_dec<DT>(h[1], (l >> 8) & 255u), pair_dec<DT>(h[2], (l >> 16) & 255u), pair_dec<DT>(h[3], l >> 24)};
     }
 }
 
@@ -220,16 +220,16 @@ __global__ __launch_bounds__(256) void vit_head(const void *__restrict__ xh, con
     for (int q4 = 0; q4 < 4; ++q4) {
         const int row = min(row0 + wave * 4 + q4, B - 1);
         const E *ph = (const E *)xh + (int64_t)row * row_mul * ldx;
-        const _Float16 *pl = (const _Float16 *)xl + (int64_t)row * row_mul * ldx;
+        const unsigned char *pl = (const unsigned char *)xl + (int64_t)row * row_mul * ldx;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = i * 64 + lane;
             if (i * 64 < nv) {
                 const int cc = min(c, nv - 1);
                 const vec4 h4 = ((const vec4 *)ph)[cc];
-                const f16x4 l4 = ((const f16x4 *)pl)[cc];
+                const unsigned l4 = ((const unsigned *)pl)[cc];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[q4][i][e] = c < nv ? (float)h4[e] + (float)l4[e] : 0.f;
+                for (int e = 0; e < 4; ++e) v[q4][i][e] = c < nv ? pair_dec<DT>(h4[e], (l4 >> (8 * e)) & 255u) : 0.f;
             }
         }
     }

@@ -32,6 +32,15 @@ def split_point(name: str) -> None:
 
 
 TORCH16 = {HGR_BF16: torch.bfloat16, HGR_F16: torch.float16}
+# the residual stream between the folded-LayerNorm GEMMs is a PAIR (csrc/hgr_common.h: pair_split / pair_dec): hi = x rounded to the
+# MFMA type and one byte q = the next 8 mantissa bits of x (19 significant bits with f16, 3 bytes).  PAIR_LO is the byte plane's dtype.
+PAIR_LO = torch.uint8
+
+
+def pair_value(xh: torch.Tensor, xl: torch.Tensor) -> torch.Tensor:
+    """fp32 value of every row of the pair (decoded by hgr_pair_rows_f32 - the kernels' own decoder)."""
+    out = torch.empty(xh.shape, dtype=torch.float32, device=xh.device)
+    return pair_rows_f32(xh.contiguous(), xl.contiguous(), out)
 DT_OF = {torch.bfloat16: HGR_BF16, torch.float16: HGR_F16}
 
 
@@ -101,13 +110,13 @@ LN_GUARD_SUMSQ = 16384.0 ** 2
 
 def gemm_nt_res_stats(a: torch.Tensor, w: torch.Tensor, xh: torch.Tensor, xl: torch.Tensor, bias: torch.Tensor, stats: torch.Tensor,
                       tag: str = "", flag: Optional[torch.Tensor] = None) -> None:
-    """(xh, xl) += a @ w^T + bias on the residual stream kept as a 16-bit pair (x = xh + xl, xh in the MFMA type = the next GEMM's
-    A operand, xl f16) and, for the LayerNorm that follows, stats[m, slot] = (sum, sum of squares) of every 64-column slot of the
+    """(xh, xl) += a @ w^T + bias on the residual stream kept as a pair (xh = x in the MFMA type = the next GEMM's A operand, xl one
+    byte per element: the rounding error of xh on an 8-bit grid, see PAIR_LO) and, for the LayerNorm that follows, stats[m, slot] = (sum, sum of squares) of every 64-column slot of the
     new row (hgr_gemm_nt_res_stats).  `flag` (uint32 / int32 [1], zeroed by the caller): range guard, non-zero afterwards when a
     slot's sum of squares exceeded LN_GUARD_SUMSQ or was inf / NaN (hgr_gemm_nt_res_stats_guard)."""
     m, k = a.shape
     n = w.shape[0]
-    assert a.dtype == w.dtype == xh.dtype and xl.dtype == torch.float16 and xh.shape == xl.shape == (m, n) and xh.stride() == xl.stride()
+    assert a.dtype == w.dtype == xh.dtype and xl.dtype == PAIR_LO and xh.shape == xl.shape == (m, n) and xh.stride() == xl.stride()
     assert stats.dtype == torch.float32 and stats.numel() >= m * (n // 64) * 2 and a.stride(1) == w.stride(1) == xh.stride(1) == 1
     ev = _prof_begin()
     if flag is None:
@@ -178,13 +187,13 @@ def vit_embed_ln_stats(patches, cls, pos, gamma, beta, xh, xl, stats, b, g, eps=
 
 def row_stats16(x: torch.Tensor, xh: torch.Tensor, xl: torch.Tensor, stats: torch.Tensor) -> None:
     assert x.dtype == torch.float32 and x.is_contiguous() and xh.is_contiguous() and xl.is_contiguous() and xh.shape == xl.shape == x.shape
-    assert xl.dtype == torch.float16 and stats.numel() >= x.shape[0] * (x.shape[1] // 64) * 2
+    assert xl.dtype == PAIR_LO and stats.numel() >= x.shape[0] * (x.shape[1] // 64) * 2
     _lib.call("hgr_row_stats16", _dev(x), _dev(xh), _dev(xl), _dev(stats), x.shape[0], x.shape[1], DT_OF[xh.dtype], _stream())
 
 
 def pair_rows_f32(xh: torch.Tensor, xl: torch.Tensor, out: torch.Tensor, row_mul: int = 1, row_idx: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[i] = xh[src] + xl[src] (fp32), src = i * row_mul + row_idx[i]: selected rows of the 16-bit pair back in fp32."""
-    assert xh.is_contiguous() and xl.is_contiguous() and out.is_contiguous() and out.dtype == torch.float32 and out.shape[1] == xh.shape[1]
+    assert xh.is_contiguous() and xl.is_contiguous() and out.is_contiguous() and out.dtype == torch.float32 and out.shape[1] == xh.shape[1] and xl.dtype == PAIR_LO
     _lib.call("hgr_pair_rows_f32", _dev(xh), _dev(xl), _dev(out), out.shape[0], out.shape[1], row_mul, _dev(row_idx), DT_OF[xh.dtype], _stream())
     return out
 
@@ -192,7 +201,7 @@ def pair_rows_f32(xh: torch.Tensor, xl: torch.Tensor, out: torch.Tensor, row_mul
 def vit_head(xh: torch.Tensor, xl: torch.Tensor, row_mul: int, gamma: torch.Tensor, beta: torch.Tensor, eps: float, proj_t: torch.Tensor,
              out: torch.Tensor) -> torch.Tensor:
     """out[b] = LayerNorm(xh[b * row_mul] + xl[b * row_mul]) (16-bit) @ proj_t^T, fp32 [B, D] (hgr_vit_head: ln_post + visual.proj)."""
-    assert xh.dtype == proj_t.dtype and xl.dtype == torch.float16 and xh.stride() == xl.stride() and xh.stride(1) == 1
+    assert xh.dtype == proj_t.dtype and xl.dtype == PAIR_LO and xh.stride() == xl.stride() and xh.stride(1) == 1
     assert out.dtype == torch.float32 and out.is_contiguous() and proj_t.is_contiguous() and proj_t.shape[1] == xh.shape[1] and out.shape[1] == proj_t.shape[0]
     ev = _prof_begin()
     _lib.call("hgr_vit_head", _dev(xh), _dev(xl), xh.stride(0), int(row_mul), _dev(gamma), _dev(beta), float(eps), _dev(proj_t), _dev(out),

@@ -470,11 +470,18 @@ int hgr_adamw(float *p, const float *g, float *m, float *v, int64_t n, float lr,
  *     LN(x) W^T + b = rstd * ( x (gamma o W)^T - mean * s ) + c,    s_n = sum_k gamma_k W_nk,   c_n = sum_k beta_k W_nk + b_n
  * the consumer runs on the un-normalised 16-bit rows with the gamma-folded weight and the producer supplies per-row partial
  * (sum, sum of squares) per 64-column slot: the separate LayerNorm pass (118 MB of traffic per call at ViT-B/32 batch 512)
- * disappears.  Between the GEMMs the residual stream is kept as a 16-bit PAIR (xh, xl): x = xh + xl, xh = x rounded to the MFMA
- * type - it IS the consumer's A operand - and xl = f16(x - xh); 4 bytes per element like fp32, |x - xh - xl| <= 2^-22 |x| (f16)
- * / 2^-19 |x| (bf16).  Error study: tools/studies/ln_fusion_study.py.
- *   stats  fp32 [M][N/64][2]  (N = row width);  xh, xl 16-bit [M, ldx];  requirements: row width % 128 == 0; xh / xl 16-byte
- *   aligned with ldx % 8 == 0 (the producer reads and writes the pair 16 bytes per lane) and ldx < 2^23; the consumer's C 16-byte
+ * disappears.  Between the GEMMs the residual stream is kept as a PAIR (xh, xl): xh = x rounded to the MFMA type - it IS the
+ * consumer's A operand - and xl ONE BYTE q per element (round 4; rounds 2 - 3: xl = f16(x - xh)), both cut out of x's fp32 bit
+ * pattern.  With S = 13 (f16) / 16 (bf16) mantissa bits dropped by xh:
+ *     t = bits(x) + 2^(S-1);   bits(xh) = t with its low S bits cleared;   q = bits S-1 .. S-8 of t;
+ *     decode: bits(x') = bits(xh) + ((q - 128) << (S - 8))  =  bits(x) with its low S - 8 bits cleared
+ * i.e. x to 8 more mantissa bits than xh holds - 19 / 16 significant bits in 3 bytes, |x - x'| < ulp(xh) / 256; xh is x rounded to
+ * nearest with ties away from zero (round-to-nearest-even except on exact ties); below the f16 normal range the error is absolute
+ * (<= 2^-25) (csrc/hgr_common.h: pair_split / pair_dec, used by every kernel that touches the pair; hgr_pair_rows_f32 is the decoder
+ * for callers).  Error study of the folding: tools/studies/ln_fusion_study.py.
+ *   stats  fp32 [M][N/64][2]  (N = row width);  xh 16-bit [M, ldx], xl uint8 [M, ldx] (same element stride);  requirements: row
+ *   width % 128 == 0; xh / xl 16-byte
+ *   aligned with ldx % 8 == 0 (the producer reads and writes 8 columns per lane: 16 + 8 bytes) and ldx < 2^23; the consumer's C 16-byte
  *   aligned with ldc % 8 == 0, ldc < 2^23 (a tile's rows are addressed at 32-bit byte offsets from a 64-bit tile base: strided
  *   row views such as the class-token rows of a [B, L, W] stream, row stride L * W, are fine).
  * ------------------------------------------------------------------------------------------------ */
@@ -496,7 +503,7 @@ int hgr_gemm_nt_res_stats_guard(const void *A, int64_t lda, const void *W, int64
 
 /*
  * Visual head of a ViT in one launch (clip/model.py:231-233: x = ln_post(x[:, 0, :]); x = x @ proj) on the residual stream kept as
- * a 16-bit pair: row b of the result = LayerNorm(xh[b * row_mul] + xl[b * row_mul]; gamma, beta, eps) rounded to the MFMA type,
+ * a pair (above): row b of the result = LayerNorm(decode(xh, xl)[b * row_mul]; gamma, beta, eps) rounded to the MFMA type,
  * times proj_t^T (proj_t [D, W] 16-bit = visual.proj transposed), fp32 [B, D].  row_mul = tokens per image (the class token is
  * token 0).  LayerNorm arithmetic = hgr_layernorm's (two-pass statistics in fp32).  W % 32 == 0, W <= 1920, D % 4 == 0.
  */

@@ -119,9 +119,10 @@ def test_range_guard_flag_of_the_producer_gemm():
             row, col = m - 7, 700
             if case == "large":
                 x0[row, col] = 3.0e4
-            xh, xl = x0.half(), (x0 - x0.half().float()).half()
+            xh = x0.half()
+            xl = torch.full(x0.shape, 128, dtype=ops.PAIR_LO, device=DEV)          # low byte 128 = "exactly xh"
             if case == "nan":
-                xl[row, col] = float("nan")
+                xh[row, col] = float("nan")
             flag = torch.zeros(1, dtype=torch.int32, device=DEV)
             ops.gemm_nt_res_stats(a, w, xh, xl, bias, stats, flag=flag)
             bits = int(flag.item()) & 0xFFFFFFFF

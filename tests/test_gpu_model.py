@@ -341,6 +341,9 @@ def test_batch512_forward_through_graph_vs_oracle_subsample(arch, nodes, tmp_pat
     lg = model(dimg, None)                               # pure replay of the captured graph
     assert torch.equal(lg, lg_first)
     assert torch.equal(lg, model._forward_eager(dimg))   # and the eager launches give the same bits
+    # the towers really ran on the LayerNorm-folded path: a range-guard trip falls back to the fp32 stream SILENTLY apart from a warning
+    # (correct results, 20 % slower - how a decode bug of the residual pair once hid behind green tests)
+    assert model.clip_model._ln_off == set() and model.clip_model.ln_guard_tripped() == {}
     rows = torch.arange(5, 512, 11)[:48]
     got = lg[rows.to(DEV)].cpu()
     # (2) oracle image tower, the model's class matrix

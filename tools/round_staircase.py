@@ -31,7 +31,7 @@ for name, k in (("out", w), ("proj", 4 * w)):
     wt = (torch.randn(w, k, device="cuda") * 0.03).to(dt)
     b = torch.randn(w, device="cuda")
     xh = torch.randn(mmax, w, device="cuda").to(dt)
-    xl = torch.zeros(mmax, w, device="cuda", dtype=torch.float16)
+    xl = torch.full((mmax, w), 128, device="cuda", dtype=torch.uint8)
     stats = torch.empty(mmax, w // 64, 2, device="cuda")
     res = {}
     for p in panels:

@@ -38,7 +38,7 @@ def shapes():
     x768 = [rnd((M, 768)).to(DT) for _ in range(NB)]
     u3072 = [rnd((M, 3072)).to(DT) for _ in range(NB)]
     xh = [rnd((M, 768)).to(DT) for _ in range(NB)]
-    xl = [rnd((M, 768), 1e-3).to(torch.float16) for _ in range(NB)]
+    xl = [torch.full((M, 768), 128, dtype=torch.uint8, device="cuda") for _ in range(NB)]
     stats = torch.empty((M, 12, 2), dtype=torch.float32, device=DEV)
     ops.row_stats16(rnd((M, 768)), xh[0].clone(), xl[0].clone(), stats)
     w_qkv, w_out, w_fc, w_proj = rnd((2304, 768), 0.03).to(DT), rnd((768, 768), 0.03).to(DT), rnd((3072, 768), 0.03).to(DT), rnd((768, 3072), 0.03).to(DT)
