@@ -187,14 +187,10 @@ __global__ __launch_bounds__(QA_NT) void qkv_attn(QkvAttnArgs p) {
     const int m0c = m0, hc = h;
     const int nxt = cur + xwgs;
     const bool has_next = nxt < xcnt;
-    if (has_next) {
-        set_tile(xbase + nxt);
-        issueA(oA0, QA_PA0, 0); issueW(0);
-        issueA(oA1, QA_PA1, 0);
-    }
 
     // the folded-LayerNorm vectors of this lane's columns: requested now, they travel beside the statistics loads below (loaded inside
-    // the store loop every n tile waited for its own L2 round trip: six in a row per tile)
+    // the store loop every n tile waited for its own L2 round trip: six in a row per tile) - and ahead of the next tile's DMAs, whose
+    // issue time (7 instructions) then hides a part of this round trip
     f32x4 sq[6], cq[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -202,6 +198,11 @@ __global__ __launch_bounds__(QA_NT) void qkv_attn(QkvAttnArgs p) {
         const int gn = (col0 >> 6) * p.Wd + hc * 64 + (col0 & 63) + g * 4;
         sq[j] = *(const f32x4 *)(p.ln_s + gn);
         cq[j] = *(const f32x4 *)(p.ln_c + gn);
+    }
+    if (has_next) {
+        set_tile(xbase + nxt);
+        issueA(oA0, QA_PA0, 0); issueW(0);
+        issueA(oA1, QA_PA1, 0);
     }
     // ---- LayerNorm row statistics of the tile's 256 rows (thread t < 256: row t), as the consumer GEMM finalises them ----
     float2 *lnrow = (float2 *)(smem + QA_LN);

@@ -167,10 +167,11 @@ def test_two_rank_coop_context_gradient_is_identical_on_both_ranks_and_equals_on
 def test_many_rank_bench_control_flow_on_one_gpu():
     """`bench.py --gpus 8` (evaluation) with eight ranks sharing the test box's one GPU (gloo; toy size; N % 8 != 0): the 8-way control
     flow - shard bounds of the prompt shards with a short last shard, batches dealt to 8 ranks, counter all-reduce, dp_check, exactly
-    one JSON line - runs before the driver's real 8-GPU node ever does.  The test boxes allow at most 6 processes on the card at once
-    (this pytest process is one of them), so the default is 5 ranks, an odd count that divides neither the prompt list nor the
-    class count; HGR_TEST_MAX_RANKS=8 runs the full eight where nothing limits it."""
-    n = int(os.environ.get("HGR_TEST_MAX_RANKS", "5"))
+    one JSON line - runs before the driver's real 8-GPU node ever does.  The test boxes allow at most 6 processes on the card at once:
+    this pytest process and the torch.distributed.run agent are two of them (a 5-rank run was killed by the box's process guard), so
+    the default is 4 ranks on class / prompt counts that 4 does not divide; HGR_TEST_MAX_RANKS=8 runs the full eight where nothing
+    limits it."""
+    n = int(os.environ.get("HGR_TEST_MAX_RANKS", "4"))
     d = _bench(n, ["--steps", "3", "--warmup", "1", "--nodes", "1003", "--batch", "8", "--arch", "small-vit", "--no-cpu-baseline", "--no-pcie"])
     c = d["dp_check"]
     assert d["n_gpus"] == n and d["ranks_seen"] == n and d["config"]["parallelism"] == f"dp{n}" and d["config"]["global_batch"] == 8 * n
