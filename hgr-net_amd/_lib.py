@@ -88,6 +88,7 @@ SIGNATURES = {
     "hgr_gemm_nt_ln": [_p, _l, _p, _l, _p, _l, _p, _p, _p, _f, _i, _i, _i, _i, _i, _p],
     "hgr_gemm_nt_ln_mha": [_p, _l, _p, _l, _p, _p, _p, _f, _p, _l, _i, _i, _i, _i, _i, _p],
     "hgr_gemm_nt_bias_gelu_dual": [_p, _l, _p, _l, _p, _l, _p, _l, _p, _i, _i, _i, _i, _p],
+    "hgr_gemm_nt_qgelu_grad_colsum": [_p, _l, _p, _l, _p, _l, _p, _l, _p, _i, _i, _i, _i, _p],
     "hgr_vit_embed_ln_stats": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p],
     "hgr_row_stats16": [_p, _p, _p, _p, _i, _i, _i, _p],
     "hgr_pair_rows_f32": [_p, _p, _p, _i, _i, _l, _p, _i, _p],

@@ -25,7 +25,7 @@ typedef __attribute__((ext_vector_type(4))) short mha_s16x4;
 typedef __attribute__((ext_vector_type(8))) short mha_s16x8;
 
 template <int DT, int KT, bool CAUSAL>
-__global__ __launch_bounds__(256) void mha_fwd(const typename T16<DT>::elem *__restrict__ qkv,
+__global__ __launch_bounds__(256, 2) void mha_fwd(const typename T16<DT>::elem *__restrict__ qkv,
                                                typename T16<DT>::elem *__restrict__ out, int L, int H, float2 *__restrict__ stats, int QL) {
     typedef typename T16<DT>::elem E;
     typedef typename T16<DT>::vec8 vec8;
@@ -94,6 +94,9 @@ __global__ __launch_bounds__(256) void mha_fwd(const typename T16<DT>::elem *__r
             const char *kr = sK + (t * 16 + r) * 128;
             acc[t] = T16<DT>::mfma16(*(const vec8 *)(kr + sw0), q0, acc[t]);
             acc[t] = T16<DT>::mfma16(*(const vec8 *)(kr + sw1), q1, acc[t]);
+            // long sequences: without a fence every four key tiles the scheduler hoists ALL K fragments above the first MFMA (KT = 9:
+            // 438 registers -> one wave per SIMD, one workgroup per CU); with it 135 - 200 registers, two workgroups per CU
+            if (KT >= 5 && (t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
         float mx = -INFINITY;
 #pragma unroll
@@ -150,6 +153,7 @@ __global__ __launch_bounds__(256) void mha_fwd(const typename T16<DT>::elem *__r
                 }
                 o[td] = T16<DT>::mfma16(vf, pf, o[td]);
             }
+            if (KT >= 5) __builtin_amdgcn_sched_barrier(0);       // likewise for the V^T fragments
         }
         if (q < QL) {
             E *orow = out + ((int64_t)b * L + q) * W + h * 64 + g * 4;

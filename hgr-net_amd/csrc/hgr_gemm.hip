@@ -413,6 +413,23 @@ extern "C" int hgr_gemm_nt_bias_gelu_dual(const void *A, int64_t lda, const void
     return HGR_OK;
 }
 
+extern "C" int hgr_gemm_nt_qgelu_grad_colsum(const void *A, int64_t lda, const void *W, int64_t ldw, void *C, int64_t ldc, const void *pre, int64_t ldpre,
+                                             float *colsum_part, int M, int N, int K, int dtype, void *stream) {
+    if (int rc = ln_common_checks("hgr_gemm_nt_qgelu_grad_colsum", A, lda, W, ldw, M, N, K, dtype)) return rc;
+    HGR_REQUIRE(C && pre && colsum_part, "hgr_gemm_nt_qgelu_grad_colsum: null C / pre / colsum_part");
+    HGR_REQUIRE(ldc >= N && ldpre >= N && ldc % 8 == 0 && ldpre % 8 == 0 && ldc < (1 << 20) && ldpre < (1 << 20) && hgr_aligned(C, 16) && hgr_aligned(pre, 16) && hgr_aligned(colsum_part, 16),
+                "hgr_gemm_nt_qgelu_grad_colsum: C / pre / colsum_part must be 16-byte aligned, leading dimensions >= N, %% 8 == 0, < 2^20");
+    GemmArgs a;
+    ln_args(a, A, lda, W, ldw, C, ldc, M, N, K);
+    a.res = (const float *)pre; a.ldr = ldpre;
+    a.colsum = colsum_part; a.colsum_units = (M + 63) / 64;
+    dim3 grid;
+    duo_apply_plan(a, true, grid);
+    launch_duo(a, dtype, HGR_EPI_QGELU_GRAD16, false, 0, grid, (hipStream_t)stream);
+    HGR_CHECK_LAUNCH("hgr_gemm_nt_qgelu_grad_colsum");
+    return HGR_OK;
+}
+
 // ---- logits GEMM with the evaluation consumers in its epilogue ------------------------------------------------------------
 #define HGR_LE_PARAMS const void *feat16, const void *zsl_perm16, int rows, int D, int n_perm, const int32_t *tpos_perm, const int32_t *epos_perm, \
     const int32_t *level_first, int n_levels, const int32_t *filler_pos, const int32_t *train_cols, int n_train, const int32_t *test_cols, int n_test, int k, \

@@ -51,6 +51,9 @@ struct GemmArgs {
     // gemm_nt_duo tail plan (duo_plan): blocks [0, nbig) = full 256 x 128 tiles on row panels [0, big_panels), the remaining blocks =
     // 128 x 128 half tiles on the rows behind them (tiles_m_half panels of 128 rows).  No tail: nbig = grid, big_panels = tiles_m.
     int nbig, big_panels, tiles_m_half;
+    // HGR_EPI_QGELU_GRAD16 on gemm_nt_duo only (hgr_gemm_nt_qgelu_grad_colsum): column sums of the ROUNDED 16-bit outputs per 64-row
+    // unit, colsum[unit][n] for unit < colsum_units = ceil(M / 64) - the bias gradient of the layer below without a second pass over C
+    float *colsum = nullptr; int colsum_units = 0;
 };
 
 

@@ -434,7 +434,10 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
         const unsigned ldcB = (unsigned)p.ldc * 2u, ldiB = (unsigned)p.ldr * 2u;
         const unsigned cl = r8 * ldcB + c8 * 16, il = r8 * ldiB + c8 * 16;
 #pragma unroll
-        for (int a = 0; a < MH; ++a)
+        for (int a = 0; a < MH; ++a) {
+        float cs[8];                                  // QGELU_GRAD16 + colsum: this lane's 8 columns summed over its rows of the 64-row unit
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cs[e] = 0.f;
 #pragma unroll
         for (int ih = 0; ih < 2; ++ih) {
             const int rl = a * 64 + ih * 32;
@@ -465,7 +468,25 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
                     }
                 }
                 *(u32x4 *)(cw + (cl + (rl + q * 8) * ldcB)) = __builtin_bit_cast(u32x4, o);
+                if (EPI == HGR_EPI_QGELU_GRAD16 && p.colsum) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) cs[e] += (float)o[e];
+                }
             }
+        }
+        if (EPI == HGR_EPI_QGELU_GRAD16 && p.colsum) {
+            // lanes r8 = 0..7 of a column chunk hold disjoint rows: fixed-order butterfly, then one 32-byte row segment per chunk
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                cs[e] += __shfl_xor(cs[e], 8); cs[e] += __shfl_xor(cs[e], 16); cs[e] += __shfl_xor(cs[e], 32);
+            }
+            const int unit = (int)((wrow + a * 64) >> 6);
+            if (r8 == 0 && unit < p.colsum_units) {
+                float *dst = p.colsum + (int64_t)unit * p.N + wcol + c8 * 8;
+                *(f32x4 *)dst = (f32x4){cs[0], cs[1], cs[2], cs[3]};
+                *(f32x4 *)(dst + 4) = (f32x4){cs[4], cs[5], cs[6], cs[7]};
+            }
+        }
         }
         return;
     }
@@ -718,6 +739,49 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
                 *(typename T16<DT>::vec4 *)((E *)p.C + (int64_t)m * p.ldc + n) = pre;
                 *(typename T16<DT>::vec4 *)((E *)p.ln_xh + (int64_t)m * p.ln_ldx + n) =
                     cvt4<DT>(quick_gelu_train((float)pre[0]), quick_gelu_train((float)pre[1]), quick_gelu_train((float)pre[2]), quick_gelu_train((float)pre[3]));
+            }
+        }
+        return;
+    }
+    if (EPI == HGR_EPI_QGELU_GRAD16 && p.colsum) {
+        // edge tile (rows beyond M; the host entry guarantees N % 128 == 0 and vector access): the same products and roundings from the
+        // accumulator layout, rows >= M contribute nothing; a 16-lane group (r) holds the 16 rows of an m tile -> butterfly over r
+#pragma unroll
+        for (int a = 0; a < MH; ++a) {
+            f32x4 cs[2][2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) cs[b][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + wm * WR + a * 64 + i * 16 + r;
+                const bool ok = m < p.M;
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int n = n0 + wn * 64 + b * 32 + j * 16 + g * 4;
+                    if (!ok) continue;
+                    const typename T16<DT>::vec4 idn = *(const typename T16<DT>::vec4 *)((const E *)(const void *)p.res + (int64_t)m * p.ldr + n);
+                    typename T16<DT>::vec4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { o[e] = (E)(acc[a][b][i][j][e] * quick_gelu_grad((float)idn[e])); cs[b][j][e] += (float)o[e]; }
+                    *(typename T16<DT>::vec4 *)((E *)p.C + (int64_t)m * p.ldc + n) = o;
+                }
+            }
+            const int unit = (m0 + wm * WR + a * 64) >> 6;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x = cs[b][j][e];
+                    x += __shfl_xor(x, 1); x += __shfl_xor(x, 2); x += __shfl_xor(x, 4); x += __shfl_xor(x, 8);
+                    cs[b][j][e] = x;
+                }
+                if (r == 0 && unit < p.colsum_units) *(f32x4 *)(p.colsum + (int64_t)unit * p.N + n0 + wn * 64 + b * 32 + j * 16 + g * 4) = cs[b][j];
             }
         }
         return;

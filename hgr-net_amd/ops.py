@@ -139,6 +139,18 @@ def gemm_nt_bias_gelu_dual(a: torch.Tensor, w: torch.Tensor, pre: torch.Tensor, 
               _dev(bias), m, n, k, DT_OF[a.dtype], _stream())
 
 
+def gemm_nt_qgelu_grad_colsum(dy: torch.Tensor, wt: torch.Tensor, dx: torch.Tensor, pre: torch.Tensor, part: torch.Tensor) -> None:
+    """dx (16-bit) = (dy @ wt^T) * g'(pre) - gemm_nt(..., epilogue=EPI_QGELU_GRAD16) bit for bit - and part[u, :] = column sums of dx
+    as rounded over rows [64 u, 64 u + 64): the bias gradient of the layer below is colsum(part) (hgr_gemm_nt_qgelu_grad_colsum)."""
+    assert dy.dim() == 2 and wt.dim() == 2 and dy.dtype == wt.dtype == dx.dtype == pre.dtype and dy.stride(1) == wt.stride(1) == dx.stride(1) == pre.stride(1) == 1
+    m, k = dy.shape
+    n = wt.shape[0]
+    assert wt.shape[1] == k and dx.shape == (m, n) and pre.shape == (m, n)
+    assert part.dtype == torch.float32 and part.is_contiguous() and part.shape == ((m + 63) // 64, n)
+    _lib.call("hgr_gemm_nt_qgelu_grad_colsum", _dev(dy), dy.stride(0), _dev(wt), wt.stride(0), _dev(dx), dx.stride(0), _dev(pre), pre.stride(0),
+              _dev(part), m, n, k, DT_OF[dy.dtype], _stream())
+
+
 def gelu_dual_ok(m: int, n: int, k: int, lda: int, ldw: int) -> bool:
     """Shape contract of hgr_gemm_nt_bias_gelu_dual (the 256 x 128 tile kernel: whole column tiles, 32-bit operand offsets)."""
     return n % 128 == 0 and k % 64 == 0 and k >= 128 and m * lda * 2 < (1 << 32) and n * ldw * 2 < (1 << 32)

@@ -37,6 +37,7 @@ WGRAD_TN = os.environ.get("HGR_WGRAD", "tn") != "nt"
 # QuickGELU backward in the epilogue of the c_proj data-gradient GEMM; HGR_GELU_BWD_FUSED=0 keeps the separate pass for A/B runs
 GELU_BWD_FUSED = os.environ.get("HGR_GELU_BWD_FUSED", "1") != "0"
 GELU_FWD_FUSED = os.environ.get("HGR_GELU_FWD_FUSED", "1") != "0"     # c_fc forward writes pre-activation and activation in one launch
+COLSUM_FUSED = os.environ.get("HGR_COLSUM_FUSED", "1") != "0"         # bias gradients as by-products of the kernels that produce dY (no hgr_colsum pass over dY)
 
 
 def _pad64(n: int) -> int:
@@ -108,8 +109,11 @@ class Engine:
         self.conv = _Lin(m.visual.conv1.weight, None, dt, kpad=_pad64(3 * ps * ps))
 
     def _linear_bwd(self, lin: _Lin, dy16: torch.Tensor, x16: torch.Tensor, m: int, need_dx: bool = True,
-                    gelu_pre: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
-        """dW += dY^T X, db += colsum(dY); returns dX = dY W (16-bit) if wanted.  dy16 [m, n], x16 [m, k]."""
+                    gelu_pre: Optional[torch.Tensor] = None, dy_colsum: Optional[torch.Tensor] = None,
+                    dx_colsum: Optional[list] = None) -> Optional[torch.Tensor]:
+        """dW += dY^T X, db += colsum(dY); returns dX = dY W (16-bit) if wanted.  dy16 [m, n], x16 [m, k].
+        ``dy_colsum``: per-64-row column sums of dy16 its producer already made ([ceil(m / 64), n] fp32): db comes from them,
+        dy16 is not read a third time.  ``dx_colsum`` (a list, with ``gelu_pre``): receives such sums of the returned dX."""
         dev, dt = self.dev, self.dt
         xq = x16[:, : lin.k] if x16.shape[1] != lin.k else x16
         if WGRAD_TN and lin.n % 8 == 0 and lin.k % 8 == 0 and dy16.stride(0) % 8 == 0 and xq.stride(0) % 8 == 0 \
@@ -129,8 +133,11 @@ class Engine:
             else:
                 gw.view(-1).add_(part[0])
             if lin.bias is not None:
-                ops.colsum(dy16, _grad(lin.bias), self.scratch(((m + 511) // 512) * lin.n), accumulate=True)
-            return self._linear_dx(lin, dy16, m, gelu_pre) if need_dx else None
+                if dy_colsum is not None:
+                    ops.colsum(dy_colsum, _grad(lin.bias), self.scratch(((dy_colsum.shape[0] + 511) // 512) * lin.n), accumulate=True)
+                else:
+                    ops.colsum(dy16, _grad(lin.bias), self.scratch(((m + 511) // 512) * lin.n), accumulate=True)
+            return self._linear_dx(lin, dy16, m, gelu_pre, dx_colsum) if need_dx else None
         mp = _pad64(m)
         alloc = torch.empty if mp == m else torch.zeros           # the pad columns must be zero, the rest is overwritten
         dyt = alloc(lin.n, mp, dtype=dt, device=dev)
@@ -164,7 +171,7 @@ class Engine:
             ops.colsum(dy16, _grad(lin.bias), self.scratch(((m + 511) // 512) * lin.n), accumulate=True)
         return self._linear_dx(lin, dy16, m, gelu_pre) if need_dx else None
 
-    def _linear_dx(self, lin: _Lin, dy16: torch.Tensor, m: int, gelu_pre: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def _linear_dx(self, lin: _Lin, dy16: torch.Tensor, m: int, gelu_pre: Optional[torch.Tensor] = None, dx_colsum: Optional[list] = None) -> torch.Tensor:
         """dX = dY W (16-bit).  With ``gelu_pre`` (the QuickGELU pre-activation that produced this layer's input) the GEMM's
         epilogue multiplies by g'(pre): the result is the gradient w.r.t. the pre-activation, no separate activation pass."""
         dx = torch.empty(m, lin.k, dtype=self.dt, device=self.dev)
@@ -172,7 +179,14 @@ class Engine:
             raise HgrError("backward GEMM needs the output width to be a multiple of 64")
         wt = lin.wt16[:, : lin.n] if lin.wt16.shape[1] == lin.n else lin.wt16
         if gelu_pre is not None:
-            ops.gemm_nt(dy16, wt, dx, residual=gelu_pre, epilogue=EPI_QGELU_GRAD16, n=lin.k)
+            if dx_colsum is not None and COLSUM_FUSED and ops.gelu_dual_ok(m, lin.k, wt.shape[1], dy16.stride(0), wt.stride(0)) \
+                    and wt.shape[0] == lin.k and gelu_pre.stride(0) % 8 == 0 and m >= 256:
+                # the column sums of dX (= the bias gradient of the layer below) leave the same epilogue (hgr_gemm_nt_qgelu_grad_colsum)
+                part = torch.empty((m + 63) // 64, lin.k, dtype=torch.float32, device=self.dev)
+                ops.gemm_nt_qgelu_grad_colsum(dy16, wt, dx, gelu_pre, part)
+                dx_colsum.append(part)
+            else:
+                ops.gemm_nt(dy16, wt, dx, residual=gelu_pre, epilogue=EPI_QGELU_GRAD16, n=lin.k)
         else:
             ops.gemm_nt(dy16, wt, dx, n=lin.k)
         return dx
@@ -217,13 +231,14 @@ class Engine:
         ops.cast16(dx, dy)               # later 16-bit copies of dx come out of the LayerNorm backward that updates it
         for k, (x0, h1, qkv, att, x1, h2, a, u, st) in zip(reversed(blocks), reversed(saves)):
             # x2 = x1 + c_proj(gelu(c_fc(ln_2(x1))))
+            da_sums: list = []
             if GELU_BWD_FUSED:      # d(pre-activation) straight from the c_proj data-gradient GEMM (HGR_EPI_QGELU_GRAD16)
-                da = self._linear_bwd(k.w_proj, dy, u, m, gelu_pre=a)
+                da = self._linear_bwd(k.w_proj, dy, u, m, gelu_pre=a, dx_colsum=da_sums)
             else:
                 du = self._linear_bwd(k.w_proj, dy, u, m)
                 da = torch.empty_like(a)
                 ops.quickgelu16(a, da, du=du)
-            dh2 = self._linear_bwd(k.w_fc, da, h2, m)
+            dh2 = self._linear_bwd(k.w_fc, da, h2, m, dy_colsum=da_sums[0] if da_sums else None)
             ops.layernorm_bwd(dh2, x1, k.ln2.weight.data, dx, _grad(k.ln2.weight), _grad(k.ln2.bias), scr, dx16=dy)
             # x1 = x0 + out_proj(attn(in_proj(ln_1(x0))))
             datt = self._linear_bwd(k.w_out, dy, att, m)
@@ -280,14 +295,17 @@ class Engine:
         self._linear_bwd(self.conv, d16, s["patches"], b * l, need_dx=False)                # zero class rows add nothing
 
     # -- text tower -------------------------------------------------------------------------------
-    def text_fwd(self, tokens: torch.Tensor, ctx: Optional[torch.nn.Parameter] = None):
+    def text_fwd(self, tokens: torch.Tensor, ctx: Optional[torch.nn.Parameter] = None, l: Optional[int] = None):
+        """``l``: the trimmed sequence length (last EOT position + 1 over these prompts) when the caller knows it on the host;
+        None reads it back from the device (one synchronisation)."""
         m, dt, dev = self.m, self.dt, self.dev
         tokens = tokens.long()
         n = tokens.shape[0]
         w = m.transformer.width
         eot = torch.empty(n, dtype=torch.int32, device=dev)
         ops.eot_index(tokens, eot)
-        l = int(eot.max().item()) + 1
+        if l is None:
+            l = int(eot.max().item()) + 1
         x = torch.empty(n * l, w, dtype=torch.float32, device=dev)
         ops.text_embed(tokens, m.token_embedding.weight.data, m.positional_embedding.data, x, l)
         if ctx is not None:
@@ -343,6 +361,32 @@ class OMTrainer:
         # gradients equal the one-rank step's up to the fp32 order of the cross-rank sums (<= 1e-4).  The head's FLOPs are then
         # replicated on every rank (B_total x <= 257 x D per inner step, fp32): reproducibility across world sizes, not speed.
         self.dp_exact_head = os.environ.get("HGR_DP_EXACT_HEAD", "0") == "1"
+        self._pin = {}                   # pinned host staging for the step's index lists, one buffer per use (see _stage_ints)
+        self._eot_host = None            # EOT position of every node's prompt (host copy, made once): the trimmed length without a mid-step sync
+
+    def _stage_ints(self, lists, dtype=torch.int32, slot: str = "loc"):
+        """The step's host-made index lists on the device through ONE asynchronous copy out of a persistent pinned buffer: a
+        `torch.tensor(list, device=...)` per inner step is a synchronous pageable copy, i.e. a drain of the launch queue each time
+        (measured on the ViT-L/14 step: ~20 copies, 0.1 - 0.7 ms of idle GPU each, 4.5 ms of a 234 ms step).  Returns one device
+        view per list (segments start at multiples of 4 elements).  A `slot` is written once per step, and the step ends in a host
+        synchronisation (the loss float), so the previous step's copy out of it has completed before it is overwritten."""
+        dev = self.engine.dev
+        offs, total = [], 0
+        for l in lists:
+            offs.append(total)
+            total += (len(l) + 3) // 4 * 4
+        total = max(total, 4)
+        item = torch.empty((), dtype=dtype).element_size()
+        pin = self._pin.get(slot)
+        if pin is None or pin.numel() < total * item:
+            pin = self._pin[slot] = torch.empty(max(total * item, 1 << 16), dtype=torch.uint8, pin_memory=True)
+        host = pin[: total * item].view(dtype)
+        hn = host.numpy()
+        for l, o in zip(lists, offs):
+            hn[o: o + len(l)] = l
+        devbuf = torch.empty(total, dtype=dtype, device=dev)
+        devbuf.copy_(host, non_blocking=True)
+        return [devbuf[o: o + len(l)] for l, o in zip(lists, offs)]
 
     def _head(self, img_n, dimg_n, tfeat, label_pos: int, weight, loss_acc, ce_out=None, replicas: int = 1):
         """logits = img_n tn^T * exp(logit_scale); CE (all rows share the label); gradients of the three inputs.  ``replicas`` > 1
@@ -376,6 +420,15 @@ class OMTrainer:
         return dtfeat
 
     # -- prompt-parallel text tower (data-parallel training) ---------------------------------------------------------------
+    def _trimmed_len(self, ids) -> int:
+        """Token count up to and including the last EOT among the prompts `ids` (clip/model.py:350: the EOT token is the row's
+        arg-max) from a host copy of the per-node EOT positions, made once - Engine.text_fwd would otherwise read it back from the
+        device in the middle of the step, with the image tower's forward still in the queue."""
+        nt = self.tree.node_tokens
+        if self._eot_host is None or self._eot_host[0] != (nt.data_ptr(), tuple(nt.shape)):
+            self._eot_host = ((nt.data_ptr(), tuple(nt.shape)), nt.argmax(dim=-1).cpu().numpy())
+        return int(self._eot_host[1][ids].max()) + 1
+
     def _text_shard(self, n_u: int):
         """Contiguous shard [lo, hi) of the step's n_u distinct prompts for this rank, shard size ns = ceil(n_u / world) (the last
         shards may be short or empty); every rank encodes exactly ns rows so that the all-gather is regular - missing rows are
@@ -407,7 +460,7 @@ class OMTrainer:
             raise HgrError("data-parallel OM step: the ranks drew different negative classes (seed `random` identically on every rank and "
                            "hand every rank its rows of the SAME single-class batch); prompt-parallel text encoding needs one prompt list")
         mine = uniq[lo:hi] + [uniq[0]] * (ns - (hi - lo))
-        feat_l, tsave = e.text_fwd(tree.node_tokens[torch.tensor(mine, device=e.dev)], ctx)
+        feat_l, tsave = e.text_fwd(tree.node_tokens[self._stage_ints([mine], torch.int64, "uniq")[0]], ctx, l=self._trimmed_len(mine))
         self.last_text_rows = ns
         full = torch.empty(world, ns, feat_l.shape[1], dtype=torch.float32, device=e.dev)
         dist.all_gather(list(full.unbind(0)), feat_l.contiguous(), group=self.dp_group)
@@ -478,7 +531,8 @@ class OMTrainer:
         if dp is not None:
             tfeat_u, tsave = self._text_features_dp(uniq, getattr(tree, "ctx", None))
         else:
-            tfeat_u, tsave = e.text_fwd(tree.node_tokens[torch.tensor(uniq, device=e.dev)], getattr(tree, "ctx", None))
+            tfeat_u, tsave = e.text_fwd(tree.node_tokens[self._stage_ints([uniq], torch.int64, "uniq")[0]], getattr(tree, "ctx", None),
+                                        l=self._trimmed_len(uniq))
             self.last_text_rows = len(uniq)
         dtfeat_u = torch.zeros_like(tfeat_u)
         exact = dp is not None and self.dp_exact_head
@@ -493,8 +547,9 @@ class OMTrainer:
             dimg_h = torch.zeros_like(img_h)
         adaptive = tree.opts.weights == "adaptive"
         ces = torch.zeros(len(picks), 1, dtype=torch.float32, device=e.dev) if adaptive else None
+        locs = self._stage_ints([[where[i] for i in ids] for ids, _, _, _ in picks])
         for j, (ids, pos, wgt, _) in enumerate(picks):
-            loc = torch.tensor([where[i] for i in ids], dtype=torch.int32, device=e.dev)
+            loc = locs[j]
             tfeat = torch.empty(len(ids), tfeat_u.shape[1], dtype=torch.float32, device=e.dev)
             ops.rows_gather(tfeat_u, loc, tfeat)
             dtfeat = self._head(img_h, dimg_h, tfeat, pos, wgt, loss_acc, ces[j: j + 1] if adaptive else None, replicas)

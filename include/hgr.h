@@ -534,6 +534,14 @@ int hgr_gemm_nt_ln_mha(const void *XH, int64_t ldx, const void *Wfold, int64_t l
  * Same shape contract as hgr_gemm_nt_ln (N % 128 == 0, K >= 128, operands below 4 GB). */
 int hgr_gemm_nt_bias_gelu_dual(const void *A, int64_t lda, const void *W, int64_t ldw, void *pre, int64_t ldpre, void *post, int64_t ldpost,
                                const float *bias, int M, int N, int K, int dtype, void *stream);
+/* Backward of the same MLP, data gradient of c_proj with the QuickGELU derivative and the bias gradient of c_fc in one launch:
+ *   C [M, ldc] (16-bit) = (A W^T) * g'(pre)              - hgr_gemm_nt with HGR_EPI_QGELU_GRAD16, bit for bit
+ *   colsum_part [ceil(M / 64), N] (fp32, every entry written) = column sums of C AS ROUNDED over rows [64 u, 64 u + 64)
+ * i.e. d(c_fc.bias) = sum_u colsum_part[u] (hgr_colsum over it), without the second pass over the [M, N] gradient that
+ * hgr_colsum(C) costs (the reference's autograd sums grad_output per Linear: torch/nn/functional.linear backward behind
+ * model/clip_tree.py:274 `loss.backward()`).  Shape contract of hgr_gemm_nt_ln (N % 128 == 0, K >= 128, operands below 4 GB). */
+int hgr_gemm_nt_qgelu_grad_colsum(const void *A, int64_t lda, const void *W, int64_t ldw, void *C, int64_t ldc, const void *pre, int64_t ldpre,
+                                  float *colsum_part, int M, int N, int K, int dtype, void *stream);
 /* hgr_vit_embed_ln whose output rows leave as the pair + slot statistics (input of the first block) */
 int hgr_vit_embed_ln_stats(const float *patches, const float *class_embedding, const float *positional_embedding,
                            const float *gamma, const float *beta, void *xh, void *xl, float *stats,

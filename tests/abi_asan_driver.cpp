@@ -95,6 +95,8 @@ int main() {
     EXPECT_FAIL(hgr_gemm_nt(h16, 64, h16, 64, f32, 64, nullptr, h16, 64, 4, 4, 64, HGR_F16, HGR_EPI_QGELU_GRAD16, 1, nullptr));       // fp32 output
     EXPECT_FAIL(hgr_gemm_nt_bias_gelu_dual(h16, 128, h16, 128, h16, 100, h16, 128, f32, 4, 100, 128, HGR_F16, nullptr));               // N % 128
     EXPECT_FAIL(hgr_gemm_nt_bias_gelu_dual(h16, 128, h16, 128, h16, 128, nullptr, 128, f32, 4, 128, 128, HGR_F16, nullptr));           // post missing
+    EXPECT_FAIL(hgr_gemm_nt_qgelu_grad_colsum(h16, 128, h16, 128, h16, 100, h16, 128, f32, 4, 100, 128, HGR_F16, nullptr));            // N % 128
+    EXPECT_FAIL(hgr_gemm_nt_qgelu_grad_colsum(h16, 128, h16, 128, h16, 128, h16, 128, nullptr, 4, 128, 128, HGR_F16, nullptr));        // colsum_part missing
     EXPECT_FAIL(hgr_mha_stats(h16, h16, nullptr, 1, 50, 12, 0, HGR_F16, nullptr));
     EXPECT_FAIL(hgr_mha_bwd_stats(h16, h16, h16, h16, nullptr, 1, 50, 12, 0, HGR_F16, nullptr));
     EXPECT_FAIL(hgr_mha_bwd_stats(h16, h16, h16, h16, f32, 1, 400, 12, 0, HGR_F16, nullptr));                                           // L > 320

@@ -467,6 +467,37 @@ def test_gemm_qgelu_grad16_epilogue(dt, tile, m, n, k):
 
 
 @pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("m,n,k", [(512, 256, 128), (1000, 384, 192), (2560, 3072, 768), (77, 128, 128), (33 * 256 + 128, 2048, 256), (4181, 1024, 512)])
+def test_gemm_nt_qgelu_grad_colsum_equals_gemm_then_colsum(dt, m, n, k):
+    """hgr_gemm_nt_qgelu_grad_colsum: the 16-bit data gradient equals hgr_gemm_nt(HGR_EPI_QGELU_GRAD16) bit for bit, and the sum of the
+    per-64-row column sums equals the column sums of that ROUNDED output (full tiles, half tiles of the tail plan, a ragged last panel,
+    a launch of fewer rows than one tile).  The sums are fp32 adds of the same values in another order: tolerance, not bits."""
+    dy = _rand((m, k), 3 * m + n, 0.5).to(dt).to(DEV)
+    wt = _rand((n, k), 5 * n + k, 0.2).to(dt).to(DEV)
+    pre = _rand((m, n), 7 * n + m, 1.5).to(dt).to(DEV)
+    out = torch.full((m, n), 7.0, dtype=dt, device=DEV)
+    units = (m + 63) // 64
+    part = torch.full((units, n), float("nan"), dtype=torch.float32, device=DEV)
+    ops.gemm_nt_qgelu_grad_colsum(dy, wt, out, pre, part)
+    ref = torch.empty(m, n, dtype=dt, device=DEV)
+    ops.gemm_nt(dy, wt, ref, residual=pre, epilogue=ops.EPI_QGELU_GRAD16)
+    assert torch.equal(out, ref)
+    assert bool(torch.isfinite(part).all()), "every (unit, column) entry must be written"
+    # unit by unit against a double-precision sum of the rounded rows
+    pad = torch.zeros(units * 64, n, dtype=torch.float64, device=DEV)
+    pad[:m] = ref.double()
+    want = pad.view(units, 64, n).sum(dim=1)
+    scale = float(pad.abs().view(units, 64, n).sum(dim=1).max()) + 1e-30
+    assert float((part.double() - want).abs().max()) <= 64 * 2.0 ** -24 * scale
+    # and through hgr_colsum into a bias gradient
+    gb = torch.zeros(n, dtype=torch.float32, device=DEV)
+    ops.colsum(part, gb, torch.empty(max(1 << 16, ((units + 511) // 512) * n), dtype=torch.float32, device=DEV), accumulate=True)
+    gb_ref = torch.zeros(n, dtype=torch.float32, device=DEV)
+    ops.colsum(ref, gb_ref, torch.empty(max(1 << 16, ((m + 511) // 512) * n), dtype=torch.float32, device=DEV), accumulate=True)
+    assert float((gb - gb_ref).abs().max()) <= 1e-5 * float(ref.float().abs().sum(dim=0).max()) + 1e-6
+
+
+@pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("m,n,k", [(512, 256, 128), (1000, 384, 192), (2560, 3072, 768), (77, 128, 128)])
 def test_gemm_nt_bias_gelu_dual_equals_two_passes(dt, m, n, k):
     """hgr_gemm_nt_bias_gelu_dual: the pre-activation equals hgr_gemm_nt(+bias) bit for bit and the activation equals
