@@ -55,9 +55,11 @@ SIGNATURES = {
     "hgr_quickgelu16": [_p, _p, _p, _l, _i, _i, _p],
     "hgr_layernorm_bwd": [_p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _l, _p, _f, _i, _p],
     "hgr_layernorm_bwd_cast": [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _l, _p, _f, _i, _p],
+    "hgr_layernorm_bwd_cast_colsum": [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _l, _p, _f, _i, _p],
     "hgr_layernorm_bwd_scratch_floats": [_i, _i],
     "hgr_mha_bwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "hgr_mha_bwd_stats": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "hgr_mha_bwd_colsum": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "hgr_ce_rows": [_p, _l, _p, _i, _i, _f, _p, _p, _l, _p],
     "hgr_l2norm_bwd": [_p, _p, _p, _i, _i, _i, _p],
     "hgr_matmul_f32": [_p, _l, _l, _p, _l, _l, _p, _l, _i, _i, _i, _f, _i, _p],

@@ -210,14 +210,14 @@ template <int DT, bool DYF32, int NV>
 __global__ __launch_bounds__(256) void layernorm_bwd(const void *__restrict__ dy, const float *__restrict__ x, const float *__restrict__ gamma,
                                                      float *__restrict__ dx, float *__restrict__ pg, float *__restrict__ pb,
                                                      int rows, int W, int64_t row_mul, const int32_t *__restrict__ row_idx, float eps,
-                                                     typename T16<DT>::elem *__restrict__ dx16) {
+                                                     typename T16<DT>::elem *__restrict__ dx16, float *__restrict__ pc) {
     typedef typename T16<DT>::elem E;
     const int lane = threadIdx.x & 63;
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
     const int nv = W >> 2;
-    f32x4 ag[NV], ab[NV];
+    f32x4 ag[NV], ab[NV], ac[NV];      // ac: column sums of the ROUNDED dx16 rows this wave wrote (pc != null) - the bias gradient of the Linear that consumes dx16
 #pragma unroll
-    for (int i = 0; i < NV; ++i) { ag[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; ab[i] = ag[i]; }
+    for (int i = 0; i < NV; ++i) { ag[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; ab[i] = ag[i]; ac[i] = ag[i]; }
     for (int row = wid; row < rows; row += nw) {
         const int64_t src = (int64_t)row * row_mul + (row_idx ? row_idx[row] : 0);
         const f32x4 *xr = (const f32x4 *)(x + src * W);
@@ -276,7 +276,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd(const void *__restrict__ dy
                 for (int e = 0; e < 4; ++e) o[e] += rstd * (g[i][e] - mg - v[i][e] * mgx);
                 dxr[c] = o;
                 // the updated gradient also as the 16-bit operand of the next data-/weight-gradient GEMMs (what hgr_cast16 of dx gives)
-                if (dx16) ((typename T16<DT>::vec4 *)(dx16 + src * W))[c] = cvt4<DT>(o[0], o[1], o[2], o[3]);
+                if (dx16) {
+                    const typename T16<DT>::vec4 h = cvt4<DT>(o[0], o[1], o[2], o[3]);
+                    ((typename T16<DT>::vec4 *)(dx16 + src * W))[c] = h;
+                    if (pc)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ac[i][e] += (float)h[e];
+                }
             }
         }
     }
@@ -286,6 +292,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd(const void *__restrict__ dy
         if (c < nv) {
             ((f32x4 *)(pg + (int64_t)wid * W))[c] = ag[i];
             ((f32x4 *)(pb + (int64_t)wid * W))[c] = ab[i];
+            if (pc) ((f32x4 *)(pc + (int64_t)wid * W))[c] = ac[i];
         }
     }
 }
@@ -351,7 +358,7 @@ __device__ __forceinline__ void mm16_bt(f32x16 &acc, const typename T16<DT>::ele
 template <int DT, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void mha_bwd_tiled(const typename T16<DT>::elem *__restrict__ qkv, const typename T16<DT>::elem *__restrict__ outp,
                                                         const typename T16<DT>::elem *__restrict__ dout, typename T16<DT>::elem *__restrict__ dqkv, int L, int H,
-                                                        const float2 *__restrict__ stats) {
+                                                        const float2 *__restrict__ stats, float *__restrict__ colpart) {
     typedef typename T16<DT>::elem E;
     typedef typename T16<DT>::vec8 vec8;
     typedef typename T16<DT>::vec4 vec4;
@@ -409,12 +416,15 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_tiled(const typename T16<DT>::
             *(vec8 *)&dst[id >> 3][(id & 7) * 8] = v[j];
         }
     };
-    auto write_rows = [&](E *dstg, int64_t stride, int r0, const f32x16 &acc) {      // 16-bit global rows from an accumulator quadrant
+    // 16-bit global rows from an accumulator quadrant; returns this lane's column sum of the values AS ROUNDED (rows < L)
+    auto write_rows = [&](E *dstg, int64_t stride, int r0, const f32x16 &acc) {
+        float cs = 0.f;
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
             const int row = r0 + wr * 32 + HGR_ACC_ROW(g, hh);
-            if (row < L) dstg[(int64_t)row * stride + wc * 32 + r32] = (E)acc[g];
+            if (row < L) { const E v = (E)acc[g]; dstg[(int64_t)row * stride + wc * 32 + r32] = v; cs += (float)v; }
         }
+        return cs;
     };
     // masked, scaled score of (query q, key k) from a raw dot product
     auto score = [&](float raw, int q, int k) { return (k >= L || (CAUSAL && k > q)) ? -INFINITY : raw * 0.125f; };
@@ -480,6 +490,7 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_tiled(const typename T16<DT>::
     f32x16 dq[5];
 #pragma unroll
     for (int i = 0; i < 5; ++i) dq[i] = (f32x16){0.f};
+    float csq = 0.f, csk = 0.f, csv = 0.f;                       // column sums of the rounded dq / dk / dv rows (colpart)
     vec8 pq[2], po[2];                                           // Q / dO rows of the next (key block, query block) pair, in flight
     fetch(pq, base, ld, 0);
     fetch(po, dob, W, 0);
@@ -528,12 +539,29 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_tiled(const typename T16<DT>::
             mm16_bt<DT>(dq[qi], sDS, wr * 32, sK, wc * 32, lane); // dQ_i += dS K      (k = keys; reading dS through the transposing read
                                                                   // too, out of its [key][query] image, measured 7 % slower than this row-major copy)
         }
-        write_rows(dqb + W, ld, kj * 64, dk);
-        write_rows(dqb + 2 * W, ld, kj * 64, dv);
+        csk += write_rows(dqb + W, ld, kj * 64, dk);
+        csv += write_rows(dqb + 2 * W, ld, kj * 64, dv);
     }
 #pragma unroll
     for (int qi = 0; qi < 5; ++qi)
-        if (qi < nb) write_rows(dqb, ld, qi * 64, dq[qi]);
+        if (qi < nb) csq += write_rows(dqb, ld, qi * 64, dq[qi]);
+    if (colpart) {
+        // column sums of this (batch, head)'s dq / dk / dv rows = its share of the in_proj bias gradient: lane halves (hh) by shuffle,
+        // the two wave rows through LDS (the tiles are dead), then colpart[b][which * W + h * 64 + c] - every entry written once
+        float *sc = (float *)smem;                  // [3][2][64]
+        csq += __shfl_xor(csq, 32); csk += __shfl_xor(csk, 32); csv += __shfl_xor(csv, 32);
+        __syncthreads();
+        if (hh == 0) {
+            sc[(0 * 2 + wr) * 64 + wc * 32 + r32] = csq;
+            sc[(1 * 2 + wr) * 64 + wc * 32 + r32] = csk;
+            sc[(2 * 2 + wr) * 64 + wc * 32 + r32] = csv;
+        }
+        __syncthreads();
+        if (tid < 192) {
+            const int which = tid >> 6, c = tid & 63;
+            colpart[(int64_t)b * 3 * W + which * W + h * 64 + c] = sc[(which * 2 + 0) * 64 + c] + sc[(which * 2 + 1) * 64 + c];
+        }
+    }
 }
 
 // Same arithmetic for short sequences (text prompts are ~8-20 tokens after EOT trimming): LP = 16 or 32 padded
@@ -568,7 +596,7 @@ __device__ __forceinline__ void mm16k_bt(f32x16 &acc, const typename T16<DT>::el
 
 template <int DT, bool CAUSAL>
 __global__ __launch_bounds__(64) void mha_bwd_wave(const typename T16<DT>::elem *__restrict__ qkv, const typename T16<DT>::elem *__restrict__ dout,
-                                                   typename T16<DT>::elem *__restrict__ dqkv, int L, int H) {
+                                                   typename T16<DT>::elem *__restrict__ dqkv, int L, int H, float *__restrict__ colpart) {
     typedef typename T16<DT>::elem E;
     typedef typename T16<DT>::vec8 vec8;
     typedef typename T16<DT>::vec4 vec4;
@@ -641,12 +669,22 @@ __global__ __launch_bounds__(64) void mha_bwd_wave(const typename T16<DT>::elem 
         mm16k_bt<DT>(dq, sDS, LT, sK, LR, half * 32, 2, lane);          // dQ[q][d] = sum_j dS[q][j] K[j][d]
         mm16k_bt<DT>(dk, sDSt, LT, sQ, LR, half * 32, 2, lane);         // dK[j][d] = sum_q dS[q][j] Q[q][d]
         mm16k_bt<DT>(dv, sPt, LT, sO, LR, half * 32, 2, lane);          // dV[j][d] = sum_q P[q][j] dO[q][d]
+        float cq = 0.f, ck = 0.f, cv = 0.f;
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
             const int row = HGR_ACC_ROW(g, hh);
             if (row < L) {
                 E *o = dqb + (int64_t)row * ld + half * 32 + r32;
-                o[0] = (E)dq[g]; o[W] = (E)dk[g]; o[2 * W] = (E)dv[g];
+                const E vq = (E)dq[g], vk = (E)dk[g], vv = (E)dv[g];
+                o[0] = vq; o[W] = vk; o[2 * W] = vv;
+                cq += (float)vq; ck += (float)vk; cv += (float)vv;
+            }
+        }
+        if (colpart) {      // column sums of the rounded rows (the in_proj bias gradient's share of this (batch, head)), see mha_bwd_tiled
+            cq += __shfl_xor(cq, 32); ck += __shfl_xor(ck, 32); cv += __shfl_xor(cv, 32);
+            if (hh == 0) {
+                float *cp = colpart + (int64_t)b * 3 * W + h * 64 + half * 32 + r32;
+                cp[0] = cq; cp[W] = ck; cp[2 * W] = cv;
             }
         }
     }
@@ -972,7 +1010,7 @@ extern "C" int hgr_quickgelu16(const void *a, const void *du, void *out, int64_t
 }
 
 static int layernorm_bwd_entry(const char *name, const void *dy, int dy_f32, const float *x, const float *gamma, float *dx, void *dx16, float *dgamma, float *dbeta,
-                               float *scratch, int rows, int W, int64_t row_mul, const int32_t *row_idx, float eps, int dtype, void *stream) {
+                               float *scratch, int rows, int W, int64_t row_mul, const int32_t *row_idx, float eps, int dtype, void *stream, float *dx16_colsum = nullptr) {
     HGR_REQUIRE(dy && x && gamma && dx && dgamma && dbeta && scratch, "%s: null operand", name);
     HGR_REQUIRE(rows >= 1 && W >= 4 && W % 4 == 0 && W <= 4096 && row_mul >= 1, "%s: rows=%d W=%d unsupported", name, rows, W);
     HGR_REQUIRE(dtype == HGR_BF16 || dtype == HGR_F16, "%s: bad dtype %d", name, dtype);
@@ -981,21 +1019,24 @@ static int layernorm_bwd_entry(const char *name, const void *dy, int dy_f32, con
     const int nw = blocks * 4;
     float *pg = scratch, *pb = scratch + (int64_t)nw * W;
     float *cs = pb + (int64_t)nw * W;                                   // colsum scratch: ceil(nw/512) * W floats
+    float *pc = dx16_colsum ? cs + ((int64_t)(nw + 511) / 512) * W : nullptr;   // third partial matrix behind it (hgr_layernorm_bwd_scratch_floats counts it)
     hipStream_t s = (hipStream_t)stream;
     const int nvl = (W / 4 + 63) / 64;
 #define HGR_LNB(NVV)                                                                                                             \
     do {                                                                                                                         \
-        if (dy_f32 && dtype == HGR_BF16) hipLaunchKernelGGL((layernorm_bwd<HGR_BF16, true, NVV>), dim3(blocks), dim3(256), 0, s, dy, x, gamma, dx, pg, pb, rows, W, row_mul, row_idx, eps, (__bf16 *)dx16); \
-        else if (dy_f32) hipLaunchKernelGGL((layernorm_bwd<HGR_F16, true, NVV>), dim3(blocks), dim3(256), 0, s, dy, x, gamma, dx, pg, pb, rows, W, row_mul, row_idx, eps, (_Float16 *)dx16); \
-        else if (dtype == HGR_BF16) hipLaunchKernelGGL((layernorm_bwd<HGR_BF16, false, NVV>), dim3(blocks), dim3(256), 0, s, dy, x, gamma, dx, pg, pb, rows, W, row_mul, row_idx, eps, (__bf16 *)dx16); \
-        else hipLaunchKernelGGL((layernorm_bwd<HGR_F16, false, NVV>), dim3(blocks), dim3(256), 0, s, dy, x, gamma, dx, pg, pb, rows, W, row_mul, row_idx, eps, (_Float16 *)dx16); \
+        if (dy_f32 && dtype == HGR_BF16) hipLaunchKernelGGL((layernorm_bwd<HGR_BF16, true, NVV>), dim3(blocks), dim3(256), 0, s, dy, x, gamma, dx, pg, pb, rows, W, row_mul, row_idx, eps, (__bf16 *)dx16, pc); \
+        else if (dy_f32) hipLaunchKernelGGL((layernorm_bwd<HGR_F16, true, NVV>), dim3(blocks), dim3(256), 0, s, dy, x, gamma, dx, pg, pb, rows, W, row_mul, row_idx, eps, (_Float16 *)dx16, pc); \
+        else if (dtype == HGR_BF16) hipLaunchKernelGGL((layernorm_bwd<HGR_BF16, false, NVV>), dim3(blocks), dim3(256), 0, s, dy, x, gamma, dx, pg, pb, rows, W, row_mul, row_idx, eps, (__bf16 *)dx16, pc); \
+        else hipLaunchKernelGGL((layernorm_bwd<HGR_F16, false, NVV>), dim3(blocks), dim3(256), 0, s, dy, x, gamma, dx, pg, pb, rows, W, row_mul, row_idx, eps, (_Float16 *)dx16, pc); \
     } while (0)
     if (nvl <= 1) HGR_LNB(1); else if (nvl <= 2) HGR_LNB(2); else if (nvl <= 4) HGR_LNB(4); else if (nvl <= 8) HGR_LNB(8); else HGR_LNB(16);
 #undef HGR_LNB
     HGR_CHECK_LAUNCH(name);
     int rc = hgr_colsum(pg, W, nw, W, 1, HGR_BF16, dgamma, 1, 1.0f, cs, stream);
     if (rc) return rc;
-    return hgr_colsum(pb, W, nw, W, 1, HGR_BF16, dbeta, 1, 1.0f, cs, stream);
+    rc = hgr_colsum(pb, W, nw, W, 1, HGR_BF16, dbeta, 1, 1.0f, cs, stream);
+    if (rc || !pc) return rc;
+    return hgr_colsum(pc, W, nw, W, 1, HGR_BF16, dx16_colsum, 1, 1.0f, cs, stream);
 }
 
 extern "C" int hgr_layernorm_bwd(const void *dy, int dy_f32, const float *x, const float *gamma, float *dx, float *dgamma, float *dbeta, float *scratch,
@@ -1009,14 +1050,22 @@ extern "C" int hgr_layernorm_bwd_cast(const void *dy, int dy_f32, const float *x
     return layernorm_bwd_entry("hgr_layernorm_bwd_cast", dy, dy_f32, x, gamma, dx, dx16, dgamma, dbeta, scratch, rows, W, row_mul, row_idx, eps, dtype, stream);
 }
 
+// ... and dx16_colsum[c] += sum over the rows of dx16[:, c] as rounded: the bias gradient of the Linear whose output gradient dx16 is
+// (out_proj / c_proj of a residual block: their dY IS the residual-stream gradient), without an hgr_colsum pass over dx16
+extern "C" int hgr_layernorm_bwd_cast_colsum(const void *dy, int dy_f32, const float *x, const float *gamma, float *dx, void *dx16, float *dgamma, float *dbeta,
+                                             float *dx16_colsum, float *scratch, int rows, int W, int64_t row_mul, const int32_t *row_idx, float eps, int dtype, void *stream) {
+    HGR_REQUIRE(dx16 && dx16_colsum, "hgr_layernorm_bwd_cast_colsum: null dx16 / dx16_colsum");
+    return layernorm_bwd_entry("hgr_layernorm_bwd_cast_colsum", dy, dy_f32, x, gamma, dx, dx16, dgamma, dbeta, scratch, rows, W, row_mul, row_idx, eps, dtype, stream, dx16_colsum);
+}
+
 extern "C" int64_t hgr_layernorm_bwd_scratch_floats(int rows, int W) {
     const int blocks = rows < 4 * 512 ? (rows + 3) / 4 : 512;
     const int64_t nw = (int64_t)blocks * 4;
-    return 2 * nw * W + ((nw + 511) / 512) * W;
+    return 3 * nw * W + ((nw + 511) / 512) * W;       // dgamma / dbeta / dx16 column-sum partial rows + the colsum scratch
 }
 
 static int mha_bwd_entry(const char *name, const void *qkv, const void *out, const void *dout, void *dqkv, const float *stats,
-                         int B, int L, int heads, int causal, int dtype, void *stream) {
+                         int B, int L, int heads, int causal, int dtype, void *stream, float *colpart = nullptr) {
     HGR_REQUIRE(qkv && out && dout && dqkv && B >= 1 && heads >= 1, "%s: bad arguments", name);
     HGR_REQUIRE(L >= 1 && L <= 320, "%s: L=%d unsupported (L <= 320)", name, L);
     HGR_REQUIRE(hgr_aligned(stats, 8), "%s: stats must be 8-byte aligned", name);
@@ -1025,19 +1074,19 @@ static int mha_bwd_entry(const char *name, const void *qkv, const void *out, con
     const dim3 g(B * heads);
     if (L <= 32) {           // one 32 x 32 block per (batch, head): the statistics are recomputed in registers, `stats` is not needed
         if (dtype == HGR_BF16) {
-            if (causal) hipLaunchKernelGGL((mha_bwd_wave<HGR_BF16, true>), g, dim3(64), 0, s, (const __bf16 *)qkv, (const __bf16 *)dout, (__bf16 *)dqkv, L, heads);
-            else hipLaunchKernelGGL((mha_bwd_wave<HGR_BF16, false>), g, dim3(64), 0, s, (const __bf16 *)qkv, (const __bf16 *)dout, (__bf16 *)dqkv, L, heads);
+            if (causal) hipLaunchKernelGGL((mha_bwd_wave<HGR_BF16, true>), g, dim3(64), 0, s, (const __bf16 *)qkv, (const __bf16 *)dout, (__bf16 *)dqkv, L, heads, colpart);
+            else hipLaunchKernelGGL((mha_bwd_wave<HGR_BF16, false>), g, dim3(64), 0, s, (const __bf16 *)qkv, (const __bf16 *)dout, (__bf16 *)dqkv, L, heads, colpart);
         } else {
-            if (causal) hipLaunchKernelGGL((mha_bwd_wave<HGR_F16, true>), g, dim3(64), 0, s, (const _Float16 *)qkv, (const _Float16 *)dout, (_Float16 *)dqkv, L, heads);
-            else hipLaunchKernelGGL((mha_bwd_wave<HGR_F16, false>), g, dim3(64), 0, s, (const _Float16 *)qkv, (const _Float16 *)dout, (_Float16 *)dqkv, L, heads);
+            if (causal) hipLaunchKernelGGL((mha_bwd_wave<HGR_F16, true>), g, dim3(64), 0, s, (const _Float16 *)qkv, (const _Float16 *)dout, (_Float16 *)dqkv, L, heads, colpart);
+            else hipLaunchKernelGGL((mha_bwd_wave<HGR_F16, false>), g, dim3(64), 0, s, (const _Float16 *)qkv, (const _Float16 *)dout, (_Float16 *)dqkv, L, heads, colpart);
         }
     }
     else {
         const float2 *st = (const float2 *)stats;
 #define HGR_MT(CAUS)                                                                                                              \
     do {                                                                                                                          \
-        if (dtype == HGR_BF16) hipLaunchKernelGGL((mha_bwd_tiled<HGR_BF16, CAUS>), g, dim3(256), 0, s, (const __bf16 *)qkv, (const __bf16 *)out, (const __bf16 *)dout, (__bf16 *)dqkv, L, heads, st); \
-        else hipLaunchKernelGGL((mha_bwd_tiled<HGR_F16, CAUS>), g, dim3(256), 0, s, (const _Float16 *)qkv, (const _Float16 *)out, (const _Float16 *)dout, (_Float16 *)dqkv, L, heads, st); \
+        if (dtype == HGR_BF16) hipLaunchKernelGGL((mha_bwd_tiled<HGR_BF16, CAUS>), g, dim3(256), 0, s, (const __bf16 *)qkv, (const __bf16 *)out, (const __bf16 *)dout, (__bf16 *)dqkv, L, heads, st, colpart); \
+        else hipLaunchKernelGGL((mha_bwd_tiled<HGR_F16, CAUS>), g, dim3(256), 0, s, (const _Float16 *)qkv, (const _Float16 *)out, (const _Float16 *)dout, (_Float16 *)dqkv, L, heads, st, colpart); \
     } while (0)
         if (causal) HGR_MT(true); else HGR_MT(false);
 #undef HGR_MT
@@ -1054,6 +1103,14 @@ extern "C" int hgr_mha_bwd_stats(const void *qkv, const void *out, const void *d
                                  int B, int L, int heads, int causal, int dtype, void *stream) {
     HGR_REQUIRE(stats, "hgr_mha_bwd_stats: null stats");
     return mha_bwd_entry("hgr_mha_bwd_stats", qkv, out, dout, dqkv, stats, B, L, heads, causal, dtype, stream);
+}
+
+// ... and colsum_part[b][3W] (fp32, every entry written) = column sums over sequence b's L rows of dqkv AS ROUNDED: summed over b
+// (hgr_colsum) that is the in_proj bias gradient, without a pass over the [B*L, 3W] gradient.  stats may be NULL (recomputed).
+extern "C" int hgr_mha_bwd_colsum(const void *qkv, const void *out, const void *dout, void *dqkv, const float *stats, float *colsum_part,
+                                  int B, int L, int heads, int causal, int dtype, void *stream) {
+    HGR_REQUIRE(colsum_part, "hgr_mha_bwd_colsum: null colsum_part");
+    return mha_bwd_entry("hgr_mha_bwd_colsum", qkv, out, dout, dqkv, stats, B, L, heads, causal, dtype, stream, colsum_part);
 }
 
 extern "C" int hgr_ce_rows(const float *logits, int64_t ld, const int32_t *labels, int rows, int n, float gscale, float *loss_rows, float *dlogits, int64_t ldd, void *stream) {

@@ -405,9 +405,11 @@ class tree_model(nn.Module):
             ids.append(target)
         return ids, ids.index(target)
 
-    def get_weights(self, method, max_depth=None):
-        """Layer weights (clip_tree.py:198-219)."""
-        dev = self.device
+    def get_weights(self, method, max_depth=None, device=None):
+        """Layer weights (clip_tree.py:198-219).  ``device`` (not in the reference): where the closed-form weights are made - the
+        training step asks for "cpu" (it only needs their float values; a device tensor per inner step is a synchronous
+        host-to-device copy plus a read-back, i.e. two drains of the launch queue)."""
+        dev = self.device if device is None else device
         if method == "equal":
             return (torch.ones(max_depth) / max_depth).to(dev)
         if method == "decreasing":

@@ -608,12 +608,20 @@ def layernorm_bwd_scratch(rows: int, w: int) -> int:
 
 def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, dx: torch.Tensor, dgamma: torch.Tensor, dbeta: torch.Tensor,
                   scratch: torch.Tensor, rows: Optional[int] = None, row_mul: int = 1, row_idx: Optional[torch.Tensor] = None, eps: float = 1e-5,
-                  dx16: Optional[torch.Tensor] = None) -> None:
-    """dx[src rows] += dLN; dgamma += ...; dbeta += ...  (all fp32, accumulate).  ``dx16``: also the updated dx rows as a 16-bit copy."""
+                  dx16: Optional[torch.Tensor] = None, dx16_colsum: Optional[torch.Tensor] = None) -> None:
+    """dx[src rows] += dLN; dgamma += ...; dbeta += ...  (all fp32, accumulate).  ``dx16``: also the updated dx rows as a 16-bit copy;
+    ``dx16_colsum`` (fp32 [w], with dx16): += the column sums of those 16-bit rows (the bias gradient of the Linear they are dY of)."""
     w = x.shape[-1]
     rows = dy.shape[0] if rows is None else rows
     f32 = dy.dtype == torch.float32
     assert scratch.numel() >= layernorm_bwd_scratch(rows, w) and dy.is_contiguous()
+    if dx16 is not None and dx16_colsum is not None:
+        assert dx16.is_contiguous() and dx16.shape == dx.shape and (f32 or dx16.dtype == dy.dtype)
+        assert dx16_colsum.dtype == torch.float32 and dx16_colsum.is_contiguous() and dx16_colsum.numel() == w
+        _lib.call("hgr_layernorm_bwd_cast_colsum", _dev(dy), 1 if f32 else 0, _dev(x), _dev(gamma), _dev(dx), _dev(dx16), _dev(dgamma), _dev(dbeta),
+                  _dev(dx16_colsum), _dev(scratch), rows, w, row_mul, _dev(row_idx), eps, DT_OF[dx16.dtype], _stream())
+        return
+    assert dx16_colsum is None
     if dx16 is not None:
         assert dx16.is_contiguous() and dx16.shape == dx.shape and (f32 or dx16.dtype == dy.dtype)
         _lib.call("hgr_layernorm_bwd_cast", _dev(dy), 1 if f32 else 0, _dev(x), _dev(gamma), _dev(dx), _dev(dx16), _dev(dgamma), _dev(dbeta), _dev(scratch),
@@ -624,10 +632,18 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, dx: to
 
 
 def mha_bwd(qkv: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, dqkv: torch.Tensor, b: int, l: int, heads: int, causal: bool,
-            stats: Optional[torch.Tensor] = None) -> torch.Tensor:
+            stats: Optional[torch.Tensor] = None, colsum_part: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``colsum_part`` (fp32 [b, 3 * heads * 64], every entry written): per-sequence column sums of dqkv as rounded - summed over b
+    they are the in_proj bias gradient (hgr_mha_bwd_colsum)."""
     assert qkv.is_contiguous() and out.is_contiguous() and dout.is_contiguous() and dqkv.is_contiguous()
     if stats is not None:
         assert stats.dtype == torch.float32 and stats.is_contiguous() and stats.numel() == b * heads * l * 2
+    if colsum_part is not None:
+        assert colsum_part.dtype == torch.float32 and colsum_part.is_contiguous() and colsum_part.shape == (b, 3 * heads * 64)
+        _lib.call("hgr_mha_bwd_colsum", _dev(qkv), _dev(out), _dev(dout), _dev(dqkv), _dev(stats), _dev(colsum_part), b, l, heads, 1 if causal else 0,
+                  DT_OF[qkv.dtype], _stream())
+        return dqkv
+    if stats is not None:
         _lib.call("hgr_mha_bwd_stats", _dev(qkv), _dev(out), _dev(dout), _dev(dqkv), _dev(stats), b, l, heads, 1 if causal else 0,
                   DT_OF[qkv.dtype], _stream())
         return dqkv

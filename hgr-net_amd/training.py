@@ -110,10 +110,11 @@ class Engine:
 
     def _linear_bwd(self, lin: _Lin, dy16: torch.Tensor, x16: torch.Tensor, m: int, need_dx: bool = True,
                     gelu_pre: Optional[torch.Tensor] = None, dy_colsum: Optional[torch.Tensor] = None,
-                    dx_colsum: Optional[list] = None) -> Optional[torch.Tensor]:
+                    dx_colsum: Optional[list] = None, bias_done: bool = False) -> Optional[torch.Tensor]:
         """dW += dY^T X, db += colsum(dY); returns dX = dY W (16-bit) if wanted.  dy16 [m, n], x16 [m, k].
         ``dy_colsum``: per-64-row column sums of dy16 its producer already made ([ceil(m / 64), n] fp32): db comes from them,
-        dy16 is not read a third time.  ``dx_colsum`` (a list, with ``gelu_pre``): receives such sums of the returned dX."""
+        dy16 is not read a third time.  ``dx_colsum`` (a list, with ``gelu_pre``): receives such sums of the returned dX.
+        ``bias_done``: the producer of dy16 already added its column sums to the bias gradient (hgr_layernorm_bwd_cast_colsum)."""
         dev, dt = self.dev, self.dt
         xq = x16[:, : lin.k] if x16.shape[1] != lin.k else x16
         if WGRAD_TN and lin.n % 8 == 0 and lin.k % 8 == 0 and dy16.stride(0) % 8 == 0 and xq.stride(0) % 8 == 0 \
@@ -132,7 +133,7 @@ class Engine:
                 ops.colsum(part, gw.view(-1), self.scratch(lin.n * lin.k), accumulate=True)
             else:
                 gw.view(-1).add_(part[0])
-            if lin.bias is not None:
+            if lin.bias is not None and not bias_done:
                 if dy_colsum is not None:
                     ops.colsum(dy_colsum, _grad(lin.bias), self.scratch(((dy_colsum.shape[0] + 511) // 512) * lin.n), accumulate=True)
                 else:
@@ -142,7 +143,7 @@ class Engine:
         alloc = torch.empty if mp == m else torch.zeros           # the pad columns must be zero, the rest is overwritten
         dyt = alloc(lin.n, mp, dtype=dt, device=dev)
         xt = alloc(lin.k, mp, dtype=dt, device=dev)
-        fused_bias = lin.bias is not None and dy16.stride(0) % 8 == 0 and dy16.data_ptr() % 16 == 0
+        fused_bias = lin.bias is not None and not bias_done and dy16.stride(0) % 8 == 0 and dy16.data_ptr() % 16 == 0
         if fused_bias:      # db rides on the transposition of dY
             ops.transpose16_colsum(dy16, dyt, _grad(lin.bias), self.scratch(((m + 63) // 64) * lin.n), accumulate=True)
         else:
@@ -167,7 +168,7 @@ class Engine:
             ops.colsum(part, gw.view(-1), self.scratch(lin.n * lin.k), accumulate=True)
         else:
             ops.gemm_nt(dyt, xt, gw, epilogue=EPI_ACCUM)
-        if lin.bias is not None and not fused_bias:
+        if lin.bias is not None and not fused_bias and not bias_done:
             ops.colsum(dy16, _grad(lin.bias), self.scratch(((m + 511) // 512) * lin.n), accumulate=True)
         return self._linear_dx(lin, dy16, m, gelu_pre) if need_dx else None
 
@@ -229,23 +230,32 @@ class Engine:
         scr = self.scratch(ops.layernorm_bwd_scratch(m, w))
         dy = torch.empty(m, w, dtype=dt, device=dev)
         ops.cast16(dx, dy)               # later 16-bit copies of dx come out of the LayerNorm backward that updates it
-        for k, (x0, h1, qkv, att, x1, h2, a, u, st) in zip(reversed(blocks), reversed(saves)):
+        # bias gradients of out_proj / c_proj = column sums of the residual-stream gradient `dy`: the LayerNorm backward that writes dy
+        # adds them on its way (COLSUM_FUSED); only the stack's first dy (the cast above) goes through hgr_colsum
+        order = list(reversed(blocks))
+        proj_bias_done = False
+        for pos, (k, (x0, h1, qkv, att, x1, h2, a, u, st)) in enumerate(zip(order, reversed(saves))):
             # x2 = x1 + c_proj(gelu(c_fc(ln_2(x1))))
             da_sums: list = []
             if GELU_BWD_FUSED:      # d(pre-activation) straight from the c_proj data-gradient GEMM (HGR_EPI_QGELU_GRAD16)
-                da = self._linear_bwd(k.w_proj, dy, u, m, gelu_pre=a, dx_colsum=da_sums)
+                da = self._linear_bwd(k.w_proj, dy, u, m, gelu_pre=a, dx_colsum=da_sums, bias_done=proj_bias_done)
             else:
-                du = self._linear_bwd(k.w_proj, dy, u, m)
+                du = self._linear_bwd(k.w_proj, dy, u, m, bias_done=proj_bias_done)
                 da = torch.empty_like(a)
                 ops.quickgelu16(a, da, du=du)
             dh2 = self._linear_bwd(k.w_fc, da, h2, m, dy_colsum=da_sums[0] if da_sums else None)
-            ops.layernorm_bwd(dh2, x1, k.ln2.weight.data, dx, _grad(k.ln2.weight), _grad(k.ln2.bias), scr, dx16=dy)
+            out_b = _grad(k.w_out.bias) if COLSUM_FUSED and k.w_out.bias is not None else None
+            ops.layernorm_bwd(dh2, x1, k.ln2.weight.data, dx, _grad(k.ln2.weight), _grad(k.ln2.bias), scr, dx16=dy, dx16_colsum=out_b)
             # x1 = x0 + out_proj(attn(in_proj(ln_1(x0))))
-            datt = self._linear_bwd(k.w_out, dy, att, m)
+            datt = self._linear_bwd(k.w_out, dy, att, m, bias_done=out_b is not None)
             dqkv = torch.empty_like(qkv)
-            ops.mha_bwd(qkv, att, datt, dqkv, b, l, heads, causal, stats=st)
-            dh1 = self._linear_bwd(k.w_in, dqkv, h1, m)
-            ops.layernorm_bwd(dh1, x0, k.ln1.weight.data, dx, _grad(k.ln1.weight), _grad(k.ln1.bias), scr, dx16=dy)
+            qkv_sums = torch.empty(b, 3 * w, dtype=torch.float32, device=dev) if COLSUM_FUSED and k.w_in.bias is not None and l <= 320 else None
+            ops.mha_bwd(qkv, att, datt, dqkv, b, l, heads, causal, stats=st, colsum_part=qkv_sums)
+            dh1 = self._linear_bwd(k.w_in, dqkv, h1, m, dy_colsum=qkv_sums)
+            nxt = order[pos + 1] if pos + 1 < len(order) else None
+            proj_b = _grad(nxt.w_proj.bias) if COLSUM_FUSED and nxt is not None and nxt.w_proj.bias is not None else None
+            ops.layernorm_bwd(dh1, x0, k.ln1.weight.data, dx, _grad(k.ln1.weight), _grad(k.ln1.bias), scr, dx16=dy, dx16_colsum=proj_b)
+            proj_bias_done = proj_b is not None
         return dx
 
     # -- image tower (ViT) ----------------------------------------------------------------------
@@ -491,13 +501,16 @@ class OMTrainer:
         if not inputs.is_cuda:
             raise HgrError("train_batch needs device tensors: there is no CPU path")
         strategy = sample_strategy or tree.opts.sample_strategy
-        e.prepare()
+        # every host read-back of the step happens HERE, before the image tower is queued: behind it the host would wait for the tower's
+        # forward and the device would then idle through the host-side sampling below
+        target = int(targets[0].item()) if torch.is_tensor(targets) else int(targets[0])
         self._scale = float(e.m.logit_scale.data.exp())      # one scalar D2H per step
+        lw_host = tree.layer_weight.detach().float().cpu() if tree.opts.weights == "adaptive" else None
+        e.prepare()
         feat, isave = e.image_fwd(inputs)
         img_n = torch.empty_like(feat)
         ops.l2norm_rows(feat, y32=img_n)
         dimg_n = torch.zeros_like(img_n)                      # img_feats_.grad of the reference
-        target = int(targets[0].item()) if torch.is_tensor(targets) else int(targets[0])
         loss_acc = torch.zeros(1, 1, dtype=torch.float32, device=e.dev)
         if training_method == "OM":
             steps = tree.outer_inner_plan(target)
@@ -509,6 +522,13 @@ class OMTrainer:
         # negative sampling first (host), then ONE text-tower pass over the de-duplicated prompts of all inner steps:
         # the weights are constant within a step, so encoding each distinct prompt once and back-propagating the summed
         # feature gradient once is the same arithmetic as the reference's K x M separate encode_text + backward calls
+        # the scalar loss weights as HOST values: the closed forms are made on the CPU, `adaptive` from one read-back of layer_weight
+        # (its gradient path below stays on the device) - a device tensor + float() per inner step drained the launch queue 3 x 17 times
+        def host_weights(mode, n):
+            if mode == "adaptive":
+                return torch.softmax(100 ** lw_host[:n], dim=0)
+            return tree.get_weights(mode, n, device="cpu")
+
         picks = []
         for i, st in enumerate(steps):
             if self.contra_override is not None:
@@ -516,11 +536,11 @@ class OMTrainer:
             else:
                 ids, pos = tree.get_contra_ids(strategy, st["p_out"], st["depth"], st["parents_in"])
             if st.get("hier"):
-                wgt = tree.get_weights(tree.opts.weights, st["K"])[st["k_loop"]]
+                wgt = host_weights(tree.opts.weights, st["K"])[st["k_loop"]]
             else:
                 wmode = tree.opts.weighting
-                w_in = tree.get_weights("equal" if wmode == "out" else tree.opts.weights, st["M"])
-                w_out = tree.get_weights("equal" if wmode == "in" else tree.opts.weights, st["K"])
+                w_in = host_weights("equal" if wmode == "out" else tree.opts.weights, st["M"])
+                w_out = host_weights("equal" if wmode == "in" else tree.opts.weights, st["K"])
                 wgt = w_in[st["m_loop"]] * w_out[st["k_loop"]]
             picks.append((list(ids), pos, float(wgt), wgt))
         self.last_contra = [(ids, pos) for ids, pos, _, _ in picks]

@@ -351,6 +351,12 @@ int hgr_layernorm_bwd(const void *dy, int dy_f32, const float *x, const float *g
 int hgr_layernorm_bwd_cast(const void *dy, int dy_f32, const float *x, const float *gamma, float *dx, void *dx16, float *dgamma,
                            float *dbeta, float *scratch, int rows, int W, int64_t row_mul, const int32_t *row_idx, float eps,
                            int dtype, void *stream);
+/* The same, and dx16_colsum[c] += sum over the touched rows of dx16[:, c] AS ROUNDED (fp32 [W], accumulated): dx16 is the output
+ * gradient of the Linear that closes the residual branch behind this LayerNorm (out_proj / c_proj, clip/model.py:186-187), so this
+ * is that Linear's bias gradient - without the hgr_colsum pass over dx16 it otherwise costs. */
+int hgr_layernorm_bwd_cast_colsum(const void *dy, int dy_f32, const float *x, const float *gamma, float *dx, void *dx16, float *dgamma,
+                                  float *dbeta, float *dx16_colsum, float *scratch, int rows, int W, int64_t row_mul,
+                                  const int32_t *row_idx, float eps, int dtype, void *stream);
 int64_t hgr_layernorm_bwd_scratch_floats(int rows, int W);
 
 /* Attention backward for hgr_mha (L <= 320): dqkv [B*L, 3W] from qkv, the forward output `out` and dout [B*L, W], all
@@ -361,6 +367,11 @@ int hgr_mha_bwd(const void *qkv, const void *out, const void *dout, void *dqkv, 
  * over the score blocks less.  (L <= 32 runs the single-block kernel, which does not read them.) */
 int hgr_mha_bwd_stats(const void *qkv, const void *out, const void *dout, void *dqkv, const float *stats,
                       int B, int L, int heads, int causal, int dtype, void *stream);
+/* The same (stats may be NULL: recomputed), and colsum_part [B, 3W] (fp32, every entry written) = the column sums of sequence b's L
+ * rows of dqkv AS ROUNDED.  Summed over b (hgr_colsum) that is the in_proj bias gradient - autograd's grad_output.sum(0) behind
+ * clip/model.py:171 - without a second pass over the [B*L, 3W] gradient. */
+int hgr_mha_bwd_colsum(const void *qkv, const void *out, const void *dout, void *dqkv, const float *stats, float *colsum_part,
+                       int B, int L, int heads, int causal, int dtype, void *stream);
 
 /*
  * ---- ModifiedResNet tower in training (clip/model.py:10-150 under model/clip_tree.py:222-281; the reference's README

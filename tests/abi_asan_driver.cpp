@@ -99,8 +99,10 @@ int main() {
     EXPECT_FAIL(hgr_gemm_nt_qgelu_grad_colsum(h16, 128, h16, 128, h16, 128, h16, 128, nullptr, 4, 128, 128, HGR_F16, nullptr));        // colsum_part missing
     EXPECT_FAIL(hgr_mha_stats(h16, h16, nullptr, 1, 50, 12, 0, HGR_F16, nullptr));
     EXPECT_FAIL(hgr_mha_bwd_stats(h16, h16, h16, h16, nullptr, 1, 50, 12, 0, HGR_F16, nullptr));
+    EXPECT_FAIL(hgr_mha_bwd_colsum(h16, h16, h16, h16, f32, nullptr, 1, 50, 12, 0, HGR_F16, nullptr));                                  // colsum_part missing
     EXPECT_FAIL(hgr_mha_bwd_stats(h16, h16, h16, h16, f32, 1, 400, 12, 0, HGR_F16, nullptr));                                           // L > 320
     EXPECT_FAIL(hgr_layernorm_bwd_cast(h16, 0, f32, f32, f32, nullptr, f32, f32, f32, 4, 64, 1, nullptr, 1e-5f, HGR_F16, nullptr));
+    EXPECT_FAIL(hgr_layernorm_bwd_cast_colsum(h16, 0, f32, f32, f32, h16, f32, f32, nullptr, f32, 4, 64, 1, nullptr, 1e-5f, HGR_F16, nullptr));
     EXPECT_FAIL(hgr_layernorm_bwd_cast(h16, 0, f32, f32, f32, h16, f32, f32, f32, 4, 6, 1, nullptr, 1e-5f, HGR_F16, nullptr));         // W % 4
     EXPECT_OK(hgr_gemm_tn_tile(3072, 768) == 256 && hgr_gemm_tn_tile(200, 4096) == 128 && hgr_gemm_tn_tile(640, 640) == 128 ? 0 : -1);
     // collectives without a communicator / with bad arguments (librccl may be absent: both outcomes are failures by contract)

@@ -164,6 +164,32 @@ def test_layernorm_bwd_cast_equals_bwd_then_cast16(dt):
 
 
 @pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("rows,w", [(300, 768), (5000, 1024), (2, 512)])
+def test_layernorm_bwd_cast_colsum_equals_cast_then_colsum(dt, rows, w):
+    """hgr_layernorm_bwd_cast_colsum: dx, dgamma, dbeta, dx16 as hgr_layernorm_bwd_cast bit for bit; the accumulated column sums equal
+    those of the ROUNDED dx16 (hgr_colsum of it) up to the fp32 order of the adds, on top of what the target already held."""
+    x = _rand((rows, w), 81, 1.0).to(DEV)
+    dy = _rand((rows, w), 82, 0.5).to(dt).to(DEV)
+    g = (_rand((w,), 83, 0.2) + 1.0).to(DEV)
+    dx0 = _rand((rows, w), 84, 0.3).to(DEV)
+    scratch = torch.empty(ops.layernorm_bwd_scratch(rows, w), device=DEV)
+    dx1, dg1, db1 = dx0.clone(), torch.zeros(w, device=DEV), torch.zeros(w, device=DEV)
+    c1 = torch.empty(rows, w, dtype=dt, device=DEV)
+    ops.layernorm_bwd(dy, x, g, dx1, dg1, db1, scratch, dx16=c1)
+    start = _rand((w,), 85, 2.0).to(DEV)
+    want = start.clone()
+    ops.colsum(c1, want, torch.empty(max(1 << 16, ((rows + 511) // 512) * w), device=DEV), accumulate=True)
+    dx2, dg2, db2 = dx0.clone(), torch.zeros(w, device=DEV), torch.zeros(w, device=DEV)
+    c2 = torch.full((rows, w), 7.0, dtype=dt, device=DEV)
+    got = start.clone()
+    ops.layernorm_bwd(dy, x, g, dx2, dg2, db2, scratch, dx16=c2, dx16_colsum=got)
+    assert torch.equal(dx1, dx2) and torch.equal(dg1, dg2) and torch.equal(db1, db2) and torch.equal(c1, c2)
+    ref64 = start.double() + c1.double().sum(dim=0)
+    bound = 1e-6 * float(c1.float().abs().sum(dim=0).max()) + 1e-6
+    assert float((got.double() - ref64).abs().max()) <= bound and float((want.double() - ref64).abs().max()) <= bound
+
+
+@pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("L,causal", [(5, True), (16, True), (1, True), (12, False), (29, True), (32, True), (32, False), (50, False), (64, False), (37, True),
                                       (77, True), (65, False), (130, True), (257, False)])
 def test_mha_bwd_vs_autograd(dt, L, causal):
@@ -195,6 +221,14 @@ def test_mha_bwd_vs_autograd(dt, L, causal):
     ops.mha_bwd(qkv.to(DEV), o.detach().to(dt).to(DEV), do.to(DEV), dq2, b, L, heads, causal, stats=st)
     assert (dq2.float().cpu() - q.grad).abs().max() < tol * max(1.0, float(q.grad.abs().max()))
     assert float((dq2.float() - dqkv.float()).abs().max()) <= (2.0 ** -6 if dt == torch.bfloat16 else 2.0 ** -9) * max(1.0, float(q.grad.abs().max()))
+    # hgr_mha_bwd_colsum: the same gradients bit for bit (with and without statistics), and per sequence the column sums of the ROUNDED rows
+    for stt, want in ((st, dq2), (None, dqkv)):
+        dq3 = torch.full_like(dqkv, 7.0)
+        part = torch.full((b, 3 * w), float("nan"), device=DEV)
+        ops.mha_bwd(qkv.to(DEV), o.detach().to(dt).to(DEV), do.to(DEV), dq3, b, L, heads, causal, stats=stt, colsum_part=part)
+        assert torch.equal(dq3, want)
+        ref = want.double().view(b, L, 3 * w).sum(dim=1)
+        assert float((part.double() - ref).abs().max()) <= 1e-6 * float(want.float().abs().view(b, L, 3 * w).sum(dim=1).max()) + 1e-7
 
 
 def test_ce_l2norm_matmul_scatter():
