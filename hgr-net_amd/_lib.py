@@ -52,6 +52,7 @@ SIGNATURES = {
     "hgr_transpose16_colsum": [_p, _l, _p, _l, _i, _i, _i, _p, _i, _f, _p, _p],
     "hgr_colsum": [_p, _l, _i, _i, _i, _i, _p, _i, _f, _p, _p],
     "hgr_cast16": [_p, _p, _l, _i, _p],
+    "hgr_cast16_transpose": [_p, _l, _p, _l, _p, _l, _i, _i, _i, _p],
     "hgr_quickgelu16": [_p, _p, _p, _l, _i, _i, _p],
     "hgr_layernorm_bwd": [_p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _l, _p, _f, _i, _p],
     "hgr_layernorm_bwd_cast": [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _l, _p, _f, _i, _p],

@@ -185,6 +185,56 @@ __global__ __launch_bounds__(256) void cast16(const float *__restrict__ x, typen
     }
 }
 
+// fp32 [rows, cols] -> its 16-bit copy y [rows, ldy] AND the transposed copy yt [cols, ldyt] in one pass (64 x 64 tiles through LDS;
+// the roundings are hgr_cast16's): the per-step refresh of a Linear's training operands (forward / weight-gradient operand and the
+// [K, N] operand of dX = dY W) was three launches per weight (cast, zero fill, transpose) on ~150 weights, launch-bound at step start
+template <int DT>
+__global__ __launch_bounds__(256) void cast16_transpose(const float *__restrict__ x, int64_t ldx, typename T16<DT>::elem *__restrict__ y, int64_t ldy,
+                                                        typename T16<DT>::elem *__restrict__ yt, int64_t ldyt, int rows, int cols, int vec) {
+    typedef typename T16<DT>::elem E;
+    typedef typename T16<DT>::vec8 vec8;
+    __shared__ __attribute__((aligned(16))) E t[64][72];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int id = threadIdx.x + 256 * j;
+        const int r = id >> 3, c = (id & 7) * 8;
+        vec8 v;
+        const bool in = r0 + r < rows && c0 + c + 7 < cols;
+        if (in && vec) {
+            const f32x4 a = *(const f32x4 *)(x + (int64_t)(r0 + r) * ldx + c0 + c), b = *(const f32x4 *)(x + (int64_t)(r0 + r) * ldx + c0 + c + 4);
+            const typename T16<DT>::vec4 lo = cvt4<DT>(a[0], a[1], a[2], a[3]), hi = cvt4<DT>(b[0], b[1], b[2], b[3]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+            *(vec8 *)(y + (int64_t)(r0 + r) * ldy + c0 + c) = v;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bool ok = r0 + r < rows && c0 + c + e < cols;
+                const typename T16<DT>::vec4 q = cvt4<DT>(ok ? x[(int64_t)(r0 + r) * ldx + c0 + c + e] : 0.f, 0.f, 0.f, 0.f);
+                v[e] = q[0];
+                if (ok) y[(int64_t)(r0 + r) * ldy + c0 + c + e] = v[e];
+            }
+        }
+        *(vec8 *)&t[r][c] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int id = threadIdx.x + 256 * j;
+        const int oc = id >> 3, o8 = (id & 7) * 8;          // output row = input column oc; 8 consecutive input rows
+        if (c0 + oc >= cols) continue;
+        vec8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = t[o8 + e][oc];
+        E *dst = yt + (int64_t)(c0 + oc) * ldyt + r0 + o8;
+        if (vec && r0 + o8 + 7 < rows) *(vec8 *)dst = v;
+        else
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (r0 + o8 + e < rows) dst[e] = v[e];
+    }
+}
+
 // ---- QuickGELU forward / backward on 16-bit tensors (training keeps the pre-activation) ------------------
 __device__ __forceinline__ float sigm(float z) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z)); }
 template <int DT, bool BWD>
@@ -990,6 +1040,17 @@ extern "C" int hgr_cast16(const float *x, void *y, int64_t n, int dtype, void *s
     if (dtype == HGR_BF16) hipLaunchKernelGGL((cast16<HGR_BF16>), dim3(grid1(n / 4)), dim3(256), 0, (hipStream_t)stream, x, (__bf16 *)y, n / 4);
     else hipLaunchKernelGGL((cast16<HGR_F16>), dim3(grid1(n / 4)), dim3(256), 0, (hipStream_t)stream, x, (_Float16 *)y, n / 4);
     HGR_CHECK_LAUNCH("hgr_cast16");
+    return HGR_OK;
+}
+
+extern "C" int hgr_cast16_transpose(const float *x, int64_t ldx, void *y, int64_t ldy, void *yt, int64_t ldyt, int rows, int cols, int dtype, void *stream) {
+    HGR_REQUIRE(x && y && yt && rows >= 1 && cols >= 1 && ldx >= cols && ldy >= cols && ldyt >= rows, "hgr_cast16_transpose: bad arguments");
+    DT_OK("hgr_cast16_transpose");
+    const int vec = ldx % 4 == 0 && ldy % 8 == 0 && ldyt % 8 == 0 && hgr_aligned(x, 16) && hgr_aligned(y, 16) && hgr_aligned(yt, 16);
+    const dim3 grid((cols + 63) / 64, (rows + 63) / 64);
+    if (dtype == HGR_BF16) hipLaunchKernelGGL((cast16_transpose<HGR_BF16>), grid, dim3(256), 0, (hipStream_t)stream, x, ldx, (__bf16 *)y, ldy, (__bf16 *)yt, ldyt, rows, cols, vec);
+    else hipLaunchKernelGGL((cast16_transpose<HGR_F16>), grid, dim3(256), 0, (hipStream_t)stream, x, ldx, (_Float16 *)y, ldy, (_Float16 *)yt, ldyt, rows, cols, vec);
+    HGR_CHECK_LAUNCH("hgr_cast16_transpose");
     return HGR_OK;
 }
 

@@ -595,6 +595,14 @@ def cast16(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def cast16_transpose(x: torch.Tensor, y: torch.Tensor, yt: torch.Tensor) -> None:
+    """y[r, c] = (16-bit) x[r, c] and yt[c, r] = the same value, one launch (yt's columns beyond x.shape[0] are left as they are)."""
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 and y.stride(1) == 1 and yt.stride(1) == 1 and y.dtype == yt.dtype and y.dtype in DT_OF
+    rows, cols = x.shape
+    assert y.shape[0] == rows and y.shape[1] >= cols and yt.shape[0] >= cols and yt.stride(0) >= rows
+    _lib.call("hgr_cast16_transpose", _dev(x), x.stride(0), _dev(y), y.stride(0), _dev(yt), yt.stride(0), rows, cols, DT_OF[y.dtype], _stream())
+
+
 def quickgelu16(a: torch.Tensor, out: torch.Tensor, du: Optional[torch.Tensor] = None) -> torch.Tensor:
     """forward: out = a*sigmoid(1.702a); with du: out = du * g'(a)."""
     assert a.is_contiguous() and out.is_contiguous() and (du is None or du.is_contiguous())

@@ -54,20 +54,25 @@ class _Lin:
     """One nn.Linear-shaped weight in training form: 16-bit copy, its transpose, fp32 bias, grad targets."""
 
     def __init__(self, weight: torch.nn.Parameter, bias: Optional[torch.nn.Parameter], dt: torch.dtype, kpad: int = 0):
-        w32 = weight.data.reshape(weight.shape[0], -1).contiguous()
         self.weight, self.bias = weight, bias
-        self.n, self.k = w32.shape
-        self.w16 = torch.empty(w32.shape, dtype=dt, device=w32.device)
-        ops.cast16(w32, self.w16)
-        if kpad > self.k:                                       # forward operand zero-padded in K (patch 14: 588 -> 640)
-            wp = torch.zeros(self.n, kpad, dtype=dt, device=w32.device)
-            wp[:, : self.k] = self.w16
-            self.w16_fwd = wp
-        else:
-            self.w16_fwd = self.w16
-        self.wt16 = torch.zeros(self.k, _pad64(self.n), dtype=dt, device=w32.device)     # [K, N] for dX = dY . W
-        ops.transpose16(self.w16, self.wt16)
-        self.b32 = bias.data if bias is not None else None
+        self.n, self.k = weight.shape[0], weight.numel() // weight.shape[0]
+        dev = weight.device
+        # buffers live as long as the engine: refresh() re-derives their contents from the fp32 master every step in ONE launch
+        # (hgr_cast16_transpose); the zero padding (K of the patch-14 forward operand 588 -> 640, N of the transposed operand to a
+        # multiple of 64) is written once, here
+        kp = max(kpad, self.k)
+        self.w16_fwd = (torch.zeros if kp > self.k else torch.empty)(self.n, kp, dtype=dt, device=dev)
+        self.w16 = self.w16_fwd[:, : self.k] if kp > self.k else self.w16_fwd
+        self.wt16 = torch.zeros(self.k, _pad64(self.n), dtype=dt, device=dev)             # [K, N] for dX = dY . W
+        self.refresh()
+
+    def refresh(self) -> None:
+        """This step's 16-bit operands from the (updated) fp32 weight."""
+        w32 = self.weight.data.reshape(self.n, self.k)
+        if not w32.is_contiguous():
+            w32 = w32.contiguous()
+        ops.cast16_transpose(w32, self.w16_fwd, self.wt16)
+        self.b32 = self.bias.data if self.bias is not None else None
 
 
 class _Blk:
@@ -77,6 +82,10 @@ class _Blk:
         self.w_out = _Lin(blk.attn.out_proj.weight, blk.attn.out_proj.bias, dt)
         self.w_fc = _Lin(blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, dt)
         self.w_proj = _Lin(blk.mlp.c_proj.weight, blk.mlp.c_proj.bias, dt)
+
+    def refresh(self) -> None:
+        for lin in (self.w_in, self.w_out, self.w_fc, self.w_proj):
+            lin.refresh()
 
 
 class Engine:
@@ -98,15 +107,28 @@ class Engine:
     def prepare(self):
         """16-bit weight copies + transposes for this step (weights change every step)."""
         m, dt = self.m, self.dt
-        self.tblocks = [_Blk(b, dt) for b in m.transformer.resblocks]
+        vit = isinstance(m.visual, VisionTransformer)
+        # the operand buffers are built once per set of parameter OBJECTS (a reloaded / re-wrapped model builds them again) and
+        # refreshed in place afterwards: one launch per weight instead of allocations + cast + zero fill + transpose
+        key = tuple(id(p) for p in m.transformer.parameters()) + (tuple(id(p) for p in m.visual.parameters()) if vit else ())
+        if getattr(self, "_prep_key", None) == key:
+            for blk in self.tblocks:
+                blk.refresh()
+            if vit:
+                for blk in self.vblocks:
+                    blk.refresh()
+                self.conv.refresh()
+        else:
+            self.tblocks = [_Blk(b, dt) for b in m.transformer.resblocks]
+            if vit:
+                self.vblocks = [_Blk(b, dt) for b in m.visual.transformer.resblocks]
+                ps = m.visual.patch_size
+                self.conv = _Lin(m.visual.conv1.weight, None, dt, kpad=_pad64(3 * ps * ps))
+            self._prep_key = key
         self.rn = None
-        if not isinstance(m.visual, VisionTransformer):
+        if not vit:
             from .training_rn import RNTower                # ModifiedResNet (the reference's README trains --arch RN50)
             self.rn = RNTower(m.visual, dt, self.scratch)
-            return
-        self.vblocks = [_Blk(b, dt) for b in m.visual.transformer.resblocks]
-        ps = m.visual.patch_size
-        self.conv = _Lin(m.visual.conv1.weight, None, dt, kpad=_pad64(3 * ps * ps))
 
     def _linear_bwd(self, lin: _Lin, dy16: torch.Tensor, x16: torch.Tensor, m: int, need_dx: bool = True,
                     gelu_pre: Optional[torch.Tensor] = None, dy_colsum: Optional[torch.Tensor] = None,

@@ -334,6 +334,10 @@ int hgr_colsum(const void *x, int64_t ldx, int rows, int cols, int x_f32, int dt
 
 /* y = (16-bit) x, n % 4 == 0. */
 int hgr_cast16(const float *x, void *y, int64_t n, int dtype, void *stream);
+/* y [rows, ldy] = (16-bit) x [rows, ldx] and yt [cols, ldyt] = its transpose, one pass (hgr_cast16's roundings).  The per-step refresh
+ * of a Linear's training operands: the forward / weight-gradient operand W and the [K, N] operand of dX = dY W (utils.py:117-123 is
+ * the reference's per-step fp32 <-> fp16 weight conversion).  Columns [rows, ldyt) of yt are not written. */
+int hgr_cast16_transpose(const float *x, int64_t ldx, void *y, int64_t ldy, void *yt, int64_t ldyt, int rows, int cols, int dtype, void *stream);
 
 /* QuickGELU on 16-bit tensors (clip/model.py:162-164): forward out = a*sigmoid(1.702a); backward out = du * g'(a). */
 int hgr_quickgelu16(const void *a, const void *du, void *out, int64_t n, int backward, int dtype, void *stream);

@@ -101,6 +101,7 @@ int main() {
     EXPECT_FAIL(hgr_mha_bwd_stats(h16, h16, h16, h16, nullptr, 1, 50, 12, 0, HGR_F16, nullptr));
     EXPECT_FAIL(hgr_mha_bwd_colsum(h16, h16, h16, h16, f32, nullptr, 1, 50, 12, 0, HGR_F16, nullptr));                                  // colsum_part missing
     EXPECT_FAIL(hgr_mha_bwd_stats(h16, h16, h16, h16, f32, 1, 400, 12, 0, HGR_F16, nullptr));                                           // L > 320
+    EXPECT_FAIL(hgr_cast16_transpose(f32, 64, h16, 32, h16, 64, 64, 64, HGR_F16, nullptr));                                             // ldy < cols
     EXPECT_FAIL(hgr_layernorm_bwd_cast(h16, 0, f32, f32, f32, nullptr, f32, f32, f32, 4, 64, 1, nullptr, 1e-5f, HGR_F16, nullptr));
     EXPECT_FAIL(hgr_layernorm_bwd_cast_colsum(h16, 0, f32, f32, f32, h16, f32, f32, nullptr, f32, 4, 64, 1, nullptr, 1e-5f, HGR_F16, nullptr));
     EXPECT_FAIL(hgr_layernorm_bwd_cast(h16, 0, f32, f32, f32, h16, f32, f32, f32, 4, 6, 1, nullptr, 1e-5f, HGR_F16, nullptr));         // W % 4

@@ -145,6 +145,25 @@ def test_layernorm_bwd(w):
 
 
 @pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("n,k,ldy", [(1024, 588, 640), (768, 3072, 3072), (130, 70, 72), (64, 64, 64), (3, 5, 5)])
+def test_cast16_transpose_equals_cast16_then_transpose16(dt, n, k, ldy):
+    """hgr_cast16_transpose: both outputs carry hgr_cast16's bits (row-major copy with a wider leading dimension, transposed copy with
+    padding columns that stay untouched) - vector tiles, ragged edges and the element-wise fallback for odd strides."""
+    x = _rand((n, k), 5 * n + k, 0.7).to(DEV)
+    y = torch.full((n, ldy), 3.0, dtype=dt, device=DEV)
+    ldt = (n + 63) // 64 * 64
+    yt = torch.full((k, ldt), 5.0, dtype=dt, device=DEV)
+    ops.cast16_transpose(x, y, yt)
+    if (n * k) % 4 == 0:
+        ref = torch.empty(n, k, dtype=dt, device=DEV)
+        ops.cast16(x.contiguous(), ref)
+    else:
+        ref = x.to(dt)
+    assert torch.equal(y[:, :k], ref) and bool((y[:, k:] == 3.0).all())
+    assert torch.equal(yt[:, :n], ref.t()) and bool((yt[:, n:] == 5.0).all())
+
+
+@pytest.mark.parametrize("dt", DTS)
 def test_layernorm_bwd_cast_equals_bwd_then_cast16(dt):
     """hgr_layernorm_bwd_cast: dx, dgamma, dbeta as hgr_layernorm_bwd; the 16-bit copy equals hgr_cast16 of the updated dx."""
     rows, w = 300, 768
