@@ -164,6 +164,19 @@ __global__ __launch_bounds__(256) void colsum_reduce_deep(float *__restrict__ pa
     }
 }
 
+// few fp32 rows (the split-K slices of a weight gradient: 2 - 16 rows of N * K columns): one pass, 16-byte loads, rows added in order -
+// the band kernel + second stage above are two launches and 4-byte loads for this shape (145 reductions per ViT-L/14 training step)
+__global__ __launch_bounds__(256) void colsum_rows_f32(const float *__restrict__ x, int64_t ldx, int rows, int64_t cols4, float *__restrict__ out, int accumulate, float alpha) {
+    for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < cols4; c += (int64_t)gridDim.x * 256) {
+        f32x4 acc = ((const f32x4 *)x)[c];
+        for (int r = 1; r < rows; ++r) acc += *(const f32x4 *)(x + (int64_t)r * ldx + c * 4);
+        f32x4 o = accumulate ? ((const f32x4 *)out)[c] : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] += alpha * acc[e];
+        ((f32x4 *)out)[c] = o;
+    }
+}
+
 // second stage of every column sum: partial [nrb][cols] -> out
 void colsum_finish(float *partial, int nrb, int cols, float *out, int accumulate, float alpha, hipStream_t s) {
     if (nrb >= 2048) {
@@ -1006,6 +1019,12 @@ extern "C" int hgr_colsum(const void *x, int64_t ldx, int rows, int cols, int x_
     const int nrb = (rows + 511) / 512;
     dim3 g((cols + 63) / 64, nrb);
     hipStream_t s = (hipStream_t)stream;
+    if (x_f32 && rows <= 32 && cols % 4 == 0 && ldx % 4 == 0 && hgr_aligned(x, 16) && hgr_aligned(out, 16)) {
+        const int64_t c4 = cols / 4;
+        hipLaunchKernelGGL(colsum_rows_f32, dim3(grid1(c4)), dim3(256), 0, s, (const float *)x, ldx, rows, c4, out, accumulate, alpha);
+        HGR_CHECK_LAUNCH("hgr_colsum");
+        return HGR_OK;
+    }
     const bool vec = cols % 64 == 0 && hgr_aligned(x, 16) && ldx % (x_f32 ? 4 : 8) == 0 && rows >= 32;
     if (vec) {
         if (x_f32) hipLaunchKernelGGL((colsum_partial_vec<HGR_BF16, true>), g, dim3(256), 0, s, x, ldx, rows, cols, scratch);

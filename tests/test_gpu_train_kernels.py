@@ -144,6 +144,18 @@ def test_layernorm_bwd(w):
     assert torch.allclose(dx2.cpu(), xr2.grad, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("rows,cols,accumulate", [(1, 4096, True), (5, 3072 * 1024, True), (16, 1000, False), (32, 260, True), (7, 262, True)])
+def test_colsum_few_fp32_rows(rows, cols, accumulate):
+    """hgr_colsum on a handful of fp32 rows (the split-K slices of a weight gradient): the one-pass kernel (cols % 4 == 0) and the band
+    kernels (odd widths) against a double-precision sum, with and without accumulation and alpha."""
+    x = _rand((rows, cols), 17 * rows + cols % 1000, 1.0).to(DEV)
+    start = _rand((cols,), 19 * rows, 1.0).to(DEV)
+    out = start.clone()
+    ops.colsum(x, out, torch.empty(max(1 << 16, cols), dtype=torch.float32, device=DEV), accumulate=accumulate, alpha=0.5)
+    want = (start.double() if accumulate else 0.0) + 0.5 * x.double().sum(dim=0)
+    assert float((out.double() - want).abs().max()) <= 1e-6 * (1.0 + float(x.abs().sum(dim=0).max()))
+
+
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("n,k,ldy", [(1024, 588, 640), (768, 3072, 3072), (130, 70, 72), (64, 64, 64), (3, 5, 5)])
 def test_cast16_transpose_equals_cast16_then_transpose16(dt, n, k, ldy):
