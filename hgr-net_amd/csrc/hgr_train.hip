@@ -360,6 +360,31 @@ __global__ __launch_bounds__(256) void layernorm_bwd(const void *__restrict__ dy
     }
 }
 
+// The per-wave partial rows of layernorm_bwd -> dgamma / dbeta / (dx16 column sums), all three in ONE launch: blockIdx.y picks the
+// matrix, a block owns 64 columns and walks all nw rows (16 row groups x 16-byte loads, combined through LDS in a fixed order), then
+// accumulates into its target.  Three hgr_colsum calls were six launches of ~8 us on 2 - 8 MB each, 72 times per ViT-L/14 step.
+__global__ __launch_bounds__(256) void ln_bwd_reduce3(const float *__restrict__ p0, const float *__restrict__ p1, const float *__restrict__ p2, int nw, int W,
+                                                      float *__restrict__ o0, float *__restrict__ o1, float *__restrict__ o2) {
+    __shared__ f32x4 sm[16][16];
+    const float *src = blockIdx.y == 0 ? p0 : blockIdx.y == 1 ? p1 : p2;
+    float *dst = blockIdx.y == 0 ? o0 : blockIdx.y == 1 ? o1 : o2;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + tx * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (c < W)
+        for (int r = ty; r < nw; r += 16) acc += *(const f32x4 *)(src + (int64_t)r * W + c);
+    sm[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0 && c < W) {
+        f32x4 t = sm[0][tx];
+#pragma unroll
+        for (int g = 1; g < 16; ++g) t += sm[g][tx];
+        f32x4 o = *(const f32x4 *)(dst + c);
+        o += t;
+        *(f32x4 *)(dst + c) = o;
+    }
+}
+
 // ---- attention backward for ANY length (L <= 288 here): tiled, on the exact-fp32 MFMA ---------------------------
 // v_mfma_f32_32x32x2_f32 with operands read from fp32 LDS tiles [64][65]: lane l supplies A(i = l & 31, k = l >> 5)
 // and B(k = l >> 5, j = l & 31) per 2-deep step, so a transposed operand is just a different index function and the
@@ -1112,6 +1137,11 @@ static int layernorm_bwd_entry(const char *name, const void *dy, int dy_f32, con
     if (nvl <= 1) HGR_LNB(1); else if (nvl <= 2) HGR_LNB(2); else if (nvl <= 4) HGR_LNB(4); else if (nvl <= 8) HGR_LNB(8); else HGR_LNB(16);
 #undef HGR_LNB
     HGR_CHECK_LAUNCH(name);
+    if (hgr_aligned(dgamma, 16) && hgr_aligned(dbeta, 16) && hgr_aligned(dx16_colsum, 16)) {      // (W % 4 == 0 is required above)
+        hipLaunchKernelGGL(ln_bwd_reduce3, dim3((W + 63) / 64, pc ? 3 : 2), dim3(256), 0, s, pg, pb, pc, nw, W, dgamma, dbeta, dx16_colsum);
+        HGR_CHECK_LAUNCH(name);
+        return HGR_OK;
+    }
     int rc = hgr_colsum(pg, W, nw, W, 1, HGR_BF16, dgamma, 1, 1.0f, cs, stream);
     if (rc) return rc;
     rc = hgr_colsum(pb, W, nw, W, 1, HGR_BF16, dbeta, 1, 1.0f, cs, stream);

@@ -701,16 +701,24 @@ def gemm_nt_splitk(a: torch.Tensor, w: torch.Tensor, partial: torch.Tensor, kc: 
 
 
 def splitk_slices(tiles: int, m: int, slots: int = 512) -> int:
-    """Number of reduction slices for a split-K weight gradient with `tiles` output tiles over `m` rows: the smallest count
-    that fills >= 85 % of whole rounds of `slots` workgroups (2 per CU), each slice at least 512 rows deep."""
+    """Number of reduction slices for a split-K weight gradient with `tiles` output tiles over `m` rows, each slice at least 512
+    rows deep: from the smallest count s0 that fills >= 85 % of whole rounds of `slots` workgroups up to 1.25 s0, the one that fills
+    them best (16 tiles on 256 slots: 16 slices = 100 % instead of 14 = 87.5 %; measured on the 1024 x 1024 out_proj gradient of
+    ViT-L/14 at batch 256: the idle CUs cost more than the two extra partial tiles)."""
     smax = max(1, min(m // 512, 4096))
     best = (0.0, 1)
+    first = None
     for s in range(1, smax + 1):
         wgs = tiles * s
         eff = wgs / (-(-wgs // slots) * slots)
-        if eff >= 0.85:
-            return s
-        if eff > best[0]:
+        if first is None and eff >= 0.85:
+            first, best = s, (eff, s)
+        elif first is not None:
+            if s > max(first + 1, int(first * 1.25)):
+                break
+            if eff > best[0] + 1e-9:
+                best = (eff, s)
+        elif eff > best[0]:
             best = (eff, s)
     return best[1]
 
