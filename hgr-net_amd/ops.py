@@ -126,7 +126,7 @@ def gemm_nt_res_stats(a: torch.Tensor, w: torch.Tensor, xh: torch.Tensor, xl: to
         assert flag.numel() == 1 and flag.element_size() == 4
         _lib.call("hgr_gemm_nt_res_stats_guard", _dev(a), a.stride(0), _dev(w), w.stride(0), _dev(xh), _dev(xl), xh.stride(0), _dev(bias),
                   _dev(stats), LN_GUARD_SUMSQ, _dev(flag), m, n, k, DT_OF[a.dtype], _stream())
-    _prof_end(ev, 2.0 * m * n * k, 2 * m * k + 2 * n * k + 8 * m * n, tag)
+    _prof_end(ev, 2.0 * m * n * k, 2 * m * k + 2 * n * k + 6 * m * n + 8 * m * (n // 64), tag)     # pair: 3 bytes read + 3 written per element; slot statistics
 
 
 def gemm_nt_bias_gelu_dual(a: torch.Tensor, w: torch.Tensor, pre: torch.Tensor, post: torch.Tensor, bias: torch.Tensor) -> None:
