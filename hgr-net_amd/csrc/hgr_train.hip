@@ -460,6 +460,13 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_tiled(const typename T16<DT>::
     __shared__ __attribute__((aligned(16))) float rM[320];
     __shared__ __attribute__((aligned(16))) float rLinv[320];
     __shared__ __attribute__((aligned(16))) float rD[320];
+    // L = 64 n + 1 (ViT-L/14: 256 patches + the class token): the last token would cost a whole fifth row AND column of 64 x 64 block
+    // pairs (9 of 25) for one valid row / column.  Instead the block sweep covers the first 64 n tokens and the last token T enters as
+    // vectors: its score column / row against every token (fp32 dot products of the same 16-bit operands), rounded to 16 bit like the
+    // block path's P and dS, applied as rank-1 updates to the dK / dV / dQ accumulators, and its own three output rows as one reduction.
+    __shared__ __attribute__((aligned(16))) float tokT[4][64];        // Q[T], K[T], V[T], dO[T]
+    __shared__ __attribute__((aligned(16))) float sPc[320], sDSc[320], sPr[320], sDSr[320];   // P / dS of column T (per query) and of row T (per key)
+    __shared__ float sDT;                                                                      // D[T] = dO[T] . O[T]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
     const int r32 = lane & 31, hh = lane >> 5;
     const int b = blockIdx.x / H, h = blockIdx.x - b * H;
@@ -470,22 +477,13 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_tiled(const typename T16<DT>::
     const E *ob = outp + (int64_t)b * L * W + h * 64;
     E *dqb = dqkv + (int64_t)b * L * ld + h * 64;
     const int nb = (L + 63) / 64;
+    const bool strip = !CAUSAL && stats && L > 64 && (L & 63) == 1;   // block-uniform (the row statistics must be the forward's)
+    const int nbe = strip ? nb - 1 : nb;                              // blocks the pair sweep covers
+    const int T = L - 1;
 
-    // 64 x 64 block of 16-bit rows -> LDS row-major; rows past L are zero
-    auto load = [&](TileP dst, const E *src, int64_t stride, int r0) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int id = tid + 256 * j;                  // 512 chunks of 8 elements
-            const int r = id >> 3, c = (id & 7) * 8;
-            vec8 v;
-            if (r0 + r < L) v = *(const vec8 *)(src + (int64_t)(r0 + r) * stride + c);
-            else
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (E)0.f;
-            *(vec8 *)&dst[r][c] = v;
-        }
-    };
-    // the same in two halves, so that the NEXT block's rows travel while the current one is worked on
+    // 64 x 64 block of 16-bit rows -> registers (fetch) -> LDS row-major (put); rows past L are zero.  Every load is unconditional on a
+    // clamped row: a load under its row guard is waited for on the spot, which serialised the two to ten loads of a block (round 4:
+    // 257 tokens 714 -> 586 us with the strip path below, 50 tokens 164 -> 124 us per launch)
     auto fetch = [&](vec8 (&v)[2], const E *src, int64_t stride, int r0) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -517,12 +515,113 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_tiled(const typename T16<DT>::
     // masked, scaled score of (query q, key k) from a raw dot product
     auto score = [&](float raw, int q, int k) { return (k >= L || (CAUSAL && k > q)) ? -INFINITY : raw * 0.125f; };
 
-    // ---- sweep 0: row statistics ---------------------------------------------------------------------------------------------------------
-    for (int qi = 0; qi < nb; ++qi) {
+    float tq = 0.f, tk = 0.f, tv = 0.f;        // token T's own output rows as rounded (threads 0 .. 63 = head dimensions; colpart adds them)
+    if (strip) {
+        // One pass over the 64-row blocks replaces sweep 0: D = rowsum(dO * O); the last token's score column and row against the block
+        // (four 64-deep dot products per token, split over the four waves by dimension quarter), P / dS of that column and row rounded
+        // to 16 bit as the block path rounds them; and the block's share of token T's own rows
+        //   dQ[T] = sum_k dS[T][k] K[k],   dK[T] = sum_q dS[q][T] Q[q],   dV[T] = sum_q P[q][T] dO[q]     (T itself included).
+        const float2 *st = stats + ((int64_t)b * H + h) * L;
+        for (int i = tid; i < nb * 64; i += 256) {
+            const float2 v = i < L ? st[i] : make_float2(0.f, 0.f);
+            rM[i] = v.x; rLinv[i] = v.y;
+        }
+        if (tid < 64) {
+            tokT[0][tid] = (float)base[(int64_t)T * ld + tid];          tokT[1][tid] = (float)base[(int64_t)T * ld + W + tid];
+            tokT[2][tid] = (float)base[(int64_t)T * ld + 2 * W + tid];  tokT[3][tid] = (float)dob[(int64_t)T * W + tid];
+            const float dt_ = wave_sum(tokT[3][tid] * (float)ob[(int64_t)T * W + tid]);      // D[T], needed for row T from the first block on
+            if (tid == 0) sDT = dt_;
+        }
+        float *red = (float *)(smem + 5 * TB);          // [4][4][64] partial dot products, over the (unused) dS^T / P^T tiles
+        const TileP sOut = sDS;                         // the forward output O of the block
+        const int col = tid & 63, part = tid >> 6;
+        float aq = 0.f, ak = 0.f, av = 0.f;
+        // all ten 16-byte loads of a block in flight together (load() waits for each of its loads under its row guard), and the next
+        // block's while this one is worked on
+        vec8 fq[2], fk[2], fv[2], fo[2], fz[2];
+        fetch(fq, base, ld, 0); fetch(fk, base + W, ld, 0); fetch(fv, base + 2 * W, ld, 0); fetch(fo, dob, W, 0); fetch(fz, ob, W, 0);
+        for (int j = 0; j < nb; ++j) {
+            __syncthreads();
+            put(sQ, fq); put(sK, fk); put(sV, fv); put(sO, fo); put(sOut, fz);
+            if (j + 1 < nb) {
+                const int r1 = (j + 1) * 64;
+                fetch(fq, base, ld, r1); fetch(fk, base + W, ld, r1); fetch(fv, base + 2 * W, ld, r1); fetch(fo, dob, W, r1); fetch(fz, ob, W, r1);
+            }
+            __syncthreads();
+            {
+                const int row = tid >> 2, p4 = tid & 3;
+                float acc = 0.f;
+                for (int d = p4 * 16; d < p4 * 16 + 16; ++d) acc += (float)sO[row][d] * (float)sOut[row][d];
+                acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2);
+                if (p4 == 0) rD[j * 64 + row] = acc;
+            }
+            {
+                float sc = 0.f, dpc = 0.f, sr = 0.f, dpr = 0.f;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int d0 = part * 16 + c * 8;
+                    const vec8 q8 = *(const vec8 *)&sQ[col][d0], k8 = *(const vec8 *)&sK[col][d0], v8 = *(const vec8 *)&sV[col][d0], o8 = *(const vec8 *)&sO[col][d0];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        sc += (float)q8[e] * tokT[1][d0 + e];     // S[tok][T]  = Q[tok] . K[T]
+                        dpc += (float)o8[e] * tokT[2][d0 + e];    // dP[tok][T] = dO[tok] . V[T]
+                        sr += tokT[0][d0 + e] * (float)k8[e];     // S[T][tok]  = Q[T] . K[tok]
+                        dpr += tokT[3][d0 + e] * (float)v8[e];    // dP[T][tok] = dO[T] . V[tok]
+                    }
+                }
+                red[(0 * 4 + part) * 64 + col] = sc; red[(1 * 4 + part) * 64 + col] = dpc;
+                red[(2 * 4 + part) * 64 + col] = sr; red[(3 * 4 + part) * 64 + col] = dpr;
+            }
+            __syncthreads();
+            if (tid < 64) {
+                const int tok = j * 64 + tid;
+                float pc = 0.f, dsc = 0.f, pr = 0.f, dsr = 0.f;
+                if (tok < L) {
+                    const float sc = (red[(0 * 4 + 0) * 64 + tid] + red[(0 * 4 + 1) * 64 + tid]) + (red[(0 * 4 + 2) * 64 + tid] + red[(0 * 4 + 3) * 64 + tid]);
+                    const float dpc = (red[(1 * 4 + 0) * 64 + tid] + red[(1 * 4 + 1) * 64 + tid]) + (red[(1 * 4 + 2) * 64 + tid] + red[(1 * 4 + 3) * 64 + tid]);
+                    const float sr = (red[(2 * 4 + 0) * 64 + tid] + red[(2 * 4 + 1) * 64 + tid]) + (red[(2 * 4 + 2) * 64 + tid] + red[(2 * 4 + 3) * 64 + tid]);
+                    const float dpr = (red[(3 * 4 + 0) * 64 + tid] + red[(3 * 4 + 1) * 64 + tid]) + (red[(3 * 4 + 2) * 64 + tid] + red[(3 * 4 + 3) * 64 + tid]);
+                    pc = __expf(sc * 0.125f - rM[tok]) * rLinv[tok];
+                    pr = __expf(sr * 0.125f - rM[T]) * rLinv[T];
+                    dsc = pc * (dpc - rD[tok]) * 0.125f;
+                    dsr = pr * (dpr - sDT) * 0.125f;
+                }
+                sPc[tok] = (float)(E)pc;  sDSc[tok] = (float)(E)dsc;
+                sPr[tok] = (float)(E)pr;  sDSr[tok] = (float)(E)dsr;
+            }
+            __syncthreads();
+            {   // the block's share of token T's own rows
+                float q_ = 0.f, k_ = 0.f, v_ = 0.f;
+#pragma unroll 4
+                for (int r = part * 16; r < part * 16 + 16; ++r) {
+                    q_ += sDSr[j * 64 + r] * (float)sK[r][col];
+                    k_ += sDSc[j * 64 + r] * (float)sQ[r][col];
+                    v_ += sPc[j * 64 + r] * (float)sO[r][col];
+                }
+                aq += q_; ak += k_; av += v_;
+            }
+        }
         __syncthreads();
-        load(sQ, base, ld, qi * 64);
-        load(sO, dob, W, qi * 64);
-        load(sV, ob, W, qi * 64);                              // forward output O of this query block (in sV for the moment)
+        red[(0 * 4 + part) * 64 + col] = aq; red[(1 * 4 + part) * 64 + col] = ak; red[(2 * 4 + part) * 64 + col] = av;
+        __syncthreads();
+        if (tid < 64) {
+            const E vq = (E)((red[(0 * 4 + 0) * 64 + tid] + red[(0 * 4 + 1) * 64 + tid]) + (red[(0 * 4 + 2) * 64 + tid] + red[(0 * 4 + 3) * 64 + tid]));
+            const E vk = (E)((red[(1 * 4 + 0) * 64 + tid] + red[(1 * 4 + 1) * 64 + tid]) + (red[(1 * 4 + 2) * 64 + tid] + red[(1 * 4 + 3) * 64 + tid]));
+            const E vv = (E)((red[(2 * 4 + 0) * 64 + tid] + red[(2 * 4 + 1) * 64 + tid]) + (red[(2 * 4 + 2) * 64 + tid] + red[(2 * 4 + 3) * 64 + tid]));
+            E *o = dqb + (int64_t)T * ld + tid;
+            o[0] = vq; o[W] = vk; o[2 * W] = vv;
+            tq = (float)vq; tk = (float)vk; tv = (float)vv;
+        }
+    }
+    // ---- sweep 0: row statistics ---------------------------------------------------------------------------------------------------------
+    for (int qi = 0; qi < (strip ? 0 : nb); ++qi) {
+        {
+            vec8 fq[2], fo[2], fz[2];
+            fetch(fq, base, ld, qi * 64); fetch(fo, dob, W, qi * 64); fetch(fz, ob, W, qi * 64);
+            __syncthreads();
+            put(sQ, fq); put(sO, fo);
+            put(sV, fz);                                       // forward output O of this query block (in sV for the moment)
+        }
         __syncthreads();
         {   // D = rowsum(dO * O): 4 threads per row
             const int row = tid >> 2, part = tid & 3;
@@ -582,19 +681,23 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_tiled(const typename T16<DT>::
     vec8 pq[2], po[2];                                           // Q / dO rows of the next (key block, query block) pair, in flight
     fetch(pq, base, ld, 0);
     fetch(po, dob, W, 0);
-    for (int kj = 0; kj < nb; ++kj) {
-        __syncthreads();
-        load(sK, base + W, ld, kj * 64);
-        load(sV, base + 2 * W, ld, kj * 64);
+    for (int kj = 0; kj < nbe; ++kj) {
+        {
+            vec8 fk[2], fv[2];
+            fetch(fk, base + W, ld, kj * 64);
+            fetch(fv, base + 2 * W, ld, kj * 64);
+            __syncthreads();
+            put(sK, fk); put(sV, fv);
+        }
         f32x16 dk = {0.f}, dv = {0.f};
 #pragma unroll
         for (int qi = 0; qi < 5; ++qi) {
-            if (qi >= nb || (CAUSAL && qi < kj)) continue;       // block-uniform
+            if (qi >= nbe || (CAUSAL && qi < kj)) continue;      // block-uniform
             __syncthreads();
             put(sQ, pq);
             put(sO, po);
             {
-                const int nxt = qi + 1 < nb ? qi + 1 : (CAUSAL ? min(kj + 1, nb - 1) : 0);     // the pair after this one starts there
+                const int nxt = qi + 1 < nbe ? qi + 1 : (CAUSAL ? min(kj + 1, nbe - 1) : 0);   // the pair after this one starts there
                 fetch(pq, base, ld, nxt * 64);
                 fetch(po, dob, W, nxt * 64);
             }
@@ -627,12 +730,28 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_tiled(const typename T16<DT>::
             mm16_bt<DT>(dq[qi], sDS, wr * 32, sK, wc * 32, lane); // dQ_i += dS K      (k = keys; reading dS through the transposing read
                                                                   // too, out of its [key][query] image, measured 7 % slower than this row-major copy)
         }
+        if (strip) {         // query T against this key block: dK[k] += dS[T][k] Q[T], dV[k] += P[T][k] dO[T]
+            const float qT = tokT[0][wc * 32 + r32], oT = tokT[3][wc * 32 + r32];
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int k = kj * 64 + wr * 32 + HGR_ACC_ROW(g, hh);
+                dk[g] += sDSr[k] * qT;
+                dv[g] += sPr[k] * oT;
+            }
+        }
         csk += write_rows(dqb + W, ld, kj * 64, dk);
         csv += write_rows(dqb + 2 * W, ld, kj * 64, dv);
     }
 #pragma unroll
     for (int qi = 0; qi < 5; ++qi)
-        if (qi < nb) csq += write_rows(dqb, ld, qi * 64, dq[qi]);
+        if (qi < nbe) {
+            if (strip) {     // key T against this query block: dQ[q] += dS[q][T] K[T]
+                const float kT = tokT[1][wc * 32 + r32];
+#pragma unroll
+                for (int g = 0; g < 16; ++g) dq[qi][g] += sDSc[qi * 64 + wr * 32 + HGR_ACC_ROW(g, hh)] * kT;
+            }
+            csq += write_rows(dqb, ld, qi * 64, dq[qi]);
+        }
     if (colpart) {
         // column sums of this (batch, head)'s dq / dk / dv rows = its share of the in_proj bias gradient: lane halves (hh) by shuffle,
         // the two wave rows through LDS (the tiles are dead), then colpart[b][which * W + h * 64 + c] - every entry written once
@@ -645,9 +764,13 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_tiled(const typename T16<DT>::
             sc[(2 * 2 + wr) * 64 + wc * 32 + r32] = csv;
         }
         __syncthreads();
+        if (tid < 64) {                         // threads 0 .. 63 hold token T's rounded values of the strip path (zero otherwise)
+            sc[384 + tid] = tq; sc[384 + 64 + tid] = tk; sc[384 + 128 + tid] = tv;
+        }
+        __syncthreads();
         if (tid < 192) {
             const int which = tid >> 6, c = tid & 63;
-            colpart[(int64_t)b * 3 * W + which * W + h * 64 + c] = sc[(which * 2 + 0) * 64 + c] + sc[(which * 2 + 1) * 64 + c];
+            colpart[(int64_t)b * 3 * W + which * W + h * 64 + c] = (sc[(which * 2 + 0) * 64 + c] + sc[(which * 2 + 1) * 64 + c]) + sc[384 + which * 64 + c];
         }
     }
 }
@@ -702,11 +825,11 @@ __global__ __launch_bounds__(64) void mha_bwd_wave(const typename T16<DT>::elem 
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int id = lane + 64 * j, r = id >> 3, c = (id & 7) * 8;
-        vec8 q, k, v, o;
-        if (r < L) {
-            q = *(const vec8 *)(base + (int64_t)r * ld + c); k = *(const vec8 *)(base + (int64_t)r * ld + W + c);
-            v = *(const vec8 *)(base + (int64_t)r * ld + 2 * W + c); o = *(const vec8 *)(dob + (int64_t)r * W + c);
-        } else {
+        // unconditional loads of a clamped row (a load under a branch is waited for on the spot: four round trips instead of one), zeroed after
+        const int rc = min(r, L - 1);
+        vec8 q = *(const vec8 *)(base + (int64_t)rc * ld + c), k = *(const vec8 *)(base + (int64_t)rc * ld + W + c);
+        vec8 v = *(const vec8 *)(base + (int64_t)rc * ld + 2 * W + c), o = *(const vec8 *)(dob + (int64_t)rc * W + c);
+        if (r >= L) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) { q[e] = (E)0.f; k[e] = (E)0.f; v[e] = (E)0.f; o[e] = (E)0.f; }
         }

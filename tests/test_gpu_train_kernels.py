@@ -222,7 +222,7 @@ def test_layernorm_bwd_cast_colsum_equals_cast_then_colsum(dt, rows, w):
 
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("L,causal", [(5, True), (16, True), (1, True), (12, False), (29, True), (32, True), (32, False), (50, False), (64, False), (37, True),
-                                      (77, True), (65, False), (130, True), (257, False)])
+                                      (77, True), (65, False), (130, True), (257, False), (129, False), (193, False), (65, True), (66, False)])
 def test_mha_bwd_vs_autograd(dt, L, causal):
     b, heads = 2, 2
     w = heads * 64
