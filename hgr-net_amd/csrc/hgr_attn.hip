@@ -60,20 +60,32 @@ __global__ __launch_bounds__(256, 2) void mha_fwd(const typename T16<DT>::elem *
         q0n = *(const vec8 *)(base + qrow * ld + g * 8);
         q1n = *(const vec8 *)(base + qrow * ld + 32 + g * 8);
     }
-    // stage K (swizzled rows) and V^T (zero-filled past L: 0 * garbage must stay 0)
-    for (int idx = tid; idx < LP * 8; idx += 256) {
-        const int row = idx >> 3, c = idx & 7;
-        const int rc = min(row, L - 1);                    // unconditional loads (a load under a branch is waited for at once)
-        vec8 kv = *(const vec8 *)(base + rc * ld + W + c * 8);
-        vec8 vv = *(const vec8 *)(base + rc * ld + 2 * W + c * 8);
-        if (row >= L)
+    // stage K (swizzled rows) and V^T (zero-filled past L: 0 * garbage must stay 0).  LP * 8 = KT * 256 chunks of 16 bytes: exactly KT per
+    // thread.  ALL 2 KT loads are issued before the first LDS store: written as one loop over the chunks, hipcc kept it a loop (the trip
+    // count depends on tid as far as it can tell) with the two loads of an iteration waited for before its stores - KT serial round
+    // trips of global memory per workgroup, nine at 257 keys, which was most of this kernel's time there.
+    {
+        vec8 kv[KT], vv[KT];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { kv[e] = (E)0.f; vv[e] = (E)0.f; }
-        *(vec8 *)(sK + row * 128 + ((c ^ (row & 7)) * 16)) = kv;
-        if (VTR) *(vec8 *)(sV + row * VR + c * 8) = vv;
-        else
+        for (int it = 0; it < KT; ++it) {
+            const int idx = tid + 256 * it;
+            const int rc = min(idx >> 3, L - 1);           // unconditional loads of a clamped row (a load under a branch is waited for at once)
+            kv[it] = *(const vec8 *)(base + rc * ld + W + (idx & 7) * 8);
+            vv[it] = *(const vec8 *)(base + rc * ld + 2 * W + (idx & 7) * 8);
+        }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) sVt[(c * 8 + e) * VS + row] = vv[e];
+        for (int it = 0; it < KT; ++it) {
+            const int idx = tid + 256 * it;
+            const int row = idx >> 3, c = idx & 7;
+            if (row >= L)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { kv[it][e] = (E)0.f; vv[it][e] = (E)0.f; }
+            *(vec8 *)(sK + row * 128 + ((c ^ (row & 7)) * 16)) = kv[it];
+            if (VTR) *(vec8 *)(sV + row * VR + c * 8) = vv[it];
+            else
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sVt[(c * 8 + e) * VS + row] = vv[it][e];
+        }
     }
     __syncthreads();
 
