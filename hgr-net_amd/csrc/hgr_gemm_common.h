@@ -54,6 +54,7 @@ struct GemmArgs {
     // HGR_EPI_QGELU_GRAD16 on gemm_nt_duo only (hgr_gemm_nt_qgelu_grad_colsum): column sums of the ROUNDED 16-bit outputs per 64-row
     // unit, colsum[unit][n] for unit < colsum_units = ceil(M / 64) - the bias gradient of the layer below without a second pass over C
     float *colsum = nullptr; int colsum_units = 0;
+    int total = 0;   // gemm_nt_duo, persistent form: number of virtual blocks (0 = gridDim.x, one tile per workgroup); set by launch_duo
 };
 
 

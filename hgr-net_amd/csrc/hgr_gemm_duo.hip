@@ -42,7 +42,10 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
     typedef typename T16<DT>::vec8 vec8;
     typedef typename T16<DT>::elem E;
     constexpr int WR = 64 * MH;                    // rows of the tile one wave row owns
-    const int tid = threadIdx.x;
+    // opaque per call: inside the persistent tile loop every lane-derived offset would otherwise be hoisted out of the loop and kept
+    // live across the main loop of every tile (256 registers + up to 94 spilled; with this 220 - 241 as in the one-tile form)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -816,9 +819,14 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
     __shared__ __attribute__((aligned(1024))) char smem[DUO_LDS];
     // (measured and not kept: dealing 128 / 256 of the half tiles to the second slot of every CU in the first round, so that a CU's two
     // workgroups are out of phase - producers 62 -> 72-74 us, 131 -> 163 us: half tiles up front only delay the full tiles behind them)
-    const bool half = (int)blockIdx.x >= p.nbig;
-    const int nwg = half ? (int)gridDim.x - p.nbig : p.nbig;
-    const int orig = half ? (int)blockIdx.x - p.nbig : (int)blockIdx.x;
+    // Persistent form (p.total > gridDim.x, launch_duo): workgroup b works on the virtual blocks b, b + gridDim.x, ... - the order the
+    // dispatcher would have dealt them to its slot.  A workgroup that ends has to see its stores acknowledged before its slot is
+    // released and the next one's first operand round trip starts; here the next tile's first LDS-DMAs are in flight beside them.
+    const int total = p.total > 0 ? p.total : (int)gridDim.x;
+  for (int vb = (int)blockIdx.x; vb < total; vb += (int)gridDim.x) {
+    const bool half = vb >= p.nbig;
+    const int nwg = half ? total - p.nbig : p.nbig;
+    const int orig = half ? vb - p.nbig : vb;
     const int tiles_m = half ? p.tiles_m_half : p.big_panels;
     const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
     const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
@@ -835,6 +843,8 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
     }
     if (half) duo_tile<DT, EPI, OUT32, LN, 1, CONV>(p, smem, p.big_panels * 256 + tm * 128, tn * 128);
     else duo_tile<DT, EPI, OUT32, LN, 2, CONV>(p, smem, tm * 256, tn * 128);
+    if (vb + (int)gridDim.x < total) __syncthreads();        // every wave's epilogue has left the LDS staging slices: the next tile's DMAs may land
+  }
 }
 
 namespace {
@@ -866,7 +876,36 @@ void launch_duo_dt(const GemmArgs &a, int epi, bool out32, int ln, dim3 grid, hi
 }
 }  // namespace
 
-void launch_duo(const GemmArgs &a, int dtype, int epi, bool out32, int ln, dim3 grid, hipStream_t s) {
+// Default: at most two workgroups per CU, each walking its share of the tiles (see gemm_nt_duo); HGR_DUO_PERSIST=0 = one workgroup per
+// tile (A/B runs).  Measured on the ViT-B/32 evaluation step, interleaved pairs on one box: every launch persistent 5.064 -> 5.008 ms
+// (-1.1 %; by shape proj 128.6 -> 123.5 us, out 50.1 -> 48.5, fc unchanged), the producers only 5.137 -> 5.104 (-0.6 %).  Bit-identical.
+static int duo_persist() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("HGR_DUO_PERSIST"); v = e ? atoi(e) : 1; }
+    return v;
+}
+static int duo_slots() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t pr;
+        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? 2 * pr.multiProcessorCount : 512;
+        n &= ~7;                 // whole multiples of the 8 XCDs: virtual block v and physical block v % grid sit on the same XCD
+        if (n < 8) n = 8;
+    }
+    return n;
+}
+
+void launch_duo(const GemmArgs &a0, int dtype, int epi, bool out32, int ln, dim3 grid, hipStream_t s) {
+    GemmArgs a = a0;
+    a.total = 0;
+    // ... for the residual producers (ln == 1) on launches of up to two rounds of the chip's slots - the launches that gain (their
+    // epilogue's read-modify-write drains beside the next tile's first operand loads); HGR_DUO_PERSIST=2 makes every launch persistent.
+    // Launches of many rounds LOSE with the static deal (ViT-L/14 training step 221.2 -> 223.6 ms, RN50 step 9.58 -> 9.66 ms with
+    // every launch persistent): the dispatcher's first-free-slot order balances the slots' drifting speeds, the fixed stride does not;
+    // the consumer / plain launches of one to two rounds measured neutral to slightly negative (RN50 9.97 -> 10.03 ms).
+    const int ds = duo_slots();
+    if (duo_persist() && grid.y == 1 && !a.kc && (int)grid.x > ds && (duo_persist() >= 2 || (ln == 1 && (int)grid.x <= 2 * ds))) { a.total = (int)grid.x; grid.x = (unsigned)ds; }
     if (dtype == HGR_BF16) launch_duo_dt<HGR_BF16>(a, epi, out32, ln, grid, s);
     else launch_duo_dt<HGR_F16>(a, epi, out32, ln, grid, s);
 }
