@@ -45,7 +45,7 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
     // opaque per call: inside the persistent tile loop every lane-derived offset would otherwise be hoisted out of the loop and kept
     // live across the main loop of every tile (256 registers + up to 94 spilled; with this 220 - 241 as in the one-tile form)
     int tid = threadIdx.x;
-    asm volatile("" : "+v"(tid));
+    if (LN == 1) asm volatile("" : "+v"(tid));     // (only the producers are compiled with the tile loop)
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -822,8 +822,10 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
     // Persistent form (p.total > gridDim.x, launch_duo): workgroup b works on the virtual blocks b, b + gridDim.x, ... - the order the
     // dispatcher would have dealt them to its slot.  A workgroup that ends has to see its stores acknowledged before its slot is
     // released and the next one's first operand round trip starts; here the next tile's first LDS-DMAs are in flight beside them.
-    const int total = p.total > 0 ? p.total : (int)gridDim.x;
-  for (int vb = (int)blockIdx.x; vb < total; vb += (int)gridDim.x) {
+    // Compiled in for the residual producers (LN == 1) only: every other instantiation keeps its one-tile code, instruction for instruction.
+    constexpr bool PERSIST = LN == 1;
+    const int total = PERSIST && p.total > 0 ? p.total : (int)gridDim.x;
+  auto one_tile = [&](const int vb) {
     const bool half = vb >= p.nbig;
     const int nwg = half ? total - p.nbig : p.nbig;
     const int orig = half ? vb - p.nbig : vb;
@@ -843,8 +845,13 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
     }
     if (half) duo_tile<DT, EPI, OUT32, LN, 1, CONV>(p, smem, p.big_panels * 256 + tm * 128, tn * 128);
     else duo_tile<DT, EPI, OUT32, LN, 2, CONV>(p, smem, tm * 256, tn * 128);
-    if (vb + (int)gridDim.x < total) __syncthreads();        // every wave's epilogue has left the LDS staging slices: the next tile's DMAs may land
-  }
+  };
+    if constexpr (PERSIST) {
+        for (int vb = (int)blockIdx.x; vb < total; vb += (int)gridDim.x) {
+            one_tile(vb);
+            if (vb + (int)gridDim.x < total) __syncthreads();   // every wave's epilogue has left the LDS staging slices: the next tile's DMAs may land
+        }
+    } else one_tile((int)blockIdx.x);
 }
 
 namespace {
@@ -899,13 +906,13 @@ static int duo_slots() {
 void launch_duo(const GemmArgs &a0, int dtype, int epi, bool out32, int ln, dim3 grid, hipStream_t s) {
     GemmArgs a = a0;
     a.total = 0;
-    // ... for the residual producers (ln == 1) on launches of up to two rounds of the chip's slots - the launches that gain (their
-    // epilogue's read-modify-write drains beside the next tile's first operand loads); HGR_DUO_PERSIST=2 makes every launch persistent.
+    // ... for the residual producers (ln == 1, the only instantiations compiled with the tile loop) on launches of up to two rounds of
+    // the chip's slots - the launches that gain (their epilogue's read-modify-write drains beside the next tile's first operand loads).
     // Launches of many rounds LOSE with the static deal (ViT-L/14 training step 221.2 -> 223.6 ms, RN50 step 9.58 -> 9.66 ms with
     // every launch persistent): the dispatcher's first-free-slot order balances the slots' drifting speeds, the fixed stride does not;
     // the consumer / plain launches of one to two rounds measured neutral to slightly negative (RN50 9.97 -> 10.03 ms).
     const int ds = duo_slots();
-    if (duo_persist() && grid.y == 1 && !a.kc && (int)grid.x > ds && (duo_persist() >= 2 || (ln == 1 && (int)grid.x <= 2 * ds))) { a.total = (int)grid.x; grid.x = (unsigned)ds; }
+    if (duo_persist() && ln == 1 && grid.y == 1 && !a.kc && (int)grid.x > ds && (int)grid.x <= 2 * ds) { a.total = (int)grid.x; grid.x = (unsigned)ds; }
     if (dtype == HGR_BF16) launch_duo_dt<HGR_BF16>(a, epi, out32, ln, grid, s);
     else launch_duo_dt<HGR_F16>(a, epi, out32, ln, grid, s);
 }
