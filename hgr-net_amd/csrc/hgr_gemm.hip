@@ -120,6 +120,11 @@ extern "C" int hgr_gemm_set_tile(int tile) {
     return prev;
 }
 
+extern "C" int hgr_gemm_set_persist(int enabled) {
+    HGR_REQUIRE(enabled == 0 || enabled == 1, "hgr_gemm_set_persist: enabled must be 0 or 1, got %d", enabled);
+    return duo_set_persist(enabled);
+}
+
 extern "C" int hgr_gemm_nt(const void *A, int64_t lda, const void *W, int64_t ldw, void *C, int64_t ldc,
                            const float *bias, const void *residual, int64_t ldr,
                            int M, int N, int K, int dtype, int epilogue, int out_f32, void *stream) {

@@ -208,6 +208,7 @@ void launch_256(const GemmArgs &a, int dtype, int epi, bool out32, bool conv, di
 // gemm_nt_duo: ln = 0 plain (any epi), 1 LayerNorm producer, 2 LayerNorm consumer (epi BIAS / BIAS_QUICKGELU), 4 dual output
 // (pre-activation + QuickGELU), 5 the 3 x 3 convolution
 void launch_duo(const GemmArgs &a, int dtype, int epi, bool out32, int ln, dim3 grid, hipStream_t s);
+int duo_set_persist(int enabled);     // hgr_gemm_set_persist
 
 // first stage of hgr_logits_eval (hgr_logits_slab.hip): 512-row x 96-column tiles, one per CU, evaluation consumers in the epilogue
 struct SlabArgs {

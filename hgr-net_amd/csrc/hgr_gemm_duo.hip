@@ -886,11 +886,12 @@ void launch_duo_dt(const GemmArgs &a, int epi, bool out32, int ln, dim3 grid, hi
 // Default: at most two workgroups per CU, each walking its share of the tiles (see gemm_nt_duo); HGR_DUO_PERSIST=0 = one workgroup per
 // tile (A/B runs).  Measured on the ViT-B/32 evaluation step, interleaved pairs on one box: every launch persistent 5.064 -> 5.008 ms
 // (-1.1 %; by shape proj 128.6 -> 123.5 us, out 50.1 -> 48.5, fc unchanged), the producers only 5.137 -> 5.104 (-0.6 %).  Bit-identical.
+static int g_duo_persist = -1;                   // hgr_gemm_set_persist / HGR_DUO_PERSIST
 static int duo_persist() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("HGR_DUO_PERSIST"); v = e ? atoi(e) : 1; }
-    return v;
+    if (g_duo_persist < 0) { const char *e = getenv("HGR_DUO_PERSIST"); g_duo_persist = e ? (atoi(e) != 0) : 1; }
+    return g_duo_persist;
 }
+int duo_set_persist(int enabled) { const int prev = duo_persist(); g_duo_persist = enabled; return prev; }
 static int duo_slots() {
     static int n = 0;
     if (!n) {

@@ -240,6 +240,15 @@ def gemm_set_tail(enabled: bool, full_panels: int = -1) -> int:
     return prev
 
 
+def gemm_set_persist(enabled: bool) -> int:
+    """Persistent form of the residual-producer GEMMs on / off (hgr_gemm_set_persist); returns the previous setting."""
+    lib = _lib.load()
+    prev = lib.hgr_gemm_set_persist(1 if enabled else 0)
+    if prev < 0:
+        raise _lib.HgrError(f"hgr_gemm_set_persist failed ({prev}): {lib.hgr_last_error().decode()}")
+    return prev
+
+
 def im2col_patches(image: torch.Tensor, out: torch.Tensor, patch: int) -> torch.Tensor:
     b, c, r, r2 = image.shape
     assert c == 3 and r == r2 and image.dtype == torch.float32 and image.is_contiguous() and out.is_contiguous()

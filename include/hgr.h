@@ -11,7 +11,7 @@
  *   - plain pointers and sizes only; every tensor argument is a raw DEVICE pointer, row-major;
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); every call is asynchronous
  *     and stream-ordered, never synchronises and allocates no device memory.  The only process-wide mutable state is
- *     (a) the development knobs hgr_gemm_set_tile / hgr_gemm_set_tail (tile-plan overrides for A/B runs and tests) and
+ *     (a) the development knobs hgr_gemm_set_tile / hgr_gemm_set_tail / hgr_gemm_set_persist (plan overrides for A/B runs and tests) and
  *     (b) the optional RCCL communicator created / destroyed explicitly by hgr_comm_init / hgr_comm_destroy and
      (c) the 16-slot scratch ring of hgr_sumsq (see there);
  *   - returns 0 on success, a negative HGR_E* code otherwise; hgr_last_error() returns the message of
@@ -88,6 +88,14 @@ int hgr_gemm_set_tile(int tile);
  * Process-wide development knob like hgr_gemm_set_tile.  Returns the previous `enabled`.
  */
 int hgr_gemm_set_tail(int enabled, int full_panels);
+/*
+ * Persistent form of the residual-producer GEMMs (hgr_gemm_nt_res_stats*): on launches of one to two rounds of the chip's workgroup
+ * slots every workgroup walks its share of the tiles (tile b, b + slots, ...) instead of ending after one, so that a tile's
+ * read-modify-write of the residual pair drains beside the next tile's first operand loads.  Same tiles, same arithmetic: results are
+ * bit-identical.  enabled = 1 (default; HGR_DUO_PERSIST) / 0.  Process-wide development knob like hgr_gemm_set_tile (A/B runs, tests).
+ * Returns the previous setting.
+ */
+int hgr_gemm_set_persist(int enabled);
 
 /*
  * Patch extraction for the ViT stem: image fp32 NCHW [B,3,R,R] -> rows [B*g*g, Kp] of 16-bit

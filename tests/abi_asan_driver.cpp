@@ -44,6 +44,7 @@ int main() {
     EXPECT_FAIL(hgr_gemm_nt_res_stats(h16, 128, h16, 128, (char *)h16 + 8, h16, 128, f32, f32, 4, 128, 128, HGR_F16, nullptr));  // xh only 8-byte aligned
     EXPECT_FAIL(hgr_gemm_set_tail(2, -1)); EXPECT_FAIL(hgr_gemm_set_tail(1, -5));
     EXPECT_OK(hgr_gemm_set_tail(0, -1)); EXPECT_OK(hgr_gemm_set_tail(1, 3)); EXPECT_OK(hgr_gemm_set_tail(1, -1));
+    EXPECT_FAIL(hgr_gemm_set_persist(2)); EXPECT_OK(hgr_gemm_set_persist(0)); EXPECT_OK(hgr_gemm_set_persist(1));
     EXPECT_FAIL(hgr_gemm_nt_res_stats_guard(h16, 128, h16, 128, h16, h16, 128, f32, f32, 0.f, (uint32_t *)i32, 4, 128, 128, HGR_F16, nullptr));   // flag without a guard value
     EXPECT_FAIL(hgr_gemm_nt_res_stats_guard(h16, 128, h16, 128, h16, h16, 128, f32, f32, 1.f, (uint32_t *)(u8 + 2), 4, 128, 128, HGR_F16, nullptr)); // misaligned flag
     EXPECT_FAIL(hgr_vit_head(h16, h16, 64, 50, f32, f32, 1e-5f, h16, f32, 4, 100, 64, HGR_F16, nullptr));                        // W % 32

@@ -672,6 +672,40 @@ def test_gemm_tail_plan_is_bit_identical(dt, m, n, k, panels):
 
 
 @pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("tail", [False, True])
+@pytest.mark.parametrize("m,n,k", [(25600, 768, 768), (25600, 768, 3072), (25523, 768, 256), (40000, 768, 128), (16384, 1024, 256), (12800, 768, 192)])
+def test_gemm_res_stats_persistent_is_bit_identical(dt, tail, m, n, k):
+    """The persistent form of the residual producers (hgr_gemm_set_persist: workgroup b walks tiles b, b + 512, ... on launches of one to
+    two rounds of the chip's 512 slots) against one workgroup per tile: same tiles, same arithmetic, so pair and slot statistics must be
+    the same BITS.  600 / 940 / 512 / 300 tiles: inside the window, at its upper edge (1024 would be the last one in), exactly one
+    round and less than a round (both not persistent: the switch must then change nothing either); with and without the tail plan
+    (half tiles are the last virtual blocks), a ragged last row panel, 2- / 3-K-tile reductions."""
+    g = torch.Generator(device=DEV).manual_seed(m + n + k)
+    rnd = lambda shape, scale=1.0: scale * torch.randn(shape, generator=g, device=DEV)
+    a, w = rnd((m, k)).to(dt), rnd((n, k), 0.1).to(dt)
+    bias, x0 = rnd((n,)), rnd((m, n), 2.0)
+    xh0, xl0 = _pair(x0, dt)
+
+    def run():
+        xh, xl = xh0.clone(), xl0.clone()
+        stats = torch.zeros((m, n // 64, 2), dtype=torch.float32, device=DEV)
+        ops.gemm_nt_res_stats(a, w, xh, xl, bias, stats)
+        return xh, xl, stats
+
+    prev_t = ops.gemm_set_tail(tail)
+    prev_p = ops.gemm_set_persist(False)
+    try:
+        one = run()
+        ops.gemm_set_persist(True)
+        walk = run()
+    finally:
+        ops.gemm_set_persist(bool(prev_p))
+        ops.gemm_set_tail(bool(prev_t))
+    for x, y, name in zip(one, walk, ("xh", "xl", "stats")):
+        assert torch.equal(x, y), name
+
+
+@pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("gelu", [False, True])
 @pytest.mark.parametrize("m,n,k", [(512, 384, 128), (1000, 2304, 768), (25600, 3072, 768), (300, 128, 1024)])
 def test_gemm_nt_ln(dt, gelu, m, n, k):
