@@ -94,6 +94,7 @@ def test_tree_model_host_logic(tmp_path, golden_dir):
     for method, by_depth in table.items():
         for d, ref in by_depth.items():
             assert torch.allclose(m.get_weights(method, int(d)).float().cpu(), torch.tensor(ref), rtol=0, atol=1e-7), (method, d)
+            assert torch.equal(m.get_weights(method, int(d), device="cpu"), m.get_weights(method, int(d)).cpu()), (method, d)   # the training step's host copy
     assert abs(float(m.get_weights("adaptive", 3).sum()) - 1) < 1e-6
 
 
@@ -155,6 +156,28 @@ dist.barrier()
 if rank == 0: print("OK")
 dist.destroy_process_group()
 '''
+
+
+def test_splitk_slice_count_fills_the_chip():
+    """ops.splitk_slices (host plan of hgr_gemm_tn_splitk): from the smallest slice count that fills >= 85 % of whole rounds of the
+    workgroup slots up to 1.25 x that count, the best-filling one; every slice at least 512 rows deep; one slice when rows are few."""
+    from hgr_net_amd import ops
+    fill = lambda tiles, s, slots: tiles * s / (-(-(tiles * s) // slots) * slots)
+    assert ops.splitk_slices(16, 65792, 256) == 16                    # out_proj of ViT-L/14: 100 % instead of 14 slices = 87.5 %
+    assert ops.splitk_slices(48, 65792, 256) == 5 and ops.splitk_slices(64, 65792, 256) == 4
+    assert ops.splitk_slices(9, 81397, 256) == 28
+    assert ops.splitk_slices(1, 1000, 256) == 1 and ops.splitk_slices(300, 100, 256) == 1
+    for tiles in (1, 3, 9, 16, 27, 36, 48, 64, 100, 300, 1000):
+        for m in (600, 5000, 65792, 81397):
+            for slots in (256, 512):
+                s = ops.splitk_slices(tiles, m, slots)
+                assert 1 <= s <= max(1, m // 512)
+                reachable = [fill(tiles, t, slots) for t in range(1, max(1, min(m // 512, 4096)) + 1)]
+                if max(reachable) >= 0.85:
+                    first = next(t for t, f in enumerate(reachable, 1) if f >= 0.85)
+                    assert first <= s <= max(first + 1, int(first * 1.25)) and fill(tiles, s, slots) >= reachable[first - 1] - 1e-9
+                else:
+                    assert abs(fill(tiles, s, slots) - max(reachable)) < 1e-9
 
 
 def test_world_size_2_gloo_sharding(tmp_path):
