@@ -412,7 +412,8 @@ def train_mode(a, model, cfg, h, rank, world, group, ranks_seen, dev, real_stdou
                 "value": round(a.batch * world * a.steps / elapsed, 1), "unit": "images/sec", "n_gpus": world, "ranks_seen": ranks_seen,
                 "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "step_ms": step_ms, "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": a.train_dtype, "data": "synthetic",
-                "config": {"workload": f"{a.arch} OM training step, {a.n_ctx} CoOp context vectors, N={a.nodes} nodes, depth-{len(model.c2p[target])} class: "
+                "config": {"arch": a.arch, "nodes": a.nodes, "batch_per_gpu": a.batch, "n_ctx": a.n_ctx,
+                           "workload": f"{a.arch} OM training step, {a.n_ctx} CoOp context vectors, N={a.nodes} nodes, depth-{len(model.c2p[target])} class: "
                                        f"{len(picks)} inner steps x <= 257 prompts ({uniq} distinct, {l_txt} tokens), batch {a.batch}/GPU",
                            "global_batch": a.batch * world, "parallelism": f"dp{world}", "weights": "random-init (hash-seeded)"},
                 "roofline": {"kernel": "whole step (forward + backward GEMMs of both towers)", "bound": "mfma", "achieved": round(fl / (ms * 1e-3) / 1e12, 1),
@@ -803,7 +804,8 @@ def main():
                 "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "ranks_seen": ranks_seen, "steps": a.steps, "warmup": a.warmup,
                 "ms_per_step": round(ms, 3), "step_ms": step_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": a.image_dtype, "data": "synthetic",
-                "config": {"workload": f"{a.arch} zero-shot eval step: encode_image + L2 + [{a.batch}x{cfg['embed_dim']}]x[{cfg['embed_dim']}x{a.nodes}] logits "
+                "config": {"arch": a.arch, "nodes": a.nodes, "batch_per_gpu": a.batch, "embed_dim": cfg["embed_dim"],
+                           "workload": f"{a.arch} zero-shot eval step: encode_image + L2 + [{a.batch}x{cfg['embed_dim']}]x[{cfg['embed_dim']}x{a.nodes}] logits "
                                        f"+ top-20/top-1/level-argmax metrics (main.py:131-191; {'fused into the logits GEMM' if fused_eval else 'hgr_eval_rows on materialised logits'}), N={a.nodes} nodes, batch {a.batch}/GPU",
                            "tower_notes": ("LayerNorms folded into the GEMMs; the last image block runs out_proj / MLP / its attention row on the class-token rows only - "
                                            "the rows ln_post reads (clip/model.py:231), same bits; HGR_CLS_LAST=0 carries every token") if cfg["vision_patch_size"] else

@@ -145,11 +145,25 @@ def load() -> C.CDLL:
 
 # True only while tree_model captures the TAIL graph of a pipelined evaluation step: the host code of the step's head is walked again
 # (same views, same workspace buffers) with its launches skipped, up to ops.split_point().  Never set on any other path.
-MUTED = False
+# Launch mute of the CALLING THREAD (tree_model._eager_phase walks the head's host code with its launches muted while it captures
+# the tail graph).  Thread-local: another thread that drives ops meanwhile keeps launching.
+import threading
+
+_tls = threading.local()
+
+
+def set_muted(on: bool) -> bool:
+    prev = getattr(_tls, "muted", False)
+    _tls.muted = bool(on)
+    return prev
+
+
+def muted() -> bool:
+    return getattr(_tls, "muted", False)
 
 
 def call(name: str, *args) -> None:
-    if MUTED:
+    if getattr(_tls, "muted", False):
         return
     lib = load()
     rc = getattr(lib, name)(*args)

@@ -216,7 +216,7 @@ def _run_blocks(x: Optional[torch.Tensor], blocks, heads: int, b: int, l: int, c
         xh, xl = pair
         for i, k in enumerate(blocks):
             last_cls = cls_only_last and i == len(blocks) - 1 and l > 1 and 3 * w * l < (1 << 23)    # hgr_gemm_nt_ln: ldc < 2^23
-            fused_attn = QKV_MHA and not last_cls and ops.ln_mha_ok(w, l)
+            fused_attn = QKV_MHA and not last_cls and ops.ln_mha_ok(w, l, m, xh.stride(0))
             if last_cls:
                 # keys and values of every token, queries of the class tokens only (the one attention row that is read)
                 ch, cl = xh.view(b, l, w)[:, 0, :], xl.view(b, l, w)[:, 0, :]                  # row stride l * w

@@ -80,7 +80,11 @@ class Evaluator:
     def fused_ok(self) -> bool:
         """hgr_logits_eval needs an embedding width that is a multiple of 128 (<= 1024) and <= 32 levels."""
         d = self.model._zsl16.shape[1] if self.model._zsl16 is not None else 0
-        return d % 128 == 0 and 128 <= d <= 1024 and self.n_levels <= 32 and self.index.n_test >= max(TOPK)
+        if not (d % 128 == 0 and 128 <= d <= 1024 and self.n_levels <= 32 and self.index.n_test >= max(TOPK)):
+            return False
+        if self._plan is None:
+            self._plan = ops.LogitsEvalPlan(self.index)
+        return self._plan.supported                  # <= 32 768 level-padded columns
 
     @torch.no_grad()
     def add_images(self, imgs: torch.Tensor, target: int, targets: Optional[torch.Tensor] = None, want_outputs: bool = False):
@@ -89,6 +93,8 @@ class Evaluator:
         bit, as add_batch(model(imgs), ...); use add_batch when the caller needs the logits themselves."""
         if self._plan is None:
             self._plan = ops.LogitsEvalPlan(self.index)
+        if not self._plan.supported:                  # a hierarchy beyond hgr_logits_eval's capacity: logits + hgr_eval_rows
+            return self.add_batch(self.model(imgs), target, targets, want_outputs)
         parents, levels64, levels32, L = self._parents(target)
         tg = None
         if targets is not None:

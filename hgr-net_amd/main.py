@@ -142,6 +142,18 @@ def run(opts, loader_train=None, loader_test=None, group=None):
                        node_tokens=getattr(opts, "node_tokens", None), clip_model=getattr(opts, "clip_model", None))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    base_seed = None
+    if world > 1 and group is not None:
+        # one seed for the whole job (rank 0's --data_seed, else drawn there): the loaders' class order and the negative sampling of
+        # the OM step (Python `random`, model/clip_tree.py:116-219) must agree on every rank - each rank holds its rows of the SAME
+        # single-class batch and encodes its share of the SAME prompt list
+        import random
+        import torch.distributed as dist
+        seed_t = torch.tensor([opts.data_seed if opts.data_seed is not None else random.getrandbits(31)], dtype=torch.int64, device=device)
+        dist.broadcast(seed_t, src=0, group=group)
+        base_seed = int(seed_t.item())
+        if opts.data_seed is None:
+            opts.data_seed = base_seed
     if opts.train:
         with open(model.save_path + "arugements.log", "a") as f:
             for k, v in vars(opts).items():
@@ -160,6 +172,9 @@ def run(opts, loader_train=None, loader_test=None, group=None):
         optimizer2 = torch.optim.SGD([model.layer_weight], lr=opts.w_lr) if opts.weights == "adaptive" else None
         scheduler = cosine_lr(optimizer, opts.lr, opts.warmup_length, opts.epochs * num_batches)
         for epoch in range(opts.from_epoch + 1, opts.epochs):
+            if base_seed is not None:
+                import random
+                random.seed(base_seed * 1000003 + epoch)        # identical on every rank, fresh every epoch
             ids = model.train_index.tolist()
             loader = loader_train if opts.synthetic <= 0 else synthetic_loader(model, ids, opts.synthetic, opts.batch_size, epoch, rank, world, shard_batch=True)
             train(opts, epoch, model, loader, num_batches, optimizer, optimizer2, scheduler, device, group)

@@ -150,6 +150,7 @@ class tree_model(nn.Module):
         ignored as in the reference (clip_tree.py:328-333)."""
         if self._zsl16 is None:
             raise HgrError("call update_classifier() before forward()")
+        self.join_tail()            # a pipelined evaluation step may still be reading workspace "v" on the side stream
         if self.use_graph and inputs.is_cuda:
             return self._forward_graphed(inputs, static_output)
         return self._forward_eager(inputs)
@@ -162,6 +163,7 @@ class tree_model(nn.Module):
         Outputs are static buffers of a replayed HIP graph: consume them before the next call."""
         if self._zsl16 is None:
             raise HgrError("call update_classifier() before forward_eval()")
+        self.join_tail()
         plan.bind(self._zsl16)
         if self.use_graph and inputs.is_cuda:
             return self._forward_graphed(inputs, True, ("eval", plan, k))
@@ -225,17 +227,17 @@ class tree_model(nn.Module):
         else:
             def hook(name):
                 seen.append(name)
-                _lib.MUTED = False
+                _lib.set_muted(False)
         prev_hook, prev_tag = ops.SPLIT_HOOK, self.clip_model._img_tag
         ops.SPLIT_HOOK, self.clip_model._img_tag = hook, tag
         out = None
         try:
-            _lib.MUTED = phase == "tail"
+            _lib.set_muted(phase == "tail")
             out = self._forward_eager(inputs, mode)
         except _StopHead:
             pass
         finally:
-            _lib.MUTED = False
+            _lib.set_muted(False)
             ops.SPLIT_HOOK, self.clip_model._img_tag = prev_hook, prev_tag
         return out, bool(seen)
 
@@ -265,6 +267,15 @@ class tree_model(nn.Module):
         the same data as forward_eval: same ids.  Returns False when the step cannot be split (no HIP graphs, a tower without a
         class-token tail): the caller then takes forward_eval."""
         if not (TAIL_OVERLAP and self.use_graph and inputs.is_cuda) or self._zsl16 is None:
+            return False
+        if inputs.dtype not in (torch.float32, torch.uint8) or not inputs.is_contiguous():
+            # the head's host code is walked a second time (launches muted) to capture the tail: an input conversion would be
+            # re-executed there and captured into the tail graph - the pipelined route takes the tower's own input forms only
+            return False
+        from ..clip import model as _clip_model
+        if _clip_model.IMG_STREAMS > 1:
+            # the sliced image tower (HGR_IMG_STREAMS >= 2) names its workspace sets "v", "v1", ... itself and ignores _img_tag: both
+            # step parities would share one set and the tail of step i would race with the head of step i + 1
             return False
         plan.bind(self._zsl16)
         mode = ("eval", plan, k)

@@ -187,9 +187,14 @@ def gemm_nt_ln_mha(x16: torch.Tensor, wfold: torch.Tensor, att: torch.Tensor, ln
     return att
 
 
-def ln_mha_ok(w: int, l: int) -> bool:
-    """Shape contract of hgr_gemm_nt_ln_mha: whole sequences inside a 256-row tile, head width 64, row width a multiple of 128."""
-    return 1 <= l <= 64 and w % 128 == 0
+def ln_mha_ok(w: int, l: int, rows: Optional[int] = None, ldx: Optional[int] = None) -> bool:
+    """Shape contract of hgr_gemm_nt_ln_mha: whole sequences inside a 256-row tile, head width 64, row width a multiple of 128, and
+    (the kernel's LDS-DMA addresses its operands with 32-bit byte offsets) operands below 4 GB - larger inputs take gemm_nt_ln + mha."""
+    if not (1 <= l <= 64 and w % 128 == 0):
+        return False
+    if rows is not None and rows * (ldx if ldx is not None else w) * 2 >= (1 << 32):
+        return False
+    return 3 * w * w * 2 < (1 << 32)
 
 
 def vit_embed_ln_stats(patches, cls, pos, gamma, beta, xh, xl, stats, b, g, eps=1e-5):
@@ -464,6 +469,14 @@ class LogitsEvalPlan:
         self.zsl = None
         self._src = None
         self._ws = None
+
+    MAX_SLICES = 1024            # hgr_logits_eval: 32-column slices per row (csrc/hgr_gemm.hip) = 32 768 permuted columns
+
+    @property
+    def supported(self) -> bool:
+        """Whether hgr_logits_eval covers this hierarchy (padding every level to 32 columns brings hierarchies somewhat below
+        32 768 nodes over its capacity): callers fall back to forward() + hgr_eval_rows otherwise."""
+        return self.n_perm // self.SLICE <= self.MAX_SLICES and self.index.n_levels <= 32
 
     def bind(self, zsl16: torch.Tensor) -> "LogitsEvalPlan":
         key = (zsl16.data_ptr(), zsl16._version, tuple(zsl16.shape))

@@ -393,6 +393,7 @@ class OMTrainer:
         # gradients equal the one-rank step's up to the fp32 order of the cross-rank sums (<= 1e-4).  The head's FLOPs are then
         # replicated on every rank (B_total x <= 257 x D per inner step, fp32): reproducibility across world sizes, not speed.
         self.dp_exact_head = os.environ.get("HGR_DP_EXACT_HEAD", "0") == "1"
+        self._warned_picks = False
         self._pin = {}                   # pinned host staging for the step's index lists, one buffer per use (see _stage_ints)
         self._eot_host = None            # EOT position of every node's prompt (host copy, made once): the trimmed length without a mid-step sync
 
@@ -470,6 +471,33 @@ class OMTrainer:
         ns = -(-n_u // world)
         lo = min(n_u, rank * ns)
         return world, rank, ns, lo, min(n_u, lo + ns)
+
+    def _agree_on_picks(self, picks: list, dp):
+        """Data-parallel step: every rank must work on the SAME negatives (one prompt list, sharded over the ranks).  Ranks seeded alike
+        (main.run does that) draw the same lists and only pay a 16-byte max-reduce of a hash here; when they differ - a caller that
+        did not seed `random`, a loader that advanced it unevenly - the ranks adopt the group's first rank's draw instead of failing
+        (round-4 advisor finding: `main` raised at the first step).  The loss weights are functions of the step plan, not of the draw."""
+        import hashlib
+        import torch.distributed as dist
+        mine = [(list(ids), int(pos)) for ids, pos, _, _ in picks]
+        hsh = int.from_bytes(hashlib.sha256(repr(mine).encode()).digest()[:7], "little")
+        chk = torch.tensor([hsh, -hsh], dtype=torch.int64, device=self.engine.dev)
+        dist.all_reduce(chk, op=dist.ReduceOp.MAX, group=dp)
+        chk = chk.tolist()
+        if chk[0] == -chk[1]:
+            return picks
+        if not self._warned_picks:
+            self._warned_picks = True
+            import warnings
+            warnings.warn("data-parallel OM step: the ranks drew different negative classes (Python `random` is not seeded alike on "
+                          "every rank); every rank now takes the first rank's draw each step - seed `random` identically to avoid "
+                          "the extra broadcast")
+        box = [mine]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(dp, 0) if hasattr(dist, "get_global_rank") else 0, group=dp)
+        if len(box[0]) != len(picks):
+            raise HgrError("data-parallel OM step: the ranks planned different numbers of inner steps (different target classes?): "
+                           "hand every rank its rows of the SAME single-class batch")
+        return [(list(ids), int(pos), w, wt) for (ids, pos), (_, _, w, wt) in zip(box[0], picks)]
 
     def _text_features_dp(self, uniq: list, ctx):
         """The reference text-encodes the <= 257 prompts of every inner step on the device that owns the batch
@@ -565,11 +593,13 @@ class OMTrainer:
                 w_out = host_weights("equal" if wmode == "in" else tree.opts.weights, st["K"])
                 wgt = w_in[st["m_loop"]] * w_out[st["k_loop"]]
             picks.append((list(ids), pos, float(wgt), wgt))
+        dp = self.dp_group if self.dp_group is not None else getattr(tree, "_dp_group", None)
+        self.dp_group = dp
+        if dp is not None:
+            picks = self._agree_on_picks(picks, dp)
         self.last_contra = [(ids, pos) for ids, pos, _, _ in picks]
         uniq = sorted({i for ids, _, _, _ in picks for i in ids})
         where = {nid: j for j, nid in enumerate(uniq)}
-        dp = self.dp_group if self.dp_group is not None else getattr(tree, "_dp_group", None)
-        self.dp_group = dp
         if dp is not None:
             tfeat_u, tsave = self._text_features_dp(uniq, getattr(tree, "ctx", None))
         else:

@@ -347,6 +347,7 @@ def test_comm_file_bootstrap_default_nonce_rejects_an_old_file(tmp_path, monkeyp
     monkeypatch.setenv("TORCHELASTIC_RUN_ID", "none")
     monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
     monkeypatch.setenv("MASTER_PORT", "29500")
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
     assert not comm._nonce_is_per_run(None) and comm._nonce_is_per_run("x")
     path = str(tmp_path / "uid.bin")
     with open(path, "wb") as f:                                   # a crashed earlier run: same (degenerate) nonce, written long ago
@@ -363,3 +364,10 @@ def test_comm_file_bootstrap_default_nonce_rejects_an_old_file(tmp_path, monkeyp
     comm.destroy()
     monkeypatch.setenv("TORCHELASTIC_RUN_ID", "job-4711")
     assert comm._nonce_is_per_run(None)
+    # round-4 advisor finding: a default single-node torchrun launch (static run id "none") is per-run through the launcher's pid,
+    # so a rank that imports late is not locked out by the age rule
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "none")
+    a = comm._run_nonce(None)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "2")
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    assert comm._nonce_is_per_run(None) and comm._run_nonce(None) != a

@@ -99,6 +99,17 @@ def test_two_rank_evaluation_equals_one_rank(tmp_path):
     assert one["summary"] == two["summary"]
 
 
+def test_two_rank_om_step_with_differently_seeded_ranks(tmp_path):
+    """Round-4 advisor finding: hgr_net_amd.main seeded Python's `random` on no rank, so the ranks of a data-parallel OM step drew
+    different negatives and the prompt-parallel text tower raised at the first step.  Ranks seeded 5 and 6 here: the step completes,
+    warns once, and every rank has worked on rank 0's draw (main.run now also seeds all ranks from one broadcast value)."""
+    import math
+    two = _dp("train", 2, tmp_path / "u2.pt", HGR_TEST_UNSEEDED="1", HGR_DP_EXACT_HEAD="0")
+    assert len(two["contra_per_rank"]) == 2 and two["contra_per_rank"][0] == two["contra_per_rank"][1] == two["contra"]
+    assert math.isfinite(two["loss"]) and two["loss"] > 0.0
+    assert all(bool(g.isfinite().all()) for g in two["grads"].values())
+
+
 @pytest.mark.parametrize("exact_head", [False, True])
 def test_two_rank_om_step_equals_one_rank(tmp_path, exact_head):
     """SURVEY H7 (model/clip_tree.py:222-281): ONE single-class batch sharded over 2 ranks with identical sampling seeds,

@@ -160,7 +160,9 @@ else:
         model._dp_group = group                                  # prompt-parallel text tower (what hgr_net_amd.main.train and bench.py set)
         opt.set_late_params(model.clip_model.visual.parameters())
         model._trainer.grad_ready_hook = lambda part: opt.allreduce_part(part, group)
-    random.seed(5)
+    # HGR_TEST_UNSEEDED=1: every rank seeds `random` differently (what a caller of hgr_net_amd.main got before round 5): the step
+    # must then adopt the first rank's draw instead of raising (round-4 advisor finding)
+    random.seed(5 + (rank if os.environ.get("HGR_TEST_UNSEEDED") == "1" else 0))
     from hgr_net_amd import ops as _ops
     _ops.PROFILE = []                                            # algorithmic FLOPs of every GEMM this rank launches in the step
     loss = model.train_batch(img[lo:hi].to(dev), torch.full((hi - lo,), target, dtype=torch.long, device=dev), "OM", "topk")
@@ -182,9 +184,14 @@ else:
             box = [torch.empty_like(cg) for _ in range(world)]
             dist.all_gather(box, cg)
             ctx_all = [b.cpu() for b in box]
+    contra_all = [model._trainer.last_contra]
+    if group is not None:
+        contra_all = [None] * world
+        dist.all_gather_object(contra_all, model._trainer.last_contra)
     if rank == 0:
         uniq = len({i for ids, _ in model._trainer.last_contra for i in ids})
         torch.save({"loss": float(loss_t.item()), "grads": grads, "contra": model._trainer.last_contra, "gemm_flops": gemm_flops,
+                    "contra_per_rank": contra_all,
                     "text_rows": model._trainer.last_text_rows, "uniq": uniq, "ctx_grad_per_rank": ctx_all}, out_path)
 if group is not None:
     import torch.distributed as dist
