@@ -120,6 +120,11 @@ extern "C" int hgr_gemm_set_tile(int tile) {
     return prev;
 }
 
+extern "C" int hgr_gemm_set_ws(int enabled) {
+    HGR_REQUIRE(enabled == 0 || enabled == 1, "hgr_gemm_set_ws: enabled must be 0 or 1, got %d", enabled);
+    return ws_set(enabled);
+}
+
 extern "C" int hgr_gemm_set_persist(int enabled) {
     HGR_REQUIRE(enabled == 0 || enabled == 1, "hgr_gemm_set_persist: enabled must be 0 or 1, got %d", enabled);
     return duo_set_persist(enabled);
@@ -221,7 +226,20 @@ extern "C" int hgr_gemm_nt(const void *A, int64_t lda, const void *W, int64_t ld
     // ... and an output much narrower than its 128-column tiles (the 64-channel ResNet stage: half of every tile would be padding;
     // measured 252 vs 194 us on the 256 x 64 arrangement of the small kernel) stays where it was
     const bool duo_fits = (N + 127) / 128 * 128 - N <= N / 8;
-    if (duo_ok && (force == 2 || (force == 0 && tduo >= 256 && duo_fits))) launch_d();
+    // the role-split kernel (gemm_nt_ws: the epilogue runs in helper waves under the next tile's MFMAs) for 16-bit outputs made of whole tiles
+    // (not BIAS_QUICKGELU: in gemm_nt_duo's plain f16 instantiation hipcc fuses the last product of QuickGELU with the conversion -
+    // v_fma_mixlo_f16, ONE rounding - and does not in the row-layout epilogue; the folded-LayerNorm form, the one the towers use, matches)
+    const bool ws_epi = epilogue == HGR_EPI_NONE || epilogue == HGR_EPI_BIAS || epilogue == HGR_EPI_BIAS_RELU;
+    if (duo_ok && force == 0 && ws_enabled() && !out_f32 && ws_epi && ldc % 8 == 0 && ldc < (1 << 23) && hgr_aligned(C, 16) && (!bias || hgr_aligned(bias, 16)) &&
+        ws_covers(M, N, K, WS_PLAIN)) {
+        GemmArgs a;
+        a.A = (const char *)A; a.lda = lda; a.W = (const char *)W; a.ldw = ldw; a.C = C; a.ldc = ldc; a.bias = bias;
+        a.res = nullptr; a.ldr = 0; a.M = M; a.N = N; a.K = K;
+        a.m_fastest = ((int64_t)N * K > (int64_t)M * K) ? 1 : 0;
+        a.vec_ok = 1; a.dbg = dbg; a.kc = 0; a.csplit = 0; a.group = duo_group();
+        launch_ws(a, dtype, WS_PLAIN, epilogue == HGR_EPI_BIAS_RELU ? 2 : 0, epilogue != HGR_EPI_NONE, s);
+    }
+    else if (duo_ok && (force == 2 || (force == 0 && tduo >= 256 && duo_fits))) launch_d();
     else if (force == 128 || K < 128) launch(0, M, false);
     else if (epi_has_idn16(epilogue) && force != 256) launch(0, M, false);   // only the 128 kernel loads the identity / stores by full lines
     else if (force == 256) launch(0, M, true);
@@ -375,6 +393,11 @@ extern "C" int hgr_gemm_nt_res_stats_guard(const void *A, int64_t lda, const voi
     a.bias = bias;
     a.ln_stats = stats; a.ln_slots = N / 64; a.ln_xh = xh; a.ln_xl = xl; a.ln_ldx = ldx;
     a.ln_flag = flag; a.ln_guard = guard_sumsq;
+    if (ws_enabled() && hgr_gemm_force_tile() == 0 && ws_covers(M, N, K, WS_LNP)) {
+        launch_ws(a, dtype, WS_LNP, 0, true, (hipStream_t)stream);
+        HGR_CHECK_LAUNCH("hgr_gemm_nt_res_stats");
+        return HGR_OK;
+    }
     dim3 grid;
     duo_apply_plan(a, true, grid);
     launch_duo(a, dtype, HGR_EPI_BIAS_RESIDUAL, true, 1, grid, (hipStream_t)stream);
@@ -395,6 +418,11 @@ extern "C" int hgr_gemm_nt_ln(const void *X16, int64_t ldx, const void *Wfold, i
     GemmArgs a;
     ln_args(a, X16, ldx, Wfold, ldw, C, ldc, M, N, K);
     a.ln_stats = const_cast<float *>(stats); a.ln_slots = K / 64; a.ln_eps = eps; a.ln_s = ln_s; a.ln_c = ln_c;
+    if (ws_enabled() && hgr_gemm_force_tile() == 0 && ws_covers(M, N, K, WS_LNC)) {
+        launch_ws(a, dtype, WS_LNC, act, false, (hipStream_t)stream);
+        HGR_CHECK_LAUNCH("hgr_gemm_nt_ln");
+        return HGR_OK;
+    }
     dim3 grid;
     duo_apply_plan(a, true, grid);
     launch_duo(a, dtype, act ? HGR_EPI_BIAS_QUICKGELU : HGR_EPI_BIAS, false, 2, grid, (hipStream_t)stream);

@@ -209,6 +209,14 @@ void launch_256(const GemmArgs &a, int dtype, int epi, bool out32, bool conv, di
 // (pre-activation + QuickGELU), 5 the 3 x 3 convolution
 void launch_duo(const GemmArgs &a, int dtype, int epi, bool out32, int ln, dim3 grid, hipStream_t s);
 int duo_set_persist(int enabled);     // hgr_gemm_set_persist
+// gemm_nt_ws (hgr_gemm_ws.hip): 256 x 128 tiles, ONE persistent workgroup per CU of 4 matrix waves + 4 helper waves; the epilogue of
+// tile i runs in the helper waves under the MFMAs of tile i + 1.  Same bits as gemm_nt_duo.  mode WS_PLAIN: 16-bit C = act(A W^T
+// [+ bias]), act 0 none / 1 QuickGELU / 2 ReLU; WS_LNC: the folded-LayerNorm consumer (act 0 / 1); WS_LNP: the residual producer.
+enum { WS_PLAIN = 0, WS_LNC = 1, WS_LNP = 2 };
+bool ws_covers(int M, int N, int K, int mode);      // whole tiles, an even number >= 12 of K-tiles, at least one tile per CU
+void launch_ws(const GemmArgs &a, int dtype, int mode, int act, bool hasb, hipStream_t s);
+int ws_enabled();                     // HGR_WS (default 0: an experiment that did not beat gemm_nt_duo, kept bit-identical and tested)
+int ws_set(int enabled);              // hgr_gemm_set_ws
 
 // first stage of hgr_logits_eval (hgr_logits_slab.hip): 512-row x 96-column tiles, one per CU, evaluation consumers in the epilogue
 struct SlabArgs {

@@ -98,6 +98,20 @@ int hgr_gemm_set_tail(int enabled, int full_panels);
 int hgr_gemm_set_persist(int enabled);
 
 /*
+ * Role-split form of the tower GEMMs (round 5 EXPERIMENT; csrc/hgr_gemm_ws.hip): launches of hgr_gemm_nt (16-bit output, epilogues NONE /
+ * BIAS / BIAS_RELU), hgr_gemm_nt_ln and hgr_gemm_nt_res_stats* that are made of whole 256 x 128 tiles (M % 256 == 0, N % 128 == 0,
+ * K % 128 == 0, K >= 768, at least one tile per CU) run as ONE persistent workgroup per CU of four matrix waves (LDS fragment reads
+ * + MFMA only, fragments prefetched a phase ahead) and four helper waves that issue the operand LDS-DMAs and run the epilogue of tile
+ * i - nn.Linear's bias, QuickGELU (clip/model.py:162-164), the folded LayerNorm (clip/model.py:153-159), the residual add of
+ * clip/model.py:186-187 - under the MFMAs of tile i + 1.  Same tiles, same K order, same epilogue arithmetic as the
+ * two-workgroups-per-CU kernel: results are bit-identical (tests/test_gpu_kernels.py::test_gemm_ws_equals_duo).  It does NOT beat
+ * that kernel (the epilogue's vector instructions take the same issue slots from the SIMD's matrix wave whichever wave runs them;
+ * both forms are bound by LDS bandwidth - DESIGN.md 4.1, profiles/NOTES.md round 5), so enabled = 0 is the default (HGR_WS=1 / this
+ * call switch it on: A/B runs, tests).  Process-wide development knob like hgr_gemm_set_tile.  Returns the previous setting.
+ */
+int hgr_gemm_set_ws(int enabled);
+
+/*
  * Patch extraction for the ViT stem: image fp32 NCHW [B,3,R,R] -> rows [B*g*g, Kp] of 16-bit
  * values, g = R/P, row (b, gy, gx) holds the patch in (c, py, px) order = conv1.weight.reshape(W,-1)
  * order, zero-padded from 3*P*P to Kp (Kp % 64 == 0).  With hgr_gemm_nt this replaces

@@ -1008,3 +1008,91 @@ def test_gemm_ln_mha_equals_gemm_then_mha(dt, b, l, heads, causal):
         ref = clip_ref.mha(h, sd, "p.attn", heads, causal, clip_ref.identity).reshape(m, w)
         tol = dict(rtol=2e-2, atol=3e-2) if dt == torch.bfloat16 else dict(rtol=3e-3, atol=4e-3)
         assert torch.allclose(got.float().cpu(), ref, **tol), float((got.float().cpu() - ref).abs().max())
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_gemm_ws_equals_duo(dt):
+    """Round 5: the role-split kernel (csrc/hgr_gemm_ws.hip: four matrix waves + four helper waves per CU, the epilogue of tile i
+    under the MFMAs of tile i + 1; hgr_gemm_set_ws, off by default) gives the bits of gemm_nt_duo through every entry point it
+    covers - hgr_gemm_nt (NONE / BIAS / BIAS_RELU, 16-bit out), hgr_gemm_nt_ln (+- QuickGELU), hgr_gemm_nt_res_stats_guard (pair,
+    slot statistics, guard flag) - on launches of several tiles per workgroup (persistent walk, dump hand-over, counted waits)."""
+    from hgr_net_amd import _lib
+    from hgr_net_amd._lib import EPI_BIAS_RELU
+    lib = _lib.load()
+    g = torch.Generator(device=DEV).manual_seed(11)
+
+    def both(fn):
+        outs = []
+        for on in (0, 1):
+            prev = lib.hgr_gemm_set_ws(on)
+            try:
+                outs.append(fn())
+            finally:
+                lib.hgr_gemm_set_ws(prev)
+        torch.cuda.synchronize()
+        return outs
+
+    def mk(m, n, k):
+        a = (torch.rand(m, k, device=DEV, generator=g) * 2 - 1).to(dt)
+        w = ((torch.rand(n, k, device=DEV, generator=g) * 2 - 1) * 0.05).to(dt)
+        return a, w
+
+    # hgr_gemm_nt: 768 tiles on 256 CUs = 3 per workgroup; K = 768 (12 K-tiles: no plain-loop iteration) and 1024 (two)
+    for (m, n, k), epi in (((8192, 3072, 768), EPI_NONE), ((16384, 1536, 1024), EPI_BIAS), ((8192, 3072, 768), EPI_BIAS_RELU)):
+        a, w = mk(m, n, k)
+        bias = None if epi == EPI_NONE else torch.rand(n, device=DEV, generator=g) - 0.5
+
+        def run():
+            out = torch.full((m, n), float("nan"), dtype=dt, device=DEV)
+            ops.gemm_nt(a, w, out, bias=bias, epilogue=epi)
+            return out
+        o0, o1 = both(run)
+        assert torch.equal(o0.view(torch.int16), o1.view(torch.int16)), (m, n, k, epi)
+        ref = a.float() @ w.float().t() + (0 if bias is None else bias)
+        if epi == EPI_BIAS_RELU:
+            ref = ref.clamp_min(0)
+        assert torch.allclose(o1.float(), ref, rtol=2e-2, atol=2e-2)
+    # hgr_gemm_nt_ln: the folded-LayerNorm consumer, with and without QuickGELU
+    for (m, n, k), act in (((8192, 3072, 768), True), ((16384, 1536, 1024), False)):
+        a, w = mk(m, n, k)
+        s_, c_ = torch.rand(n, device=DEV, generator=g) - 0.5, torch.rand(n, device=DEV, generator=g) - 0.5
+        x = a.float().view(m, k // 64, 64)
+        stats = torch.stack([x.sum(-1), (x * x).sum(-1)], dim=-1).contiguous()
+
+        def run():
+            out = torch.full((m, n), float("nan"), dtype=dt, device=DEV)
+            ops.gemm_nt_ln(a, w, out, s_, c_, stats, quickgelu=act)
+            return out
+        o0, o1 = both(run)
+        assert torch.equal(o0.view(torch.int16), o1.view(torch.int16)), (m, n, k, act)
+    # hgr_gemm_nt_res_stats_guard: the residual producer (in place on the pair)
+    for m, n, k in ((25600, 768, 768), (16384, 1024, 3072)):
+        a, w = mk(m, n, k)
+        bias = torch.rand(n, device=DEV, generator=g) - 0.5
+        xh0 = (torch.rand(m, n, device=DEV, generator=g) * 4 - 2).to(dt)
+        xl0 = torch.randint(0, 256, (m, n), device=DEV, generator=g, dtype=torch.int32).to(torch.uint8)
+
+        def run():
+            xh, xl = xh0.clone(), xl0.clone()
+            st = torch.full((m, n // 64, 2), float("nan"), device=DEV)
+            flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+            ops.gemm_nt_res_stats(a, w, xh, xl, bias, st, flag=flag)
+            return xh, xl, st, flag
+        r0, r1 = both(run)
+        assert torch.equal(r0[0].view(torch.int16), r1[0].view(torch.int16)) and torch.equal(r0[1], r1[1]), (m, n, k)
+        assert torch.equal(r0[2].view(torch.int32), r1[2].view(torch.int32)) and int(r0[3]) == int(r1[3]) == 0, (m, n, k)
+    # the guard trips alike: one huge element in the old stream
+    m, n, k = 8192, 3072 // 4, 768
+    a, w = mk(m, n, k)
+    bias = torch.zeros(n, device=DEV)
+    xh0 = torch.zeros(m, n, dtype=dt, device=DEV)
+    xh0[4097, 300] = 30000.0
+
+    def run():
+        xh, xl = xh0.clone(), torch.full((m, n), 128, dtype=torch.uint8, device=DEV)
+        st = torch.empty((m, n // 64, 2), device=DEV)
+        flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+        ops.gemm_nt_res_stats(a, w, xh, xl, bias, st, flag=flag)
+        return int(flag)
+    f0, f1 = both(run)
+    assert f0 == f1 and f0 != 0
