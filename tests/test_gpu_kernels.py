@@ -1082,7 +1082,7 @@ def test_gemm_ws_equals_duo(dt):
         assert torch.equal(r0[0].view(torch.int16), r1[0].view(torch.int16)) and torch.equal(r0[1], r1[1]), (m, n, k)
         assert torch.equal(r0[2].view(torch.int32), r1[2].view(torch.int32)) and int(r0[3]) == int(r1[3]) == 0, (m, n, k)
     # the guard trips alike: one huge element in the old stream
-    m, n, k = 8192, 3072 // 4, 768
+    m, n, k = 16384, 768, 768                       # 384 tiles: covered by the role-split kernel
     a, w = mk(m, n, k)
     bias = torch.zeros(n, device=DEV)
     xh0 = torch.zeros(m, n, dtype=dt, device=DEV)
