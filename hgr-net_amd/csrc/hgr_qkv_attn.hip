@@ -86,9 +86,12 @@ __global__ __launch_bounds__(QA_NT) void qkv_attn(QkvAttnArgs p) {
         const int tm = tile / p.H;
         h = tile - tm * p.H;
         m0 = tm * rows_valid;
+        // opaque copy: every lane-derived term below is recomputed per tile instead of being kept live (and spilled) across the main loop
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const int id = (i * 8 + wave) * 64 + lane;
+            const int id = (i * 8 + wave) * 64 + ln;
             const int pr = id >> 3, c = (id & 7) ^ (pr & 7);
             if (i < 2) {
                 const int tr = (pr >> 5) * 64 + (pr & 31);
@@ -188,17 +191,18 @@ __global__ __launch_bounds__(QA_NT) void qkv_attn(QkvAttnArgs p) {
     const int nxt = cur + xwgs;
     const bool has_next = nxt < xcnt;
 
-    // the folded-LayerNorm vectors of this lane's columns: requested now, they travel beside the statistics loads below (loaded inside
-    // the store loop every n tile waited for its own L2 round trip: six in a row per tile) - and ahead of the next tile's DMAs, whose
-    // issue time (7 instructions) then hides a part of this round trip
-    f32x4 sq[6], cq[6];
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
+    // the folded-LayerNorm vectors of this lane's columns, two n tiles ahead of their use (round 5: all six pairs at once were 48
+    // registers on top of the 96 accumulators - the kernel spilled, and every reload waited with vmcnt(0) behind whatever stores were
+    // in flight); the first two pairs are requested here, beside the statistics loads and ahead of the next tile's DMAs
+    auto ln_vec = [&](int j, f32x4 &sv, f32x4 &cv) {
         const int col0 = wn * 96 + j * 16;                           // wave-uniform: part 0 = q, 1 = k, 2 = v; head dim d0 + 4 g + e
         const int gn = (col0 >> 6) * p.Wd + hc * 64 + (col0 & 63) + g * 4;
-        sq[j] = *(const f32x4 *)(p.ln_s + gn);
-        cq[j] = *(const f32x4 *)(p.ln_c + gn);
-    }
+        sv = *(const f32x4 *)(p.ln_s + gn);
+        cv = *(const f32x4 *)(p.ln_c + gn);
+    };
+    f32x4 sq[3], cq[3];                          // ring of three: n tile j in slot j % 3
+    ln_vec(0, sq[0], cq[0]);
+    ln_vec(1, sq[1], cq[1]);
     if (has_next) {
         set_tile(xbase + nxt);
         issueA(oA0, QA_PA0, 0); issueW(0);
@@ -206,8 +210,10 @@ __global__ __launch_bounds__(QA_NT) void qkv_attn(QkvAttnArgs p) {
     }
     // ---- LayerNorm row statistics of the tile's 256 rows (thread t < 256: row t), as the consumer GEMM finalises them ----
     float2 *lnrow = (float2 *)(smem + QA_LN);
-    if (tid < 256) {
-        const f32x4 *sp = (const f32x4 *)(p.ln_stats + (int64_t)min(m0c + tid, p.M - 1) * p.ln_slots * 2);
+    int tid_e = threadIdx.x;                     // (opaque: the row index of the statistics is recomputed here, not carried through the main loop)
+    asm volatile("" : "+v"(tid_e));
+    if (tid_e < 256) {
+        const f32x4 *sp = (const f32x4 *)(p.ln_stats + (int64_t)min(m0c + tid_e, p.M - 1) * p.ln_slots * 2);
         float s1 = 0.f, s2 = 0.f;
         auto fixed = [&](auto nq_tag) {
             constexpr int NQ = decltype(nq_tag)::value;
@@ -226,22 +232,25 @@ __global__ __launch_bounds__(QA_NT) void qkv_attn(QkvAttnArgs p) {
             default:
                 for (int i = 0; i < p.ln_slots / 2; ++i) { const f32x4 t = sp[i]; s1 += t[0] + t[2]; s2 += t[1] + t[3]; }
         }
-        lnrow[tid] = ln_finalize(s1, s2, 1.0f / (float)p.K, p.ln_eps);
+        lnrow[tid_e] = ln_finalize(s1, s2, 1.0f / (float)p.K, p.ln_eps);
     }
     __syncthreads();
 
     // ---- q / k / v of the tile, rounded to the MFMA type, into LDS ----
+    float2 mrq[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = wm * 64 + i * 16 + r;
-        const float2 mr = lnrow[row];
+    for (int i = 0; i < 4; ++i) mrq[i] = lnrow[wm * 64 + i * 16 + r];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const int col0 = wn * 96 + j * 16;
-            const int part = col0 >> 6, d = (col0 & 63) + g * 4;
+    for (int j = 0; j < 6; ++j) {
+        if (j + 2 < 6) ln_vec(j + 2, sq[(j + 2) % 3], cq[(j + 2) % 3]);
+        const int col0 = wn * 96 + j * 16;
+        const int part = col0 >> 6, d = (col0 & 63) + g * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = wm * 64 + i * 16 + r;
             f32x4 v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = ln_apply(mr, acc[i][j][e], sq[j][e], cq[j][e]);
+            for (int e = 0; e < 4; ++e) v[e] = ln_apply(mrq[i], acc[i][j][e], sq[j % 3][e], cq[j % 3][e]);
             // branch-free destination: V rows are 144 bytes, row-major; Q / K rows 128 bytes with the chunk swizzle of the fragment reads
             const int base = part == 2 ? QA_V : part ? QA_K : QA_Q;
             const int at = part == 2 ? row * (QA_VR * 2) + d * 2 : row * 128 + (((d >> 3) ^ (row & 7)) * 16) + (d & 4) * 2;
@@ -251,6 +260,9 @@ __global__ __launch_bounds__(QA_NT) void qkv_attn(QkvAttnArgs p) {
     __syncthreads();
 
     // ---- attention: query tile qt = rows 16 qt .. 16 qt + 15 of the tile; wave w takes tiles w and w + 8 ----
+    // (round 5, measured and not kept: the (query tile, sequence) units dealt round-robin over the waves and worked two or three at a
+    // time with interleaved instruction streams - 114 us -> 115 / 118 us per launch, one at a time 120: the phase is not bound by the
+    // latency of a unit's dependent chain; profiles/NOTES.md)
     constexpr int KT = 2;              // 64 key slots: L <= 64
     const E *sV = (const E *)(smem + QA_V);
     for (int qt = wave; qt * 16 < rows_valid; qt += 8) {
