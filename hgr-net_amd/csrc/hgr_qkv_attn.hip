@@ -203,13 +203,13 @@ __global__ __launch_bounds__(QA_NT) void qkv_attn(QkvAttnArgs p) {
     f32x4 sq[3], cq[3];                          // ring of three: n tile j in slot j % 3
     ln_vec(0, sq[0], cq[0]);
     ln_vec(1, sq[1], cq[1]);
-    if (has_next) {
-        set_tile(xbase + nxt);
-        issueA(oA0, QA_PA0, 0); issueW(0);
-        issueA(oA1, QA_PA1, 0);
-    }
-    // ---- LayerNorm row statistics of the tile's 256 rows (thread t < 256: row t), as the consumer GEMM finalises them ----
-    float2 *lnrow = (float2 *)(smem + QA_LN);
+    // ---- LayerNorm row statistics of the tile's 256 rows (thread t and t + 256: row t), as the consumer GEMM finalises them ----
+    // They are loaded, summed and written BEFORE the next tile's DMAs are issued (round 5): vmcnt retires in issue order, so behind
+    // the DMAs the wait for the statistics was a wait for the next tile's whole first K-tile.  And every LDS access from here to the
+    // barrier in front of the attention phase is inline asm: hipcc orders an LDS access it can see behind ALL LDS-DMAs in flight
+    // (vmcnt(0)) - the DMAs now land under the q / k / v conversion instead of being waited for in front of it.
+    typedef __attribute__((ext_vector_type(2))) float qa_f2;
+    const unsigned lnrow_a = (unsigned)(uintptr_t)(AS3 char *)(smem + QA_LN);
     int tid_e = threadIdx.x;                     // (opaque: the row index of the statistics is recomputed here, not carried through the main loop)
     asm volatile("" : "+v"(tid_e));
     if (tid_e < 256) {
@@ -232,14 +232,17 @@ __global__ __launch_bounds__(QA_NT) void qkv_attn(QkvAttnArgs p) {
             default:
                 for (int i = 0; i < p.ln_slots / 2; ++i) { const f32x4 t = sp[i]; s1 += t[0] + t[2]; s2 += t[1] + t[3]; }
         }
-        lnrow[tid_e] = ln_finalize(s1, s2, 1.0f / (float)p.K, p.ln_eps);
+        const float2 mr = ln_finalize(s1, s2, 1.0f / (float)p.K, p.ln_eps);
+        const qa_f2 mv = {mr.x, mr.y};
+        asm volatile("ds_write_b64 %0, %1" ::"v"(lnrow_a + tid_e * 8), "v"(mv) : "memory");
     }
-    __syncthreads();
+    HGR_RBAR();
 
     // ---- q / k / v of the tile, rounded to the MFMA type, into LDS ----
-    float2 mrq[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) mrq[i] = lnrow[wm * 64 + i * 16 + r];
+    qa_f2 mrv[4];
+    asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:128\n\tds_read_b64 %2, %4 offset:256\n\tds_read_b64 %3, %4 offset:384\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(mrv[0]), "=&v"(mrv[1]), "=&v"(mrv[2]), "=&v"(mrv[3]) : "v"(lnrow_a + (wm * 64 + r) * 8) : "memory");
+    const unsigned smem_a = (unsigned)(uintptr_t)(AS3 char *)smem;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
         if (j + 2 < 6) ln_vec(j + 2, sq[(j + 2) % 3], cq[(j + 2) % 3]);
@@ -248,16 +251,27 @@ __global__ __launch_bounds__(QA_NT) void qkv_attn(QkvAttnArgs p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = wm * 64 + i * 16 + r;
+            const float2 mri = make_float2(mrv[i][0], mrv[i][1]);
             f32x4 v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = ln_apply(mrq[i], acc[i][j][e], sq[j % 3][e], cq[j % 3][e]);
+            for (int e = 0; e < 4; ++e) v[e] = ln_apply(mri, acc[i][j][e], sq[j % 3][e], cq[j % 3][e]);
             // branch-free destination: V rows are 144 bytes, row-major; Q / K rows 128 bytes with the chunk swizzle of the fragment reads
             const int base = part == 2 ? QA_V : part ? QA_K : QA_Q;
             const int at = part == 2 ? row * (QA_VR * 2) + d * 2 : row * 128 + (((d >> 3) ^ (row & 7)) * 16) + (d & 4) * 2;
-            *(vec4 *)(smem + base + at) = cvt4<DT>(v[0], v[1], v[2], v[3]);
+            const u32x2 pk = __builtin_bit_cast(u32x2, cvt4<DT>(v[0], v[1], v[2], v[3]));
+            asm volatile("ds_write_b64 %0, %1" ::"v"(smem_a + base + at), "v"(pk) : "memory");
         }
     }
-    __syncthreads();
+    if (has_next) {
+        // (persistent) the next tile's first K-tile is requested into stage 0, which the attention phase below does not touch - HERE,
+        // behind the last wait for a global load of the epilogue: hipcc's counts for ordinary loads leave the LDS-DMAs out, so a wait
+        // for ANY load issued around the DMAs is a wait for the DMAs (vmcnt retires in issue order)
+        __builtin_amdgcn_sched_barrier(0);
+        set_tile(xbase + nxt);
+        issueA(oA0, QA_PA0, 0); issueW(0);
+        issueA(oA1, QA_PA1, 0);
+    }
+    HGR_RBAR();
 
     // ---- attention: query tile qt = rows 16 qt .. 16 qt + 15 of the tile; wave w takes tiles w and w + 8 ----
     // (round 5, measured and not kept: the (query tile, sequence) units dealt round-robin over the waves and worked two or three at a
