@@ -254,12 +254,16 @@ def dp_check_eval(model, ev, group, world: int, rank: int, elapsed_local: float,
             "num_sample_per_rank": [l[-1] for l in locals_], "ms_per_step_min": round(min(ms), 3), "ms_per_step_max": round(max(ms), 3)}
 
 
-def run_secondary(args_extra, timeout_s: int):
+HOST_PROBE_RANKS = 4            # ranks of the host-time probe: a GPU box admits at most 6 processes on its card, and this process is one of them
+
+
+def run_secondary(args_extra, timeout_s: int, env_extra=None, keep_extra=()):
     """One of the other BASELINE configs as a CHILD process of this (finished) measurement: `python bench.py <args> --secondary`;
     its single JSON line, reduced to the fields a reader needs.  Never raises: a failure is reported in place."""
     import subprocess
     cmd = [sys.executable, str(Path(__file__).resolve())] + args_extra + ["--secondary"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(env_extra or {})
     t0 = time.time()
     try:
         p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout_s, env=env)
@@ -270,7 +274,7 @@ def run_secondary(args_extra, timeout_s: int):
         return {"error": f"rc {p.returncode}", "stderr_tail": p.stderr[-400:], "cmd": " ".join(args_extra)}
     d = json.loads(lines[0])
     keep = ("metric", "value", "unit", "ms_per_step", "step_ms", "steps", "warmup", "dtype", "config", "roofline", "parity", "metrics_string", "loss_first", "loss_last",
-            "peak_memory_gib", "cpu_baseline")
+            "peak_memory_gib", "cpu_baseline") + tuple(keep_extra)
     out = {k: d[k] for k in keep if k in d}
     out["wall_s"] = round(time.time() - t0, 1)
     out["cmd"] = "python bench.py " + " ".join(args_extra)
@@ -459,6 +463,7 @@ def main():
     ap.add_argument("--no-c1", dest="c1", action="store_false", help="skip the BASELINE configs[0] CPU line (RN50, N=1000, batch 32)")
     ap.add_argument("--no-secondary", dest="secondary", action="store_false", help="default run only: skip the configs[2] / configs[4] child measurements")
     ap.add_argument("--secondary", dest="is_secondary", action="store_true", help="(internal) this process IS a secondary child: no grandchildren")
+    ap.add_argument("--no-host-probe", dest="host_probe", action="store_false", help="default run only: skip the multi-process host-time probe")
     a = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -569,20 +574,24 @@ def main():
         step(i)
     fence()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
+    host_s = 0.0                               # wall time the HOST spends inside step() - Python, two graph launches, Evaluator bookkeeping
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(a.steps):
+        th = time.perf_counter()
         step(a.warmup + i)
+        host_s += time.perf_counter() - th     # (no device sync inside: the queue is a few steps deep, the device is the slower side)
         marks[i + 1].record()                  # stream-ordered marker, no host wait: per-step p50 / p95 beside the loop mean
     fence()
     elapsed = time.perf_counter() - t0
     elapsed_local = elapsed
     step_ms = step_time_stats(marks)
+    host_ms = host_s / a.steps * 1e3
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, host_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, host_ms = float(t[0].item()), float(t[1].item())
     ms = elapsed / a.steps * 1e3
     value = a.batch * world * a.steps / elapsed
     dp_check = dp_check_eval(model, ev, group, world, rank, elapsed_local, a.steps, dev) if world > 1 else None
@@ -803,6 +812,7 @@ def main():
         line = {"metric": "images/sec over 21K-class hierarchy, batch 512; hit@1 parity vs reference",
                 "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "ranks_seen": ranks_seen, "steps": a.steps, "warmup": a.warmup,
                 "ms_per_step": round(ms, 3), "step_ms": step_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "host_ms_per_step": round(host_ms, 3),       # max over ranks: what one rank's host thread spends per step (no device sync)
                 "dtype": a.image_dtype, "data": "synthetic",
                 "config": {"arch": a.arch, "nodes": a.nodes, "batch_per_gpu": a.batch, "embed_dim": cfg["embed_dim"],
                            "workload": f"{a.arch} zero-shot eval step: encode_image + L2 + [{a.batch}x{cfg['embed_dim']}]x[{cfg['embed_dim']}x{a.nodes}] logits "
@@ -819,6 +829,19 @@ def main():
             if not dp_check["ok"]:
                 log(f"[bench] dp_check FAILED: {json.dumps(dp_check)}")
         default_run = a.arch == ARCH and a.batch == BATCH and a.nodes == N_NODES and world == 1 and group is None
+        if a.host_probe and not a.is_secondary and default_run:
+            # 8-GPU readiness that one GPU can show: the per-rank HOST cost of a step with several ranks' processes sharing the box's
+            # cores (an 8-GPU node runs 8 of these next to each other; what caps weak scaling is a host that cannot keep 8 queues
+            # fed).  HOST_PROBE_RANKS ranks time-share THIS GPU over gloo (HGR_TEST_ONE_GPU=1: RCCL refuses two ranks per device, and
+            # a GPU box admits at most 6 processes on its card - this one included), so their ms_per_step means nothing - host_ms_per_step does.
+            log(f"[bench] host probe: {HOST_PROBE_RANKS} ranks time-sharing the GPU (gloo), host time per step")
+            hp = run_secondary(["--gpus", str(HOST_PROBE_RANKS), "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-pcie", "--no-c1", "--no-plant"], 300,
+                               env_extra={"HGR_TEST_ONE_GPU": "1"}, keep_extra=("host_ms_per_step", "n_gpus"))
+            line["host_probe"] = {"ranks": HOST_PROBE_RANKS, "host_ms_per_step": hp.get("host_ms_per_step"), "host_cores": os.cpu_count(),
+                                  "share_of_step": round(hp["host_ms_per_step"] / ms, 3) if hp.get("host_ms_per_step") else None,
+                                  "note": f"max over {HOST_PROBE_RANKS} concurrent ranks on this host's cores; the GPU is time-shared, so only the host figure is meaningful",
+                                  **({"error": hp["error"], "stderr_tail": hp.get("stderr_tail")} if "error" in hp else {})}
+            line[f"host_ms_per_step_{HOST_PROBE_RANKS}proc"] = hp.get("host_ms_per_step")
         if a.secondary and not a.is_secondary and default_run:
             # BASELINE configs[2] and configs[4] beside the headline, each as a child process after the headline measurement is over
             # (its memory is released first): same harness, own JSON line, reduced here
