@@ -739,6 +739,15 @@ def main():
         dimg_c = img_c.to(dev)
         lg_g = model(dimg_c, None).float().cpu()
         err = float((lg_g - lg_c).abs().max())
+        # where that error comes from (round 5): the class-logits GEMM rounds BOTH operands to 16 bits (unit features, unit class rows);
+        # against the fp32 product of the SAME fp32 features and class matrix that is the operand-rounding share, the rest is the image
+        # tower (the oracle is handed this model's class matrix, so the text tower does not enter)
+        f32 = model.clip_model.encode_image(dimg_c).float()
+        f32 = f32 / f32.norm(dim=1, keepdim=True)
+        lg_f32 = (f32 @ model.zsl_weights.float().t()).cpu()
+        err_split = {"operand_rounding_of_the_logits_gemm": round(float((lg_g - lg_f32).abs().max()), 7),
+                     "image_tower_features": round(float((lg_f32 - lg_c).abs().max()), 7),
+                     "rms": {"operand_rounding": round(float((lg_g - lg_f32).pow(2).mean().sqrt()), 8), "image_tower": round(float((lg_f32 - lg_c).pow(2).mean().sqrt()), 8)}}
         te = model.test_index.cpu()
         # target classes of the parity batches: the step targets with the largest planted weight (so that hits, paths and points
         # actually occur) plus the first timed step's own; the same images are evaluated once per target class
@@ -795,7 +804,7 @@ def main():
         same = pred_g[:, 0] == pred_o[:, 0]
         same20 = (pred_g == pred_o).all(dim=1)
         string_g, string_o = ev_p.summary().strip(), st.summary().strip()
-        parity = {"images": int(img_c.shape[0]), "max_abs_logit_err": round(err, 6), "tolerance": 1e-3,
+        parity = {"images": int(img_c.shape[0]), "max_abs_logit_err": round(err, 6), "tolerance": 1e-3, "logit_err_decomposition": err_split,
                   "ids_from": "hgr_logits_eval (the timed, fused route)" if fused_eval else "hgr_eval_rows on forward() logits",
                   "hit1_equal": int(same.sum()), "hit1_decidable": int(decidable.sum()), "hit1_equal_decidable": int((same & decidable).sum()),
                   "top20_rows_equal": int(same20.sum()), "top20_rows_decidable": int(dec20.sum()), "top20_rows_equal_decidable": int((same20 & dec20).sum()),

@@ -849,7 +849,10 @@ __global__ __launch_bounds__(NTD, 2) void gemm_nt_duo(GemmArgs p) {
     if constexpr (PERSIST) {
         for (int vb = (int)blockIdx.x; vb < total; vb += (int)gridDim.x) {
             one_tile(vb);
-            if (vb + (int)gridDim.x < total) __syncthreads();   // every wave's epilogue has left the LDS staging slices: the next tile's DMAs may land
+            // every wave's epilogue has left the LDS staging slices: the next tile's DMAs may land.  A RAW barrier (round 5): __syncthreads()
+            // also drains vmcnt here - the workgroup waited for every store of the tile's read-modify-write to be acknowledged before the
+            // next tile's first loads were even issued, the opposite of what the persistent form is for
+            if (vb + (int)gridDim.x < total) HGR_RBAR();
         }
     } else one_tile((int)blockIdx.x);
 }
