@@ -586,12 +586,25 @@ def main():
     elapsed = time.perf_counter() - t0
     elapsed_local = elapsed
     step_ms = step_time_stats(marks)
-    host_ms = host_s / a.steps * 1e3
+    host_ms_loop = host_s / a.steps * 1e3
+    # ... inside the loop that figure includes BACK-PRESSURE: a HIP graph cannot be launched again while its previous replay is running,
+    # and the steps alternate two graph pairs - the host runs at most two steps ahead and then waits in hipGraphLaunch, so in steady
+    # state it reads ~ms_per_step whatever the host's own cost is.  The host's own cost: pairs of steps (one of each parity) behind
+    # a fence, when nothing blocks
+    host_free = []
+    for rep in range(4):
+        fence()
+        th = time.perf_counter()
+        step(a.warmup + 2 * rep)
+        step(a.warmup + 2 * rep + 1)
+        host_free.append((time.perf_counter() - th) / 2 * 1e3)
+    fence()
+    host_ms = sorted(host_free)[len(host_free) // 2]
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([elapsed, host_ms], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, host_ms, host_ms_loop], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, host_ms = float(t[0].item()), float(t[1].item())
+        elapsed, host_ms, host_ms_loop = float(t[0].item()), float(t[1].item()), float(t[2].item())
     ms = elapsed / a.steps * 1e3
     value = a.batch * world * a.steps / elapsed
     dp_check = dp_check_eval(model, ev, group, world, rank, elapsed_local, a.steps, dev) if world > 1 else None
@@ -665,8 +678,9 @@ def main():
                 f16 = torch.empty((a.batch, cfg["embed_dim"]), dtype=model._zsl16.dtype, device=dev)
                 for _ in range(5):
                     ops.l2norm_rows(model.clip_model.encode_image(batches[0]), y16=f16)
-                    ops.logits_eval(f16, ev._plan, 20, stage="tile")
-                    ops.logits_eval(f16, ev._plan, 20, stage="row")
+                    fin = f16 if ev._plan.zsl.shape[1] == f16.shape[1] else torch.cat([f16, f16], dim=1).contiguous()     # (HGR_LOGITS_SPLIT: K doubled)
+                    ops.logits_eval(fin, ev._plan, 20, stage="tile")
+                    ops.logits_eval(fin, ev._plan, 20, stage="row")
                 torch.cuda.synchronize()
                 st, ops.PROFILE = ops.PROFILE, None
                 for nm in ("tile", "row"):
@@ -821,7 +835,9 @@ def main():
         line = {"metric": "images/sec over 21K-class hierarchy, batch 512; hit@1 parity vs reference",
                 "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "ranks_seen": ranks_seen, "steps": a.steps, "warmup": a.warmup,
                 "ms_per_step": round(ms, 3), "step_ms": step_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "host_ms_per_step": round(host_ms, 3),       # max over ranks: what one rank's host thread spends per step (no device sync)
+                # max over ranks: what one rank's host thread spends per step when nothing blocks it (Python + two graph launches + Evaluator
+                # bookkeeping; median of 4 unblocked pairs) / the same inside the timed loop, where graph re-launch back-pressure is included
+                "host_ms_per_step": round(host_ms, 3), "host_ms_per_step_in_loop": round(host_ms_loop, 3),
                 "dtype": a.image_dtype, "data": "synthetic",
                 "config": {"arch": a.arch, "nodes": a.nodes, "batch_per_gpu": a.batch, "embed_dim": cfg["embed_dim"],
                            "workload": f"{a.arch} zero-shot eval step: encode_image + L2 + [{a.batch}x{cfg['embed_dim']}]x[{cfg['embed_dim']}x{a.nodes}] logits "

@@ -33,6 +33,11 @@ TEMPLATE = "a photo of a {}."     # data/templates.py TEMPLATES_SIMPLE[0], the o
 # Evaluation steps as a two-stage pipeline (forward_eval_overlapped): the class-token tail of step i beside the head of step i + 1.
 # HGR_TAIL_OVERLAP=0 (or clip_tree.TAIL_OVERLAP = False) keeps every step one graph on one stream.
 TAIL_OVERLAP = os.environ.get("HGR_TAIL_OVERLAP", "1") != "0"
+# Measurement option (round 5, off by default): feed hgr_logits_eval one operand of the class-logits product at ~22 bits instead of
+# 11 by concatenation along K - "class": [f | f] . [z_hi | z_lo]^T = f . (z_hi + z_lo), "feat": [f_hi | f_lo] . [z | z]^T - i.e. remove
+# that operand's 16-bit rounding from the logits at twice the tile stage's K (embedding widths <= 512).  bench.py's parity block shows
+# what the index comparisons gain (profiles/NOTES.md, round 5).
+LOGITS_SPLIT = os.environ.get("HGR_LOGITS_SPLIT", "")
 
 
 class _StopHead(Exception):
@@ -164,7 +169,7 @@ class tree_model(nn.Module):
         if self._zsl16 is None:
             raise HgrError("call update_classifier() before forward_eval()")
         self.join_tail()
-        plan.bind(self._zsl16)
+        plan.bind(self._eval_class_operand())
         if self.use_graph and inputs.is_cuda:
             return self._forward_graphed(inputs, True, ("eval", plan, k))
         return self._forward_eager(inputs, ("eval", plan, k))
@@ -277,7 +282,7 @@ class tree_model(nn.Module):
             # the sliced image tower (HGR_IMG_STREAMS >= 2) names its workspace sets "v", "v1", ... itself and ignores _img_tag: both
             # step parities would share one set and the tail of step i would race with the head of step i + 1
             return False
-        plan.bind(self._zsl16)
+        plan.bind(self._eval_class_operand())
         mode = ("eval", plan, k)
         st = self._pipe_state(inputs.device)
         self.clip_model.poll_ln_guard()
@@ -351,10 +356,28 @@ class tree_model(nn.Module):
             out = self._forward_eager(inputs, mode)
         return g, out
 
+    def _eval_class_operand(self):
+        """The 16-bit class matrix hgr_logits_eval multiplies with: `_zsl16`, or with HGR_LOGITS_SPLIT its K-concatenated form."""
+        split = LOGITS_SPLIT if (LOGITS_SPLIT in ("class", "feat") and 2 * self._zsl16.shape[1] <= 1024) else ""
+        if not split:
+            return self._zsl16
+        key = (split, self._zsl16.data_ptr(), self._zsl16._version, self.zsl_weights.data_ptr(), self.zsl_weights._version)
+        if getattr(self, "_zsl_split_key", None) != key:
+            z16 = self._zsl16
+            second = (self.zsl_weights.float() - z16.float()).to(z16.dtype) if split == "class" else z16
+            self._zsl_split, self._zsl_split_key = torch.cat([z16, second], dim=1).contiguous(), key
+        return self._zsl_split
+
     def _forward_eager(self, inputs, mode=None):
         feats = self.clip_model.encode_image(inputs)
         b, n = feats.shape[0], self._zsl16.shape[0]
         f16 = torch.empty(feats.shape, dtype=self._zsl16.dtype, device=feats.device)
+        if mode is not None and mode[1].zsl is not None and mode[1].zsl.shape[1] == 2 * feats.shape[1]:
+            # HGR_LOGITS_SPLIT: the features at twice the width to match the K-concatenated class matrix
+            f32 = torch.empty_like(feats)
+            ops.l2norm_rows(feats, y16=f16, y32=f32)
+            second = (f32 - f16.float()).to(f16.dtype) if LOGITS_SPLIT == "feat" else f16
+            return ops.logits_eval(torch.cat([f16, second], dim=1).contiguous(), mode[1], mode[2])
         ops.l2norm_rows(feats, y16=f16)
         if mode is not None:                                    # ("eval", plan, k): logits GEMM + evaluation fused, no logits written
             return ops.logits_eval(f16, mode[1], mode[2])
