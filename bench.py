@@ -592,13 +592,19 @@ def main():
     # state it reads ~ms_per_step whatever the host's own cost is.  The host's own cost: pairs of steps (one of each parity) behind
     # a fence, when nothing blocks
     host_free = []
+    fence()
+    acc_keep = ev.acc.clone()                  # (these extra steps must not enter the counters the line and dp_check report)
     for rep in range(4):
         fence()
         th = time.perf_counter()
-        step(a.warmup + 2 * rep)
-        step(a.warmup + 2 * rep + 1)
+        step(a.warmup + (2 * rep) % a.steps)
+        step(a.warmup + (2 * rep + 1) % a.steps)
         host_free.append((time.perf_counter() - th) / 2 * 1e3)
     fence()
+    if hasattr(model, "join_tail"):
+        model.join_tail()
+    torch.cuda.synchronize()
+    ev.acc.copy_(acc_keep)
     host_ms = sorted(host_free)[len(host_free) // 2]
     if world > 1:
         import torch.distributed as dist
