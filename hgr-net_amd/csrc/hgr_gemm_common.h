@@ -198,6 +198,25 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, const char *b
     asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
 
+// 16 MFMAs of a phase interleaved with NR LDS reads, NW LDS writes and NV vector-memory instructions (LDS-DMAs) that do not depend on
+// them: the scheduler is told to issue them in the gaps between MFMAs instead of in a block in front (gemm_nt_ws, -DHGR_DUO_PF=1)
+template <int NR, int NW, int NV, int M_, int NM = 16>
+__device__ __forceinline__ void mfma16_interleave_step() {
+    if constexpr (M_ < NM) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        constexpr int DR = (M_ + 1) * NR / NM - M_ * NR / NM, DW = (M_ + 1) * NW / NM - M_ * NW / NM, DV = (M_ + 1) * NV / NM - M_ * NV / NM;
+        if constexpr (DR > 0) __builtin_amdgcn_sched_group_barrier(0x100, DR, 0);
+        if constexpr (DW > 0) __builtin_amdgcn_sched_group_barrier(0x200, DW, 0);
+        if constexpr (DV > 0) __builtin_amdgcn_sched_group_barrier(0x020, DV, 0);
+        mfma16_interleave_step<NR, NW, NV, M_ + 1, NM>();
+    }
+}
+template <int NR, int NW, int NV>
+__device__ __forceinline__ void mfma16_interleave() { mfma16_interleave_step<NR, NW, NV, 0>(); }
+// the same over 8 MFMAs (one k half of a phase)
+template <int NR, int NW, int NV>
+__device__ __forceinline__ void mfma8_interleave() { mfma16_interleave_step<NR, NW, NV, 0, 8>(); }
+
 // ---- launchers, one per translation unit (the kernels are templates; host code selects by value) ------------------------
 enum { V128_PLAIN = 0, V128_TALL = 1, V128_CONV = 2, V128_CONV_TALL = 3 };
 // gemm_nt_128 family.  PLAIN: epi any (K == 64 with 16-bit bias epilogues takes the one-stage variant); TALL: 256 x 64 tiles,

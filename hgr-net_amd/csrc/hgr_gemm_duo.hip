@@ -99,6 +99,9 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
         return p.A + ((int64_t)(ky * p.cW + kx) * p.cC + (kq0 - tap * p.cC)) * 2;
     };
     auto issueA = [&](const unsigned (&off)[4], const unsigned (&vm)[CONV ? 4 : 1], int slot_base, int t, int h) {
+        // (HGR_GEMM_DBG, timing experiments only, wrong results: 128 = no A pieces of odd K-tiles - what sharing the A panel between two
+        // column tiles would save in LDS-DMA issue; 256 = no A pieces, 512 = no W pieces behind the first two K-tiles)
+        if (((p.dbg & 128) && (t & 1) && t > 1) || ((p.dbg & 256) && t > 1)) return;
         char *dst = ldsw + slot_base + (t & 1) * 16384;
         if (CONV) {
             int tap;
@@ -115,6 +118,7 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
         for (int i = 2 * h; i < 2 * h + 2; ++i) dma16(rA, p.A, off[i], t * 128, dst + i * 4096);
     };
     auto issueW = [&](const unsigned (&off)[2], int slot_base, int t) {
+        if ((p.dbg & 512) && t > 1) return;
         char *dst = ldsw + slot_base;
 #pragma unroll
         for (int i = 0; i < 2; ++i) dma16(rW, p.W, off[i], t * 128, dst + i * 4096);
@@ -166,7 +170,128 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
     const int offW = (wn * 32 + r) * 128;      // + n tile * 2048, within pieces W0 / W1
     const int sw0 = ((0 + g) ^ (r & 7)) * 16, sw1 = ((4 + g) ^ (r & 7)) * 16;
     vec8 af[4][2], wf0[2][2], wf1[2][2];
-    if constexpr (MH == 2) {
+    // Fragment PREFETCH form of the main loop (round 5), compiled into the folded-LayerNorm consumers (LN = 2: c_fc, in_proj, the
+    // k / v projection of the last block): measured in the ViT-B/32 step, same box, three interleaved pairs: c_fc 140.4 / 140.1 / 139.3
+    // -> 136.9 / 137.0 / 136.5 us, kv 73.5 -> 70.8; the residual producers and the patch GEMM lose 2 - 4 % with it (their epilogue
+    // and tail plan want the registers), so they keep the loop below.  -DHGR_DUO_PF=1 compiles it into every instantiation, =0 into none.
+#ifndef HGR_DUO_PF
+#define HGR_DUO_PF 2
+#endif
+    constexpr bool PF_BUILD = HGR_DUO_PF == 1 || (HGR_DUO_PF == 2 && LN == 2);
+    const bool pf_tile = MH == 2 && !CONV && PF_BUILD && m0 + 256 <= p.M && n0 + 128 <= p.N && (p.K & 127) == 0 && p.K >= 256;
+    if (pf_tile) {
+      if constexpr (MH == 2 && !CONV && PF_BUILD) {
+        // The main loop of gemm_nt_ws's matrix waves inside the two-workgroup kernel - fragments
+        // prefetched ONE PHASE AHEAD into a second register set (Gray-code quadrant walk alternating between even and odd K-tiles: four
+        // fragment sets), reads / DMA issue interleaved with the MFMAs, so that no MFMA burst starts with a wait for its own LDS reads.
+        //     ph1: Q(X, W0)   prefetch Y(t)                issues W0(t+1) x2, X'(t+2) x4     wait: W1(t) landed      (vmcnt 6)
+        //     ph2: Q(Y, W0)   prefetch W1(t)               issues Y'(t+2) x4
+        //     ph3: Q(Y, W1)                                issues W1(t+1) x2                 wait: W0(t+1) landed    (vmcnt 10)
+        //     ph4: Q(X, W1)   prefetch W0(t+1), X(t+1)
+        // (even t: X = A0, Y = A1; odd t: X = A1, Y = A0; X' / Y' = the piece kinds read in ph4(t+1) / ph1(t+2))
+        vec8 afB[4][2];
+        auto &afA = af;
+        auto rdW = [&](vec8 (&wf)[2][2], int base) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                wf[j][0] = *(const vec8 *)(smem + base + offW + j * 2048 + sw0);
+                wf[j][1] = *(const vec8 *)(smem + base + offW + j * 2048 + sw1);
+            }
+        };
+        auto rdA = [&](vec8 (&a)[4][2], int base) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i][0] = *(const vec8 *)(smem + base + offA + i * 2048 + sw0);
+                a[i][1] = *(const vec8 *)(smem + base + offA + i * 2048 + sw1);
+            }
+        };
+        auto rdA2 = [&](vec8 (&a)[4][2], int base, int h) {           // m tiles 2 h, 2 h + 1 of a set
+#pragma unroll
+            for (int i = 2 * h; i < 2 * h + 2; ++i) {
+                a[i][0] = *(const vec8 *)(smem + base + offA + i * 2048 + sw0);
+                a[i][1] = *(const vec8 *)(smem + base + offA + i * 2048 + sw1);
+            }
+        };
+        // the 8 MFMAs of one k half of a quadrant (independent accumulators; the two halves are separate scheduling regions, so that the
+        // scheduler cannot put the two dependent MFMAs of an accumulator back to back)
+        auto mmk = [&](f32x4 (&q)[4][2], const vec8 (&wf)[2][2], const vec8 (&a)[4][2], int kk) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) q[i][j] = T16<DT>::mfma16(wf[j][kk], a[i][kk], q[i][j]);
+        };
+        // One lane offset per operand: instruction i of a piece reads piece rows 32 i + 8 wave + lane / 8, i.e. tile rows that differ from
+        // instruction 0's by a wave-uniform constant (A: 0, 32, 128, 160 rows, + 64 for A1; W: 0, 64 rows, + 32 for W1) - the constant
+        // rides in the scalar offset with the K advance (interior tiles: no row clamp).  2 address registers instead of 12.
+        const unsigned laneA = oA0[0], laneW = oW0[0];
+        const int rowA = (int)p.lda * 2, rowW = (int)p.ldw * 2;
+        auto pfA = [&](int half, int slot_base, int tt) {            // half 0 = piece A0 (m-half 0 rows), 1 = A1
+            char *dst = ldsw + slot_base + (tt & 1) * 16384;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dma16(rA, p.A, laneA, tt * 128 + ((i >> 1) * 128 + (i & 1) * 32 + half * 64) * rowA, dst + i * 4096);
+        };
+        auto pfW = [&](int half, int slot_base, int tt) {
+            char *dst = ldsw + slot_base;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) dma16(rW, p.W, laneW, tt * 128 + (i * 64 + half * 32) * rowW, dst + i * 4096);
+        };
+        // issue order of the steady state: ... A0(0), A1(0), W0(0) | A1(1), A0(1), W1(0)
+        pfA(0, DUO_A0, 0); pfA(1, DUO_A1, 0); pfW(0, DUO_W0, 0);
+        pfA(1, DUO_A1, 1); pfA(0, DUO_A0, 1); pfW(1, DUO_W1, 0);
+        HGR_RWAIT(10);              // A0(0), A1(0), W0(0) landed
+        rdW(wf0, DUO_W0);
+        rdA(afA, DUO_A0);
+        HGR_RBAR();
+        // MODE 0: t + 2 < nk, 1: t = nk - 2, 2: t = nk - 1
+        auto kt = [&](int t, auto odd_tag, auto mode_tag) __attribute__((always_inline)) {
+            constexpr bool ODD = decltype(odd_tag)::value;
+            constexpr int MODE = decltype(mode_tag)::value;
+            const int cb = (t & 1) * 16384, nb = ((t + 1) & 1) * 16384;      // this K-tile's / the next one's A buffer
+            // every phase = two scheduling regions (k half 0, k half 1): 8 MFMAs each with half of the phase's reads / DMAs in their gaps
+            // ---- ph1 ----
+            if (MODE <= 1) pfW(0, DUO_W0, t + 1);
+            if (ODD) { rdA2(afA, DUO_A0 + cb, 0); mmk(acc[1][0], wf0, afB, 0); } else { rdA2(afB, DUO_A1 + cb, 0); mmk(acc[0][0], wf0, afA, 0); }
+            if (MODE <= 1) mfma8_interleave<4, 0, 2>(); else mfma8_interleave<4, 0, 0>();
+            __builtin_amdgcn_sched_barrier(0);
+            if (MODE == 0) pfA(ODD ? 1 : 0, ODD ? DUO_A1 : DUO_A0, t + 2);
+            if (ODD) { rdA2(afA, DUO_A0 + cb, 1); mmk(acc[1][0], wf0, afB, 1); } else { rdA2(afB, DUO_A1 + cb, 1); mmk(acc[0][0], wf0, afA, 1); }
+            if (MODE == 0) mfma8_interleave<4, 0, 4>(); else mfma8_interleave<4, 0, 0>();
+            if (MODE == 0) HGR_RWAIT(6); else if (MODE == 1) HGR_RWAIT(2); else HGR_RWAIT(0);
+            // ---- ph2 ----
+            rdW(wf1, DUO_W1);
+            if (ODD) mmk(acc[0][0], wf0, afA, 0); else mmk(acc[1][0], wf0, afB, 0);
+            mfma8_interleave<4, 0, 0>();
+            __builtin_amdgcn_sched_barrier(0);
+            if (MODE == 0) pfA(ODD ? 0 : 1, ODD ? DUO_A0 : DUO_A1, t + 2);
+            if (ODD) mmk(acc[0][0], wf0, afA, 1); else mmk(acc[1][0], wf0, afB, 1);
+            if (MODE == 0) mfma8_interleave<0, 0, 4>();
+            HGR_RBAR();
+            // ---- ph3 ----
+            if (ODD) mmk(acc[0][1], wf1, afA, 0); else mmk(acc[1][1], wf1, afB, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (MODE <= 1) pfW(1, DUO_W1, t + 1);
+            if (ODD) mmk(acc[0][1], wf1, afA, 1); else mmk(acc[1][1], wf1, afB, 1);
+            if (MODE <= 1) mfma8_interleave<0, 0, 2>();
+            if (MODE == 0) HGR_RWAIT(10); else if (MODE == 1) HGR_RWAIT(2); else HGR_RBAR();
+            // ---- ph4 ----
+            if (MODE <= 1) { rdW(wf0, DUO_W0); if (ODD) rdA2(afA, DUO_A0 + nb, 0); else rdA2(afB, DUO_A1 + nb, 0); }
+            if (ODD) mmk(acc[1][1], wf1, afB, 0); else mmk(acc[0][1], wf1, afA, 0);
+            if (MODE <= 1) mfma8_interleave<8, 0, 0>();
+            __builtin_amdgcn_sched_barrier(0);
+            if (MODE <= 1) { if (ODD) rdA2(afA, DUO_A0 + nb, 1); else rdA2(afB, DUO_A1 + nb, 1); }
+            if (ODD) mmk(acc[1][1], wf1, afB, 1); else mmk(acc[0][1], wf1, afA, 1);
+            if (MODE <= 1) mfma8_interleave<4, 0, 0>();
+            HGR_RBAR();
+        };
+        // K-tiles in (even, odd) pairs, nk even (checked above): no run-time parity branch inside the loop
+        for (int t = 0; t + 2 < nk; t += 2) {
+            kt(t, std::false_type(), std::integral_constant<int, 0>());
+            kt(t + 1, std::true_type(), std::integral_constant<int, 0>());
+        }
+        kt(nk - 2, std::false_type(), std::integral_constant<int, 1>());
+        kt(nk - 1, std::true_type(), std::integral_constant<int, 2>());
+      }
+    } else if constexpr (MH == 2) {
         // prologue in steady-state order: A0(0), A1(0), W0(0), W1(0), A0(1)
         issueA(oA0, vA0, DUO_A0, 0, 0); issueA(oA0, vA0, DUO_A0, 0, 1);
         issueA(oA1, vA1, DUO_A1, 0, 0); issueA(oA1, vA1, DUO_A1, 0, 1);
