@@ -177,6 +177,9 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
 #ifndef HGR_DUO_PF
 #define HGR_DUO_PF 2
 #endif
+#ifndef HGR_DUO_PF_DMA_FIRST
+#define HGR_DUO_PF_DMA_FIRST 0      // experiment: 1 = a region's LDS-DMAs in front of its MFMAs instead of in their gaps
+#endif
     constexpr bool PF_BUILD = HGR_DUO_PF == 1 || (HGR_DUO_PF == 2 && LN == 2);
     const bool pf_tile = MH == 2 && !CONV && PF_BUILD && m0 + 256 <= p.M && n0 + 128 <= p.N && (p.K & 127) == 0 && p.K >= 256;
     if (pf_tile) {
@@ -251,11 +254,11 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
             // ---- ph1 ----
             if (MODE <= 1) pfW(0, DUO_W0, t + 1);
             if (ODD) { rdA2(afA, DUO_A0 + cb, 0); mmk(acc[1][0], wf0, afB, 0); } else { rdA2(afB, DUO_A1 + cb, 0); mmk(acc[0][0], wf0, afA, 0); }
-            if (MODE <= 1) mfma8_interleave<4, 0, 2>(); else mfma8_interleave<4, 0, 0>();
+            if (MODE <= 1) mfma8_interleave<4, 0, HGR_DUO_PF_DMA_FIRST ? 0 : 2>(); else mfma8_interleave<4, 0, 0>();
             __builtin_amdgcn_sched_barrier(0);
             if (MODE == 0) pfA(ODD ? 1 : 0, ODD ? DUO_A1 : DUO_A0, t + 2);
             if (ODD) { rdA2(afA, DUO_A0 + cb, 1); mmk(acc[1][0], wf0, afB, 1); } else { rdA2(afB, DUO_A1 + cb, 1); mmk(acc[0][0], wf0, afA, 1); }
-            if (MODE == 0) mfma8_interleave<4, 0, 4>(); else mfma8_interleave<4, 0, 0>();
+            if (MODE == 0) mfma8_interleave<4, 0, HGR_DUO_PF_DMA_FIRST ? 0 : 4>(); else mfma8_interleave<4, 0, 0>();
             if (MODE == 0) HGR_RWAIT(6); else if (MODE == 1) HGR_RWAIT(2); else HGR_RWAIT(0);
             // ---- ph2 ----
             rdW(wf1, DUO_W1);
@@ -264,14 +267,14 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
             __builtin_amdgcn_sched_barrier(0);
             if (MODE == 0) pfA(ODD ? 0 : 1, ODD ? DUO_A0 : DUO_A1, t + 2);
             if (ODD) mmk(acc[0][0], wf0, afA, 1); else mmk(acc[1][0], wf0, afB, 1);
-            if (MODE == 0) mfma8_interleave<0, 0, 4>();
+            if (MODE == 0) mfma8_interleave<0, 0, HGR_DUO_PF_DMA_FIRST ? 0 : 4>();
             HGR_RBAR();
             // ---- ph3 ----
             if (ODD) mmk(acc[0][1], wf1, afA, 0); else mmk(acc[1][1], wf1, afB, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (MODE <= 1) pfW(1, DUO_W1, t + 1);
             if (ODD) mmk(acc[0][1], wf1, afA, 1); else mmk(acc[1][1], wf1, afB, 1);
-            if (MODE <= 1) mfma8_interleave<0, 0, 2>();
+            if (MODE <= 1) mfma8_interleave<0, 0, HGR_DUO_PF_DMA_FIRST ? 0 : 2>();
             if (MODE == 0) HGR_RWAIT(10); else if (MODE == 1) HGR_RWAIT(2); else HGR_RBAR();
             // ---- ph4 ----
             if (MODE <= 1) { rdW(wf0, DUO_W0); if (ODD) rdA2(afA, DUO_A0 + nb, 0); else rdA2(afB, DUO_A1 + nb, 0); }
