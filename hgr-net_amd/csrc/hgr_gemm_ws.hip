@@ -15,7 +15,8 @@
 //   * waves 4-7 (the SIMD partners of waves 0-3): issue every LDS-DMA (the counted vmcnt waits are theirs), pick the dumped
 //     accumulators up from LDS in row layout (a lane owns 8 consecutive columns of a row: every global access is 16 bytes per lane over
 //     whole lines), and run the epilogue - bias / QuickGELU / ReLU, the folded-LayerNorm consumer, the residual producer with its pair
-//     read-modify-write and slot statistics - one 8-row pass per phase UNDER the next tile's MFMAs.
+//     read-modify-write and slot statistics - as half passes (8 rows x 4 of a lane's 8 columns) spread over the next tile's phases,
+//     UNDER its MFMAs.
 // LDS: gemm_nt_duo's 80 KB of operand pieces (A0 / A1 double-buffered, W0 / W1 single) + a 64 KB dump slot + 4 KB of row statistics.
 //
 // Phase plan (t = K-tile, X = the A piece of ph1 / ph4, Y = the other one; even t: X = A0, odd t: X = A1):
@@ -31,7 +32,10 @@
 //
 // What bounds the main loop (ablation builds, HGR_WS_DBG, c_fc shape 25 600 x 3 072 x 768, one MI355X; profiles/NOTES.md round 5):
 // everything 123 us; no MFMAs 87 (the LDS-DMA fill alone: 1.47 GB per launch at 17 TB/s, the chip's L2 -> LDS rate); no DMAs 103;
-// MFMAs + barriers only 66 (ideal 57); fragment reads + barriers only 51.  A 256 x 128 tile is FILL-bound, not matrix-bound.
+// MFMAs + barriers only 66 (ideal 57); fragment reads + barriers only 51.  A lone matrix wave per SIMD stalls on its own fragment reads
+// (~27 cycles each), and the epilogue's vector instructions cost its SIMD's matrix wave the same issue slots whichever wave runs them:
+// RESULT - bit-identical to gemm_nt_duo and NOT faster on any tower shape (c_fc 129 -> 136 us, out_proj 42 -> 48.5, c_proj 119 -> 123);
+// off by default (HGR_WS / hgr_gemm_set_ws).  Its matrix-wave loop lives on in gemm_nt_duo's LayerNorm consumers (-DHGR_DUO_PF).
 // =================================================================================================
 #include "hgr_gemm_common.h"
 

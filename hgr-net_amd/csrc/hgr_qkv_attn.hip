@@ -39,6 +39,7 @@ struct QkvAttnArgs {
     void *out; int64_t ldo;              // att [M, Wd] 16-bit
     int M, K, Wd, L, H, S;               // S = sequences per tile, rows per tile = S * L
     int tiles_m;
+    int hsplit;                          // raster: 1 = an XCD walks whole row tiles (all heads); 2 = the XCDs in two head halves x four row quarters
 };
 
 namespace {
@@ -71,9 +72,15 @@ __global__ __launch_bounds__(QA_NT) void qkv_attn(QkvAttnArgs p) {
     // are a contiguous window - the 12 heads of ~3 row panels beside the 3.5 MB of folded weights.  grid = tiles: one tile per
     // workgroup.  grid = CUs (the default): PERSISTENT workgroups; the next tile's first K-tile is requested before this tile's
     // attention phase, so its prologue latency (and a workgroup launch) is off the critical path.
+    // p.hsplit == 2: XCD x owns the head half x & 1 of the row tiles of quarter x >> 1 - its L2 then holds HALF of the folded weights
+    // (1.8 MB at 12 heads) beside the row panels in flight, instead of re-reading all of them in every round of tiles.
     const int ntiles = p.tiles_m * p.H, orig = blockIdx.x, G = gridDim.x;
     const int xcd = orig & 7, q8 = ntiles >> 3, r8 = ntiles & 7;
-    const int xbase = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8, xcnt = q8 + (xcd < r8 ? 1 : 0);
+    const bool split = p.hsplit == 2;
+    const int mlo = split ? (xcd >> 1) * p.tiles_m / 4 : 0;
+    const int HS = split ? p.H >> 1 : p.H, hbase = split ? (xcd & 1) * HS : 0;
+    const int xbase = split ? 0 : xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int xcnt = split ? (((xcd >> 1) + 1) * p.tiles_m / 4 - mlo) * HS : q8 + (xcd < r8 ? 1 : 0);
     const int xwgs = (G >> 3) + (xcd < (G & 7) ? 1 : 0);
     int cur = orig >> 3;                                     // index of this workgroup's tile inside the XCD's range
     if (cur >= xcnt) return;
@@ -83,9 +90,9 @@ __global__ __launch_bounds__(QA_NT) void qkv_attn(QkvAttnArgs p) {
     unsigned oA0[2], oA1[2], oW[3];
     int m0, h;
     auto set_tile = [&](int tile) {
-        const int tm = tile / p.H;
-        h = tile - tm * p.H;
-        m0 = tm * rows_valid;
+        const int tq = tile / HS;
+        h = hbase + tile - tq * HS;
+        m0 = (mlo + tq) * rows_valid;
         // opaque copy: every lane-derived term below is recomputed per tile instead of being kept live (and spilled) across the main loop
         int ln = lane;
         asm volatile("" : "+v"(ln));
@@ -277,6 +284,9 @@ __global__ __launch_bounds__(QA_NT) void qkv_attn(QkvAttnArgs p) {
     // (round 5, measured and not kept: the (query tile, sequence) units dealt round-robin over the waves and worked two or three at a
     // time with interleaved instruction streams - 114 us -> 115 / 118 us per launch, one at a time 120: the phase is not bound by the
     // latency of a unit's dependent chain; profiles/NOTES.md)
+    // (also measured and not kept: hipcc holds the seven next-tile DMAs above as pending through this loop and puts s_waitcnt vmcnt(0) in
+    // front of the transposing V reads of every pass - a wait for the previous query tile's output stores too.  With those DMAs
+    // written as inline asm the wait is gone and the launch takes 109.6 us against 108.7: it was never exposed)
     constexpr int KT = 2;              // 64 key slots: L <= 64
     const E *sV = (const E *)(smem + QA_V);
     for (int qt = wave; qt * 16 < rows_valid; qt += 8) {
@@ -373,6 +383,15 @@ static int qa_persist() {
     if (v < 0) { const char *e = getenv("HGR_QA_PERSIST"); v = e ? atoi(e) : 1; }
     return v;
 }
+// The two-head-half raster (QkvAttnArgs::hsplit), default on; HGR_QA_HSPLIT=0 = every XCD walks whole row tiles.  Measured on the
+// ViT-B/32 evaluation step (two interleaved rounds, one box): counter reads per launch 194 -> 155 MB, 112.3 -> 110.7 us, step 4.951 ->
+// 4.928 ms; bit-identical (a tile's arithmetic does not depend on where it runs).  The same split of gemm_nt_duo's raster (two column
+// halves x four row quarters for c_fc) changed neither its reads (207 -> 203 MB) nor its time and is not in the tree; profiles/NOTES.md
+static int qa_hsplit() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("HGR_QA_HSPLIT"); v = e ? atoi(e) : 1; }
+    return v;
+}
 static int qa_cus() {
     static int n = 0;
     if (!n) {
@@ -386,6 +405,7 @@ static int qa_cus() {
 
 void launch_qkv_attn(const QkvAttnArgs &a, int dtype, bool causal, hipStream_t s) {
     const int tiles = a.tiles_m * a.H;
+    // (eight-XCD raster; a launch of fewer than 8 row tiles keeps the plain walk)
     const dim3 grid((unsigned)(qa_persist() ? (tiles < qa_cus() ? tiles : qa_cus()) : tiles)), block(QA_NT);
     if (dtype == HGR_BF16) {
         if (causal) hipLaunchKernelGGL((qkv_attn<HGR_BF16, true>), grid, block, 0, s, a);
@@ -418,6 +438,7 @@ extern "C" int hgr_gemm_nt_ln_mha(const void *X16, int64_t ldx, const void *Wfol
     a.ln_stats = stats; a.ln_slots = K / 64; a.ln_eps = eps; a.out = att; a.ldo = ldatt;
     a.M = (int)M; a.K = K; a.Wd = Wd; a.L = L; a.H = heads; a.S = 256 / L; a.tiles_m = (B + a.S - 1) / a.S;
     HGR_REQUIRE((int64_t)a.tiles_m * heads < (1ll << 31), "hgr_gemm_nt_ln_mha: grid too large");
+    a.hsplit = (qa_hsplit() && heads % 2 == 0 && a.tiles_m >= 8) ? 2 : 1;
     launch_qkv_attn(a, dtype, causal != 0, (hipStream_t)stream);
     HGR_CHECK_LAUNCH("hgr_gemm_nt_ln_mha");
     return HGR_OK;
