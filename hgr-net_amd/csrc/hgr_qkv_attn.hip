@@ -438,7 +438,9 @@ extern "C" int hgr_gemm_nt_ln_mha(const void *X16, int64_t ldx, const void *Wfol
     a.ln_stats = stats; a.ln_slots = K / 64; a.ln_eps = eps; a.out = att; a.ldo = ldatt;
     a.M = (int)M; a.K = K; a.Wd = Wd; a.L = L; a.H = heads; a.S = 256 / L; a.tiles_m = (B + a.S - 1) / a.S;
     HGR_REQUIRE((int64_t)a.tiles_m * heads < (1ll << 31), "hgr_gemm_nt_ln_mha: grid too large");
-    a.hsplit = (qa_hsplit() && heads % 2 == 0 && a.tiles_m >= 8) ? 2 : 1;
+    // ... where the folded weights do not fit an L2 beside the panels in flight anyway (>= 2 MB: width 768 = 3.5 MB); below that the split
+    // only reads every row panel on two XCDs (text tower, width 512 = 1.5 MB: 111 -> 188 MB per launch, same time)
+    a.hsplit = (qa_hsplit() && heads % 2 == 0 && a.tiles_m >= 8 && 3ll * Wd * K * 2 >= (2ll << 20)) ? 2 : 1;
     launch_qkv_attn(a, dtype, causal != 0, (hipStream_t)stream);
     HGR_CHECK_LAUNCH("hgr_gemm_nt_ln_mha");
     return HGR_OK;
