@@ -9,12 +9,20 @@ int hgr_conv3x3_c32_launch(const void *x, const void *w, const float *bias, void
 namespace {
 constexpr int BM = 128, BN = 128;
 
-// development knobs of gemm_nt_duo, read once: HGR_GEMM_GROUP (raster group, default 4), HGR_GEMM_DBG (bit 8: sc1 output stores)
-int duo_group() {
+// development knobs of gemm_nt_duo, read once: HGR_GEMM_GROUP (raster group; default by shape, duo_group_for), HGR_GEMM_DBG (bit 8: sc1 output stores)
+int duo_group_env() {
     static int g = -1;
-    if (g < 0) { const char *e = getenv("HGR_GEMM_GROUP"); g = e ? atoi(e) : 4; if (g < 1) g = 4; }
+    if (g < 0) { const char *e = getenv("HGR_GEMM_GROUP"); g = e ? atoi(e) : 0; if (g < 0) g = 0; }
     return g;
 }
+int duo_group() { return duo_group_env() ? duo_group_env() : 4; }          // gemm_nt_ws (no plan)
+// Row panels per raster group of a gemm_nt_duo launch (duo_apply_plan).  By shape unless HGR_GEMM_GROUP=n forces n: 4 (64 tiles in flight per
+// XCD = 4 row panels x 16 column panels), but ONE for launches of at most 8 column panels - the few tiles that share an activation
+// panel are then dispatched back to back instead of 4 slots apart.  Measured (tools/raster_split_ab.sh, FETCH_SIZE per launch, ViT-B/32
+// step): the N = 768 producers 250 -> 222 MB (group 2: 232, 8: 280), patch GEMM 345 -> < 300; c_fc (24 column panels) 207 MB at 4,
+// 241 / 270 at 2 / 1, 219 at 8.  Step times of all three BASELINE configurations unchanged (tools/group_ab.sh: 4.953 vs 4.949 ms,
+// 10.08 vs 10.09 ms, 224.1 vs 224.8 ms): this trims fabric traffic, not time.
+int duo_group_for(int tiles_n) { return duo_group_env() ? duo_group_env() : (tiles_n <= 8 ? 1 : 4); }
 int duo_dbg() {
     static int d = -1;
     if (d < 0) { const char *e = getenv("HGR_GEMM_DBG"); d = e ? atoi(e) : 0; }
@@ -91,6 +99,7 @@ DuoPlan duo_plan(int M, int N, bool allow_tail) {
 void duo_apply_plan(GemmArgs &a, bool allow_tail, dim3 &grid) {
     const DuoPlan pl = duo_plan(a.M, a.N, allow_tail);
     a.nbig = pl.nbig; a.big_panels = pl.big_panels; a.tiles_m_half = pl.tiles_m_half;
+    a.group = a.m_fastest ? duo_group() : duo_group_for((a.N + 127) / 128);
     if (duo_dbg() & 64) fprintf(stderr, "[duo_plan] M=%d N=%d K=%d -> %d full panels (%d tiles) + %d half panels, grid %d\n",
                                      a.M, a.N, a.K, pl.big_panels, pl.nbig, pl.tiles_m_half, pl.grid);
     grid = dim3((unsigned)pl.grid);
