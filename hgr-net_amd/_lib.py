@@ -27,6 +27,7 @@ SIGNATURES = {
     "hgr_gemm_set_tail": [_i, _i],
     "hgr_gemm_set_persist": [_i],
     "hgr_gemm_set_ws": [_i],
+    "hgr_gemm_set_p8": [_i],
     "hgr_im2col_patches": [_p, _p, _i, _i, _i, _i, _i, _p],
     "hgr_im2col_patches_ex": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "hgr_vit_assemble": [_p, _p, _p, _i, _i, _i, _p],

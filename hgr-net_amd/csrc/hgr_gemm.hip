@@ -134,6 +134,11 @@ extern "C" int hgr_gemm_set_ws(int enabled) {
     return ws_set(enabled);
 }
 
+extern "C" int hgr_gemm_set_p8(int mode) {
+    HGR_REQUIRE(mode >= 0 && mode <= 2, "hgr_gemm_set_p8: mode must be 0 (never), 1 (wherever it covers) or 2 (by shape), got %d", mode);
+    return p8_set(mode);
+}
+
 extern "C" int hgr_gemm_set_persist(int enabled) {
     HGR_REQUIRE(enabled == 0 || enabled == 1, "hgr_gemm_set_persist: enabled must be 0 or 1, got %d", enabled);
     return duo_set_persist(enabled);
@@ -427,6 +432,11 @@ extern "C" int hgr_gemm_nt_ln(const void *X16, int64_t ldx, const void *Wfold, i
     GemmArgs a;
     ln_args(a, X16, ldx, Wfold, ldw, C, ldc, M, N, K);
     a.ln_stats = const_cast<float *>(stats); a.ln_slots = K / 64; a.ln_eps = eps; a.ln_s = ln_s; a.ln_c = ln_c;
+    if (hgr_gemm_force_tile() == 0 && p8_wanted(M, N, K)) {
+        launch_p8(a, dtype, act, (hipStream_t)stream);
+        HGR_CHECK_LAUNCH("hgr_gemm_nt_ln");
+        return HGR_OK;
+    }
     if (ws_enabled() && hgr_gemm_force_tile() == 0 && ws_covers(M, N, K, WS_LNC)) {
         launch_ws(a, dtype, WS_LNC, act, false, (hipStream_t)stream);
         HGR_CHECK_LAUNCH("hgr_gemm_nt_ln");

@@ -236,6 +236,11 @@ bool ws_covers(int M, int N, int K, int mode);      // whole tiles, an even numb
 void launch_ws(const GemmArgs &a, int dtype, int mode, int act, bool hasb, hipStream_t s);
 int ws_enabled();                     // HGR_WS (default 0: an experiment that did not beat gemm_nt_duo, kept bit-identical and tested)
 int ws_set(int enabled);              // hgr_gemm_set_ws
+// hgr_gemm_p8.hip: the LayerNorm-folded consumer as one persistent 512-thread workgroup per CU on 256 x 256 tiles
+bool p8_covers(int M, int N, int K);
+void launch_p8(const GemmArgs &a, int dtype, int act, hipStream_t s);
+bool p8_wanted(int M, int N, int K);  // by shape, or as forced by HGR_P8 / hgr_gemm_set_p8
+int p8_set(int mode);                 // hgr_gemm_set_p8: 0 never, 1 wherever it covers, 2 by shape (default)
 
 // first stage of hgr_logits_eval (hgr_logits_slab.hip): 512-row x 96-column tiles, one per CU, evaluation consumers in the epilogue
 struct SlabArgs {

@@ -112,6 +112,16 @@ int hgr_gemm_set_persist(int enabled);
 int hgr_gemm_set_ws(int enabled);
 
 /*
+ * The LayerNorm-folded consumer GEMM (hgr_gemm_nt_ln) also exists as ONE persistent 512-thread workgroup per CU on 256 x 256 tiles
+ * (csrc/hgr_gemm_p8.hip: the main loop of hgr_gemm_nt_ln_mha with a store epilogue): 2/3 of the staged bytes per flop of the
+ * 256 x 128 two-workgroup kernel, bit-identical to it (tests/test_gpu_kernels.py::test_gemm_p8_equals_duo).  It wins with long K and
+ * many tiles per CU (25 600 x 3 072 x 3 072: 1 108 -> 1 228 TF/s; ViT-L/14's c_fc -4.4 %) and is level or behind on ViT-B/32's shapes,
+ * so mode 2 (the default) picks it by shape: whole 256 x 256 tiles, K >= 1 024, >= 4 tiles per CU.  0 = never, 1 = wherever whole
+ * tiles cover the launch (A/B runs, tests).  Process-wide development knob like hgr_gemm_set_tile.  Returns the previous mode.
+ */
+int hgr_gemm_set_p8(int mode);
+
+/*
  * Patch extraction for the ViT stem: image fp32 NCHW [B,3,R,R] -> rows [B*g*g, Kp] of 16-bit
  * values, g = R/P, row (b, gy, gx) holds the patch in (c, py, px) order = conv1.weight.reshape(W,-1)
  * order, zero-padded from 3*P*P to Kp (Kp % 64 == 0).  With hgr_gemm_nt this replaces

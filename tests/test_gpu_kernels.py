@@ -1011,6 +1011,44 @@ def test_gemm_ln_mha_equals_gemm_then_mha(dt, b, l, heads, causal):
 
 
 @pytest.mark.parametrize("dt", DTS)
+def test_gemm_p8_equals_duo(dt):
+    """Round 5: the persistent 256 x 256 form of the LayerNorm-folded consumer GEMM (csrc/hgr_gemm_p8.hip, hgr_gemm_set_p8: one 512-thread
+    workgroup per CU walks its XCD's tiles, the next tile's first K-tile requested ahead of the store epilogue) gives the bits of
+    gemm_nt_duo through hgr_gemm_nt_ln (clip/model.py:177-187: ln_2 -> c_fc -> QuickGELU), on launches of one to several tiles per
+    workgroup, every statistics-slot count the epilogue unrolls, and agrees with an fp32 LayerNorm + linear of the same rows."""
+    from hgr_net_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device=DEV).manual_seed(23)
+    # (m, n, k), QuickGELU: 768 / 1024 / 512 / 320 / 320 tiles on 256 CUs; K = 512 ... 1024 (ln_slots 8, 12, 16) and 640 (10), 384 (the generic loop)
+    for (m, n, k), act in (((16384, 3072, 768), True), ((16384, 4096, 512), False), ((16384, 2048, 1024), True), ((20480, 1024, 640), False),
+                           ((8192, 2560, 384), True)):
+        a = (torch.rand(m, k, device=DEV, generator=g) * 2 - 1 + 0.3 * torch.rand(m, 1, device=DEV, generator=g)).to(dt)
+        w = ((torch.rand(n, k, device=DEV, generator=g) * 2 - 1) * 0.05).to(dt)
+        s_ = w.float().sum(1)                                          # gamma = 1: ln_s = row sums of the folded weight
+        c_ = torch.rand(n, device=DEV, generator=g) - 0.5
+        x = a.float().view(m, k // 64, 64)
+        stats = torch.stack([x.sum(-1), (x * x).sum(-1)], dim=-1).contiguous()
+        outs = []
+        for mode in (0, 1):
+            prev = lib.hgr_gemm_set_p8(mode)
+            try:
+                out = torch.full((m, n), float("nan"), dtype=dt, device=DEV)
+                ops.gemm_nt_ln(a, w, out, s_, c_, stats, quickgelu=act)
+                outs.append(out)
+            finally:
+                lib.hgr_gemm_set_p8(prev)
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)), (m, n, k, act)
+        rows = slice(0, 1024)
+        ref = torch.nn.functional.layer_norm(a[rows].float(), (k,), eps=1e-5) @ w.float().t() + c_
+        if act:
+            ref = ref * torch.sigmoid(1.702 * ref)
+        tol = dict(rtol=3e-2, atol=3e-2) if dt == torch.bfloat16 else dict(rtol=5e-3, atol=5e-3)
+        assert torch.allclose(outs[1][rows].float(), ref, **tol), float((outs[1][rows].float() - ref).abs().max())
+    assert lib.hgr_gemm_set_p8(2) in (0, 1, 2)                         # back to "by shape", whatever a failed case left behind
+
+
+@pytest.mark.parametrize("dt", DTS)
 def test_gemm_ws_equals_duo(dt):
     """Round 5: the role-split kernel (csrc/hgr_gemm_ws.hip: four matrix waves + four helper waves per CU, the epilogue of tile i
     under the MFMAs of tile i + 1; hgr_gemm_set_ws, off by default) gives the bits of gemm_nt_duo through every entry point it
