@@ -280,9 +280,9 @@ int p8_set(int mode) { const int prev = p8_mode(); g_p8 = mode; return prev; }
 // By shape: measured against gemm_nt_duo (tools/p8_bench.py, back to back, one MI355X, bit-identical): 25 600 x 3 072 x 3 072
 // 436 -> 394 us (1 108 -> 1 228 TF/s), ViT-L/14's c_fc 65 536 x 4 096 x 1 024 543 -> 519, ViT-B/32's c_fc (K = 768, 4.7 tiles per CU)
 // 128.0 -> 126.2 back to back and 132.5 -> 131.8 in the step (the step itself unchanged), its k / v projection (2.3 tiles per CU)
-// 70.9 -> 74.3: a K-tile of this form takes ~3 400 clocks where fill, matrix and LDS time are ~2 000 each (the LDS serves 192 KB of
-// fragment reads + 64 KB of DMA writes per K-tile = its whole bandwidth), and a tile's epilogue runs beside nothing - so it pays
-// with long K and many tiles per CU only.
+// 70.9 -> 74.3: a K-tile of this form takes ~3 400 clocks where fill, matrix and LDS time are ~2 000 each (ablation builds at
+// K = 3 072: 390 us; no fragment reads 378; no LDS-DMA behind the prologue 318; neither 274 - the fill that does not overlap is
+// added), and a tile's prologue and epilogue run beside nothing - so it pays with long K and many tiles per CU only.
 bool p8_wanted(int M, int N, int K) {
     const int m = p8_mode();
     if (!m || !p8_covers(M, N, K)) return false;
