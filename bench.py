@@ -166,6 +166,53 @@ def cpu_baseline(sd, zsl_cpu, arch="ViT-B/32", c1=True):
     return out
 
 
+def power_probe(run_step, fence, want: int = 5, max_s: float = 6.0):
+    """Socket power and shader clock WHILE the steps run: rocm-smi polled from a thread over extra steps behind the timed region (a child
+    process per sample: nothing of it runs inside the timed loop).  The tower GEMMs hold the package at its power limit and the clock
+    below its 2.4 GHz maximum, so `roofline.peak` (quoted at 2.4 GHz) is not reachable at any utilisation - the line says at which
+    clock the measured rate was obtained.  None if rocm-smi is absent or prints something else."""
+    import shutil
+    import subprocess
+    import threading
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(exe):
+        return None
+    samples, stop = [], threading.Event()
+
+    def poll():
+        while not stop.is_set() and len(samples) < want + 1:
+            try:
+                out = subprocess.run([exe, "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=10).stdout
+                best = None
+                for card, d in json.loads(out).items():
+                    pw = [float(v) for k, v in d.items() if "power (w)" in k.lower() and str(v).replace(".", "", 1).isdigit()]
+                    ck = [float(str(v).strip("()").lower().replace("mhz", "")) for k, v in d.items() if k.lower().startswith("sclk clock speed")]
+                    if pw and ck and (best is None or pw[0] > best[0]):
+                        best = (pw[0], ck[0])                       # the busy card: the one this process drives
+                if best:
+                    samples.append(best)
+            except Exception:  # noqa: BLE001 - a probe: any failure just ends it
+                return
+            time.sleep(0.1)
+    th = threading.Thread(target=poll, daemon=True)
+    t0 = time.perf_counter()
+    th.start()
+    i = 0
+    while th.is_alive() and time.perf_counter() - t0 < max_s:
+        run_step(i)
+        i += 1
+        if i % 8 == 0:
+            fence()
+    stop.set()
+    th.join(timeout=15)
+    fence()
+    use = samples[1:] if len(samples) > 1 else samples              # the first sample may predate the ramp
+    if not use:
+        return None
+    return {"socket_w": round(sum(p for p, _ in use) / len(use), 1), "sclk_mhz": round(sum(c for _, c in use) / len(use), 1), "samples": len(use),
+            "steps_run": i, "how": "rocm-smi --showpower --showclocks polled over extra steps behind the timed region"}
+
+
 def step_time_stats(events) -> dict:
     """Per-step intervals from the hipEvents recorded on the launch stream behind every timed step (event i = end of step i's
     launches in stream order): median / p95 / min / max in ms.  A slow box or a hiccup shows up here; the headline stays the loop mean."""
@@ -464,6 +511,7 @@ def main():
     ap.add_argument("--no-secondary", dest="secondary", action="store_false", help="default run only: skip the configs[2] / configs[4] child measurements")
     ap.add_argument("--secondary", dest="is_secondary", action="store_true", help="(internal) this process IS a secondary child: no grandchildren")
     ap.add_argument("--no-host-probe", dest="host_probe", action="store_false", help="default run only: skip the multi-process host-time probe")
+    ap.add_argument("--no-power-probe", dest="power_probe", action="store_false", help="skip the rocm-smi power / clock samples taken over extra steps behind the timed region")
     a = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -604,6 +652,12 @@ def main():
     if hasattr(model, "join_tail"):
         model.join_tail()
     torch.cuda.synchronize()
+    power = None
+    if world == 1 and a.power_probe:           # (one rank only: the extra steps are not matched on other ranks)
+        power = power_probe(lambda i: step(a.warmup + i % a.steps), fence)
+        if hasattr(model, "join_tail"):
+            model.join_tail()
+        torch.cuda.synchronize()
     ev.acc.copy_(acc_keep)
     host_ms = sorted(host_free)[len(host_free) // 2]
     if world > 1:
@@ -661,6 +715,11 @@ def main():
                     shapes.setdefault(tag or "untagged", []).append((s_.elapsed_time(e_) * 1e-3, fl))
             roof["by_shape"] = {k: {"launches": len(v), "avg_us": round(sum(t for t, _ in v) / len(v) * 1e6, 1),
                                     "tflops": round(sum(f for _, f in v) / sum(t for t, _ in v) / 1e12, 1)} for k, v in sorted(shapes.items())}
+        if roof and power:
+            # `peak` is the nominal figure at the 2.4 GHz maximum; under the tower GEMMs the package sits at its power limit and the clock
+            # below that: the same peak at the clock the steps actually ran at, and the fraction of THAT
+            at = PEAK_TFLOPS_BF16 * power["sclk_mhz"] / 2400.0
+            roof["power"] = dict(power, peak_at_sclk=round(at, 1), frac_at_sclk=round(roof["achieved"] / at, 4))
         if roof:
             # the launches of the last image block and the visual head, which act on the class-token rows only ("the last image block")
             small = {}

@@ -10,10 +10,12 @@
 // of the bytes per flop, fill and matrix time per K-tile about equal (~2 000 clocks each).
 //
 // 8 waves as 4 (M) x 2 (N); a wave owns 64 x 128 = 4 x 8 MFMA tiles = 128 accumulator registers.  A K-tile is staged as three pieces
-// cut by the phase that reads them (PA0 = rows 0-31 of every wave row, 16 KB; PA1 = rows 32-63, 16 KB; PW = the 256 weight rows, 32 KB),
-// two stages of 64 KB, every piece refilled for K-tile t + 2 as soon as both ping-pong groups have read it:
-//     ph1(t): issues PA1(t+1) x2                reads W (16 x ds_read_b128), A rows 0-31 (4 x)   waits vmcnt(8): PA1(t) landed
-//     ph2(t): issues PA0(t+2) x2, PW(t+2) x4    reads A rows 32-63 (4 x)                          waits vmcnt(8): PA0(t+1), PW(t+1) landed
+// cut by the phase that reads them (PA = the 256 activation rows, 32 KB; PW0 / PW1 = the weight rows of columns 0-63 / 64-127 of every
+// wave column, 16 KB each), two stages of 64 KB, every piece refilled for K-tile t + 2 as soon as both ping-pong groups have read it:
+//     ph1(t): reads A (8 x ds_read_b128), W columns 0-63 (8 x)    issues PW1(t+1) x2               waits vmcnt(8): PW1(t) landed
+//     ph2(t): reads W columns 64-127 (8 x), A fragments stay       issues PA(t+2) x4, PW0(t+2) x2   waits vmcnt(8): PA(t+1), PW0(t+1) landed
+// (a phase's LDS-DMAs behind its reads: an LDS-DMA can stall at the CU's one address path; the split by COLUMNS balances the phases'
+// LDS time - 16 + 8 reads where a split by rows has 20 + 4 against MFMA bursts of equal length)
 // 32 MFMAs per wave and phase; waves 0-3 and 4-7 (one of each per SIMD) run one barrier interval apart.  Same operand roles and K order
 // per output element as gemm_nt_duo, hence the same accumulator bits; the epilogue is its consumer epilogue, expression for expression.
 //
@@ -28,8 +30,8 @@
 namespace hgr_gemm {
 namespace {
 constexpr int P8_NT = 512;
-constexpr int P8_STAGE = 65536;                              // PA0 16 K | PA1 16 K | PW 32 K
-constexpr int P8_PA0 = 0, P8_PA1 = 16384, P8_PW = 32768;
+constexpr int P8_STAGE = 65536;                              // PA 32 K | PW0 16 K | PW1 16 K
+constexpr int P8_PA = 0, P8_PW0 = 32768, P8_PW1 = 49152;
 constexpr int P8_RS = 144;                                   // staging row: 64 columns x 2 B + 16 B pad
 constexpr int P8_STG = P8_STAGE;                             // 8 waves x 64 rows x 144 B = 73 728 B: stage 1 and the 8 KB behind it
 constexpr int P8_LN = P8_STG + 8 * 64 * P8_RS;               // 256 x (mean, rstd)
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(P8_NT) void gemm_nt_p8(GemmArgs p) {
     if (cur >= xcnt) return;
 
     // per-lane source offsets of one K-tile's LDS-DMA instructions (bytes from A / W; operands < 4 GB, whole tiles: checked on the host)
-    unsigned oA0[2], oA1[2], oW[4];
+    unsigned oA[4], oW0[2], oW1[2];
     int m0, n0;
     auto set_tile = [&](int tile) {
         const int tm = tile / p.tiles_n;
@@ -71,46 +73,46 @@ __global__ __launch_bounds__(P8_NT) void gemm_nt_p8(GemmArgs p) {
         for (int i = 0; i < 4; ++i) {
             const int id = (i * 8 + wave) * 64 + ln;
             const int pr = id >> 3, c = (id & 7) ^ (pr & 7);
+            oA[i] = (unsigned)(((int64_t)(m0 + pr) * p.lda + c * 8) * 2);          // piece row pr = tile row pr
             if (i < 2) {
-                const int tr = (pr >> 5) * 64 + (pr & 31);
-                oA0[i] = (unsigned)(((int64_t)(m0 + tr) * p.lda + c * 8) * 2);
-                oA1[i] = (unsigned)(((int64_t)(m0 + tr + 32) * p.lda + c * 8) * 2);
+                const int tc = (pr >> 6) * 128 + (pr & 63);                        // piece row pr of PW0 = tile column tc; PW1: + 64
+                oW0[i] = (unsigned)(((int64_t)(n0 + tc) * p.ldw + c * 8) * 2);
+                oW1[i] = (unsigned)(((int64_t)(n0 + tc + 64) * p.ldw + c * 8) * 2);
             }
-            oW[i] = (unsigned)(((int64_t)(n0 + pr) * p.ldw + c * 8) * 2);
         }
     };
     set_tile(xbase + cur);
     char *const ldsw = smem + wave * 1024;
     const __amdgpu_buffer_rsrc_t rA = dma_rsrc(p.A), rW = dma_rsrc(p.W);
-    auto issueA = [&](const unsigned (&off)[2], int piece, int t) {
+    auto issueA = [&](int t) {
+        char *dst = ldsw + (t & 1) * P8_STAGE + P8_PA;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma16(rA, p.A, oA[i], t * 128, dst + i * 8192);
+    };
+    auto issueW = [&](const unsigned (&off)[2], int piece, int t) {
         char *dst = ldsw + (t & 1) * P8_STAGE + piece;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) dma16(rA, p.A, off[i], t * 128, dst + i * 8192);
-    };
-    auto issueW = [&](int t) {
-        char *dst = ldsw + (t & 1) * P8_STAGE + P8_PW;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dma16(rW, p.W, oW[i], t * 128, dst + i * 8192);
+        for (int i = 0; i < 2; ++i) dma16(rW, p.W, off[i], t * 128, dst + i * 8192);
     };
 
     const int nk = p.K / 64;    // even, >= 4 (host)
-    const int offA = (wm * 32 + r) * 128;          // + m tile (0, 1) * 2048 within PA0 / PA1
-    const int offW = (wn * 128 + r) * 128;         // + n tile * 2048 within PW
+    const int offA = (wm * 64 + r) * 128;          // + m tile (0 .. 3) * 2048 within PA
+    const int offW = (wn * 64 + r) * 128;          // + n tile (0 .. 3) * 2048 within PW0 / PW1
     const int sw0 = ((0 + g) ^ (r & 7)) * 16, sw1 = ((4 + g) ^ (r & 7)) * 16;
-    vec8 wf[8][2], af[2][2];
+    vec8 wf[4][2], af[4][2];
 
-    // prologue in steady-state order: PA0(0), PW(0) | PA1(0) | PA0(1), PW(1)
-    issueA(oA0, P8_PA0, 0); issueW(0);
-    issueA(oA1, P8_PA1, 0);
-    issueA(oA0, P8_PA0, 1); issueW(1);
+    // prologue in steady-state order: PA(0), PW0(0) | PW1(0) | PA(1), PW0(1)
+    issueA(0); issueW(oW0, P8_PW0, 0);
+    issueW(oW1, P8_PW1, 0);
+    issueA(1); issueW(oW0, P8_PW0, 1);
   for (;;) {
     f32x4 acc[4][8];            // [m tile][n tile]: C[wm*64 + 16 i + r][wn*128 + 16 j + 4 g .. + 3]
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // PA0(0), PW(0) landed: my 8 youngest operations are PA1(0) x2 + PA0(1), PW(1) x6 (first tile), or - across a tile seam, where the
-    // previous tile's output stores sit between PA1(0) and PA0(1) in issue order - PA0(1), PW(1) x6 and two of those stores
+    // PA(0), PW0(0) landed: my 8 youngest operations are PW1(0) x2 + PA(1), PW0(1) x6 (first tile), or - across a tile seam, where the
+    // previous tile's output stores sit between PW1(0) and PA(1) in issue order - PA(1), PW0(1) x6 and two of those stores
     HGR_RWAIT(8);
     if (wn) HGR_MBAR();         // ping-pong: group 1 runs one barrier interval behind group 0
 
@@ -118,43 +120,43 @@ __global__ __launch_bounds__(P8_NT) void gemm_nt_p8(GemmArgs p) {
     auto ktile = [&](int t, auto mode_tag) {
         constexpr int MODE = decltype(mode_tag)::value;
         const char *st = smem + (t & 1) * P8_STAGE;
-        // ---- ph1: rows 0-31 of the wave x all 128 columns ----
-        if (MODE <= 1) issueA(oA1, P8_PA1, t + 1);              // its slot was last read in ph2(t - 1), two barriers ago
+        // ---- ph1: all 64 rows of the wave x its columns 0-63 ----
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            wf[j][0] = *(const vec8 *)(st + P8_PW + offW + j * 2048 + sw0);
-            wf[j][1] = *(const vec8 *)(st + P8_PW + offW + j * 2048 + sw1);
+        for (int j = 0; j < 4; ++j) {
+            wf[j][0] = *(const vec8 *)(st + P8_PW0 + offW + j * 2048 + sw0);
+            wf[j][1] = *(const vec8 *)(st + P8_PW0 + offW + j * 2048 + sw1);
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            af[i][0] = *(const vec8 *)(st + P8_PA0 + offA + i * 2048 + sw0);
-            af[i][1] = *(const vec8 *)(st + P8_PA0 + offA + i * 2048 + sw1);
+        for (int i = 0; i < 4; ++i) {
+            af[i][0] = *(const vec8 *)(st + P8_PA + offA + i * 2048 + sw0);
+            af[i][1] = *(const vec8 *)(st + P8_PA + offA + i * 2048 + sw1);
         }
-        if (MODE <= 1) HGR_RWAIT(8); else HGR_RWAIT(0);         // PA1(t) landed
+        if (MODE <= 1) issueW(oW1, P8_PW1, t + 1);              // behind the reads; its slot was last read in ph2(t - 1), two barriers ago
+        if (MODE <= 1) HGR_RWAIT(8); else HGR_RWAIT(0);         // PW1(t) landed
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[i][j] = T16<DT>::mfma16(wf[j][kk], af[i][kk], acc[i][j]);
+                for (int j = 0; j < 4; ++j) acc[i][j] = T16<DT>::mfma16(wf[j][kk], af[i][kk], acc[i][j]);
         __builtin_amdgcn_s_setprio(0);
         HGR_MBAR();
-        // ---- ph2: rows 32-63 ----
-        if (MODE == 0) { issueA(oA0, P8_PA0, t + 2); issueW(t + 2); }     // read in ph1(t), two barriers ago
+        // ---- ph2: columns 64-127, the A fragments stay ----
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            af[i][0] = *(const vec8 *)(st + P8_PA1 + offA + i * 2048 + sw0);
-            af[i][1] = *(const vec8 *)(st + P8_PA1 + offA + i * 2048 + sw1);
+        for (int j = 0; j < 4; ++j) {
+            wf[j][0] = *(const vec8 *)(st + P8_PW1 + offW + j * 2048 + sw0);
+            wf[j][1] = *(const vec8 *)(st + P8_PW1 + offW + j * 2048 + sw1);
         }
-        if (MODE == 0) HGR_RWAIT(8); else if (MODE == 1) HGR_RWAIT(2); else HGR_RBAR();      // PA0(t+1), PW(t+1) landed
+        if (MODE == 0) { issueA(t + 2); issueW(oW0, P8_PW0, t + 2); }     // read in ph1(t), two barriers ago
+        if (MODE == 0) HGR_RWAIT(8); else if (MODE == 1) HGR_RWAIT(2); else HGR_RBAR();      // PA(t+1), PW0(t+1) landed
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[2 + i][j] = T16<DT>::mfma16(wf[j][kk], af[i][kk], acc[2 + i][j]);
+                for (int j = 0; j < 4; ++j) acc[i][4 + j] = T16<DT>::mfma16(wf[j][kk], af[i][kk], acc[i][4 + j]);
         __builtin_amdgcn_s_setprio(0);
         HGR_MBAR();
     };
@@ -206,8 +208,8 @@ __global__ __launch_bounds__(P8_NT) void gemm_nt_p8(GemmArgs p) {
         // (persistent) the next tile's first K-tile into stage 0, which the epilogue does not touch - behind the epilogue's last global load
         __builtin_amdgcn_sched_barrier(0);
         set_tile(xbase + nxt);
-        issueA(oA0, P8_PA0, 0); issueW(0);
-        issueA(oA1, P8_PA1, 0);
+        issueA(0); issueW(oW0, P8_PW0, 0);
+        issueW(oW1, P8_PW1, 0);
     }
 
     // ---- y = act(rstd (acc - mean s_n) + c_n), rounded to the MFMA type, through the wave's staging slice, two column halves ----
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(P8_NT) void gemm_nt_p8(GemmArgs p) {
     }
     HGR_RBAR();                 // every wave has left the staging slices: stage 1 may be refilled
     if (!has_next) break;
-    issueA(oA0, P8_PA0, 1); issueW(1);
+    issueA(1); issueW(oW0, P8_PW0, 1);
     cur = nxt;
   }
 }

@@ -46,6 +46,12 @@ namespace {
 typedef __attribute__((ext_vector_type(4))) short qa_s16x4;
 typedef __attribute__((ext_vector_type(8))) short qa_s16x8;
 
+// a phase's LDS-DMAs are issued BEHIND its fragment reads (as in gemm_nt_duo): an LDS-DMA instruction can stall at the CU's one
+// vector-memory address path, and in front of the reads that stall delayed the reads, the wait and the MFMA burst behind them.  Three
+// interleaved pairs, one box: 110.1 -> 107.9 us per launch, bit-identical.  -DHGR_QA_ISSUE_LATE=0: the round-4 order
+#ifndef HGR_QA_ISSUE_LATE
+#define HGR_QA_ISSUE_LATE 1
+#endif
 constexpr int QA_NT = 512;
 constexpr int QA_STAGE = 57344;                              // PA0 16 K | PA1 16 K | PW 24 K
 constexpr int QA_PA0 = 0, QA_PA1 = 16384, QA_PW = 32768;
@@ -149,7 +155,9 @@ __global__ __launch_bounds__(QA_NT) void qkv_attn(QkvAttnArgs p) {
         constexpr int MODE = decltype(mode_tag)::value;
         const char *st = smem + (t & 1) * QA_STAGE;
         // ---- ph1: rows 0-31 of the wave x all 96 columns ----
+#if !HGR_QA_ISSUE_LATE
         if (MODE <= 1) issueA(oA1, QA_PA1, t + 1);              // its slot was last read in ph2(t - 1), two barriers ago
+#endif
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             wf[j][0] = *(const vec8 *)(st + QA_PW + offW + j * 2048 + sw0);
@@ -160,6 +168,9 @@ __global__ __launch_bounds__(QA_NT) void qkv_attn(QkvAttnArgs p) {
             af[i][0] = *(const vec8 *)(st + QA_PA0 + offA + i * 2048 + sw0);
             af[i][1] = *(const vec8 *)(st + QA_PA0 + offA + i * 2048 + sw1);
         }
+#if HGR_QA_ISSUE_LATE
+        if (MODE <= 1) issueA(oA1, QA_PA1, t + 1);
+#endif
         if (MODE <= 1) HGR_RWAIT(7); else HGR_RWAIT(0);         // PA1(t) landed
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -171,12 +182,17 @@ __global__ __launch_bounds__(QA_NT) void qkv_attn(QkvAttnArgs p) {
         __builtin_amdgcn_s_setprio(0);
         HGR_MBAR();
         // ---- ph2: rows 32-63 ----
+#if !HGR_QA_ISSUE_LATE
         if (MODE == 0) { issueA(oA0, QA_PA0, t + 2); issueW(t + 2); }     // read in ph1(t), two barriers ago
+#endif
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             af[i][0] = *(const vec8 *)(st + QA_PA1 + offA + i * 2048 + sw0);
             af[i][1] = *(const vec8 *)(st + QA_PA1 + offA + i * 2048 + sw1);
         }
+#if HGR_QA_ISSUE_LATE
+        if (MODE == 0) { issueA(oA0, QA_PA0, t + 2); issueW(t + 2); }
+#endif
         if (MODE == 0) HGR_RWAIT(7); else if (MODE == 1) HGR_RWAIT(2); else HGR_RBAR();      // PA0(t+1), PW(t+1) landed
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll

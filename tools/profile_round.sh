@@ -21,14 +21,14 @@ cd /tmp
 python3 "$ROOT/bench.py" $ARGS > "$OUT/bench.json" 2> "$OUT/bench.err"
 echo "[profile] bench done: $(cut -c1-200 "$OUT/bench.json")"
 
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o "$TAG" -- python3 "$ROOT/bench.py" $ARGS --no-cpu-baseline --no-pcie --no-secondary --no-host-probe \
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o "$TAG" -- python3 "$ROOT/bench.py" $ARGS --no-cpu-baseline --no-pcie --no-secondary --no-host-probe --no-power-probe \
     > "$OUT/bench_under_rocprof.json" 2> "$OUT/rocprof_stats.err"
 echo "[profile] kernel-trace stats done"
 
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o fetch -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-pcie --no-secondary --no-host-probe \
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o fetch -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-pcie --no-secondary --no-host-probe --no-power-probe \
     > /dev/null 2> "$OUT/rocprof_fetch.err"
 echo "[profile] FETCH_SIZE pass done"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o write -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-pcie --no-secondary --no-host-probe \
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o write -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-pcie --no-secondary --no-host-probe --no-power-probe \
     > /dev/null 2> "$OUT/rocprof_write.err"
 echo "[profile] WRITE_SIZE pass done"
 
@@ -56,7 +56,7 @@ profile_config() {   # <name> <bench args...>
     echo "[profile] $NAME done"
 }
 if [ "${PROFILE_SECONDARY:-1}" != "0" ]; then
-    profile_config rn50 --arch RN50 --nodes 20842 --steps 8 --warmup 2 --no-pcie --no-cpu-baseline --secondary
+    profile_config rn50 --arch RN50 --nodes 20842 --steps 8 --warmup 2 --no-pcie --no-cpu-baseline --no-power-probe --secondary
     profile_config train_l14 --mode train --arch ViT-L/14 --n-ctx 16 --batch 256 --steps 2 --warmup 1 --secondary
 fi
 # profiles/ on the box is outside gpurun_out/: ship copies back through it
