@@ -44,7 +44,9 @@ def launch_ranks(argv, n: int) -> int:
         port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), str(Path(__file__).resolve())] + list(argv)
+    import uuid
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HGR_COMM_NONCE", uuid.uuid4().hex)       # one per-run value every rank inherits (hgr_net_amd.comm's file bootstrap)
     p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)          # stderr passes through
     lines = []
     for line in p.stdout:
@@ -301,7 +303,12 @@ def dp_check_eval(model, ev, group, world: int, rank: int, elapsed_local: float,
             "num_sample_per_rank": [l[-1] for l in locals_], "ms_per_step_min": round(min(ms), 3), "ms_per_step_max": round(max(ms), 3)}
 
 
-HOST_PROBE_RANKS = 4            # ranks of the host-time probe: a GPU box admits at most 6 processes on its card, and this process is one of them
+# ranks of the host-time probe: a GPU box admits at most 6 processes on its card; this process, the rank launcher's children and a
+# rocm-smi poll are among them - 4 ranks fit, 5 were killed by the box's process guard (round 6) - so 4, not 8.  What an 8-rank node
+# takes from a rank is its share of the host's cores, and that IS reproduced: every probe rank confines itself to
+# 1 / HOST_PROBE_SHARE of them (HGR_HOST_SHARE, os.sched_setaffinity), the slice rank r of an 8-rank job would own
+HOST_PROBE_RANKS = 4
+HOST_PROBE_SHARE = 8
 
 
 def run_secondary(args_extra, timeout_s: int, env_extra=None, keep_extra=()):
@@ -536,6 +543,13 @@ def main():
     one_gpu = os.environ.get("HGR_TEST_ONE_GPU") == "1"
     if one_gpu:
         local = 0
+    share = int(os.environ.get("HGR_HOST_SHARE", "0") or 0)
+    if share > 1 and hasattr(os, "sched_setaffinity"):
+        # host probe: this rank on the cores rank (rank % share) of a `share`-rank job would have to itself
+        cores = sorted(os.sched_getaffinity(0))
+        per = max(1, len(cores) // share)
+        mine = cores[(rank % share) * per:(rank % share + 1) * per] or cores[:per]
+        os.sched_setaffinity(0, mine)
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     group = None
@@ -897,6 +911,21 @@ def main():
                           "(target_rank_differs - target_rank_differs_decidable of images x target_classes samples): metrics_string_explained"}
 
     if rank == 0:
+        # short scalar copies of the nested blocks (a record that keeps only the scalar fields of `roofline` / `config` still shows them)
+        if roof:
+            for k_, v_ in (roof.get("by_shape") or {}).items():
+                roof["us_" + k_] = v_.get("avg_us")
+            tail_ = roof.get("class_token_tail_us") or {}
+            if tail_:
+                roof["us_cls_tail_wo_kv"] = round(sum(v for k, v in tail_.items() if k != "kv"), 1)
+            lgm = roof.get("logits_gemm") or {}
+            for k_, n_ in (("us", "us_logits_eval"), ("tile_stage_us", "us_logits_tile"), ("tile_stage_frac_mfma", "frac_logits_tile"), ("row_stage_us", "us_logits_row")):
+                if k_ in lgm:
+                    roof[n_] = lgm[k_]
+        parity_short = None
+        if parity:
+            parity_short = (f"hit1 {parity['hit1_equal']}/{parity['images']} top20rows {parity['top20_rows_equal']}/{parity['images']} "
+                            f"levelids {parity['level_ids_equal']}/{parity['level_ids_total']} maxerr {parity['max_abs_logit_err']:.1e} string_equal {parity['metrics_string_equal']}")
         line = {"metric": "images/sec over 21K-class hierarchy, batch 512; hit@1 parity vs reference",
                 "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "ranks_seen": ranks_seen, "steps": a.steps, "warmup": a.warmup,
                 "ms_per_step": round(ms, 3), "step_ms": step_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -911,7 +940,7 @@ def main():
                                            "the rows ln_post reads (clip/model.py:231), same bits; HGR_CLS_LAST=0 carries every token") if cfg["vision_patch_size"] else
                                           "ModifiedResNet: NHWC 16-bit activations, BatchNorm folded, 1x1 convolutions as GEMMs, 3x3 as implicit GEMMs",
                            "global_batch": a.batch * world, "parallelism": f"dp{world}", "text_dtype": a.text_dtype,
-                           "weights": "random-init (hash-seeded), no checkpoint offline"},
+                           "weights": "random-init (hash-seeded), no checkpoint offline", "parity_ids": parity_short},
                 "roofline": roof, "cpu_baseline": cpu, "parity": parity, "pcie_inclusive": pcie, "metrics_string": summary.strip(),
                 "planted_signal": planted}
         if dp_check is not None:
@@ -926,10 +955,12 @@ def main():
             # a GPU box admits at most 6 processes on its card - this one included), so their ms_per_step means nothing - host_ms_per_step does.
             log(f"[bench] host probe: {HOST_PROBE_RANKS} ranks time-sharing the GPU (gloo), host time per step")
             hp = run_secondary(["--gpus", str(HOST_PROBE_RANKS), "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-pcie", "--no-c1", "--no-plant"], 300,
-                               env_extra={"HGR_TEST_ONE_GPU": "1"}, keep_extra=("host_ms_per_step", "n_gpus"))
-            line["host_probe"] = {"ranks": HOST_PROBE_RANKS, "host_ms_per_step": hp.get("host_ms_per_step"), "host_cores": os.cpu_count(),
+                               env_extra={"HGR_TEST_ONE_GPU": "1", "HGR_HOST_SHARE": str(HOST_PROBE_SHARE)}, keep_extra=("host_ms_per_step", "n_gpus"))
+            line["host_probe"] = {"ranks": HOST_PROBE_RANKS, "cores_per_rank": max(1, len(os.sched_getaffinity(0)) // HOST_PROBE_SHARE) if hasattr(os, "sched_getaffinity") else None,
+                                  "host_ms_per_step": hp.get("host_ms_per_step"), "host_cores": os.cpu_count(),
                                   "share_of_step": round(hp["host_ms_per_step"] / ms, 3) if hp.get("host_ms_per_step") else None,
-                                  "note": f"max over {HOST_PROBE_RANKS} concurrent ranks on this host's cores; the GPU is time-shared, so only the host figure is meaningful",
+                                  "note": f"max over {HOST_PROBE_RANKS} concurrent ranks (what a one-GPU box admits beside this process), each confined to 1/{HOST_PROBE_SHARE} "
+                                          f"of this host's cores - the share of a rank of an 8-GPU job; the GPU is time-shared, so only the host figure is meaningful",
                                   **({"error": hp["error"], "stderr_tail": hp.get("stderr_tail")} if "error" in hp else {})}
             line[f"host_ms_per_step_{HOST_PROBE_RANKS}proc"] = hp.get("host_ms_per_step")
         if a.secondary and not a.is_secondary and default_run:

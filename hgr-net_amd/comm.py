@@ -47,35 +47,41 @@ def init_from_torch(group=None) -> None:
     init(rank, world, box[0])
 
 
-def _single_node() -> bool:
-    """Every rank of the job is a child of ONE launcher process on this host (torchrun --nnodes=1, bench.py --gpus N)."""
-    lws, ws = os.environ.get("LOCAL_WORLD_SIZE"), os.environ.get("WORLD_SIZE")
-    return bool(lws and ws and lws == ws)
-
-
 def _run_nonce(nonce: Optional[str]) -> bytes:
-    """16 bytes that identify THIS run: every rank derives them from what the launcher gave all of them (an explicit
-    `nonce`, else HGR_COMM_NONCE, else MASTER_ADDR:MASTER_PORT + torchelastic's run id - and, on one node, the launcher's pid:
-    the ranks are its children, and a later run has another launcher)."""
+    """16 bytes that identify THIS run: every rank derives them from what the launcher gave ALL of them - an explicit `nonce`, else
+    HGR_COMM_NONCE (bench.py --gpus N and hgr_net_amd.main export a fresh one to their ranks), else MASTER_ADDR:MASTER_PORT +
+    torchelastic's run id.  (Round 5 mixed in os.getppid() on one node; ranks started through a per-rank wrapper - numactl, a shell
+    hop - then derived different nonces and timed out.  Nothing rank-local enters the nonce any more.)"""
     import hashlib
     if nonce is None:
         nonce = os.environ.get("HGR_COMM_NONCE") or ":".join(os.environ.get(k, "") for k in ("MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"))
-        if not os.environ.get("HGR_COMM_NONCE") and _single_node():
-            nonce += f":ppid{os.getppid()}"
     return hashlib.sha256(nonce.encode()).digest()[:16]
 
 
 def _nonce_is_per_run(nonce: Optional[str]) -> bool:
-    """Whether the run nonce really differs from run to run: an explicit one (argument or HGR_COMM_NONCE), a torchelastic run id
-    other than the static default 'none', or a single-node launch (launcher pid).  MASTER_ADDR:MASTER_PORT alone repeat across
-    runs (29500) or are empty."""
-    return bool(nonce or os.environ.get("HGR_COMM_NONCE") or os.environ.get("TORCHELASTIC_RUN_ID", "none") not in ("", "none") or _single_node())
+    """Whether the run nonce really differs from run to run: an explicit one (argument or HGR_COMM_NONCE) or a torchelastic run id
+    other than the static default 'none'.  MASTER_ADDR:MASTER_PORT alone repeat across runs (29500) or are empty."""
+    return bool(nonce or os.environ.get("HGR_COMM_NONCE") or os.environ.get("TORCHELASTIC_RUN_ID", "none") not in ("", "none"))
 
 
-_T_IMPORT = time.time()          # a lower bound of "this run started": an id file written long before it belongs to another run
-# without a per-run nonce (multi-node launch with the static run id): rank 0 may have published up to this long before a slower rank
-# imported this module (HGR_COMM_STALE_S; first `import torch` on a fresh box alone can take minutes)
-STALE_SLACK_S = float(os.environ.get("HGR_COMM_STALE_S", "300"))
+def _process_start_time() -> float:
+    """When THIS process was started (epoch seconds, /proc): the ranks of a run are started together, long before a slow first
+    `import torch` finishes - so 'written after I was started' tells this run's id file from a crashed earlier run's without
+    allowing for import time."""
+    try:
+        with open("/proc/self/stat") as f:
+            fields = f.read().rsplit(")", 1)[1].split()            # fields[0] = field 3 (state); starttime = field 22
+        with open("/proc/stat") as f:
+            btime = next(int(l.split()[1]) for l in f if l.startswith("btime"))
+        return btime + int(fields[19]) / os.sysconf("SC_CLK_TCK")
+    except Exception:
+        return time.time()
+
+
+_T_START = _process_start_time()
+# without a per-run nonce (static run id): an id file older than this process by more than HGR_COMM_STALE_S belongs to another run
+# (ranks of one launch start within seconds of each other; round 5 measured from the module import and needed 300 s for slow imports)
+STALE_SLACK_S = float(os.environ.get("HGR_COMM_STALE_S", "30"))
 
 
 def init_from_file(path: str, rank: int, world: int, timeout_s: float = 120.0, nonce: Optional[str] = None) -> None:
@@ -88,7 +94,7 @@ def init_from_file(path: str, rank: int, world: int, timeout_s: float = 120.0, n
     if not per_run and rank == 0:
         import warnings
         warnings.warn("hgr comm: no per-run nonce (pass nonce=, set HGR_COMM_NONCE, or launch with a torchelastic run id): a crashed run's id "
-                      f"file at {path} is told apart by its age (older than this process by more than HGR_COMM_STALE_S = {STALE_SLACK_S:.0f} s = stale) "
+                      f"file at {path} is told apart by its age (written before this process started, by more than HGR_COMM_STALE_S = {STALE_SLACK_S:.0f} s = stale) "
                       "or by being replaced while a rank waits")
     if rank == 0:
         try:
@@ -109,7 +115,7 @@ def init_from_file(path: str, rank: int, world: int, timeout_s: float = 120.0, n
             sig = (st.st_ino, st.st_mtime_ns)
             if first_seen is None:
                 first_seen = sig
-            fresh = per_run or rank == 0 or sig != first_seen or st.st_mtime >= _T_IMPORT - STALE_SLACK_S
+            fresh = per_run or rank == 0 or sig != first_seen or st.st_mtime >= _T_START - STALE_SLACK_S
         except FileNotFoundError:
             blob, fresh = b"", True
             first_seen = first_seen or (-1, -1)

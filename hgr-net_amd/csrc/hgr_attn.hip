@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void mha_fwd(const typename T16<DT>::elem *
             E *orow = out + ((int64_t)b * L + q) * W + h * 64 + g * 4;
 #pragma unroll
             for (int td = 0; td < 4; ++td)
-                *(vec4 *)(orow + td * 16) = cvt4<DT>(o[td][0] * inv, o[td][1] * inv, o[td][2] * inv, o[td][3] * inv);
+                *(u32x2 *)(orow + td * 16) = (u32x2){mul_pack16<DT>(o[td][0], inv, o[td][1], inv), mul_pack16<DT>(o[td][2], inv, o[td][3], inv)};   // product rounded ONCE to f16 (hgr_gemm_common.h): qkv_attn's twin
         }
     }
 }

@@ -4,10 +4,22 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "../../include/hgr.h"
 
 #define HGR_WAVE 64
+
+// Ablation switches (HGR_GEMM_DBG, HGR_WS_DBG, HGR_LS_DBG, HGR_LE_DBG: parts of a kernel left out for timing experiments - WRONG
+// results) exist in `make lab` builds only (-DHGR_LAB, ../lib/libhgr_lab.so).  In libhgr.so HGR_LAB_ON() is the constant false: the
+// branches fold away and no environment variable can switch a product kernel into a wrong-result mode.
+#ifdef HGR_LAB
+#define HGR_LAB_ON(expr) (expr)
+static inline int hgr_lab_env(const char *name) { const char *e = getenv(name); return e ? atoi(e) : 0; }
+#else
+#define HGR_LAB_ON(expr) false
+static inline int hgr_lab_env(const char *) { return 0; }
+#endif
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
@@ -54,6 +66,36 @@ template <int DT> __device__ __forceinline__ typename T16<DT>::vec4 cvt4(float a
     return r;
 }
 
+// (a0 b0 + c0, a1 b1 + c1) as a packed pair of the MFMA type, first value in the low half.  f16: v_fma_mixlo_f16 / v_fma_mixhi_f16 - the
+// fp32 FMA rounded ONCE to f16, and two instructions where fma + fma + convert were three; bf16 (no such instruction): fp32 FMA, then
+// v_cvt_pk_bf16_f32.  Written as inline asm because hipcc makes this choice by context (round 5: one kernel form fused the product
+// with its conversion and its twin did not; round 6: without the SLP vectoriser the choice flipped in gemm_nt_duo and not in
+// qkv_attn): every kernel that rounds a folded-LayerNorm output - or its QuickGELU - to 16 bits goes through these two functions.
+template <int DT> __device__ __forceinline__ unsigned fma_pack16(float a0, float b0, float c0, float a1, float b1, float c1) {
+    if (DT == HGR_F16) {
+        unsigned d;
+        asm("v_fma_mixlo_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a0), "v"(b0), "v"(c0));
+        asm("v_fma_mixhi_f16 %0, %1, %2, %3" : "+v"(d) : "v"(a1), "v"(b1), "v"(c1));
+        return d;
+    }
+    typedef __attribute__((ext_vector_type(2))) __bf16 b2;
+    b2 r;
+    r[0] = (__bf16)__builtin_fmaf(a0, b0, c0); r[1] = (__bf16)__builtin_fmaf(a1, b1, c1);
+    return __builtin_bit_cast(unsigned, r);
+}
+template <int DT> __device__ __forceinline__ unsigned mul_pack16(float a0, float b0, float a1, float b1) {
+    if (DT == HGR_F16) {
+        unsigned d;
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(d) : "v"(a0), "v"(b0));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(d) : "v"(a1), "v"(b1));
+        return d;
+    }
+    typedef __attribute__((ext_vector_type(2))) __bf16 b2;
+    b2 r;
+    r[0] = (__bf16)(a0 * b0); r[1] = (__bf16)(a1 * b1);
+    return __builtin_bit_cast(unsigned, r);
+}
+
 // ---- the residual stream's 16-bit-plus-8-bit PAIR (round 4) ----------------------------------------------------------------------
 // x (fp32) is kept as hi - x in the MFMA type (f16 / bf16: it IS the next GEMM's A operand) - and ONE byte q, both cut out of x's own
 // bit pattern.  With S = 13 (f16) / 16 (bf16) mantissa bits dropped by hi:
@@ -77,6 +119,50 @@ template <int DT> __device__ __forceinline__ void pair_split(float x, typename T
         if ((t & 0x7FFFFFFFu) < 0x38800000u) q = 128u;
         hi = (typename T16<DT>::elem)__uint_as_float(t & ~((1u << S) - 1u));
     } else hi = __builtin_bit_cast(typename T16<DT>::elem, (unsigned short)(t >> 16));
+}
+// The same split for TWO values at a time as the hot epilogues use it (gemm_nt_duo's residual producer: ~8 -> ~5 vector instructions
+// per element, round 6): returns the two hi halves packed in one dword (x0 low) and the rounded bit patterns tq0 / tq1 whose bits
+// S-1 .. S-8 are the two q bytes - for f16 already replaced by a pattern with q = 128 below the f16 normal range.  Same bits as
+// pair_split(): f16 hi = ONE v_cvt_pk_f16_f32 of the masked patterns; the range test is a float compare with |.| as a source modifier.
+template <int DT> __device__ __forceinline__ unsigned pair_split2(float x0, float x1, unsigned &tq0, unsigned &tq1) {
+    constexpr int S = DT == HGR_F16 ? 13 : 16;
+    const unsigned t0 = __float_as_uint(x0) + (1u << (S - 1)), t1 = __float_as_uint(x1) + (1u << (S - 1));
+    if (DT == HGR_F16) {
+        typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+        h2 h;
+#if defined(HGR_PAIR_RTZ) && HGR_PAIR_RTZ       // experiment: truncating conversion of t instead of mask + exact conversion (differs below the f16 normal range only)
+        h = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(__uint_as_float(t0), __uint_as_float(t1)));
+#else
+        h[0] = (_Float16)__uint_as_float(t0 & ~((1u << S) - 1u));
+        h[1] = (_Float16)__uint_as_float(t1 & ~((1u << S) - 1u));
+#endif
+        tq0 = __builtin_fabsf(__uint_as_float(t0)) < 6.103515625e-05f ? (128u << (S - 8)) : t0;
+        tq1 = __builtin_fabsf(__uint_as_float(t1)) < 6.103515625e-05f ? (128u << (S - 8)) : t1;
+        return __builtin_bit_cast(unsigned, h);
+    }
+    tq0 = t0; tq1 = t1;
+    return __builtin_amdgcn_perm(t1, t0, 0x07060302u);        // (t1 & 0xFFFF0000) | (t0 >> 16)
+}
+// byte BYTE of q4 = bits S-1 .. S-8 of tq, the other bytes kept (BYTE 0: cleared): ONE SDWA shift that writes a single destination
+// byte, where shift + mask + or (and the compiler's per-element compare / select on the shifted byte) were ~4 instructions
+template <int DT, int BYTE> __device__ __forceinline__ void pair_put_q(unsigned &q4, unsigned tq) {
+    constexpr int S = DT == HGR_F16 ? 13 : 16;
+    const unsigned sh = S - 8;
+    if (BYTE == 0) asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD" : "=v"(q4) : "v"(sh), "v"(tq));
+    else if (BYTE == 1) asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(q4) : "v"(sh), "v"(tq));
+    else if (BYTE == 2) asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(q4) : "v"(sh), "v"(tq));
+    else asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(q4) : "v"(sh), "v"(tq));
+}
+// pair_dec() of byte BYTE of q4 (four q bytes as they are stored): the byte select rides in the shift (SDWA), the - 128 in a 3-input add
+template <int DT, int BYTE> __device__ __forceinline__ float pair_dec4(typename T16<DT>::elem hi, unsigned q4) {
+    constexpr int S = DT == HGR_F16 ? 13 : 16;
+    const unsigned sh = S - 8;
+    unsigned qs;
+    if (BYTE == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(qs) : "v"(sh), "v"(q4));
+    else if (BYTE == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(qs) : "v"(sh), "v"(q4));
+    else if (BYTE == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(qs) : "v"(sh), "v"(q4));
+    else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(qs) : "v"(sh), "v"(q4));
+    return __uint_as_float(__float_as_uint((float)hi) + qs + (unsigned)(-(128 << (S - 8))));
 }
 template <int DT> __device__ __forceinline__ float pair_dec(typename T16<DT>::elem hi, unsigned q) {
     constexpr int S = DT == HGR_F16 ? 13 : 16;

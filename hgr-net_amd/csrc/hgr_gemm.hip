@@ -25,7 +25,7 @@ int duo_group() { return duo_group_env() ? duo_group_env() : 4; }          // ge
 int duo_group_for(int tiles_n) { return duo_group_env() ? duo_group_env() : (tiles_n <= 8 ? 1 : 4); }
 int duo_dbg() {
     static int d = -1;
-    if (d < 0) { const char *e = getenv("HGR_GEMM_DBG"); d = e ? atoi(e) : 0; }
+    if (d < 0) d = hgr_lab_env("HGR_GEMM_DBG");          // lab builds only (hgr_common.h): 0 in libhgr.so
     return d;
 }
 
@@ -166,7 +166,7 @@ extern "C" int hgr_gemm_nt(const void *A, int64_t lda, const void *W, int64_t ld
     if (epilogue == HGR_EPI_BIAS_RESIDUAL) vec = vec && (ldr % 4 == 0) && hgr_aligned(residual, 16);
     if (epi_has_idn16(epilogue)) vec = vec && (ldr % 4 == 0) && hgr_aligned(residual, 8);
     static int dbg = -1, split_env = -1;
-    if (dbg < 0) { const char *e = getenv("HGR_GEMM_DBG"); dbg = e ? atoi(e) : 0; }
+    if (dbg < 0) dbg = hgr_lab_env("HGR_GEMM_DBG");
     if (split_env < 0) { const char *e = getenv("HGR_GEMM_SPLIT"); split_env = e ? atoi(e) : 1; }
     hipStream_t s = (hipStream_t)stream;
     const size_t csz = out_f32 ? 4 : 2, rsz = epi_has_idn16(epilogue) ? 2 : 4;
@@ -522,7 +522,7 @@ static int logits_eval_stages(int stages, const void *feat16, const void *zsl_pe
     SlabArgs a;
     a.A = (const char *)feat16; a.lda = D; a.W = (const char *)zsl_perm16; a.ldw = D; a.M = rows; a.K = D; a.Np = n_perm;
     a.tpos = tpos_perm; a.epos = epos_perm; a.S = S;
-    { static int d = -1; if (d < 0) { const char *e = getenv("HGR_LS_DBG"); d = e ? atoi(e) : 0; } a.dbg = d; }
+    { static int d = -1; if (d < 0) d = hgr_lab_env("HGR_LS_DBG"); a.dbg = d; }
     a.ev_key = (unsigned long long *)workspace;
     a.ev_tmax = (float *)((char *)workspace + (size_t)rows * S * 8);
     a.ev_p1 = (int *)((char *)workspace + (size_t)rows * S * 16);

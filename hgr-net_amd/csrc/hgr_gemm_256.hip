@@ -99,7 +99,7 @@ __global__ __launch_bounds__(NT256) void gemm_nt_256(GemmArgs p) {
             src[3][j] = p.A + ((int64_t)min(m0 + ra0 + 64, p.M - 1) * p.lda + c * 8) * 2;
         }
     }
-    const bool do_mma = p.dbg != 1, do_ld = p.dbg != 2;
+    const bool do_mma = !HGR_LAB_ON(p.dbg == 1), do_ld = !HGR_LAB_ON(p.dbg == 2);
     auto issue = [&](int kind, int t) {
         if (!do_ld) return;
         char *dst = smem + (t & 1) * (4 * PIECE) + kind * PIECE + wave * 1024;
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(NT256) void gemm_nt_256(GemmArgs p) {
     ktile(nk - 2, std::integral_constant<int, 1>());
     ktile(nk - 1, std::integral_constant<int, 2>());
     if (!wm) HGR_MBAR();
-    if (p.dbg == 3) { if (acc[0][0][0][0][0] == 123.456f) ((float *)p.C)[0] = 1.f; return; }
+    if (HGR_LAB_ON(p.dbg == 3)) { if (acc[0][0][0][0][0] == 123.456f) ((float *)p.C)[0] = 1.f; return; }
     // group 0 waits for group 1's last interval: every LDS read is done, no DMA in flight
 
     // tile (a, b, i, j) of this lane holds C[m][n .. n+3],
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(NT256) void gemm_nt_256(GemmArgs p) {
                 const int row = q * 8 + rr;
                 const int m = m0 + wm * 128 + row;
                 const u32x4 v = *(const u32x4 *)(my + row * RS + ch * 16);
-                if (p.dbg == 4) { if (v[0] == 0x12345678u) ((float *)p.C)[0] = 1.f; continue; }
+                if (HGR_LAB_ON(p.dbg == 4)) { if (v[0] == 0x12345678u) ((float *)p.C)[0] = 1.f; continue; }
                 E *dst = dst0 + (int64_t)q * 8 * p.ldc;
                 if (FULL) *(u32x4 *)dst = v;
                 else if (m < p.M) {

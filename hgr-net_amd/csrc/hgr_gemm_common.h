@@ -92,6 +92,60 @@ __device__ __forceinline__ float ln_apply(float2 mr, float acc, float s_n, float
     return __builtin_fmaf(mr.y, __builtin_fmaf(-mr.x, s_n, acc), c_n);
 }
 
+// four consecutive outputs of a folded-LayerNorm consumer, rounded to the MFMA type: rstd (acc - mean s_n) + c_n [through QuickGELU]
+template <int DT, bool GELU> __device__ __forceinline__ u32x2 ln_out16(float2 mr, f32x4 acc, f32x4 s4, f32x4 c4);
+
+// The folded LayerNorm's output through QuickGELU in 4 plain + 2 quarter-rate vector instructions per element (round 6; ln_apply +
+// quick_gelu: 5 + 2).  With k = -1.702 log2(e) and the row's rstd and the column's c pre-multiplied by k (once per row / column):
+//     w = k v  straight out of the second FMA,   e = 2^w,   v sigmoid(1.702 v) = v / (1 + e) = w / (k + k e)
+// Every folded-LayerNorm consumer with QuickGELU (gemm_nt_duo, gemm_nt_ws, gemm_nt_p8) goes through this function, so they keep
+// rounding alike.  -DHGR_QGELU_W=0 restores ln_apply + quick_gelu (A/B builds).
+#ifndef HGR_QGELU_W
+#define HGR_QGELU_W 1
+#endif
+constexpr float QG_K = -1.702f * 1.4426950408889634f;
+__device__ __forceinline__ float ln_apply_gelu(float2 mr, float acc, float s_n, float c_n) {
+#if HGR_QGELU_W
+    const float w = __builtin_fmaf(mr.y * QG_K, __builtin_fmaf(-mr.x, s_n, acc), c_n * QG_K);
+    return w * __builtin_amdgcn_rcpf(__builtin_fmaf(QG_K, __builtin_amdgcn_exp2f(w), QG_K));
+#else
+    return quick_gelu(ln_apply(mr, acc, s_n, c_n));
+#endif
+}
+
+template <int DT, bool GELU> __device__ __forceinline__ u32x2 ln_out16(float2 mr, f32x4 acc, f32x4 s4, f32x4 c4) {
+    u32x2 o;
+    if (GELU) {
+#if HGR_QGELU_W
+        const float rk = mr.y * QG_K;
+        float w[4], r[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            w[e] = __builtin_fmaf(rk, __builtin_fmaf(-mr.x, s4[e], acc[e]), c4[e] * QG_K);
+            r[e] = __builtin_amdgcn_rcpf(__builtin_fmaf(QG_K, __builtin_amdgcn_exp2f(w[e]), QG_K));
+        }
+        o[0] = mul_pack16<DT>(w[0], r[0], w[1], r[1]);
+        o[1] = mul_pack16<DT>(w[2], r[2], w[3], r[3]);
+#else
+        float v[4], r[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = ln_apply(mr, acc[e], s4[e], c4[e]);
+            r[e] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * v[e]));
+        }
+        o[0] = mul_pack16<DT>(v[0], r[0], v[1], r[1]);
+        o[1] = mul_pack16<DT>(v[2], r[2], v[3], r[3]);
+#endif
+    } else {
+        float u[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) u[e] = __builtin_fmaf(-mr.x, s4[e], acc[e]);
+        o[0] = fma_pack16<DT>(mr.y, u[0], c4[0], mr.y, u[1], c4[1]);
+        o[1] = fma_pack16<DT>(mr.y, u[2], c4[2], mr.y, u[3], c4[3]);
+    }
+    return o;
+}
+
 __host__ __device__ constexpr bool epi_has_bias(int epi) { return epi != HGR_EPI_NONE && epi != HGR_EPI_ACCUM && epi != HGR_EPI_QGELU_GRAD16; }
 __host__ __device__ constexpr bool epi_has_idn16(int epi) { return epi == HGR_EPI_BIAS_ADD16_RELU || epi == HGR_EPI_QGELU_GRAD16; }
 

@@ -25,6 +25,9 @@
 
 namespace hgr_gemm {
 
+#ifndef HGR_PAIR_V2
+#define HGR_PAIR_V2 1           // 0: the round-5 form of the producer's pair split (A/B builds)
+#endif
 constexpr int NTD = 256;
 constexpr int DUO_A0 = 0, DUO_A1 = 32768, DUO_W0 = 65536, DUO_W1 = 73728, DUO_LDS = 81920;
 
@@ -101,7 +104,7 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
     auto issueA = [&](const unsigned (&off)[4], const unsigned (&vm)[CONV ? 4 : 1], int slot_base, int t, int h) {
         // (HGR_GEMM_DBG, timing experiments only, wrong results: 128 = no A pieces of odd K-tiles - what sharing the A panel between two
         // column tiles would save in LDS-DMA issue; 256 = no A pieces, 512 = no W pieces behind the first two K-tiles)
-        if (((p.dbg & 128) && (t & 1) && t > 1) || ((p.dbg & 256) && t > 1)) return;
+        if (HGR_LAB_ON(((p.dbg & 128) && (t & 1) && t > 1) || ((p.dbg & 256) && t > 1))) return;
         char *dst = ldsw + slot_base + (t & 1) * 16384;
         if (CONV) {
             int tap;
@@ -118,7 +121,7 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
         for (int i = 2 * h; i < 2 * h + 2; ++i) dma16(rA, p.A, off[i], t * 128, dst + i * 4096);
     };
     auto issueW = [&](const unsigned (&off)[2], int slot_base, int t) {
-        if ((p.dbg & 512) && t > 1) return;
+        if (HGR_LAB_ON((p.dbg & 512) && t > 1)) return;
         char *dst = ldsw + slot_base;
 #pragma unroll
         for (int i = 0; i < 2; ++i) dma16(rW, p.W, off[i], t * 128, dst + i * 4096);
@@ -461,7 +464,7 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
     HGR_MBAR();                 // every wave's LDS reads are done, no DMA in flight: the staging area is free
     // the epilogue is VALU / LDS work next to the partner workgroup's MFMA clusters (priority 1): run it above them, or its
     // instructions only get the issue slots the matrix stream leaves over (HGR_GEMM_DBG bit 16 = off, for A/B runs)
-    if (!(p.dbg & 16)) __builtin_amdgcn_s_setprio(3);
+    if (!HGR_LAB_ON(p.dbg & 16)) __builtin_amdgcn_s_setprio(3);
 
     // tile (a, b, i, j) of this lane holds C[m][n .. n+3],  m = m0 + wm*128 + a*64 + i*16 + r,  n = n0 + wn*64 + b*32 + j*16 + g*4
     constexpr bool HAS_BIAS = epi_has_bias(EPI);
@@ -496,11 +499,11 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
         for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            f32x4 v;
-            if (LN == 2) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = ln_apply(mr, acc[a][b][i][j][e], lsq[b][j][e], bq[b][j][e]);
-            } else v = acc[a][b][i][j] + bq[b][j];
+            if (LN == 2) {           // rounding to 16 bits in ONE defined form (ln_out16, hgr_gemm_common.h)
+                *(u32x2 *)(my + (a * 64 + i * 16 + r) * RS + (b * 32 + j * 16 + g * 4) * 2) = ln_out16<DT, EPI == HGR_EPI_BIAS_QUICKGELU>(mr, acc[a][b][i][j], lsq[b][j], bq[b][j]);
+                continue;
+            }
+            f32x4 v = acc[a][b][i][j] + bq[b][j];
             if (EPI == HGR_EPI_BIAS_QUICKGELU) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
@@ -518,7 +521,7 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
         char *cw = (char *)p.C + ((int64_t)(m0 + wm * WR) * p.ldc + n0 + wn * 64) * 2;
         const unsigned ldcB = (unsigned)p.ldc * 2u;
         const unsigned cl = (unsigned)rr * ldcB + ch * 16;
-        if (p.dbg & 8) {
+        if (HGR_LAB_ON(p.dbg & 8)) {
 #pragma unroll
             for (int q = 0; q < 8 * MH; ++q) store16_sc1(cw + (cl + q * 8 * ldcB), *(const u32x4 *)(my + (q * 8 + rr) * RS + ch * 16));
             return;
@@ -669,7 +672,7 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
                     ohb[buf][q] = *(const u32x4 *)(hw + (xo + (rl + q * 8) * ldxB));
                     // (HGR_GEMM_DBG bit 64, measurement only: the pair's low half is neither read nor written - the bound of what any
                     // narrower encoding of it can save: 5.12 -> 4.88 ms per step with the 16-bit low half of round 3)
-                    if (!(p.dbg & 64)) olb[buf][q] = *(const u32x2 *)(lw + (lo8 + (rl + q * 8) * ldlB));
+                    if (!HGR_LAB_ON(p.dbg & 64)) olb[buf][q] = *(const u32x2 *)(lw + (lo8 + (rl + q * 8) * ldlB));
                     else olb[buf][q] = (u32x2){0x80808080u, 0x80808080u};
                 }
             };
@@ -697,11 +700,34 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
                     const vec8 oh = __builtin_bit_cast(vec8, ohb[pb][q]);
                     const u32x2 ol = olb[pb][q];
                     float v[8];
+#if HGR_PAIR_V2
+                    // (acc + bias) + old x (pair_dec4: hi's bits + the low byte's 8 mantissa bits)
+                    v[0] = (lo4[0] + b8lo[0]) + pair_dec4<DT, 0>(oh[0], ol[0]); v[1] = (lo4[1] + b8lo[1]) + pair_dec4<DT, 1>(oh[1], ol[0]);
+                    v[2] = (lo4[2] + b8lo[2]) + pair_dec4<DT, 2>(oh[2], ol[0]); v[3] = (lo4[3] + b8lo[3]) + pair_dec4<DT, 3>(oh[3], ol[0]);
+                    v[4] = (hi4[0] + b8hi[0]) + pair_dec4<DT, 0>(oh[4], ol[1]); v[5] = (hi4[1] + b8hi[1]) + pair_dec4<DT, 1>(oh[5], ol[1]);
+                    v[6] = (hi4[2] + b8hi[2]) + pair_dec4<DT, 2>(oh[6], ol[1]); v[7] = (hi4[3] + b8hi[3]) + pair_dec4<DT, 3>(oh[7], ol[1]);
+#else
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {              // (acc + bias) + old x (pair_dec: hi's bits + the low byte's 8 mantissa bits)
                         v[e] = (lo4[e] + b8lo[e]) + pair_dec<DT>(oh[e], (ol[0] >> (8 * e)) & 255u);
                         v[e + 4] = (hi4[e] + b8hi[e]) + pair_dec<DT>(oh[e + 4], (ol[1] >> (8 * e)) & 255u);
                     }
+#endif
+#if HGR_PAIR_V2
+                    // pair_split()'s bits through pair_split2 / pair_put_q (hgr_common.h): ~5 instead of ~8 vector instructions per element
+                    u32x4 nh;
+                    u32x2 nl;
+                    {
+                        unsigned tq[8];
+#pragma unroll
+                        for (int e2 = 0; e2 < 4; ++e2) nh[e2] = pair_split2<DT>(v[2 * e2], v[2 * e2 + 1], tq[2 * e2], tq[2 * e2 + 1]);
+                        unsigned n0, n1;
+                        pair_put_q<DT, 0>(n0, tq[0]); pair_put_q<DT, 1>(n0, tq[1]); pair_put_q<DT, 2>(n0, tq[2]); pair_put_q<DT, 3>(n0, tq[3]);
+                        pair_put_q<DT, 0>(n1, tq[4]); pair_put_q<DT, 1>(n1, tq[5]); pair_put_q<DT, 2>(n1, tq[6]); pair_put_q<DT, 3>(n1, tq[7]);
+                        nl = (u32x2){n0, n1};
+                    }
+                    *(u32x4 *)(hw + (xo + (rl + q * 8) * ldxB)) = nh;
+#else
                     vec8 nh;
                     u32x2 nl = (u32x2){0u, 0u};
 #pragma unroll
@@ -715,12 +741,13 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
                         nl[1] |= q1 << (8 * e);
                     }
                     *(u32x4 *)(hw + (xo + (rl + q * 8) * ldxB)) = __builtin_bit_cast(u32x4, nh);
-                    if (!(p.dbg & 64)) *(u32x2 *)(lw + (lo8 + (rl + q * 8) * ldlB)) = nl;
+#endif
+                    if (!HGR_LAB_ON(p.dbg & 64)) *(u32x2 *)(lw + (lo8 + (rl + q * 8) * ldlB)) = nl;
                     s1[q] = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
                     s2[q] = (__builtin_fmaf(v[0], v[0], v[1] * v[1]) + __builtin_fmaf(v[2], v[2], v[3] * v[3])) +
                             (__builtin_fmaf(v[4], v[4], v[5] * v[5]) + __builtin_fmaf(v[6], v[6], v[7] * v[7]));
                 }
-                if (p.dbg & 32) continue;
+                if (HGR_LAB_ON(p.dbg & 32)) continue;
 #define HGR_DPP_STAGE8(CTRL) _Pragma("unroll") for (int q = 0; q < 2; ++q) { \
                     s1[q] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1[q]), CTRL, 0xF, 0xF, true)); \
                     s2[q] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s2[q]), CTRL, 0xF, 0xF, true)); }
@@ -766,7 +793,7 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
                 vq[q] = *(const f32x4 *)(my + (q * 4 + rq) * RS + cq * 16);
                 if (HAS_ADD) vq[q] += ad[q];
             }
-            if (p.dbg & 8) {
+            if (HGR_LAB_ON(p.dbg & 8)) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) store16_sc1(cw + (cl + (rl + q * 4) * ldcB), __builtin_bit_cast(u32x4, vq[q]));
             } else {
@@ -794,13 +821,8 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
             for (int j = 0; j < 2; ++j) {
                 const int n = n0 + wn * 64 + b * 32 + j * 16 + g * 4;
                 const f32x4 sq = *(const f32x4 *)(p.ln_s + n), cq4 = *(const f32x4 *)(p.ln_c + n);
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = ln_apply(mr, acc[a][b][i][j][e], sq[e], cq4[e]);
-                    if (EPI == HGR_EPI_BIAS_QUICKGELU) v[e] = quick_gelu(v[e]);
-                }
-                store_quad<DT, HGR_EPI_NONE, OUT32>(p, v, m, n);
+                // (N is a multiple of 128 and the rows allow vector access by the host's contract: a whole quad, the same rounding as interior tiles)
+                *(u32x2 *)((E *)p.C + (int64_t)m * p.ldc + n) = ln_out16<DT, EPI == HGR_EPI_BIAS_QUICKGELU>(mr, acc[a][b][i][j], sq, cq4);
             }
         }
         return;

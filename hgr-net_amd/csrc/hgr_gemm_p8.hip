@@ -231,14 +231,7 @@ __global__ __launch_bounds__(P8_NT) void gemm_nt_p8(GemmArgs p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float2 mri = make_float2(mrv[i][0], mrv[i][1]);
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = ln_apply(mri, acc[i][j][e], sv[e], cv[e]);
-                if (ACT) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
-                }
-                const u32x2 pk = __builtin_bit_cast(u32x2, cvt4<DT>(v[0], v[1], v[2], v[3]));
+                const u32x2 pk = ln_out16<DT, ACT != 0>(mri, acc[i][j], sv, cv);
                 asm volatile("ds_write_b64 %0, %1" ::"v"(stg + (i * 16 + re) * P8_RS + (jj * 16 + ge * 4) * 2), "v"(pk) : "memory");
             }
         }

@@ -382,19 +382,22 @@ __global__ __launch_bounds__(WS_NT) void gemm_nt_ws(GemmArgs p) {
                 }
             }
         } else {
-            typename T16<DT>::vec4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float y;
-                if constexpr (MODE == WS_LNC) y = ln_apply(make_float2(mrow[P][0], mrow[P][1]), x[e], eb[SECOND ? 1 : 0][e], eb[SECOND ? 3 : 2][e]);
-                else y = HASB ? x[e] + eb[SECOND ? 1 : 0][e] : x[e];
-                if (ACT == 1) y = quick_gelu(y);
-                if (ACT == 2) y = fmaxf(y, 0.f);
-                o[e] = (E)y;
-            }
-            if constexpr (!SECOND) knh = __builtin_bit_cast(u32x2, o);
+            u32x2 o2;
+            if constexpr (MODE == WS_LNC) o2 = ln_out16<DT, ACT == 1>(make_float2(mrow[P][0], mrow[P][1]), x, eb[SECOND ? 1 : 0], eb[SECOND ? 3 : 2]);   // gemm_nt_duo's rounding
             else {
-                const u32x2 hh = __builtin_bit_cast(u32x2, o);
+                typename T16<DT>::vec4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float y = HASB ? x[e] + eb[SECOND ? 1 : 0][e] : x[e];
+                    if (ACT == 1) y = quick_gelu(y);
+                    if (ACT == 2) y = fmaxf(y, 0.f);
+                    o[e] = (E)y;
+                }
+                o2 = __builtin_bit_cast(u32x2, o);
+            }
+            if constexpr (!SECOND) knh = o2;
+            else {
+                const u32x2 hh = o2;
                 if (DBG & 8) asm volatile("" :: "v"(hh));
                 else *(u32x4 *)(cw + (row * ldcB + ch * 16)) = (u32x4){knh[0], knh[1], hh[0], hh[1]};
             }
@@ -582,9 +585,10 @@ bool ws_covers(int M, int N, int K, int mode) {
 
 template <int DT, int MODE, int ACT, bool HASB, int NQ>
 static void ws_launch_one(const GemmArgs &a, dim3 g, hipStream_t s) {
-    static int dbg = -1;
-    if (dbg < 0) { const char *e = getenv("HGR_WS_DBG"); dbg = e ? atoi(e) : 0; }
     const dim3 b(WS_NT);
+#ifdef HGR_LAB                   // ablation builds of the bare product (wrong results): `make lab` only
+    static int dbg = -1;
+    if (dbg < 0) dbg = hgr_lab_env("HGR_WS_DBG");
     if constexpr (DT == HGR_F16 && MODE == WS_PLAIN && ACT == 0 && !HASB) {
         switch (dbg) {           // ablation builds of the bare product only
             case 1: hipLaunchKernelGGL((gemm_nt_ws<DT, MODE, ACT, HASB, NQ, 1>), g, b, 0, s, a); return;
@@ -598,6 +602,7 @@ static void ws_launch_one(const GemmArgs &a, dim3 g, hipStream_t s) {
             default: break;
         }
     }
+#endif
     hipLaunchKernelGGL((gemm_nt_ws<DT, MODE, ACT, HASB, NQ>), g, b, 0, s, a);
 }
 

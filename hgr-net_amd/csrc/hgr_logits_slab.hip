@@ -69,7 +69,7 @@ __global__ __launch_bounds__(LS_NT) void logits_slab(SlabArgs p) {
 #pragma unroll
         for (int u = 0; u < 6; ++u) {
             const int id = min(tid + u * LS_NT, nw - 1);
-            tw[u] = (p.dbg & 16) ? 0u : *(const unsigned *)(p.W + ((int64_t)(n0 + id / spr) * p.ldw) * 2 + (id % spr) * 64);
+            tw[u] = HGR_LAB_ON(p.dbg & 16) ? 0u : *(const unsigned *)(p.W + ((int64_t)(n0 + id / spr) * p.ldw) * 2 + (id % spr) * 64);
         }
         const int rows_here = min(512, p.M - m0), na = rows_here * spr;
         const int id = min((int)(blockIdx.x >> 3) * LS_NT + tid, na - 1);
@@ -78,13 +78,13 @@ __global__ __launch_bounds__(LS_NT) void logits_slab(SlabArgs p) {
     char *const ldsw = smem + wave * 1024;
     const __amdgpu_buffer_rsrc_t rA = dma_rsrc(p.A), rW = dma_rsrc(p.W);
     auto issueA = [&](const unsigned (&off)[4], int piece, int t) {
-        if (p.dbg & 2) return;
+        if (HGR_LAB_ON(p.dbg & 2)) return;
         char *dst = ldsw + (t & 1) * LS_STAGE + piece;
 #pragma unroll
         for (int i = 0; i < 4; ++i) dma16(rA, p.A, off[i], t * 128, dst + i * 8192);
     };
     auto issueW = [&](int t) {
-        if (p.dbg & 4) return;
+        if (HGR_LAB_ON(p.dbg & 4)) return;
         char *dst = ldsw + (t & 1) * LS_STAGE + LS_PW;
 #pragma unroll
         for (int i = 0; i < 2; ++i) dma16(rW, p.W, oW[i], t * 128, dst + i * 8192);
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(LS_NT) void logits_slab(SlabArgs p) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 6; ++j) if (!(p.dbg & 1)) acc[i][j] = T16<DT>::mfma16(wf[j][kk], af[i][kk], acc[i][j]);
+                for (int j = 0; j < 6; ++j) if (!HGR_LAB_ON(p.dbg & 1)) acc[i][j] = T16<DT>::mfma16(wf[j][kk], af[i][kk], acc[i][j]);
         __builtin_amdgcn_s_setprio(0);
         HGR_MBAR();
         // ---- ph2: rows 32-63 ----
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(LS_NT) void logits_slab(SlabArgs p) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 6; ++j) if (!(p.dbg & 1)) acc[2 + i][j] = T16<DT>::mfma16(wf[j][kk], af[i][kk], acc[2 + i][j]);
+                for (int j = 0; j < 6; ++j) if (!HGR_LAB_ON(p.dbg & 1)) acc[2 + i][j] = T16<DT>::mfma16(wf[j][kk], af[i][kk], acc[2 + i][j]);
         __builtin_amdgcn_s_setprio(0);
         HGR_MBAR();
     };
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(LS_NT) void logits_slab(SlabArgs p) {
     ktile(nk - 1, std::integral_constant<int, 2>());
     if (!pg) HGR_MBAR();        // (barrier counts of the two groups balanced; nothing below touches LDS)
 
-    if (p.dbg & 8) { if (acc[0][0][0] == 123.456f && acc[3][5][3] == 1.f) p.ev_key[0] = 1ull; return; }
+    if (HGR_LAB_ON(p.dbg & 8)) { if (acc[0][0][0] == 123.456f && acc[3][5][3] == 1.f) p.ev_key[0] = 1ull; return; }
     // ---- evaluation consumers.  Lane (r, g) holds, of row m = m0 + 64 wave + 16 i + r, the columns n0 + 16 j + 4 g + e (e = 0..3)
     // of n tile j; a 32-column slice = n tiles 2 s, 2 s + 1, the other 3/4 of its columns sit in the lanes r + 16, r + 32, r + 48 ----
     int tp[6][4], ep[6][4];

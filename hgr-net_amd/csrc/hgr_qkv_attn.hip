@@ -60,10 +60,18 @@ constexpr int QA_VR = 72;
 constexpr int QA_Q = QA_STAGE, QA_K = QA_Q + 32768, QA_V = QA_K + 32768, QA_LN = QA_V + 256 * QA_VR * 2;
 constexpr int QA_LDS = QA_LN + 2048;                         // 161 792 B of the CU's 163 840
 
+#ifdef HGR_LAB
+// lab builds only: s_memtime stamps of wave 0 around the sections of the workgroup's SECOND tile (steady state), read back through
+// hgr_lab_qa_stamps (tools/qa_stamps.py): 0 tile start, 1 main loop done, 2 row statistics in LDS, 3 q / k / v in LDS, 4 attention done
+__device__ unsigned long long qa_lab_stamps[1024 * 8];
+#define QA_STAMP(i) do { if (threadIdx.x == 0 && lab_tile == 1) qa_lab_stamps[(blockIdx.x & 1023) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define QA_STAMP(i) do { } while (0)
+#endif
+
 template <int DT, bool CAUSAL>
 __global__ __launch_bounds__(QA_NT) void qkv_attn(QkvAttnArgs p) {
     typedef typename T16<DT>::vec8 vec8;
-    typedef typename T16<DT>::vec4 vec4;
     typedef typename T16<DT>::elem E;
     __shared__ __attribute__((aligned(1024))) char smem[QA_LDS];
 
@@ -139,7 +147,14 @@ __global__ __launch_bounds__(QA_NT) void qkv_attn(QkvAttnArgs p) {
     issueA(oA0, QA_PA0, 0); issueW(0);
     issueA(oA1, QA_PA1, 0);
     issueA(oA0, QA_PA0, 1); issueW(1);
+#ifdef HGR_LAB
+  int lab_tile = -1;
+#endif
   for (;;) {
+#ifdef HGR_LAB
+    ++lab_tile;
+#endif
+    QA_STAMP(0);
     f32x4 acc[4][6];            // [m tile][n tile]: C[wm*64 + 16 i + r][wn*96 + 16 j + 4 g .. + 3]
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -208,6 +223,7 @@ __global__ __launch_bounds__(QA_NT) void qkv_attn(QkvAttnArgs p) {
     ktile(nk - 2, std::integral_constant<int, 1>());
     ktile(nk - 1, std::integral_constant<int, 2>());
     if (!wn) HGR_MBAR();        // group 0 waits for group 1's last interval: every LDS read is done, no DMA in flight
+    QA_STAMP(1);
     // this tile's coordinates for the epilogue; then (persistent) the next tile's first K-tile is requested into stage 0, which the
     // attention phase below does not touch
     const int m0c = m0, hc = h;
@@ -260,6 +276,7 @@ __global__ __launch_bounds__(QA_NT) void qkv_attn(QkvAttnArgs p) {
         asm volatile("ds_write_b64 %0, %1" ::"v"(lnrow_a + tid_e * 8), "v"(mv) : "memory");
     }
     HGR_RBAR();
+    QA_STAMP(2);
 
     // ---- q / k / v of the tile, rounded to the MFMA type, into LDS ----
     qa_f2 mrv[4];
@@ -275,13 +292,10 @@ __global__ __launch_bounds__(QA_NT) void qkv_attn(QkvAttnArgs p) {
         for (int i = 0; i < 4; ++i) {
             const int row = wm * 64 + i * 16 + r;
             const float2 mri = make_float2(mrv[i][0], mrv[i][1]);
-            f32x4 v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = ln_apply(mri, acc[i][j][e], sq[j % 3][e], cq[j % 3][e]);
             // branch-free destination: V rows are 144 bytes, row-major; Q / K rows 128 bytes with the chunk swizzle of the fragment reads
             const int base = part == 2 ? QA_V : part ? QA_K : QA_Q;
             const int at = part == 2 ? row * (QA_VR * 2) + d * 2 : row * 128 + (((d >> 3) ^ (row & 7)) * 16) + (d & 4) * 2;
-            const u32x2 pk = __builtin_bit_cast(u32x2, cvt4<DT>(v[0], v[1], v[2], v[3]));
+            const u32x2 pk = ln_out16<DT, false>(mri, acc[i][j], sq[j % 3], cq[j % 3]);        // the consumer GEMM's rounding (hgr_gemm_common.h)
             asm volatile("ds_write_b64 %0, %1" ::"v"(smem_a + base + at), "v"(pk) : "memory");
         }
     }
@@ -295,6 +309,7 @@ __global__ __launch_bounds__(QA_NT) void qkv_attn(QkvAttnArgs p) {
         issueA(oA1, QA_PA1, 0);
     }
     HGR_RBAR();
+    QA_STAMP(3);
 
     // ---- attention: query tile qt = rows 16 qt .. 16 qt + 15 of the tile; wave w takes tiles w and w + 8 ----
     // (round 5, measured and not kept: the (query tile, sequence) units dealt round-robin over the waves and worked two or three at a
@@ -382,11 +397,13 @@ __global__ __launch_bounds__(QA_NT) void qkv_attn(QkvAttnArgs p) {
             // product and 16-bit conversion in one expression, as in hgr_mha: for f16 hipcc fuses them into v_fma_mixlo_f16 (ONE rounding);
             // a product kept in fp32 and converted later rounds twice and differs by one f16 ulp in ~3e-5 of the elements
             for (int td = 0; td < 4; ++td)
-                *(vec4 *)(orow + td * 16) = cvt4<DT>(res[td][0] * rinv, res[td][1] * rinv, res[td][2] * rinv, res[td][3] * rinv);
+                *(u32x2 *)(orow + td * 16) = (u32x2){mul_pack16<DT>(res[td][0], rinv, res[td][1], rinv), mul_pack16<DT>(res[td][2], rinv, res[td][3], rinv)};
         }
     }
+    QA_STAMP(4);
     if (!has_next) break;
     __syncthreads();            // every wave's attention reads are done: stage 1 (under Q / K) may be refilled
+    QA_STAMP(5);
     issueA(oA0, QA_PA0, 1); issueW(1);
     cur = nxt;
   }
@@ -461,3 +478,10 @@ extern "C" int hgr_gemm_nt_ln_mha(const void *X16, int64_t ldx, const void *Wfol
     HGR_CHECK_LAUNCH("hgr_gemm_nt_ln_mha");
     return HGR_OK;
 }
+
+#ifdef HGR_LAB
+extern "C" int hgr_lab_qa_stamps(unsigned long long *host_out, int n_words) {
+    if (!host_out || n_words < 1 || n_words > 1024 * 8) return HGR_EINVAL;
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(hgr_gemm::qa_lab_stamps), (size_t)n_words * 8, 0, hipMemcpyDeviceToHost) == hipSuccess ? HGR_OK : HGR_ELAUNCH;
+}
+#endif

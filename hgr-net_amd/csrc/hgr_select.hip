@@ -589,7 +589,7 @@ __global__ __launch_bounds__(LE_NT, 4) void logits_eval_rows(const void *__restr
         if (lane == 0 && mine) atomicAdd(&s_nonempty, mine);     // one LDS atomic per WAVE (same-address LDS atomics serialise)
     }
     __syncthreads();
-    const bool want_k = k > 0 && dbg != 1;
+    const bool want_k = k > 0 && !HGR_LAB_ON(dbg == 1);
     if (wave == 0 && want_k && s_nonempty >= k) {
         // threshold t: any value such that at least k DISTINCT test elements are >= t will do (a smaller t only lengthens the
         // candidate list).  Lane l holds the maxima of slices l, l + 64, ...; m = the largest of them.  The k-th largest of the 64
@@ -666,7 +666,7 @@ __global__ __launch_bounds__(LE_NT, 4) void logits_eval_rows(const void *__restr
         if (lane == 0 && out_top1) out_top1[row] = top.p < n_train ? train_cols[top.p] : -1;
     }
     if (!want_k) return;
-    if (dbg == 2) return;
+    if (HGR_LAB_ON(dbg == 2)) return;
     const float t = s_t;
     // a group whose maximum reaches t holds a candidate: its (value, position) are already known from the tile stage; only when its
     // SECOND largest value reaches t too (two of the best k in one 16-column group, or a tie at the maximum) the group is recomputed
@@ -682,7 +682,7 @@ __global__ __launch_bounds__(LE_NT, 4) void logits_eval_rows(const void *__restr
     }
     __syncthreads();
     int ncand = s_ncand;
-    if (dbg == 3) return;
+    if (HGR_LAB_ON(dbg == 3)) return;
     // visitor(value, test position) over every test element of the candidate groups; a wave takes TWO groups per trip (two
     // independent accumulators, 16 class-row fragments in flight).  Fragments: A operand = 16 class rows x 32 k (lane (r16, g): row
     // r16, k = 32 kk + 8 g ..), B operand = the image's feature for every one of its 16 "rows" m (from LDS, same address for all r16).
@@ -731,7 +731,7 @@ __global__ __launch_bounds__(LE_NT, 4) void logits_eval_rows(const void *__restr
         }
     });
     __syncthreads();
-    if (dbg == 4) return;
+    if (HGR_LAB_ON(dbg == 4)) return;
     const int cnt = s_cnt;
     if (cnt <= LE_CAP) {
         for (int c = tid; c < cnt; c += LE_NT) {
@@ -774,7 +774,7 @@ int hgr_logits_eval_rows_launch(const void *feat, const void *zslp, int D, int S
                                 const int32_t *epos, const int32_t *test_cols, int n_test, int k, int32_t *out_level, int32_t *out_top1,
                                 int32_t *out_topk, int rows, int dtype, void *stream) {
     static int dbg = -1;                              // HGR_LE_DBG = 1..4: leave the row stage after level / threshold / candidate list / scan (timing experiments only)
-    if (dbg < 0) { const char *e = getenv("HGR_LE_DBG"); dbg = e ? atoi(e) : 0; }
+    if (dbg < 0) dbg = hgr_lab_env("HGR_LE_DBG");   // lab builds only
     if (dtype == HGR_BF16) hipLaunchKernelGGL((logits_eval_rows<HGR_BF16>), dim3(rows), dim3(LE_NT), 0, (hipStream_t)stream, feat, zslp, D, S, keys, tmax, gp1, gm2, level_first,
                                               n_levels, filler_pos, train_cols, n_train, epos, test_cols, n_test, k, out_level, out_top1, out_topk, dbg, rows);
     else hipLaunchKernelGGL((logits_eval_rows<HGR_F16>), dim3(rows), dim3(LE_NT), 0, (hipStream_t)stream, feat, zslp, D, S, keys, tmax, gp1, gm2, level_first,

@@ -33,11 +33,14 @@ TEMPLATE = "a photo of a {}."     # data/templates.py TEMPLATES_SIMPLE[0], the o
 # Evaluation steps as a two-stage pipeline (forward_eval_overlapped): the class-token tail of step i beside the head of step i + 1.
 # HGR_TAIL_OVERLAP=0 (or clip_tree.TAIL_OVERLAP = False) keeps every step one graph on one stream.
 TAIL_OVERLAP = os.environ.get("HGR_TAIL_OVERLAP", "1") != "0"
-# Measurement option (round 5, off by default): feed hgr_logits_eval one operand of the class-logits product at ~22 bits instead of
-# 11 by concatenation along K - "class": [f | f] . [z_hi | z_lo]^T = f . (z_hi + z_lo), "feat": [f_hi | f_lo] . [z | z]^T - i.e. remove
-# that operand's 16-bit rounding from the logits at twice the tile stage's K (embedding widths <= 512).  bench.py's parity block shows
-# what the index comparisons gain (profiles/NOTES.md, round 5).
-LOGITS_SPLIT = os.environ.get("HGR_LOGITS_SPLIT", "")
+# The class operand of the class-logits product at ~22 bits instead of 11, by concatenation along K (round 5; the default of BOTH
+# routes - forward() and the fused evaluation - since round 6): "class": [f | f] . [z_hi | z_lo]^T = f . (z_hi + z_lo) removes the 16-bit
+# rounding of the class rows from the logits - the rounding that flips top-k / level ids against the fp32 reference (every class row
+# is rounded differently; the feature row's rounding moves all of a row's logits together) - at twice the K of an 11 GFLOP product
+# (+0.2 % per step).  Embedding widths <= 512 (the evaluation kernel keeps K <= 1 024); wider towers (RN50: 1 024) keep the plain
+# 16-bit operand.  HGR_LOGITS_SPLIT=none switches it off, =feat splits the feature operand instead ([f_hi | f_lo] . [z | z]^T: measured,
+# gains nothing; profiles/NOTES.md, round 5).
+LOGITS_SPLIT = os.environ.get("HGR_LOGITS_SPLIT", "class")
 
 
 class _StopHead(Exception):
@@ -169,7 +172,7 @@ class tree_model(nn.Module):
         if self._zsl16 is None:
             raise HgrError("call update_classifier() before forward_eval()")
         self.join_tail()
-        plan.bind(self._eval_class_operand())
+        plan.bind(self._eval_class_operand(), self._zsl16.shape[1])
         if self.use_graph and inputs.is_cuda:
             return self._forward_graphed(inputs, True, ("eval", plan, k))
         return self._forward_eager(inputs, ("eval", plan, k))
@@ -282,7 +285,7 @@ class tree_model(nn.Module):
             # the sliced image tower (HGR_IMG_STREAMS >= 2) names its workspace sets "v", "v1", ... itself and ignores _img_tag: both
             # step parities would share one set and the tail of step i would race with the head of step i + 1
             return False
-        plan.bind(self._eval_class_operand())
+        plan.bind(self._eval_class_operand(), self._zsl16.shape[1])
         mode = ("eval", plan, k)
         st = self._pipe_state(inputs.device)
         self.clip_model.poll_ln_guard()
@@ -372,18 +375,25 @@ class tree_model(nn.Module):
         feats = self.clip_model.encode_image(inputs)
         b, n = feats.shape[0], self._zsl16.shape[0]
         f16 = torch.empty(feats.shape, dtype=self._zsl16.dtype, device=feats.device)
-        if mode is not None and mode[1].zsl is not None and mode[1].zsl.shape[1] == 2 * feats.shape[1]:
-            # HGR_LOGITS_SPLIT: the features at twice the width to match the K-concatenated class matrix
-            f32 = torch.empty_like(feats)
-            ops.l2norm_rows(feats, y16=f16, y32=f32)
-            second = (f32 - f16.float()).to(f16.dtype) if LOGITS_SPLIT == "feat" else f16
-            return ops.logits_eval(torch.cat([f16, second], dim=1).contiguous(), mode[1], mode[2])
-        ops.l2norm_rows(feats, y16=f16)
+        zc = self._eval_class_operand() if mode is None else mode[1].zsl       # both routes multiply with the same class operand
+        if zc is not None and zc.shape[1] == 2 * feats.shape[1]:
+            # LOGITS_SPLIT: the features at twice the width to match the K-concatenated class matrix
+            if LOGITS_SPLIT == "feat":
+                f32 = torch.empty_like(feats)
+                ops.l2norm_rows(feats, y16=f16, y32=f32)
+                second = (f32 - f16.float()).to(f16.dtype)
+            else:
+                ops.l2norm_rows(feats, y16=f16)
+                second = f16
+            fin = torch.cat([f16, second], dim=1)
+        else:
+            ops.l2norm_rows(feats, y16=f16)
+            fin, zc = f16, (self._zsl16 if mode is None else zc)
         if mode is not None:                                    # ("eval", plan, k): logits GEMM + evaluation fused, no logits written
-            return ops.logits_eval(f16, mode[1], mode[2])
+            return ops.logits_eval(fin, mode[1], mode[2])
         ld = (n + 63) // 64 * 64                   # 16-byte aligned rows for the vector stores
         logits = torch.empty((b, ld), dtype=torch.float32, device=feats.device)
-        ops.gemm_nt(f16, self._zsl16, logits, n=n, tag="logits")
+        ops.gemm_nt(fin, zc, logits, n=n, tag="logits")
         return logits[:, :n]
 
     # ---------------------------------------------------------------------------------------------

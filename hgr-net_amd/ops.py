@@ -478,7 +478,10 @@ class LogitsEvalPlan:
         32 768 nodes over its capacity): callers fall back to forward() + hgr_eval_rows otherwise."""
         return self.n_perm // self.SLICE <= self.MAX_SLICES and self.index.n_levels <= 32
 
-    def bind(self, zsl16: torch.Tensor) -> "LogitsEvalPlan":
+    def bind(self, zsl16: torch.Tensor, algo_d: Optional[int] = None) -> "LogitsEvalPlan":
+        """``algo_d``: the embedding width the product stands for when zsl16 is a K-concatenated operand (clip_tree.LOGITS_SPLIT) -
+        profiling reports the ALGORITHMIC flops 2 B N D, not the doubled K."""
+        self.algo_d = int(algo_d or zsl16.shape[1])
         key = (zsl16.data_ptr(), zsl16._version, tuple(zsl16.shape))
         if self._src != key:
             z = zsl16[self.perm]
@@ -511,7 +514,8 @@ def logits_eval(feat16: torch.Tensor, plan: LogitsEvalPlan, k: int, stage: str =
               _dev(feat16), _dev(plan.zsl), rows, d, plan.n_perm, _dev(plan.tpos), _dev(plan.epos), _dev(plan.level_first),
               ix.n_levels, _dev(ix.filler), _dev(ix.train_cols), ix.n_train, _dev(ix.test_cols), ix.n_test, k,
               _dev(lvl), _dev(top1), _dev(topk), _dev(plan.workspace(rows, dev)), DT_OF[feat16.dtype], _stream())
-    _prof_end(ev, 2.0 * rows * ix.n_nodes * d, 2 * rows * d + 2 * ix.n_nodes * d, "logits_eval" + ("_" + stage if stage else ""))
+    da = getattr(plan, "algo_d", d)
+    _prof_end(ev, 2.0 * rows * ix.n_nodes * da, 2 * rows * da + 2 * ix.n_nodes * da, "logits_eval" + ("_" + stage if stage else ""))
     return lvl, top1, topk
 
 

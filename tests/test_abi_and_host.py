@@ -2,6 +2,7 @@
 without a GPU), host logic of tree_model / parallel sharding, and a world-size-2 gloo run."""
 import json
 import os
+import time
 import re
 import subprocess
 import sys
@@ -352,7 +353,7 @@ def test_comm_file_bootstrap_default_nonce_rejects_an_old_file(tmp_path, monkeyp
     path = str(tmp_path / "uid.bin")
     with open(path, "wb") as f:                                   # a crashed earlier run: same (degenerate) nonce, written long ago
         f.write(comm._run_nonce(None) + b"\x09" * comm.ID_BYTES)
-    old = comm._T_IMPORT - comm.STALE_SLACK_S - 100.0
+    old = comm._T_START - comm.STALE_SLACK_S - 100.0
     os.utime(path, (old, old))
     with pytest.raises(_lib.HgrError, match="stale"):
         comm.init_from_file(path, rank=1, world=2, timeout_s=0.3)
@@ -364,10 +365,14 @@ def test_comm_file_bootstrap_default_nonce_rejects_an_old_file(tmp_path, monkeyp
     comm.destroy()
     monkeypatch.setenv("TORCHELASTIC_RUN_ID", "job-4711")
     assert comm._nonce_is_per_run(None)
-    # round-4 advisor finding: a default single-node torchrun launch (static run id "none") is per-run through the launcher's pid,
-    # so a rank that imports late is not locked out by the age rule
+    # round-5 advisor finding: nothing rank-local (the parent pid of round 5) enters the nonce - ranks behind per-rank wrappers must
+    # derive the same one; a launcher-provided HGR_COMM_NONCE makes a static-run-id launch per-run
     monkeypatch.setenv("TORCHELASTIC_RUN_ID", "none")
     a = comm._run_nonce(None)
     monkeypatch.setenv("LOCAL_WORLD_SIZE", "2")
     monkeypatch.setenv("WORLD_SIZE", "2")
+    assert not comm._nonce_is_per_run(None) and comm._run_nonce(None) == a
+    monkeypatch.setenv("HGR_COMM_NONCE", "launcher-made")
     assert comm._nonce_is_per_run(None) and comm._run_nonce(None) != a
+    # the age rule counts from the PROCESS start (not the module import): a slow import does not lock a rank out
+    assert comm._T_START <= time.time() and comm.STALE_SLACK_S <= 60
