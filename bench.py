@@ -180,19 +180,29 @@ def power_probe(run_step, fence, want: int = 5, max_s: float = 6.0):
     if not os.path.exists(exe):
         return None
     samples, stop = [], threading.Event()
+    # the card THIS process drives, by PCI address (round-5 advisor finding: "the card that draws most" can be another job's GPU on a
+    # shared node or under HIP_VISIBLE_DEVICES); a node whose cards cannot be told apart is not probed rather than misattributed
+    mine = None
+    try:
+        pr = torch.cuda.get_device_properties(torch.cuda.current_device())
+        want_bus = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}".lower()
+        buses = json.loads(subprocess.run([exe, "--showbus", "--json"], capture_output=True, text=True, timeout=10).stdout)
+        hits = [c for c, d in buses.items() if any(want_bus in str(v).lower() for v in d.values())]
+        mine = hits[0] if len(hits) == 1 else (next(iter(buses)) if len(buses) == 1 else None)
+    except Exception:  # noqa: BLE001
+        mine = None
+    if mine is None:
+        return None
 
     def poll():
         while not stop.is_set() and len(samples) < want + 1:
             try:
                 out = subprocess.run([exe, "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=10).stdout
-                best = None
-                for card, d in json.loads(out).items():
-                    pw = [float(v) for k, v in d.items() if "power (w)" in k.lower() and str(v).replace(".", "", 1).isdigit()]
-                    ck = [float(str(v).strip("()").lower().replace("mhz", "")) for k, v in d.items() if k.lower().startswith("sclk clock speed")]
-                    if pw and ck and (best is None or pw[0] > best[0]):
-                        best = (pw[0], ck[0])                       # the busy card: the one this process drives
-                if best:
-                    samples.append(best)
+                d = json.loads(out).get(mine, {})
+                pw = [float(v) for k, v in d.items() if "power (w)" in k.lower() and str(v).replace(".", "", 1).isdigit()]
+                ck = [float(str(v).strip("()").lower().replace("mhz", "")) for k, v in d.items() if k.lower().startswith("sclk clock speed")]
+                if pw and ck:
+                    samples.append((pw[0], ck[0]))
             except Exception:  # noqa: BLE001 - a probe: any failure just ends it
                 return
             time.sleep(0.1)

@@ -96,6 +96,17 @@ template <int DT> __device__ __forceinline__ unsigned mul_pack16(float a0, float
     return __builtin_bit_cast(unsigned, r);
 }
 
+// one product rounded ONCE to the MFMA type (scalar form of mul_pack16: the compiler packs the halves); conv16: a plain conversion that
+// the compiler cannot merge with the arithmetic in front of it (it is handed the value through an opaque register copy)
+template <int DT> __device__ __forceinline__ typename T16<DT>::elem mul16(float a, float b) {
+    if (DT == HGR_F16) {
+        unsigned d;
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
+        return __builtin_bit_cast(typename T16<DT>::elem, (unsigned short)d);
+    }
+    return (typename T16<DT>::elem)(a * b);
+}
+
 // ---- the residual stream's 16-bit-plus-8-bit PAIR (round 4) ----------------------------------------------------------------------
 // x (fp32) is kept as hi - x in the MFMA type (f16 / bf16: it IS the next GEMM's A operand) - and ONE byte q, both cut out of x's own
 // bit pattern.  With S = 13 (f16) / 16 (bf16) mantissa bits dropped by hi:

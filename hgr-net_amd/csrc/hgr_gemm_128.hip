@@ -204,16 +204,17 @@ __global__ __launch_bounds__(NT) void gemm_nt_128(GemmArgs p) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     f32x4 v = acc[i][j] + bq[i];
-                    if (EPI == HGR_EPI_BIAS_QUICKGELU) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
-                    }
                     if (EPI == HGR_EPI_BIAS_RELU) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
                     }
                     const int row = j * 16 + r;
-                    *(typename T16<DT>::vec4 *)(my + row * 128 + (((i * 2 + (g >> 1)) ^ (row & 7)) * 16) + (g & 1) * 8) = cvt4<DT>(v[0], v[1], v[2], v[3]);
+                    typename T16<DT>::vec4 o4;
+                    if (EPI == HGR_EPI_BIAS_QUICKGELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o4[e] = quick_gelu16<DT>(v[e]);            // product + rounding as one operation (hgr_gemm_common.h)
+                    } else o4 = cvt4<DT>(v[0], v[1], v[2], v[3]);
+                    *(typename T16<DT>::vec4 *)(my + row * 128 + (((i * 2 + (g >> 1)) ^ (row & 7)) * 16) + (g & 1) * 8) = o4;
                 }
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
@@ -242,10 +243,18 @@ __global__ __launch_bounds__(NT) void gemm_nt_128(GemmArgs p) {
                 const f32x4 lo = *(const f32x4 *)(my + row * 256 + (((2 * och) ^ (row & 15)) * 16));
                 const f32x4 hi = *(const f32x4 *)(my + row * 256 + (((2 * och + 1) ^ (row & 15)) * 16));
                 float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                if (EPI == HGR_EPI_QGELU_GRAD16) {
+                    const typename T16<DT>::vec8 iv = __builtin_bit_cast(typename T16<DT>::vec8, idn[h][q]);
+                    typename T16<DT>::vec8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = mul16<DT>(v[e], quick_gelu_grad((float)iv[e]));      // one rounding, as in every form of this epilogue
+                    *(u32x4 *)(dst + (int64_t)(h * 32 + q * 8) * p.ldc) = __builtin_bit_cast(u32x4, o);
+                    continue;
+                }
                 if (HAS_IDN) {
                     const typename T16<DT>::vec8 iv = __builtin_bit_cast(typename T16<DT>::vec8, idn[h][q]);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = EPI == HGR_EPI_QGELU_GRAD16 ? v[e] * quick_gelu_grad((float)iv[e]) : v[e] + (float)iv[e];
+                    for (int e = 0; e < 8; ++e) v[e] = v[e] + (float)iv[e];
                 }
                 if (EPI == HGR_EPI_BIAS_RELU || EPI == HGR_EPI_BIAS_ADD16_RELU) {
 #pragma unroll

@@ -278,15 +278,16 @@ __global__ __launch_bounds__(NT256) void gemm_nt_256(GemmArgs p) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 f32x4 v = acc[a][b][i][j] + bq[b][j];
-                if (EPI == HGR_EPI_BIAS_QUICKGELU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
-                }
                 if (EPI == HGR_EPI_BIAS_RELU) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
                 }
-                *(typename T16<DT>::vec4 *)(my + (a * 64 + i * 16 + r) * RS + (b * 32 + j * 16 + g * 4) * 2) = cvt4<DT>(v[0], v[1], v[2], v[3]);
+                typename T16<DT>::vec4 o4;
+                if (EPI == HGR_EPI_BIAS_QUICKGELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o4[e] = quick_gelu16<DT>(v[e]);
+                } else o4 = cvt4<DT>(v[0], v[1], v[2], v[3]);
+                *(typename T16<DT>::vec4 *)(my + (a * 64 + i * 16 + r) * RS + (b * 32 + j * 16 + g * 4) * 2) = o4;
             }
             // LDS ops of one wave complete in order, and the slice is private to the wave: no barrier needed
             const int ch = lane & 7, rr = lane >> 3;

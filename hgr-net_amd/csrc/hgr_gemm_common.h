@@ -68,10 +68,15 @@ __device__ __forceinline__ float quick_gelu(float v) {
 }
 
 
+// QuickGELU to 16 bits, the product rounded once (mul16: hipcc merges a product with its conversion in some kernel forms and not in
+// others - every form goes through these)
+template <int DT> __device__ __forceinline__ typename T16<DT>::elem quick_gelu16(float v) {
+    return mul16<DT>(v, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * v)));
+}
 // the expression hgr_quickgelu16 (hgr_train.hip) evaluates, operation for operation: the dual-output forward must give its bits
-__device__ __forceinline__ float quick_gelu_train(float x) {
+template <int DT> __device__ __forceinline__ typename T16<DT>::elem quick_gelu_train16(float x) {
     const float z = 1.702f * x;
-    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z));
+    return mul16<DT>(x, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z)));
 }
 // d/dx of quick_gelu: s (1 + 1.702 x (1 - s)), s = sigmoid(1.702 x) - the expression of hgr_quickgelu16's backward
 __device__ __forceinline__ float quick_gelu_grad(float x) {
@@ -157,6 +162,8 @@ __device__ __forceinline__ void store_quad(const GemmArgs &p, f32x4 v, int m, in
     if (n + 3 < p.N && p.vec_ok) {
         if (epi_has_bias(EPI)) v += *(const f32x4 *)(p.bias + n);
         if (EPI == HGR_EPI_ACCUM) v += *(const f32x4 *)((const float *)p.C + (int64_t)m * p.ldc + n);
+        const f32x4 v0 = v;                 // before the last product (QuickGELU / its gradient): the 16-bit forms round that product once
+        f32x4 gq = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (EPI == HGR_EPI_BIAS_QUICKGELU) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
@@ -165,26 +172,38 @@ __device__ __forceinline__ void store_quad(const GemmArgs &p, f32x4 v, int m, in
         if (epi_has_idn16(EPI)) {
             const typename T16<DT>::vec4 idn = *(const typename T16<DT>::vec4 *)((const E *)(const void *)p.res + (int64_t)m * p.ldr + n);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = EPI == HGR_EPI_QGELU_GRAD16 ? v[e] * quick_gelu_grad((float)idn[e]) : v[e] + (float)idn[e];
+            for (int e = 0; e < 4; ++e) {
+                if (EPI == HGR_EPI_QGELU_GRAD16) { gq[e] = quick_gelu_grad((float)idn[e]); v[e] = v[e] * gq[e]; }
+                else v[e] = v[e] + (float)idn[e];
+            }
         }
         if (EPI == HGR_EPI_BIAS_RELU || EPI == HGR_EPI_BIAS_ADD16_RELU) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
         if (OUT32) *(f32x4 *)((float *)p.C + (int64_t)m * p.ldc + n) = v;
-        else *(typename T16<DT>::vec4 *)((E *)p.C + (int64_t)m * p.ldc + n) = cvt4<DT>(v[0], v[1], v[2], v[3]);
+        else if (EPI == HGR_EPI_BIAS_QUICKGELU || EPI == HGR_EPI_QGELU_GRAD16) {
+            typename T16<DT>::vec4 o;                      // the last product and the rounding as ONE operation (v0 = its first factor)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = EPI == HGR_EPI_BIAS_QUICKGELU ? quick_gelu16<DT>(v0[e]) : mul16<DT>(v0[e], gq[e]);
+            *(typename T16<DT>::vec4 *)((E *)p.C + (int64_t)m * p.ldc + n) = o;
+        } else *(typename T16<DT>::vec4 *)((E *)p.C + (int64_t)m * p.ldc + n) = cvt4<DT>(v[0], v[1], v[2], v[3]);
         return;
     }
     for (int e = 0; e < 4 && n + e < p.N; ++e) {
         float x = v[e];
         if (epi_has_bias(EPI)) x += p.bias[n + e];
         if (EPI == HGR_EPI_ACCUM) x += ((const float *)p.C)[(int64_t)m * p.ldc + n + e];
+        const float x0 = x;
+        float gx = 0.f;
         if (EPI == HGR_EPI_BIAS_QUICKGELU) x = quick_gelu(x);
         if (EPI == HGR_EPI_BIAS_RESIDUAL) x += p.res[(int64_t)m * p.ldr + n + e];
         if (EPI == HGR_EPI_BIAS_ADD16_RELU) x += (float)((const E *)(const void *)p.res)[(int64_t)m * p.ldr + n + e];
-        if (EPI == HGR_EPI_QGELU_GRAD16) x *= quick_gelu_grad((float)((const E *)(const void *)p.res)[(int64_t)m * p.ldr + n + e]);
+        if (EPI == HGR_EPI_QGELU_GRAD16) { gx = quick_gelu_grad((float)((const E *)(const void *)p.res)[(int64_t)m * p.ldr + n + e]); x *= gx; }
         if (EPI == HGR_EPI_BIAS_RELU || EPI == HGR_EPI_BIAS_ADD16_RELU) x = fmaxf(x, 0.f);
         if (OUT32) ((float *)p.C)[(int64_t)m * p.ldc + n + e] = x;
+        else if (EPI == HGR_EPI_BIAS_QUICKGELU) ((E *)p.C)[(int64_t)m * p.ldc + n + e] = quick_gelu16<DT>(x0);
+        else if (EPI == HGR_EPI_QGELU_GRAD16) ((E *)p.C)[(int64_t)m * p.ldc + n + e] = mul16<DT>(x0, gx);
         else ((E *)p.C)[(int64_t)m * p.ldc + n + e] = (E)x;
     }
 }
@@ -209,6 +228,13 @@ template <int DT, int EPI, bool OUT32>
 __device__ __forceinline__ void store_quad_full(const GemmArgs &p, f32x4 v, f32x4 bq, f32x4 addend, int m, int n) {
     typedef typename T16<DT>::elem E;
     if (epi_has_bias(EPI)) v += bq;
+    if (!OUT32 && (EPI == HGR_EPI_BIAS_QUICKGELU || EPI == HGR_EPI_QGELU_GRAD16)) {
+        typename T16<DT>::vec4 o;                          // the last product rounded once (mul16)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = EPI == HGR_EPI_BIAS_QUICKGELU ? quick_gelu16<DT>(v[e]) : mul16<DT>(v[e], quick_gelu_grad(addend[e]));
+        *(typename T16<DT>::vec4 *)((E *)p.C + (int64_t)m * p.ldc + n) = o;
+        return;
+    }
     if (EPI == HGR_EPI_BIAS_QUICKGELU) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);

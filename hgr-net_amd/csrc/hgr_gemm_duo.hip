@@ -504,15 +504,16 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
                 continue;
             }
             f32x4 v = acc[a][b][i][j] + bq[b][j];
-            if (EPI == HGR_EPI_BIAS_QUICKGELU) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
-            }
             if (EPI == HGR_EPI_BIAS_RELU) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
             }
-            *(typename T16<DT>::vec4 *)(my + (a * 64 + i * 16 + r) * RS + (b * 32 + j * 16 + g * 4) * 2) = cvt4<DT>(v[0], v[1], v[2], v[3]);
+            typename T16<DT>::vec4 o4;
+            if (EPI == HGR_EPI_BIAS_QUICKGELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o4[e] = quick_gelu16<DT>(v[e]);
+            } else o4 = cvt4<DT>(v[0], v[1], v[2], v[3]);
+            *(typename T16<DT>::vec4 *)(my + (a * 64 + i * 16 + r) * RS + (b * 32 + j * 16 + g * 4) * 2) = o4;
         }
         }
         // addresses = wave-uniform 64-bit base + 32-bit per-lane byte offset (one VALU add per store; a 64-bit row * ldc product
@@ -539,7 +540,7 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
                 const vec8 h = __builtin_bit_cast(vec8, v);
                 vec8 o;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (E)quick_gelu_train((float)h[e]);
+                for (int e = 0; e < 8; ++e) o[e] = quick_gelu_train16<DT>((float)h[e]);
                 *(u32x4 *)(gw + (gl + q * 8 * ldgB)) = __builtin_bit_cast(u32x4, o);
             }
             return;
@@ -594,8 +595,8 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     if (EPI == HGR_EPI_QGELU_GRAD16) {          // dL/dpre = dL/dpost * g'(pre): the hgr_quickgelu16 backward, one rounding
-                        o[e] = (E)(lo[e] * quick_gelu_grad((float)iv[e]));
-                        o[e + 4] = (E)(hi[e] * quick_gelu_grad((float)iv[e + 4]));
+                        o[e] = mul16<DT>(lo[e], quick_gelu_grad((float)iv[e]));
+                        o[e + 4] = mul16<DT>(hi[e], quick_gelu_grad((float)iv[e + 4]));
                     } else {
                         o[e] = (E)fmaxf(lo[e] + (float)iv[e], 0.f);
                         o[e + 4] = (E)fmaxf(hi[e] + (float)iv[e + 4], 0.f);
@@ -891,7 +892,7 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
                 const typename T16<DT>::vec4 pre = cvt4<DT>(v[0], v[1], v[2], v[3]);
                 *(typename T16<DT>::vec4 *)((E *)p.C + (int64_t)m * p.ldc + n) = pre;
                 *(typename T16<DT>::vec4 *)((E *)p.ln_xh + (int64_t)m * p.ln_ldx + n) =
-                    cvt4<DT>(quick_gelu_train((float)pre[0]), quick_gelu_train((float)pre[1]), quick_gelu_train((float)pre[2]), quick_gelu_train((float)pre[3]));
+                    (typename T16<DT>::vec4){quick_gelu_train16<DT>((float)pre[0]), quick_gelu_train16<DT>((float)pre[1]), quick_gelu_train16<DT>((float)pre[2]), quick_gelu_train16<DT>((float)pre[3])};
             }
         }
         return;
@@ -919,7 +920,7 @@ __device__ __forceinline__ void duo_tile(const GemmArgs &p, char *smem, const in
                     const typename T16<DT>::vec4 idn = *(const typename T16<DT>::vec4 *)((const E *)(const void *)p.res + (int64_t)m * p.ldr + n);
                     typename T16<DT>::vec4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { o[e] = (E)(acc[a][b][i][j][e] * quick_gelu_grad((float)idn[e])); cs[b][j][e] += (float)o[e]; }
+                    for (int e = 0; e < 4; ++e) { o[e] = mul16<DT>(acc[a][b][i][j][e], quick_gelu_grad((float)idn[e])); cs[b][j][e] += (float)o[e]; }
                     *(typename T16<DT>::vec4 *)((E *)p.C + (int64_t)m * p.ldc + n) = o;
                 }
             }

@@ -389,9 +389,8 @@ __global__ __launch_bounds__(WS_NT) void gemm_nt_ws(GemmArgs p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float y = HASB ? x[e] + eb[SECOND ? 1 : 0][e] : x[e];
-                    if (ACT == 1) y = quick_gelu(y);
                     if (ACT == 2) y = fmaxf(y, 0.f);
-                    o[e] = (E)y;
+                    o[e] = ACT == 1 ? quick_gelu16<DT>(y) : (E)y;
                 }
                 o2 = __builtin_bit_cast(u32x2, o);
             }

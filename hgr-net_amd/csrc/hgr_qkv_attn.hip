@@ -49,6 +49,21 @@ typedef __attribute__((ext_vector_type(8))) short qa_s16x8;
 // a phase's LDS-DMAs are issued BEHIND its fragment reads (as in gemm_nt_duo): an LDS-DMA instruction can stall at the CU's one
 // vector-memory address path, and in front of the reads that stall delayed the reads, the wait and the MFMA burst behind them.  Three
 // interleaved pairs, one box: 110.1 -> 107.9 us per launch, bit-identical.  -DHGR_QA_ISSUE_LATE=0: the round-4 order
+#ifndef HGR_QA_VASM
+#define HGR_QA_VASM 1
+#endif
+// Experiment, OFF (-DHGR_QA_STATS_DMA=1 builds it): the tile's raw slot statistics staged by LDS-DMA into the V region (unused while the
+// main loop runs) during the second-last K-tile - the six DMAs per wave (waves 0-3) ride in the in-order vmcnt stream of the main loop,
+// the two counted waits of that K-tile allow for them, the last K-tile's vmcnt(0) completes them - instead of a dependent global round
+// trip between the main loop and the q / k / v conversion.  Measured twice in round 6 (tools/qa_stamps.py + three interleaved rounds of
+// the image tower each): (a) issued behind the seam barrier: statistics section 1 880 -> 1 160 ticks of a 37 400-tick tile, launch
+// 107.6 -> 108.6 us, tower 4.78 -> 4.81 ms; (b) issued mid-loop as built here: section 1 880 -> 1 160 again, main loop 23 050 -> 24 000,
+// tile 37 364 -> 37 664, tower 4.78 -> 4.80 ms.  The round trip is real (5 % of a tile) but whatever removes it gives the time back
+// elsewhere; round 4 found the same with a third placement.  Under the package power limit idle cycles are not free
+// time to be harvested: the clock drops when they are filled.
+#ifndef HGR_QA_STATS_DMA
+#define HGR_QA_STATS_DMA 0
+#endif
 #ifndef HGR_QA_ISSUE_LATE
 #define HGR_QA_ISSUE_LATE 1
 #endif
@@ -59,12 +74,15 @@ constexpr int QA_PA0 = 0, QA_PA1 = 16384, QA_PW = 32768;
 constexpr int QA_VR = 72;
 constexpr int QA_Q = QA_STAGE, QA_K = QA_Q + 32768, QA_V = QA_K + 32768, QA_LN = QA_V + 256 * QA_VR * 2;
 constexpr int QA_LDS = QA_LN + 2048;                         // 161 792 B of the CU's 163 840
+constexpr int QA_ST = QA_V;                                  // staged slot statistics [q < 8][256 rows] x 16 B = 32 KB of V's 36 KB (HGR_QA_STATS_DMA)
 
 #ifdef HGR_LAB
 // lab builds only: s_memtime stamps of wave 0 around the sections of the workgroup's SECOND tile (steady state), read back through
 // hgr_lab_qa_stamps (tools/qa_stamps.py): 0 tile start, 1 main loop done, 2 row statistics in LDS, 3 q / k / v in LDS, 4 attention done
 __device__ unsigned long long qa_lab_stamps[1024 * 8];
-#define QA_STAMP(i) do { if (threadIdx.x == 0 && lab_tile == 1) qa_lab_stamps[(blockIdx.x & 1023) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define QA_STAMP(i) do { if (threadIdx.x == 0 && lab_tile == 1) { qa_lab_stamps[(blockIdx.x & 1023) * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+        if ((i) == 0) qa_lab_stamps[(blockIdx.x & 1023) * 8 + 6] = __builtin_amdgcn_s_memrealtime(); \
+        if ((i) == 5) qa_lab_stamps[(blockIdx.x & 1023) * 8 + 7] = __builtin_amdgcn_s_memrealtime(); } } while (0)      /* 6, 7: the 100 MHz clock at stamps 0 and 5 */
 #else
 #define QA_STAMP(i) do { } while (0)
 #endif
@@ -136,6 +154,19 @@ __global__ __launch_bounds__(QA_NT) void qkv_attn(QkvAttnArgs p) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) dma16(rW, p.W, oW[i], t * 128, dst + i * 8192);
     };
+    // Slot statistics of the tile at m0 (waves 0-3: row 64 wave + lane, entry q = slots 2 q, 2 q + 1) -> LDS [q][row], issued at the top
+    // of the second-last K-tile; read back by the wave that issued it (thread t: row t).
+    const int nq = p.ln_slots >> 1;
+    const bool st_dma = HGR_QA_STATS_DMA && !(p.ln_slots & 1) && (nq == 2 || nq == 4 || nq == 5 || nq == 6 || nq == 8);
+    const __amdgpu_buffer_rsrc_t rS = dma_rsrc(p.ln_stats);
+    auto issueStats = [&]() {
+        if (!st_dma || wave >= 4) return;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const unsigned so = (unsigned)min(m0 + wave * 64 + ln, p.M - 1) * (unsigned)(p.ln_slots * 8);
+        char *dst = smem + QA_ST + wave * 1024;
+        for (int q = 0; q < nq; ++q) dma16(rS, (const char *)p.ln_stats, so, q * 16, dst + q * 4096);
+    };
 
     const int nk = p.K / 64;    // >= 2 (host guarantees)
     const int offA = (wm * 32 + r) * 128;          // + m tile (0, 1) * 2048 within PA0 / PA1
@@ -169,6 +200,7 @@ __global__ __launch_bounds__(QA_NT) void qkv_attn(QkvAttnArgs p) {
     auto ktile = [&](int t, auto mode_tag) {
         constexpr int MODE = decltype(mode_tag)::value;
         const char *st = smem + (t & 1) * QA_STAGE;
+        if (MODE == 1) issueStats();          // m0 is still this tile's (set_tile for the next one runs in the epilogue); V is free: the seam barrier is behind us
         // ---- ph1: rows 0-31 of the wave x all 96 columns ----
 #if !HGR_QA_ISSUE_LATE
         if (MODE <= 1) issueA(oA1, QA_PA1, t + 1);              // its slot was last read in ph2(t - 1), two barriers ago
@@ -186,7 +218,9 @@ __global__ __launch_bounds__(QA_NT) void qkv_attn(QkvAttnArgs p) {
 #if HGR_QA_ISSUE_LATE
         if (MODE <= 1) issueA(oA1, QA_PA1, t + 1);
 #endif
-        if (MODE <= 1) HGR_RWAIT(7); else HGR_RWAIT(0);         // PA1(t) landed
+        if (MODE == 1 && st_dma && wave < 4) {                  // + this wave's nq statistics DMAs, issued at the top of this K-tile
+            switch (nq) { case 2: HGR_RWAIT(9); break; case 4: HGR_RWAIT(11); break; case 5: HGR_RWAIT(12); break; case 6: HGR_RWAIT(13); break; default: HGR_RWAIT(15); }
+        } else if (MODE <= 1) HGR_RWAIT(7); else HGR_RWAIT(0);  // PA1(t) landed
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
@@ -208,7 +242,9 @@ __global__ __launch_bounds__(QA_NT) void qkv_attn(QkvAttnArgs p) {
 #if HGR_QA_ISSUE_LATE
         if (MODE == 0) { issueA(oA0, QA_PA0, t + 2); issueW(t + 2); }
 #endif
-        if (MODE == 0) HGR_RWAIT(7); else if (MODE == 1) HGR_RWAIT(2); else HGR_RBAR();      // PA0(t+1), PW(t+1) landed
+        if (MODE == 1 && st_dma && wave < 4) {
+            switch (nq) { case 2: HGR_RWAIT(4); break; case 4: HGR_RWAIT(6); break; case 5: HGR_RWAIT(7); break; case 6: HGR_RWAIT(8); break; default: HGR_RWAIT(10); }
+        } else if (MODE == 0) HGR_RWAIT(7); else if (MODE == 1) HGR_RWAIT(2); else HGR_RBAR();      // PA0(t+1), PW(t+1) landed
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
@@ -254,6 +290,23 @@ __global__ __launch_bounds__(QA_NT) void qkv_attn(QkvAttnArgs p) {
     if (tid_e < 256) {
         const f32x4 *sp = (const f32x4 *)(p.ln_stats + (int64_t)min(m0c + tid_e, p.M - 1) * p.ln_slots * 2);
         float s1 = 0.f, s2 = 0.f;
+        if (st_dma) {
+            // four entries at a time, summed in slot order like the loads of the other path (entries >= nq are whatever V held: read,
+            // never summed); inline asm: an LDS read the compiler can see is ordered behind every LDS-DMA in flight
+            const unsigned sa = (unsigned)(uintptr_t)(AS3 char *)(smem + QA_ST) + (unsigned)tid_e * 16u;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f32x4 tl[4];
+                if (h == 0) asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:4096\n\tds_read_b128 %2, %4 offset:8192\n\tds_read_b128 %3, %4 offset:12288\n\ts_waitcnt lgkmcnt(0)"
+                                         : "=&v"(tl[0]), "=&v"(tl[1]), "=&v"(tl[2]), "=&v"(tl[3]) : "v"(sa) : "memory");
+                else asm volatile("ds_read_b128 %0, %4 offset:16384\n\tds_read_b128 %1, %4 offset:20480\n\tds_read_b128 %2, %4 offset:24576\n\tds_read_b128 %3, %4 offset:28672\n\ts_waitcnt lgkmcnt(0)"
+                                  : "=&v"(tl[0]), "=&v"(tl[1]), "=&v"(tl[2]), "=&v"(tl[3]) : "v"(sa) : "memory");
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (h * 4 + i < nq) { s1 += tl[i][0] + tl[i][2]; s2 += tl[i][1] + tl[i][3]; }
+                if (nq <= 4) break;
+            }
+        } else {
         auto fixed = [&](auto nq_tag) {
             constexpr int NQ = decltype(nq_tag)::value;
             f32x4 t[NQ];
@@ -270,6 +323,7 @@ __global__ __launch_bounds__(QA_NT) void qkv_attn(QkvAttnArgs p) {
             case 16: fixed(std::integral_constant<int, 8>()); break;
             default:
                 for (int i = 0; i < p.ln_slots / 2; ++i) { const f32x4 t = sp[i]; s1 += t[0] + t[2]; s2 += t[1] + t[3]; }
+        }
         }
         const float2 mr = ln_finalize(s1, s2, 1.0f / (float)p.K, p.ln_eps);
         const qa_f2 mv = {mr.x, mr.y};
@@ -319,7 +373,28 @@ __global__ __launch_bounds__(QA_NT) void qkv_attn(QkvAttnArgs p) {
     // front of the transposing V reads of every pass - a wait for the previous query tile's output stores too.  With those DMAs
     // written as inline asm the wait is gone and the launch takes 109.6 us against 108.7: it was never exposed)
     constexpr int KT = 2;              // 64 key slots: L <= 64
-    const E *sV = (const E *)(smem + QA_V);
+    // Round 6 (tools/qa_stamps.py: the phases behind the main loop were 39 % of a tile - statistics 5, q / k / v 11, attention 14 + 9 at
+    // the seam barrier for the waves that have three units): a unit = (16-query tile, sequence) is a chain of LDS and cross-lane
+    // latencies, not of arithmetic - ~2 800 cycles for 16 MFMAs.  Same arithmetic, element for element (hgr_mha's), laid out for latency:
+    //   * ALL of a unit's fragment reads - 8 K reads and the 16 transposing V reads - are issued before its first MFMA (the compiler's
+    //     own order was read 2 / wait / 2 MFMAs, four times, then the V reads behind the softmax);
+    //   * the row maximum and the row sum cross the four lane groups through v_permlane16_swap / v_permlane32_swap (vector ALU)
+    //     instead of four dependent ds_bpermute round trips; a + b of the SAME pair in both lanes is the same sum in either order;
+    //   * the lane-constant part of the key mask (slots past the sequence) is an additive 0 / -inf vector (one FMA with the exact
+    //     scaling by 1/8 where multiply, compare and select were three instructions).
+    f32x4 kbias[2 * KT];
+    int ln_a = lane;                     // opaque copy: lane constants the compiler would otherwise hoist out of the tile loop and carry (spill) through the main loop
+    asm volatile("" : "+v"(ln_a));
+    const int g_a = ln_a >> 4;
+#pragma unroll
+    for (int t = 0; t < 2 * KT; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) kbias[t][e] = (t * 16 + g_a * 4 + e >= p.L) ? -INFINITY : 0.f;
+    auto x16max = [](float v) { auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false); return fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1])); };
+    auto x32max = [](float v) { auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false); return fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1])); };
+    auto x16add = [](float v) { auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false); return __uint_as_float(a[0]) + __uint_as_float(a[1]); };
+    auto x32add = [](float v) { auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false); return __uint_as_float(a[0]) + __uint_as_float(a[1]); };
+    AS3 const char *const ldsV = (AS3 const char *)(smem + QA_V);
     for (int qt = wave; qt * 16 < rows_valid; qt += 8) {
         const int qrow = qt * 16 + r;                                // this lane's query row inside the tile
         const int myseq = min(qrow / p.L, p.S - 1);
@@ -333,28 +408,53 @@ __global__ __launch_bounds__(QA_NT) void qkv_attn(QkvAttnArgs p) {
         for (int s = s_lo; s <= s_hi; ++s) {
             const int kb = s * p.L;                                  // first key row of sequence s
             const int q = qrow - kb;                                 // query position inside the sequence (meaningful when myseq == s)
-            f32x4 sc[2 * KT];
+            // ---- every fragment of the unit: K (A operand of S^T = K Q^T), V^T (A operand of O^T = V^T P^T; hgr_mha's transposing reads:
+            //      V^T[d = 16 td + r][keys 32 ks + 4 g .. + 3, 32 ks + 16 + 4 g .. + 3]) ----
+            vec8 kf[2 * KT][2];
 #pragma unroll
             for (int t = 0; t < 2 * KT; ++t) {
-                sc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 const int krow = min(kb + t * 16 + r, 255);          // key slots past the sequence are masked below: any finite row will do
                 const char *kr = smem + QA_K + krow * 128;
-                sc[t] = T16<DT>::mfma16(*(const vec8 *)(kr + (((0 + g) ^ (krow & 7)) * 16)), q0, sc[t]);
-                sc[t] = T16<DT>::mfma16(*(const vec8 *)(kr + (((4 + g) ^ (krow & 7)) * 16)), q1, sc[t]);
+                kf[t][0] = *(const vec8 *)(kr + (((0 + g) ^ (krow & 7)) * 16));
+                kf[t][1] = *(const vec8 *)(kr + (((4 + g) ^ (krow & 7)) * 16));
             }
+            qa_s16x4 vlo[KT][4], vhi[KT][4];
+#pragma unroll
+            for (int ks = 0; ks < KT; ++ks) {
+                const int v0 = min(kb + ks * 32 + g * 4 + (r >> 2), 255), v1 = min(kb + ks * 32 + 16 + g * 4 + (r >> 2), 255);
+#if HGR_QA_VASM
+                // as inline asm: hipcc puts s_waitcnt vmcnt(0) in front of a transposing read it can see while LDS-DMAs are pending (the
+                // next tile's first K-tile, requested above, lands in stage 0 - never in V) - here that is also a wait for the previous
+                // unit's output stores.  The reads are waited for by hand in front of the P V products (QA_V_WAIT).
+                const unsigned a0 = (unsigned)(uintptr_t)ldsV + (unsigned)((v0 * QA_VR + (r & 3) * 4) * 2), a1 = (unsigned)(uintptr_t)ldsV + (unsigned)((v1 * QA_VR + (r & 3) * 4) * 2);
+                asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:32\n\tds_read_b64_tr_b16 %2, %4 offset:64\n\tds_read_b64_tr_b16 %3, %4 offset:96"
+                             : "=&v"(vlo[ks][0]), "=&v"(vlo[ks][1]), "=&v"(vlo[ks][2]), "=&v"(vlo[ks][3]) : "v"(a0));
+                asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:32\n\tds_read_b64_tr_b16 %2, %4 offset:64\n\tds_read_b64_tr_b16 %3, %4 offset:96"
+                             : "=&v"(vhi[ks][0]), "=&v"(vhi[ks][1]), "=&v"(vhi[ks][2]), "=&v"(vhi[ks][3]) : "v"(a1));
+#else
+#pragma unroll
+                for (int td = 0; td < 4; ++td) {
+                    vlo[ks][td] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AS3 qa_s16x4 *)(ldsV + (v0 * QA_VR + td * 16 + (r & 3) * 4) * 2));
+                    vhi[ks][td] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AS3 qa_s16x4 *)(ldsV + (v1 * QA_VR + td * 16 + (r & 3) * 4) * 2));
+                }
+#endif
+            }
+            f32x4 sc[2 * KT];
+#pragma unroll
+            for (int t = 0; t < 2 * KT; ++t) sc[t] = T16<DT>::mfma16(kf[t][0], q0, (f32x4){0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+            for (int t = 0; t < 2 * KT; ++t) sc[t] = T16<DT>::mfma16(kf[t][1], q1, sc[t]);
             float mx = -INFINITY;
 #pragma unroll
             for (int t = 0; t < 2 * KT; ++t)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int key = t * 16 + g * 4 + e;
-                    float x = sc[t][e] * 0.125f;      // 64^-0.5, exact
-                    if (key >= p.L || (CAUSAL && key > q)) x = -INFINITY;
+                    float x = __builtin_fmaf(sc[t][e], 0.125f, kbias[t][e]);      // 64^-0.5, exact; -inf on the slots past the sequence
+                    if (CAUSAL && t * 16 + g_a * 4 + e > q) x = -INFINITY;
                     sc[t][e] = x;
                     mx = fmaxf(mx, x);
                 }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            mx = x32max(x16max(mx));
             float sum = 0.f;
 #pragma unroll
             for (int t = 0; t < 2 * KT; ++t)
@@ -364,24 +464,26 @@ __global__ __launch_bounds__(QA_NT) void qkv_attn(QkvAttnArgs p) {
                     sc[t][e] = pexp;
                     sum += pexp;
                 }
-            sum += __shfl_xor(sum, 16);
-            sum += __shfl_xor(sum, 32);
+            sum = x16add(sum);
+            sum = x32add(sum);
             const float inv = 1.0f / sum;
             f32x4 o[4];
 #pragma unroll
             for (int td = 0; td < 4; ++td) o[td] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#if HGR_QA_VASM
+            // every V^T fragment has landed (they were issued before the softmax); the registers pass through the statement so that no
+            // product can be scheduled in front of it
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vlo[0][0]), "+v"(vlo[0][1]), "+v"(vlo[0][2]), "+v"(vlo[0][3]), "+v"(vhi[0][0]), "+v"(vhi[0][1]), "+v"(vhi[0][2]), "+v"(vhi[0][3]),
+                                                  "+v"(vlo[1][0]), "+v"(vlo[1][1]), "+v"(vlo[1][2]), "+v"(vlo[1][3]), "+v"(vhi[1][0]), "+v"(vhi[1][1]), "+v"(vhi[1][2]), "+v"(vhi[1][3]));
+#endif
 #pragma unroll
             for (int ks = 0; ks < KT; ++ks) {
                 vec8 pf;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { pf[e] = (E)sc[2 * ks][e]; pf[4 + e] = (E)sc[2 * ks + 1][e]; }
-                const int v0 = min(kb + ks * 32 + g * 4 + (r >> 2), 255), v1 = min(kb + ks * 32 + 16 + g * 4 + (r >> 2), 255);
 #pragma unroll
                 for (int td = 0; td < 4; ++td) {
-                    // A operand = V^T[d = 16 td + r][keys 32 ks + 4 g .. + 3, 32 ks + 16 + 4 g .. + 3] (hgr_mha's transposing reads)
-                    const qa_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AS3 qa_s16x4 *)(sV + v0 * QA_VR + td * 16 + (r & 3) * 4));
-                    const qa_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AS3 qa_s16x4 *)(sV + v1 * QA_VR + td * 16 + (r & 3) * 4));
-                    const vec8 vf = __builtin_bit_cast(vec8, (qa_s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                    const vec8 vf = __builtin_bit_cast(vec8, (qa_s16x8)__builtin_shufflevector(vlo[ks][td], vhi[ks][td], 0, 1, 2, 3, 4, 5, 6, 7));
                     o[td] = T16<DT>::mfma16(vf, pf, o[td]);
                 }
             }
@@ -394,15 +496,14 @@ __global__ __launch_bounds__(QA_NT) void qkv_attn(QkvAttnArgs p) {
         if (qrow < rows_valid && m0c + qrow < p.M) {
             E *orow = (E *)p.out + (int64_t)(m0c + qrow) * p.ldo + hc * 64 + g * 4;
 #pragma unroll
-            // product and 16-bit conversion in one expression, as in hgr_mha: for f16 hipcc fuses them into v_fma_mixlo_f16 (ONE rounding);
-            // a product kept in fp32 and converted later rounds twice and differs by one f16 ulp in ~3e-5 of the elements
+            // product and 16-bit conversion as ONE operation, as in hgr_mha (mul_pack16: v_fma_mixlo / mixhi_f16 - one rounding)
             for (int td = 0; td < 4; ++td)
                 *(u32x2 *)(orow + td * 16) = (u32x2){mul_pack16<DT>(res[td][0], rinv, res[td][1], rinv), mul_pack16<DT>(res[td][2], rinv, res[td][3], rinv)};
         }
     }
     QA_STAMP(4);
     if (!has_next) break;
-    __syncthreads();            // every wave's attention reads are done: stage 1 (under Q / K) may be refilled
+    __syncthreads();            // every wave's attention reads are done: stage 1 (under Q / K) may be refilled, V is free
     QA_STAMP(5);
     issueA(oA0, QA_PA0, 1); issueW(1);
     cur = nxt;

@@ -254,7 +254,6 @@ template <int DT, bool BWD>
 __global__ __launch_bounds__(256) void gelu16(const typename T16<DT>::elem *__restrict__ a, const typename T16<DT>::elem *__restrict__ du,
                                               typename T16<DT>::elem *__restrict__ out, int64_t n8) {
     typedef typename T16<DT>::vec8 vec8;
-    typedef typename T16<DT>::elem E;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
         const vec8 av = ((const vec8 *)a)[i];
         vec8 dv, o;
@@ -262,7 +261,7 @@ __global__ __launch_bounds__(256) void gelu16(const typename T16<DT>::elem *__re
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float x = (float)av[e], s = sigm(1.702f * x);
-            o[e] = BWD ? (E)((float)dv[e] * s * (1.0f + 1.702f * x * (1.0f - s))) : (E)(x * s);
+            o[e] = BWD ? mul16<DT>((float)dv[e] * s, 1.0f + 1.702f * x * (1.0f - s)) : mul16<DT>(x, s);      // the last product rounded once: the GEMM epilogues' twin
         }
         ((vec8 *)out)[i] = o;
     }

@@ -149,10 +149,10 @@ def run(opts, loader_train=None, loader_test=None, group=None):
         # single-class batch and encodes its share of the SAME prompt list
         import random
         import torch.distributed as dist
-        seed_t = torch.tensor([opts.data_seed if opts.data_seed is not None else random.getrandbits(31)], dtype=torch.int64, device=device)
+        seed_t = torch.tensor([opts.data_seed if getattr(opts, "data_seed", None) is not None else random.getrandbits(31)], dtype=torch.int64, device=device)
         dist.broadcast(seed_t, src=0, group=group)
         base_seed = int(seed_t.item())
-        if opts.data_seed is None:
+        if getattr(opts, "data_seed", None) is None:
             opts.data_seed = base_seed
     if opts.train:
         with open(model.save_path + "arugements.log", "a") as f:

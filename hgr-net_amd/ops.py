@@ -189,7 +189,9 @@ def gemm_nt_ln_mha(x16: torch.Tensor, wfold: torch.Tensor, att: torch.Tensor, ln
 
 def ln_mha_ok(w: int, l: int, rows: Optional[int] = None, ldx: Optional[int] = None) -> bool:
     """Shape contract of hgr_gemm_nt_ln_mha: whole sequences inside a 256-row tile, head width 64, row width a multiple of 128, and
-    (the kernel's LDS-DMA addresses its operands with 32-bit byte offsets) operands below 4 GB - larger inputs take gemm_nt_ln + mha."""
+    (the kernel's LDS-DMA addresses its operands with 32-bit byte offsets) operands below 4 GB.  Larger inputs are REJECTED further
+    down as well: hgr_gemm_nt_ln has the same 32-bit offsets (ln_common_checks raises HgrError) - slice the batch (the towers' callers
+    never get there: 4 GB of 16-bit rows is 2.8 M tokens of width 768)."""
     if not (1 <= l <= 64 and w % 128 == 0):
         return False
     if rows is not None and rows * (ldx if ldx is not None else w) * 2 >= (1 << 32):

@@ -481,9 +481,15 @@ class OMTrainer:
         import torch.distributed as dist
         mine = [(list(ids), int(pos)) for ids, pos, _, _ in picks]
         hsh = int.from_bytes(hashlib.sha256(repr(mine).encode()).digest()[:7], "little")
-        chk = torch.tensor([hsh, -hsh], dtype=torch.int64, device=self.engine.dev)
+        # (max hash, -min hash, max length, -min length) in ONE reduce: every rank - the source rank included - learns whether the
+        # draws differ AND whether the plans differ in length, so a length mismatch raises on all ranks together (round-5 advisor
+        # finding: only the non-source ranks raised, the source went on into the next collective and hung until the timeout)
+        chk = torch.tensor([hsh, -hsh, len(mine), -len(mine)], dtype=torch.int64, device=self.engine.dev)
         dist.all_reduce(chk, op=dist.ReduceOp.MAX, group=dp)
         chk = chk.tolist()
+        if chk[2] != -chk[3]:
+            raise HgrError("data-parallel OM step: the ranks planned different numbers of inner steps (different target classes?): "
+                           "hand every rank its rows of the SAME single-class batch")
         if chk[0] == -chk[1]:
             return picks
         if not self._warned_picks:
@@ -494,9 +500,6 @@ class OMTrainer:
                           "the extra broadcast")
         box = [mine]
         dist.broadcast_object_list(box, src=dist.get_global_rank(dp, 0) if hasattr(dist, "get_global_rank") else 0, group=dp)
-        if len(box[0]) != len(picks):
-            raise HgrError("data-parallel OM step: the ranks planned different numbers of inner steps (different target classes?): "
-                           "hand every rank its rows of the SAME single-class batch")
         return [(list(ids), int(pos), w, wt) for (ids, pos), (_, _, w, wt) in zip(box[0], picks)]
 
     def _text_features_dp(self, uniq: list, ctx):

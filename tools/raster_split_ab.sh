@@ -6,7 +6,7 @@ set -eo pipefail
 ROOT=$PWD; OUT=$PWD/$1; shift
 ARMS=("$@")
 mkdir -p "$OUT"; export TMPDIR=/tmp
-B="--no-cpu-baseline --no-pcie --no-secondary --no-host-probe"
+B="--no-cpu-baseline --no-pcie --no-secondary --no-host-probe --no-power-probe"
 for r in 1 2; do
   for arm in "${ARMS[@]}"; do
     read -r -a w <<< "$arm"; tag=${w[0]}
