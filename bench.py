@@ -617,7 +617,20 @@ def main():
     t0 = time.time()
     model.update_classifier(group=group)
     torch.cuda.synchronize()
-    log(f"[bench] update_classifier (text tower, {a.nodes} prompts, one-off, untimed): {time.time() - t0:.2f}s")
+    t_uc_first = time.time() - t0
+    # once more, warm (prepared weights and workspace exist): what the one-off costs a rank - with N > 1 its own shard of the prompts
+    # plus the all-gather of the class rows (hgr_net_amd.parallel.sharded_text_features)
+    if group is not None:
+        import torch.distributed as dist
+        dist.barrier()
+    t0 = time.time()
+    model.update_classifier(group=group)
+    torch.cuda.synchronize()
+    t_uc = time.time() - t0
+    uc_all = _gather_obj(round(t_uc, 4), world) if world > 1 else [round(t_uc, 4)]
+    uc_info = {"s_per_rank_max": max(uc_all), "s_per_rank_min": min(uc_all), "first_call_s": round(t_uc_first, 2), "prompts_per_rank": -(-a.nodes // world),
+               "how": "second (warm) call of update_classifier: text tower over this rank's shard of the N prompts" + (" + all-gather of the class rows" if world > 1 else "") + "; one-off per evaluation, outside the timed region"}
+    log(f"[bench] update_classifier (text tower, {a.nodes} prompts, one-off, untimed): first {t_uc_first:.2f}s, warm {t_uc:.3f}s")
     model.zsl_unplanted = model.zsl_weights
     # the planted rows are those of EVERY rank's step targets, so that all ranks evaluate against the same class matrix
     all_targets = [te[(7 * i + r) % len(te)] for r in range(world) for i in range(a.steps + a.warmup)]
@@ -779,6 +792,26 @@ def main():
                 tile = roof["logits_gemm"].get("tile_stage_us")
                 if tile:
                     roof["logits_gemm"]["tile_stage_frac_mfma"] = round(lg[0][1] / (tile * 1e-6) / 1e12 / PEAK_TFLOPS_BF16, 4)
+                # beside it: the PLAIN product - hgr_gemm_nt writing the fp32 logits (forward()'s kernel on the 11-bit class operand, K = D) -
+                # against both of its roofs: 2 B N D flop, 2 B D + 2 N D + 4 B N bytes (the fp32 output co-binds it to HBM, H2)
+                n_, d_ = model._zsl16.shape
+                ld_ = (n_ + 63) // 64 * 64
+                lgt = torch.empty((a.batch, ld_), dtype=torch.float32, device=dev)
+                ts = []
+                for _ in range(7):
+                    ops.l2norm_rows(model.clip_model.encode_image(batches[0]), y16=f16)          # operands as cold as in the step
+                    e0_, e1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0_.record()
+                    ops.gemm_nt(f16, model._zsl16, lgt, n=n_)
+                    e1_.record()
+                    torch.cuda.synchronize()
+                    ts.append(e0_.elapsed_time(e1_) * 1e-3)
+                tp = sorted(ts)[len(ts) // 2]
+                fl_, by_ = 2.0 * a.batch * n_ * d_, 2.0 * a.batch * d_ + 2.0 * n_ * d_ + 4.0 * a.batch * n_
+                roof["logits_gemm"]["plain_gemm_nt_fp32_out"] = {"us": round(tp * 1e6, 1), "tflops": round(fl_ / tp / 1e12, 1), "frac_mfma": round(fl_ / tp / 1e12 / PEAK_TFLOPS_BF16, 4),
+                                                                "gbps": round(by_ / tp / 1e9, 1), "frac_hbm": round(by_ / tp / 8e12, 4),
+                                                                "bound_at_hbm_peak_us": round(by_ / 8e12 * 1e6, 1), "bound_at_mfma_peak_us": round(fl_ / (PEAK_TFLOPS_BF16 * 1e12) * 1e6, 1)}
+                del lgt
 
     # PCIe-inclusive rate (never `value`): the same step fed from pinned HOST memory with uint8 NHWC crops (what a
     # JPEG decoder hands over), H2D on a copy stream double-buffered against compute, normalisation fused into the
@@ -932,6 +965,9 @@ def main():
             for k_, n_ in (("us", "us_logits_eval"), ("tile_stage_us", "us_logits_tile"), ("tile_stage_frac_mfma", "frac_logits_tile"), ("row_stage_us", "us_logits_row")):
                 if k_ in lgm:
                     roof[n_] = lgm[k_]
+            pl_ = lgm.get("plain_gemm_nt_fp32_out") or {}
+            if pl_:
+                roof["us_logits_plain"], roof["frac_logits_plain_mfma"], roof["frac_logits_plain_hbm"] = pl_["us"], pl_["frac_mfma"], pl_["frac_hbm"]
         parity_short = None
         if parity:
             parity_short = (f"hit1 {parity['hit1_equal']}/{parity['images']} top20rows {parity['top20_rows_equal']}/{parity['images']} "
@@ -952,7 +988,7 @@ def main():
                            "global_batch": a.batch * world, "parallelism": f"dp{world}", "text_dtype": a.text_dtype,
                            "weights": "random-init (hash-seeded), no checkpoint offline", "parity_ids": parity_short},
                 "roofline": roof, "cpu_baseline": cpu, "parity": parity, "pcie_inclusive": pcie, "metrics_string": summary.strip(),
-                "planted_signal": planted}
+                "planted_signal": planted, "update_classifier": uc_info}
         if dp_check is not None:
             line["dp_check"] = dp_check
             if not dp_check["ok"]:

@@ -617,6 +617,39 @@ def test_gemm_nt_res_stats(dt, m, n, k):
 
 
 @pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("m", [256, 200])
+def test_gemm_nt_res_stats_pair_corner_cases(dt, m):
+    """The producer's own split / decode of the residual pair (round 6: pair_split2 / pair_put_q / pair_dec4 - a float compare with |.| and
+    SDWA byte shifts where the first form masked, compared and shifted per element) on the values that separate the forms: zeros of
+    both signs, fp32 denormals, the f16 subnormal range and its upper edge, mantissa carries into the next binade, the largest f16,
+    negative twins.  With A = 0 the product vanishes: the new pair must be the reference encoder's split of (old value + bias),
+    interior tiles (m = 256) and the guarded edge-tile path (m = 200) alike."""
+    n, k = 128, 128
+    sp = torch.tensor([0.0, -0.0, 1e-40, -1e-40, 1e-8, -1e-8, 5.9e-8, 2.98e-8, 6e-5, -6e-5, 6.2e-5, 6.103515625e-05, 6.1035e-05, -6.1035e-05, 3.0517578125e-05,
+                       1.9999, -1.9999, 2047.9999, -2047.9999, 65000.0, -65000.0, 0.999755859375, 0.99987793, 1.0, -1.0, 3.14159, 1e-3, -1e-3, 0.33333334, 1024.5,
+                       7.62939453125e-06, -7.62939453125e-06], dtype=torch.float32)
+    x0 = sp.repeat((m * n + sp.numel() - 1) // sp.numel())[: m * n].view(m, n).contiguous().to(DEV)
+    x0 = x0 * (1.0 + 2.0 ** -12 * (torch.arange(m, device=DEV) % 7).float()[:, None])        # walk the low mantissa bits row by row
+    xh0, xl0 = _pair(x0, dt)
+    old = ops.pair_value(xh0, xl0)
+    a = torch.zeros(m, k, dtype=dt, device=DEV)
+    w = _rand((n, k), 5, 0.1).to(dt).to(DEV)
+    for bias_val in (0.0, 2.0 ** -20, -3.0e-5):
+        bias = torch.full((n,), bias_val, dtype=torch.float32, device=DEV)
+        xh, xl = xh0.clone(), xl0.clone()
+        stats = torch.empty(m, n // 64, 2, dtype=torch.float32, device=DEV)
+        ops.gemm_nt_res_stats(a, w, xh, xl, bias, stats)
+        want = (0.0 + bias[None, :]) + old                          # the kernel's association: (product + bias) + old value
+        rh, rl = _pair(want, dt)
+        assert torch.equal(xh.view(torch.int16), rh.view(torch.int16)), (bias_val, int((xh != rh).sum()))
+        assert torch.equal(xl, rl), (bias_val, int((xl != rl).sum()))
+        back = ops.pair_value(xh, xl)
+        assert torch.isfinite(back).all()
+        ref = _slot_stats(want.cpu())
+        assert torch.allclose(stats.cpu()[..., 0], ref[..., 0], rtol=1e-5, atol=1e-2) and torch.allclose(stats.cpu()[..., 1], ref[..., 1], rtol=1e-5, atol=1e2)
+
+
+@pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("m,n,k,panels", [(25600, 768, 768, -1), (25600, 768, 3072, -1), (25600, 2304, 768, 86), (25523, 768, 128, -1),
                                            (25600, 768, 192, 0), (25600, 768, 256, 1), (25600, 768, 256, 99), (26000, 1536, 256, -1)])
 def test_gemm_tail_plan_is_bit_identical(dt, m, n, k, panels):
