@@ -792,6 +792,22 @@ def main():
                 tile = roof["logits_gemm"].get("tile_stage_us")
                 if tile:
                     roof["logits_gemm"]["tile_stage_frac_mfma"] = round(lg[0][1] / (tile * 1e-6) / 1e12 / PEAK_TFLOPS_BF16, 4)
+                if ev._plan.zsl.shape[1] != f16.shape[1]:
+                    # ... and the tile stage on the plain 16-bit class operand (K = D, HGR_LOGITS_SPLIT=none): what the ~22-bit operand of the
+                    # default route costs the kernel north_star prices (its K is doubled for the same algorithmic product)
+                    ops.PROFILE = []
+                    ev._plan.bind(model._zsl16, model._zsl16.shape[1])
+                    for _ in range(5):
+                        ops.l2norm_rows(model.clip_model.encode_image(batches[0]), y16=f16)
+                        ops.logits_eval(f16, ev._plan, 20, stage="tile")
+                    torch.cuda.synchronize()
+                    st2, ops.PROFILE = ops.PROFILE, None
+                    ev._plan.bind(model._eval_class_operand(), model._zsl16.shape[1])
+                    ts = sorted(s_.elapsed_time(e_) * 1e3 for (name, s_, e_, fl, by, tag) in st2 if tag == "logits_eval_tile")
+                    if ts:
+                        t11 = ts[len(ts) // 2]
+                        roof["logits_gemm"]["tile_stage_us_plain_16bit_operand"] = round(t11, 1)
+                        roof["logits_gemm"]["tile_stage_frac_mfma_plain_16bit_operand"] = round(lg[0][1] / (t11 * 1e-6) / 1e12 / PEAK_TFLOPS_BF16, 4)
                 # beside it: the PLAIN product - hgr_gemm_nt writing the fp32 logits (forward()'s kernel on the 11-bit class operand, K = D) -
                 # against both of its roofs: 2 B N D flop, 2 B D + 2 N D + 4 B N bytes (the fp32 output co-binds it to HBM, H2)
                 n_, d_ = model._zsl16.shape
