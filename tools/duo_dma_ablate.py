@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Dev tool (round 5): gemm_nt_duo with parts of its LDS-DMA stream left out (HGR_GEMM_DBG = 128: no A pieces of odd K-tiles,
 256: no A pieces, 512: no W pieces, behind the first two K-tiles; wrong results) - what the operand fill costs the two-workgroup form.
-One process per setting."""
+One process per setting.
+(round 6: these switches exist in the lab build only - `make -C hgr-net_amd/csrc lab`, then HGR_LIB=$PWD/hgr-net_amd/lib/libhgr_lab.so)"""
 import os, sys, json
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent))

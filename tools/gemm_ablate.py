@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Dev tool: time one GEMM shape under HGR_GEMM_DBG / HGR_GEMM_TILE settings (run once per setting)."""
+"""Dev tool: time one GEMM shape under HGR_GEMM_DBG / HGR_GEMM_TILE settings (run once per setting).
+(round 6: these switches exist in the lab build only - `make -C hgr-net_amd/csrc lab`, then HGR_LIB=$PWD/hgr-net_amd/lib/libhgr_lab.so)"""
 import sys, os, json
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Dev tool: hgr_logits_eval (both stages) against hgr_gemm_nt + hgr_eval_rows at the bench shape (512 x 21 841 x 512), graph
-replays of back-to-back launches; HGR_LE_DBG=1..4 cuts the row stage short (timing of its parts)."""
+replays of back-to-back launches; HGR_LE_DBG=1..4 cuts the row stage short (timing of its parts).
+(round 6: these switches exist in the lab build only - `make -C hgr-net_amd/csrc lab`, then HGR_LIB=$PWD/hgr-net_amd/lib/libhgr_lab.so)"""
 import json
 import sys
 from pathlib import Path

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Dev tool (round 5): time the bare product of gemm_nt_ws under HGR_WS_DBG (one process per setting; wrong results by design for
-DBG != 0: 1 no MFMAs, 2 no LDS-DMAs, 4 no fragment reads, 8 no epilogue stores; sums combine)."""
+DBG != 0: 1 no MFMAs, 2 no LDS-DMAs, 4 no fragment reads, 8 no epilogue stores; sums combine).
+(round 6: these switches exist in the lab build only - `make -C hgr-net_amd/csrc lab`, then HGR_LIB=$PWD/hgr-net_amd/lib/libhgr_lab.so)"""
 import os, sys, json
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent))
