@@ -124,11 +124,14 @@ __global__ __launch_bounds__(256, 2) void mha_fwd(const typename T16<DT>::elem *
         mx = fmaxf(mx, __shfl_xor(mx, 16));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         float sum = 0.f;
+        // e^(s - mx) as 2^(s log2e - mx log2e): one FMA + v_exp_f32 per element where subtract, multiply, v_exp_f32 were three (round 6;
+        // qkv_attn evaluates the same expression)
+        const float nmx = -mx * 1.4426950408889634f;
 #pragma unroll
         for (int t = 0; t < 2 * KT; ++t)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float pexp = __expf(acc[t][e] - mx);
+                const float pexp = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[t][e], 1.4426950408889634f, nmx));
                 acc[t][e] = pexp;
                 sum += pexp;
             }

@@ -456,11 +456,12 @@ __global__ __launch_bounds__(QA_NT) void qkv_attn(QkvAttnArgs p) {
                 }
             mx = x32max(x16max(mx));
             float sum = 0.f;
+            const float nmx = -mx * 1.4426950408889634f;                          // e^(s - mx) = 2^(s log2e - mx log2e): FMA + v_exp_f32, as hgr_mha
 #pragma unroll
             for (int t = 0; t < 2 * KT; ++t)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float pexp = __expf(sc[t][e] - mx);
+                    const float pexp = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[t][e], 1.4426950408889634f, nmx));
                     sc[t][e] = pexp;
                     sum += pexp;
                 }
@@ -487,7 +488,11 @@ __global__ __launch_bounds__(QA_NT) void qkv_attn(QkvAttnArgs p) {
                     o[td] = T16<DT>::mfma16(vf, pf, o[td]);
                 }
             }
-            if (myseq == s) {
+            if (s_lo == s_hi) {                 // (wave-uniform) the query tile lies inside one sequence: no per-lane selection, no copies
+                rinv = inv;
+#pragma unroll
+                for (int td = 0; td < 4; ++td) res[td] = o[td];
+            } else if (myseq == s) {
                 rinv = inv;
 #pragma unroll
                 for (int td = 0; td < 4; ++td) res[td] = o[td];
