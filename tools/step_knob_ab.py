@@ -45,6 +45,9 @@ what = sys.argv[1] if len(sys.argv) > 1 else "tail"
 from hgr_net_amd import ops
 if what == "tail":
     arms = [("tail_off", lambda: ops.gemm_set_tail(False)), ("tail_on", lambda: ops.gemm_set_tail(True, -1))]
+elif what == "p8":           # gemm_nt_p8 by shape (2, the default: none of ViT-B/32's launches) / wherever it covers (1: c_fc, kv)
+    from hgr_net_amd import _lib
+    arms = [(f"p8={v}", (lambda v=v: _lib.load().hgr_gemm_set_p8(v))) for v in (2, 1)]
 elif what == "attr":
     import importlib
     mod, name, vals = importlib.import_module(sys.argv[2]), sys.argv[3], sys.argv[4:]
